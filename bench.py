@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the batched LQR/iLQR hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
+random LQR, state_dim=16, action_dim=8, horizon=50, batch=65 536 independent
+instances PER GPU (weak scaling), fp32.  One "step" = one pass of the hot path over
+the batch = 65 536 LQR solves (Riccati backward sweep + closed-loop rollout) in one
+kernel launch; for an LQR problem one solve is one iLQR iteration.
+Inputs are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see the task contract) with `roofline` for the
+dominant kernel and `cpu_baseline` (the oracle's C port timed on this host).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tf-mpc_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+N_STATE, N_ACTION, HORIZON, BATCH = 16, 8, 50, 65536
+PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md:41-42 (vector == f32-MFMA dense peak)
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md:36 (spec)
+
+
+def lqr_flops_per_solve(n, m, T):
+    """ALGORITHMIC flops of one LQR solve (multiply-add = 2 flop, no
+    symmetry savings): backward 50.6 kflop/step + forward 2.2 kflop/step at n=16, m=8."""
+    d = n + m
+    backward = (2 * d * n * n + 2 * d * d * n + 4 * d * n) + (2.0 / 3.0 * m ** 3 + 2 * m * m * (n + 1)) \
+        + (6 * n * n * m + 2 * n * m * m + 6 * n * m) + (2 * m * m + 2 * m + 2 * n * n + 2 * n)
+    forward = 2 * m * n + 2 * n * d + 2 * d * d + 2 * d
+    return T * (backward + forward) + 2 * n * n + 2 * n
+
+
+def lqr_bytes_per_solve(n, m, T):
+    """ALGORITHMIC (compulsory) HBM bytes of one solve: read F, f, C, c, x0; write
+    states, actions, costs (9 132 B at n=16, m=8, T=50)."""
+    d = n + m
+    return 4 * (n * d + n + d * d + d + n) + 4 * ((T + 1) * n + T * m + (T + 1))
+
+
+def cpu_baseline(n, m, T, target_seconds=12.0):
+    """The oracle's C port of the reference equations, OpenMP over instances on all
+    host cores, on a bounded sample of the same workload."""
+    from oracle import c_oracle
+    import problems
+
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, c_oracle.max_threads()))
+    calib = 64 * threads
+    F, f, C, c, x0 = problems.make_lqr_batch_fast(calib, n, m, seed=99)
+    c_oracle.lqr_solve(F, f, C, c, x0, T, dtype=np.float32, nthreads=threads)       # warm up threads
+    t0 = time.perf_counter()
+    c_oracle.lqr_solve(F, f, C, c, x0, T, dtype=np.float32, nthreads=threads)
+    rate = calib / (time.perf_counter() - t0)
+    sample = int(min(BATCH, max(calib, rate * target_seconds)))
+    reps = -(-sample // calib)
+    Fs, fs, Cs, cs, xs = (np.concatenate([a] * reps)[:sample] for a in (F, f, C, c, x0))
+    t0 = time.perf_counter()
+    c_oracle.lqr_solve(Fs, fs, Cs, cs, xs, T, dtype=np.float32, nthreads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "iterations/s", "cores": threads, "kind": "port",
+            "sample": f"{sample} of {BATCH} instances of the same workload (n={n}, m={m}, T={T}, fp32), "
+                      f"C restatement of lqr.py, OpenMP x{threads}, {dt:.1f} s",
+            "host_cpus": cores}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help="instances per GPU (default = BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from tfmpc import _hip
+    from tfmpc.parallel import gather_trajectories
+    from tfmpc.solvers.lqr import LQR
+    import problems
+
+    n, m, T, B = N_STATE, N_ACTION, HORIZON, args.batch
+    # each rank owns its own contiguous shard of the global batch (weak scaling)
+    F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=1234 + rank)
+    lqr = LQR(F, f, C, c)
+    x0_dev = lqr._prep_x0(x0)
+    lib = _hip.require_gpu()
+    kernel = lib.tfmpc_lqr_kernel_name(n, m, T).decode()
+    ws = None
+
+    def step():
+        nonlocal ws
+        out = lqr.solve_device(x0_dev, T, workspace=ws)
+        ws = out["workspace"]
+        return out
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for s, e in ev:
+        s.record()              # HIP events on the stream the kernel is launched on
+        out = step()
+        e.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if ev else float("nan")
+
+    status_bad = int((out["status"] != 0).sum())
+    # the one collective of the path: gather the result trajectories on rank 0 (outside
+    # the timed region: it happens once per job, not per step)
+    gathered = gather_trajectories(out["states"], out["actions"], out["costs"]) if world > 1 else None
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        kmax = torch.tensor([kernel_ms], device="cuda", dtype=torch.float64)
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+        kernel_ms = float(kmax.item())
+
+    if rank == 0:
+        total_solves = B * world * args.steps
+        value = total_solves / elapsed
+        flops = lqr_flops_per_solve(n, m, T) * B
+        achieved = flops / (kernel_ms * 1e-3) / 1e12
+        line = {
+            "metric": "iLQR iterations/sec (batch x horizon) at n=16,m=8,T=50",
+            "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "random LQR n=16 m=8 horizon=50, batch=65536 per GPU (BASELINE configs[2]); "
+                                   "one LQR solve = one iLQR iteration",
+                       "state_dim": n, "action_dim": m, "horizon": T, "batch_per_gpu": B,
+                       "global_batch": B * world, "parallelism": f"batch-sharded x{world}, one gather at the end",
+                       "kernel": kernel},
+            "timestep_iterations_per_s": value * T,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": None,
+                         "kernel_ms": kernel_ms, "algorithmic_flop_per_iteration": lqr_flops_per_solve(n, m, T),
+                         "algorithmic_bytes_per_iteration": lqr_bytes_per_solve(n, m, T),
+                         "hbm_frac_at_algorithmic_bytes": lqr_bytes_per_solve(n, m, T) * B / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+            "status_flagged_instances": status_bad,
+        }
+        if gathered is not None:
+            line["gathered_states_shape"] = list(gathered[0].shape)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(n, m, T)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,119 @@
+// lqr_dispatch.hip -- extern "C" entry points of the LQR path (include/tfmpc_hip.h):
+// argument checks, kernel-variant choice, launch.  No allocation, no sync.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "lqr_kernels.h"
+
+using namespace tfmpc;
+
+namespace {
+
+bool want_mfma(int n, int m)
+{
+    const char *force = std::getenv("TFMPC_LQR_KERNEL");   // "generic" | "mfma" (testing / A-B timing)
+    if (force && std::strcmp(force, "generic") == 0) return false;
+    return lqr_mfma_supported(n, m);
+}
+
+int check_common(int B, int n, int m, int T, const void *F, const void *f, const void *C, const void *c)
+{
+    if (B < 0 || n <= 0 || m <= 0 || T < 0) return TFMPC_ERR_ARG;
+    if (!F || !f || !C || !c) return TFMPC_ERR_ARG;
+    if (!want_mfma(n, m) && lqr_generic_smem_bytes(n, m) > kMaxLdsBytes) return TFMPC_ERR_UNSUPPORTED;
+    return TFMPC_OK;
+}
+
+int run(const LqrArgs &a, bool bw, bool fw, void *stream)
+{
+    if (a.B == 0) return TFMPC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (want_mfma(a.n, a.m)) return lqr_mfma_launch(a, bw, fw, s);
+    return lqr_generic_launch(a, bw, fw, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tfmpc_version(void) { return 100; }
+
+const char *tfmpc_lqr_kernel_name(int n, int m, int T)
+{
+    (void)T;
+    if (n <= 0 || m <= 0) return "invalid";
+    if (want_mfma(n, m)) return "mfma_16x8";
+    if (lqr_generic_smem_bytes(n, m) > kMaxLdsBytes) return "unsupported";
+    return "generic_wave";
+}
+
+size_t tfmpc_lqr_workspace_bytes(int B, int n, int m, int T)
+{
+    if (B <= 0 || n <= 0 || m <= 0 || T <= 0) return 0;
+    return (size_t)B * T * m * (n + 1) * sizeof(float);
+}
+
+int tfmpc_lqr_backward_f32(int B, int n, int m, int T, const float *F, long strideF, const float *f,
+                           long stride_f, const float *C, long strideC, const float *c, long stride_c,
+                           float *K, float *k, float *V, float *v, float *cst, int32_t *status, void *stream)
+{
+    int rc = check_common(B, n, m, T, F, f, C, c);
+    if (rc != TFMPC_OK) return rc;
+    if (T > 0 && B > 0 && (!K || !k)) return TFMPC_ERR_ARG;
+    LqrArgs a{};
+    a.B = B; a.n = n; a.m = m; a.T = T;
+    a.F = F; a.f = f; a.C = C; a.c = c;
+    a.sF = strideF; a.sf = stride_f; a.sC = strideC; a.sc = stride_c;
+    a.K = K; a.k = k; a.sK = (long)T * m * n; a.sk = (long)T * m;
+    a.V = V; a.v = v; a.cst = cst; a.status = status;
+    return run(a, true, false, stream);
+}
+
+int tfmpc_lqr_forward_f32(int B, int n, int m, int T, const float *F, long strideF, const float *f,
+                          long stride_f, const float *C, long strideC, const float *c, long stride_c,
+                          const float *K, long strideK, const float *k, long stride_k, const float *x0,
+                          float *states, float *actions, float *costs, void *stream)
+{
+    int rc = check_common(B, n, m, T, F, f, C, c);
+    if (rc != TFMPC_OK) return rc;
+    if (B > 0 && (!x0 || !states || !costs)) return TFMPC_ERR_ARG;
+    if (B > 0 && T > 0 && (!K || !k || !actions)) return TFMPC_ERR_ARG;
+    LqrArgs a{};
+    a.B = B; a.n = n; a.m = m; a.T = T;
+    a.F = F; a.f = f; a.C = C; a.c = c; a.x0 = x0;
+    a.sF = strideF; a.sf = stride_f; a.sC = strideC; a.sc = stride_c;
+    a.K = const_cast<float *>(K); a.k = const_cast<float *>(k); a.sK = strideK; a.sk = stride_k;
+    a.states = states; a.actions = actions; a.costs = costs;
+    return run(a, false, true, stream);
+}
+
+int tfmpc_lqr_solve_f32(int B, int n, int m, int T, const float *F, long strideF, const float *f,
+                        long stride_f, const float *C, long strideC, const float *c, long stride_c,
+                        const float *x0, float *states, float *actions, float *costs, float *K, float *k,
+                        float *V, float *v, float *cst, int32_t *status, void *workspace,
+                        size_t workspace_bytes, void *stream)
+{
+    int rc = check_common(B, n, m, T, F, f, C, c);
+    if (rc != TFMPC_OK) return rc;
+    if (B > 0 && (!x0 || !states || !costs)) return TFMPC_ERR_ARG;
+    if (B > 0 && T > 0 && !actions) return TFMPC_ERR_ARG;
+    if (B > 0 && T > 0 && (!K || !k)) {
+        // gains are not a requested output: keep them in caller-provided scratch
+        if (!workspace || workspace_bytes < tfmpc_lqr_workspace_bytes(B, n, m, T)) return TFMPC_ERR_WORKSPACE;
+        float *w = static_cast<float *>(workspace);
+        if (!K) { K = w; }
+        if (!k) { k = w + (size_t)B * T * m * n; }
+    }
+    LqrArgs a{};
+    a.B = B; a.n = n; a.m = m; a.T = T;
+    a.F = F; a.f = f; a.C = C; a.c = c; a.x0 = x0;
+    a.sF = strideF; a.sf = stride_f; a.sC = strideC; a.sc = stride_c;
+    a.K = K; a.k = k; a.sK = (long)T * m * n; a.sk = (long)T * m;
+    a.V = V; a.v = v; a.cst = cst;
+    a.states = states; a.actions = actions; a.costs = costs; a.status = status;
+    return run(a, true, true, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,35 @@
+// lqr_kernels.h -- internal launch interface shared by the LQR kernel variants and
+// the C-ABI dispatcher (lqr_dispatch.hip).  Not installed; the public contract is
+// include/tfmpc_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/tfmpc_hip.h"
+
+namespace tfmpc {
+
+// gfx950: 160 KiB of LDS per CU, all of it addressable by one workgroup.
+constexpr size_t kMaxLdsBytes = 160 * 1024;
+
+struct LqrArgs {
+    int B, n, m, T;
+    const float *F, *f, *C, *c, *x0;
+    long sF, sf, sC, sc;          // batch strides (elements), 0 = shared
+    float *K, *k;                 // [B][T][m][n], [B][T][m]  (read by forward-only launches)
+    long sK, sk;                  // batch strides of K, k
+    float *V, *v, *cst;           // optional value-function outputs
+    float *states, *actions, *costs;
+    int32_t *status;
+};
+
+size_t lqr_generic_smem_bytes(int n, int m);
+int lqr_generic_launch(const LqrArgs &a, bool backward, bool forward, hipStream_t stream);
+
+// MFMA variant for the BASELINE.json headline shape (lqr_mfma16x8.hip).
+bool lqr_mfma_supported(int n, int m);
+int lqr_mfma_launch(const LqrArgs &a, bool backward, bool forward, hipStream_t stream);
+
+}  // namespace tfmpc

@@ -1,0 +1,121 @@
+// wave_ops.h -- building blocks for "one wavefront owns one problem instance".
+//
+// gfx950 only: a wavefront is 64 lanes, a workgroup here is exactly one wave, and
+// every matrix of the instance lives in that wave's LDS slice.  Because the
+// workgroup is a single wave, __syncthreads() costs an s_waitcnt (the s_barrier
+// is elided by the compiler) and is used purely as the LDS/global ordering fence
+// between a phase that writes a tile and the phase that reads it across lanes.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace tfmpc {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+// Fence between cross-lane producer/consumer phases of one wave.
+__device__ __forceinline__ void wsync() { __syncthreads(); }
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+
+// Odd leading dimension: a column walk (stride ld) then touches every LDS bank.
+__host__ __device__ __forceinline__ int odd_ld(int x) { return x | 1; }
+
+// out(i, j) = init(i, j) + sum_k a(i, k) * b(k, j), i < M, j < N, wave-cooperative:
+// output elements are dealt round-robin to the 64 lanes.
+template <class FA, class FB, class FInit, class FOut>
+__device__ __forceinline__ void wave_matmul(int M, int N, int K, FA a, FB b, FInit init, FOut out)
+{
+    const int total = M * N;
+    for (int idx = lane_id(); idx < total; idx += kWave) {
+        const int i = idx / N;
+        const int j = idx - i * N;
+        float s = init(i, j);
+        for (int kk = 0; kk < K; ++kk) s = fmaf(a(i, kk), b(kk, j), s);
+        out(i, j, s);
+    }
+}
+
+// Global -> LDS copy of a row-major [rows][cols] matrix into leading dimension ld.
+__device__ __forceinline__ void load_matrix(float *dst, int ld, const float *src, int rows, int cols)
+{
+    const int total = rows * cols;
+    for (int idx = lane_id(); idx < total; idx += kWave) {
+        const int r = idx / cols;
+        dst[r * ld + (idx - r * cols)] = src[idx];
+    }
+}
+
+__device__ __forceinline__ void store_matrix(float *dst, const float *src, int ld, int rows, int cols)
+{
+    const int total = rows * cols;
+    for (int idx = lane_id(); idx < total; idx += kWave) {
+        const int r = idx / cols;
+        dst[idx] = src[r * ld + (idx - r * cols)];
+    }
+}
+
+// In-place Gauss-Jordan elimination of the augmented system aug[rows][width]
+// (leading dimension ld) whose first `rows` columns hold the square matrix; on
+// return columns rows..width-1 hold A^{-1} * RHS.
+//   PIVOT = true : partial (row) pivoting -- the general inverse of lqr.py:84.
+//   PIVOT = false: no pivoting; for a symmetric matrix every pivot is positive
+//                  iff the matrix is positive definite, which is the failure test
+//                  of tf.linalg.cholesky in ilqr.py:358.  `active` (may be null)
+//                  marks rows that take part; inactive rows/cols must already
+//                  be identity rows (box-QP free/clamped split).
+// fac[rows] and prow[width] are LDS scratch.  Returns 0, or 1 if a pivot was
+// zero (PIVOT) / non-positive or NaN (!PIVOT).  All lanes return the same value.
+template <bool PIVOT>
+__device__ __forceinline__ int wave_gauss_jordan(float *aug, int ld, int rows, int width, float *fac, float *prow)
+{
+    const int lane = lane_id();
+    int bad = 0;
+    for (int p = 0; p < rows; ++p) {
+        int piv = p;
+        if (PIVOT) {
+            float best = fabsf(aug[p * ld + p]);
+            for (int i = p + 1; i < rows; ++i) {
+                const float a = fabsf(aug[i * ld + p]);
+                if (a > best) { best = a; piv = i; }
+            }
+        }
+        const float pv = aug[piv * ld + p];
+        if (PIVOT ? (pv == 0.0f) : !(pv > 0.0f)) bad = 1;
+        const float inv = 1.0f / pv;
+        // stage the (scaled) pivot row and the multiplier column
+        for (int j = lane; j < width; j += kWave) prow[j] = aug[piv * ld + j] * inv;
+        for (int i = lane; i < rows; i += kWave) fac[i] = aug[i * ld + p];
+        wsync();
+        if (PIVOT && piv != p) {
+            // move row p into slot piv (its multiplier is fac[p])
+            for (int j = lane; j < width; j += kWave) aug[piv * ld + j] = aug[p * ld + j];
+            if (lane == 0) fac[piv] = fac[p];
+            wsync();
+        }
+        const int total = rows * width;
+        for (int idx = lane; idx < total; idx += kWave) {
+            const int i = idx / width;
+            const int j = idx - i * width;
+            aug[i * ld + j] = (i == p) ? prow[j] : fmaf(-fac[i], prow[j], aug[i * ld + j]);
+        }
+        wsync();
+    }
+    return bad;
+}
+
+}  // namespace tfmpc

@@ -1,0 +1,81 @@
+"""ctypes binding of ``libtfmpc_hip.so`` (C ABI: ``include/tfmpc_hip.h``).
+
+torch is imported first on purpose: torch-ROCm ships its own ``libamdhip64.so.7``
+and the dynamic loader reuses that already-loaded runtime for our library, so
+kernels launched here see torch's allocations and streams.
+"""
+
+import ctypes
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libtfmpc_hip.so")
+_lib = None
+
+ERRORS = {-1: "bad argument", -2: "shape not supported by any kernel variant",
+          -3: "kernel launch failed", -4: "workspace too small"}
+
+ST_SINGULAR, ST_NOT_PD, ST_NAN, ST_QP_MAXITER, ST_MAX_ATTEMPTS = 1, 2, 4, 8, 16
+
+_P, _I, _L, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t
+
+_SIGNATURES = {
+    "tfmpc_version": (ctypes.c_int, []),
+    "tfmpc_lqr_kernel_name": (ctypes.c_char_p, [_I, _I, _I]),
+    "tfmpc_lqr_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "tfmpc_lqr_backward_f32": (_I, [_I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L,
+                                    _P, _P, _P, _P, _P, _P, _P]),
+    "tfmpc_lqr_forward_f32": (_I, [_I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L,
+                                   _P, _L, _P, _L, _P, _P, _P, _P, _P]),
+    "tfmpc_lqr_solve_f32": (_I, [_I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P,
+                                 _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+}
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load the shared library (works without a GPU; used by the symbol tests)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"tfmpc: HIP library not built ({_LIB_PATH} missing). Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C tf-mpc_amd/csrc`. "
+                "There is no CPU fallback.")
+        lib = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def require_gpu():
+    """The product path runs on the GPU or not at all."""
+    lib = load()
+    if not torch.cuda.is_available():
+        raise RuntimeError("tfmpc: no ROCm GPU visible; the LQR/iLQR solvers only run as HIP kernels "
+                           "on gfx950 (no CPU fallback).")
+    return lib
+
+
+def default_device():
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"tfmpc: {what} failed: {ERRORS.get(rc, rc)}")

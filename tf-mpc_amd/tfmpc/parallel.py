@@ -1,0 +1,50 @@
+"""Multi-GPU use of the path: problem instances are independent, so the batch is
+sharded over one process per GPU with NO collective during the solve; the only
+exchange is ONE gather of the result trajectories at the end (RCCL over xGMI when
+the tensors are on GPUs, gloo on CPU in the tests).  SURVEY.md §8(e)."""
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total, world_size, rank):
+    """Contiguous block split of ``total`` instances over ``world_size`` ranks."""
+    base, rem = divmod(int(total), int(world_size))
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def shard(tensor, world_size=None, rank=None):
+    """This rank's contiguous block of a batch-major tensor."""
+    world_size = dist.get_world_size() if world_size is None else world_size
+    rank = dist.get_rank() if rank is None else rank
+    lo, hi = shard_bounds(tensor.shape[0], world_size, rank)
+    return tensor[lo:hi]
+
+
+def gather_trajectories(states, actions, costs, dst=0, group=None):
+    """Gather per-rank result shards ``states[b,T+1,n,1]``, ``actions[b,T,m,1]``,
+    ``costs[b,T+1,...]`` on rank ``dst`` as ONE collective over a single packed
+    buffer.  Shards may differ in size by one instance.  Returns the concatenated
+    tensors on ``dst`` and ``None`` elsewhere."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return states, actions, costs
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    b = states.shape[0]
+    per = states[0].numel() + actions[0].numel() + costs[0].numel()
+    sizes = torch.tensor([b], device=states.device, dtype=torch.int64)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)          # 8 bytes per rank; sizes only
+    all_b = [int(s.item()) for s in all_sizes]
+    bmax = max(all_b)
+    packed = torch.zeros((bmax, per), device=states.device, dtype=states.dtype)
+    packed[:b] = torch.cat([states.reshape(b, -1), actions.reshape(b, -1), costs.reshape(b, -1)], dim=1)
+    recv = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
+    dist.gather(packed, recv, dst=dst, group=group)        # the one data-path collective
+    if rank != dst:
+        return None
+    full = torch.cat([r[:nb] for r, nb in zip(recv, all_b)], dim=0)
+    ns, na = states[0].numel(), actions[0].numel()
+    B = full.shape[0]
+    return (full[:, :ns].reshape(B, *states.shape[1:]), full[:, ns:ns + na].reshape(B, *actions.shape[1:]),
+            full[:, ns + na:].reshape(B, *costs.shape[1:]))
