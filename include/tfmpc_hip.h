@@ -88,6 +88,113 @@ int tfmpc_lqr_solve_f32(int B, int n, int m, int T,
                         float *K, float *k, float *V, float *v, float *cst,
                         int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
 
+
+/* --------------------------------------------------------------- iLQR --------
+ * Control-limited iLQR (tfmpc/solvers/ilqr.py) over the reference's differentiable
+ * environments (tfmpc/envs).  An environment is described by a kind tag plus
+ * parameter arrays; Jacobians / Hessians are closed forms evaluated on the device
+ * (the reference obtains them by autodiff, tfmpc/envs/diffenv.py:13-101).
+ */
+#define TFMPC_ENV_LQ 0          /* (F, f, C, c) of tfmpc/solvers/lqr.py:36-57 as an env: n != m allowed */
+#define TFMPC_ENV_NAVLQR 1      /* tfmpc/envs/lqr/navigation/__init__.py:8-47                           */
+#define TFMPC_ENV_NAVIGATION 2  /* tfmpc/envs/navigation/__init__.py:9-74  (cec=True)                   */
+#define TFMPC_ENV_HVAC 3        /* tfmpc/envs/hvac/__init__.py:8-149                                    */
+#define TFMPC_ENV_RESERVOIR 4   /* tfmpc/envs/reservoir/__init__.py:9-105 (cec=True)                    */
+#define TFMPC_ENV_MAX_PARAMS 10
+#define TFMPC_MAX_ALPHAS 16
+
+/* Parameter arrays p[i] per kind (device pointers, fp32; stride[i] = element
+ * distance between instances, 0 = shared by the whole batch):
+ *   LQ         p0 F[n][n+m]  p1 f[n]  p2 C[n+m][n+m]  p3 c[n+m]
+ *   NAVLQR     p0 goal[n]; scalar[0] = beta
+ *   NAVIGATION p0 goal[n]  p1 center[Z][n]  p2 decay[Z]           (n_zones = Z, n <= 8)
+ *   HVAC       p0 temp_outside  p1 temp_hall  p2 temp_lower_bound  p3 temp_upper_bound
+ *              p4 adj_outside/R_outside  p5 adj_hall/R_hall  p6 capacity  p7 air_max   (all [n])
+ *              p8 G[n][n] = (adj | adj^T) / R_wall
+ *   RESERVOIR  p0 max_res_cap  p1 lower_bound  p2 upper_bound  p3 low_penalty  p4 high_penalty
+ *              p5 set_point_penalty  p6 rain_shape*rain_scale   (all [n])  p7 downstream[n][n]
+ * low[m] / high[m]: action bounds (+-inf allowed, shared by the batch); `bounded`
+ * is gym's Box.is_bounded(): every bound finite (ilqr.py:136). */
+typedef struct TfmpcEnv {
+    int32_t kind, n, m, n_zones, bounded, reserved0, reserved1, reserved2;
+    const float *low, *high;
+    const float *p[TFMPC_ENV_MAX_PARAMS];
+    int64_t stride[TFMPC_ENV_MAX_PARAMS];
+    float scalar[4];
+} TfmpcEnv;
+
+/* Solver hyper-parameters (ilqr.py:27-37) + the line-search step sizes
+ * np.geomspace(1, alpha_min, 11) (ilqr.py:322) computed by the host. */
+typedef struct TfmpcIlqrConfig {
+    float atol;             /* 5e-3 */
+    int32_t max_iterations; /* 100  */
+    float mu_min;           /* 1e-6 */
+    float delta_0;          /* 2.0  */
+    float c1;               /* 0.0  */
+    int32_t n_alphas;       /* 11   */
+    float alphas[TFMPC_MAX_ALPHAS];
+    int32_t max_attempts;   /* cap on rejected backward/line-search attempts per solve (the
+                               reference loops without bound, ilqr.py:238-270) */
+} TfmpcIlqrConfig;
+
+/* iLQR.start (ilqr.py:53-82) with the random actions injected: roll the env from
+ * x0[B][n] under actions[B][T][m]; writes states[B][T+1][n], costs[B][T+1]. */
+int tfmpc_ilqr_rollout_f32(const TfmpcEnv *env, int B, int T, const float *x0, const float *actions,
+                           float *states, float *costs, void *stream);
+
+/* iLQR.derivatives (ilqr.py:84-92) = DiffEnv.get_linear_transition / get_quadratic_cost /
+ * get_quadratic_final_cost (diffenv.py:13-101) at every (x_t, u_t), t < T, and at x_T.
+ * states[B][T+1][n], actions[B][T][m].  Outputs (any may be NULL): f[B][T][n],
+ * f_x[B][T][n][n], f_u[B][T][n][m], l[B][T], l_x[B][T][n], l_u[B][T][m], l_xx[B][T][n][n],
+ * l_uu[B][T][m][m], l_ux[B][T][m][n], l_xu[B][T][n][m]; final fl[B], fl_x[B][n], fl_xx[B][n][n]. */
+int tfmpc_ilqr_derivatives_f32(const TfmpcEnv *env, int B, int T, const float *states, const float *actions,
+                               float *f, float *f_x, float *f_u, float *l, float *l_x, float *l_u,
+                               float *l_xx, float *l_uu, float *l_ux, float *l_xu,
+                               float *fl, float *fl_x, float *fl_xx, void *stream);
+
+/* iLQR.backward (ilqr.py:94-172) on materialised models (layouts as above).  mu[B]
+ * (mu_stride 1) or one shared value (mu_stride 0).  Controller per step: Cholesky-type
+ * solve (:357-362), box-QP (:364-387 + tfmpc/utils/optimization.py:6-101) when `bounded`
+ * and V_xx != 0, bang-bang otherwise (:140-141).  Outputs K[B][T][m][n], k[B][T][m], J[B],
+ * dV1[B], dV2[B]; status[B] gets TFMPC_ST_NOT_PD where the reference would raise
+ * InvalidArgumentError (outputs of that instance are then undefined). */
+int tfmpc_ilqr_backward_f32(int B, int n, int m, int T, const float *actions,
+                            const float *f_x, const float *f_u, const float *l, const float *l_x,
+                            const float *l_u, const float *l_xx, const float *l_uu, const float *l_xu,
+                            const float *fl, const float *fl_x, const float *fl_xx,
+                            const float *low, const float *high, int bounded,
+                            const float *mu, long mu_stride,
+                            float *K, float *k, float *J, float *dV1, float *dV2, int32_t *status, void *stream);
+
+/* iLQR.forward (ilqr.py:174-212): closed-loop rollout around (x[B][T+1][n], u[B][T][m])
+ * with gains K, k and step alpha[B] (alpha_stride 1) or shared (0).  Outputs states,
+ * actions, costs[B][T+1], J[B], residual[B]. */
+int tfmpc_ilqr_forward_f32(const TfmpcEnv *env, int B, int T, const float *x, const float *u,
+                           const float *K, const float *k, const float *alpha, long alpha_stride,
+                           float *states, float *actions, float *costs, float *J, float *residual,
+                           void *stream);
+
+size_t tfmpc_ilqr_workspace_bytes(int B, int n, int m, int T);
+
+/* iLQR.solve (ilqr.py:214-283) in ONE launch: each wave runs its instance's whole
+ * iteration loop (linearise on the fly, regularised backward pass with the local
+ * Cholesky-failure retry of :285-315, 11-point line search :317-355, mu/delta schedule
+ * :259-270, both convergence tests :243-257).  u_init[B][T][m] are the start actions
+ * (ilqr.py:70 draws them from TF's RNG; the host injects them).  Outputs: the final
+ * nominal trajectory states[B][T+1][n], actions[B][T][m], costs[B][T+1];
+ * iterations[B] = the reference's returned loop index; status[B]. */
+int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B, int T,
+                         const float *x0, const float *u_init,
+                         float *states, float *actions, float *costs,
+                         int32_t *iterations, int32_t *status,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* projected_newton_qp (tfmpc/utils/optimization.py:6-101): B independent box QPs
+ * min 1/2 x^T H x + q^T x, low <= x <= high.  H[B][m][m], q/low/high/x0[B][m];
+ * outputs x[B][m], free[B][m] (1.0 / 0.0), status[B]. */
+int tfmpc_boxqp_f32(int B, int m, const float *H, const float *q, const float *low, const float *high,
+                    const float *x0, float *x, float *free_mask, int32_t *status, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

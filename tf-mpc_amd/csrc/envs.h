@@ -1,0 +1,456 @@
+// envs.h -- device-side models of the reference's differentiable environments.
+//
+// The reference gets every Jacobian/Hessian from TensorFlow autodiff
+// (tfmpc/envs/diffenv.py:13-101).  Here each env carries its closed-form
+// derivatives (each confirmed against the reference's own
+// tests/test_env_*.py and, in tests/, against an independent torch-autodiff
+// restatement).  All functions are wave-cooperative: the 64 lanes of the wave that
+// owns the instance call them together; x, u and every output live in that wave's
+// LDS.  Dense outputs (f_x[n][n], f_u[n][m], l_xx ...) use leading dimension
+// odd_ld(cols) like the rest of the wave kernels.
+//
+//   kind            reference file                              parameters p[i]
+//   ENV_LQ          tfmpc/solvers/lqr.py:36-57                  F[n][n+m], f[n], C[d][d], c[d]
+//   ENV_NAVLQR      tfmpc/envs/lqr/navigation/__init__.py:30-47 goal[n]; scalar[0] = beta
+//   ENV_NAVIGATION  tfmpc/envs/navigation/__init__.py:34-74     goal[2], center[Z][2], decay[Z]
+//   ENV_HVAC        tfmpc/envs/hvac/__init__.py:69-149          temp_outside, temp_hall, lower, upper,
+//                                                               k_out = adj_out/R_out, k_hall = adj_hall/R_hall,
+//                                                               capacity, air_max, G[n][n] = (adj|adj^T)/R_wall
+//   ENV_RESERVOIR   tfmpc/envs/reservoir/__init__.py:47-105     max_res_cap, lower, upper, low_penalty,
+//                                                               high_penalty, set_point_penalty,
+//                                                               rain = shape*scale, downstream[n][n]
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/tfmpc_hip.h"
+#include "wave_ops.h"
+
+namespace tfmpc {
+
+// Per-wave LDS copy of one instance's env parameters.
+struct EnvLds {
+    int n, m, zones;
+    float beta;
+    const float *p[TFMPC_ENV_MAX_PARAMS];
+    const float *low, *high;   // [m]
+};
+
+__host__ __device__ inline int env_param_len(int kind, int i, int n, int m, int zones)
+{
+    const int d = n + m;
+    switch (kind) {
+    case TFMPC_ENV_LQ: { const int len[4] = {n * d, n, d * d, d}; return i < 4 ? len[i] : 0; }
+    case TFMPC_ENV_NAVLQR: return i == 0 ? n : 0;
+    case TFMPC_ENV_NAVIGATION: { const int len[3] = {n, zones * n, zones}; return i < 3 ? len[i] : 0; }
+    case TFMPC_ENV_HVAC: return i < 8 ? n : (i == 8 ? n * n : 0);
+    case TFMPC_ENV_RESERVOIR: return i < 7 ? n : (i == 7 ? n * n : 0);
+    }
+    return 0;
+}
+
+__host__ __device__ inline size_t env_lds_floats(int kind, int n, int m, int zones)
+{
+    size_t s = 2 * (size_t)m;
+    for (int i = 0; i < TFMPC_ENV_MAX_PARAMS; ++i) s += env_param_len(kind, i, n, m, zones);
+    return s;
+}
+
+// Copies instance b's parameters (and the action bounds) into LDS at `base`;
+// returns the first free float after them.
+__device__ inline float *env_load(EnvLds &e, const TfmpcEnv &g, int b, float *base)
+{
+    const int lane = lane_id();
+    e.n = g.n; e.m = g.m; e.zones = g.n_zones; e.beta = g.scalar[0];
+    float *p = base;
+    for (int i = 0; i < TFMPC_ENV_MAX_PARAMS; ++i) {
+        const int len = env_param_len(g.kind, i, g.n, g.m, g.n_zones);
+        e.p[i] = p;
+        if (len > 0) {
+            const float *src = g.p[i] + (size_t)b * g.stride[i];
+            for (int j = lane; j < len; j += kWave) p[j] = src[j];
+            p += len;
+        }
+    }
+    float *lo = p, *hi = p + g.m;
+    for (int j = lane; j < g.m; j += kWave) { lo[j] = g.low[j]; hi[j] = g.high[j]; }
+    e.low = lo; e.high = hi;
+    return p + 2 * g.m;
+}
+
+__device__ __forceinline__ float signf(float y) { return (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f); }
+
+template <int KIND> struct Env;
+
+// ----------------------------------------------------------------------- LQ ---
+template <> struct Env<TFMPC_ENV_LQ> {
+    // x' = F [x;u] + f                                               lqr.py:36-39
+    static __device__ void transition(const EnvLds &e, const float *x, const float *u, float *xn)
+    {
+        const int n = e.n, m = e.m, d = n + m;
+        const float *F = e.p[0], *f = e.p[1];
+        for (int i = lane_id(); i < n; i += kWave) {
+            float s = f[i];
+            for (int j = 0; j < n; ++j) s = fmaf(F[i * d + j], x[j], s);
+            for (int j = 0; j < m; ++j) s = fmaf(F[i * d + n + j], u[j], s);
+            xn[i] = s;
+        }
+    }
+    // 1/2 z^T C z + c^T z                                            lqr.py:41-47
+    static __device__ float cost(const EnvLds &e, const float *x, const float *u)
+    {
+        const int n = e.n, m = e.m, d = n + m;
+        const float *C = e.p[2], *c = e.p[3];
+        float part = 0.0f;
+        for (int r = lane_id(); r < d; r += kWave) {
+            float cz = 0.0f;
+            for (int j = 0; j < n; ++j) cz = fmaf(C[r * d + j], x[j], cz);
+            for (int j = 0; j < m; ++j) cz = fmaf(C[r * d + n + j], u[j], cz);
+            const float zr = r < n ? x[r] : u[r - n];
+            part += zr * (0.5f * cz + c[r]);
+        }
+        return wave_sum(part);
+    }
+    // 1/2 x^T C_xx x + c_x^T x                                       lqr.py:49-57
+    static __device__ float final_cost(const EnvLds &e, const float *x)
+    {
+        const int n = e.n, d = n + e.m;
+        const float *C = e.p[2], *c = e.p[3];
+        float part = 0.0f;
+        for (int r = lane_id(); r < n; r += kWave) {
+            float cz = 0.0f;
+            for (int j = 0; j < n; ++j) cz = fmaf(C[r * d + j], x[j], cz);
+            part += x[r] * (0.5f * cz + c[r]);
+        }
+        return wave_sum(part);
+    }
+    static __device__ float linearize(const EnvLds &e, const float *x, const float *u, float *fx, float *fu,
+                                      float *lx, float *lu, float *lxx, float *luu, float *lux)
+    {
+        const int n = e.n, m = e.m, d = n + m, ldn = odd_ld(n), ldm = odd_ld(m);
+        const float *F = e.p[0], *C = e.p[2], *c = e.p[3];
+        const int lane = lane_id();
+        for (int idx = lane; idx < n * d; idx += kWave) {
+            const int i = idx / d, j = idx - i * d;
+            if (j < n) fx[i * ldn + j] = F[idx]; else fu[i * ldm + (j - n)] = F[idx];
+        }
+        // gradient / Hessian of 1/2 z^T C z + c^T z use the symmetric part of C
+        for (int r = lane; r < d; r += kWave) {
+            float g = c[r];
+            for (int j = 0; j < d; ++j) {
+                const float zj = j < n ? x[j] : u[j - n];
+                g = fmaf(0.5f * (C[r * d + j] + C[j * d + r]), zj, g);
+            }
+            if (r < n) lx[r] = g; else lu[r - n] = g;
+        }
+        for (int idx = lane; idx < d * d; idx += kWave) {
+            const int r = idx / d, j = idx - r * d;
+            const float h = 0.5f * (C[r * d + j] + C[j * d + r]);
+            if (r < n && j < n) lxx[r * ldn + j] = h;
+            else if (r >= n && j >= n) luu[(r - n) * ldm + (j - n)] = h;
+            else if (r >= n) lux[(r - n) * ldn + j] = h;
+        }
+        return cost(e, x, u);
+    }
+    static __device__ float final_quad(const EnvLds &e, const float *x, float *lx, float *lxx)
+    {
+        const int n = e.n, d = n + e.m, ldn = odd_ld(n);
+        const float *C = e.p[2], *c = e.p[3];
+        for (int r = lane_id(); r < n; r += kWave) {
+            float g = c[r];
+            for (int j = 0; j < n; ++j) g = fmaf(0.5f * (C[r * d + j] + C[j * d + r]), x[j], g);
+            lx[r] = g;
+        }
+        for (int idx = lane_id(); idx < n * n; idx += kWave) {
+            const int r = idx / n, j = idx - r * n;
+            lxx[r * ldn + j] = 0.5f * (C[r * d + j] + C[j * d + r]);
+        }
+        return final_cost(e, x);
+    }
+};
+
+// ------------------------------------------------------------------- NAVLQR ---
+template <> struct Env<TFMPC_ENV_NAVLQR> {
+    static __device__ void transition(const EnvLds &e, const float *x, const float *u, float *xn)
+    {
+        for (int i = lane_id(); i < e.n; i += kWave) xn[i] = x[i] + u[i];            // :32
+    }
+    static __device__ float cost(const EnvLds &e, const float *x, const float *u)
+    {
+        const float *g = e.p[0];
+        float c1 = 0.0f, c2 = 0.0f;
+        for (int i = lane_id(); i < e.n; i += kWave) {
+            const float dx = x[i] - g[i];
+            c1 = fmaf(dx, dx, c1);
+            c2 = fmaf(u[i], u[i], c2);
+        }
+        return wave_sum(c1) + e.beta * wave_sum(c2);                                 // :39-41
+    }
+    static __device__ float final_cost(const EnvLds &e, const float *x)
+    {
+        const float *g = e.p[0];
+        float c1 = 0.0f;
+        for (int i = lane_id(); i < e.n; i += kWave) {
+            const float dx = x[i] - g[i];
+            c1 = fmaf(dx, dx, c1);
+        }
+        return wave_sum(c1);                                                          // :47
+    }
+    static __device__ float linearize(const EnvLds &e, const float *x, const float *u, float *fx, float *fu,
+                                      float *lx, float *lu, float *lxx, float *luu, float *lux)
+    {
+        const int n = e.n, ldn = odd_ld(n);
+        const float *g = e.p[0];
+        for (int idx = lane_id(); idx < n * n; idx += kWave) {
+            const int i = idx / n, j = idx - i * n;
+            const float id = (i == j) ? 1.0f : 0.0f;
+            fx[i * ldn + j] = id;
+            fu[i * ldn + j] = id;
+            lxx[i * ldn + j] = 2.0f * id;
+            luu[i * ldn + j] = 2.0f * e.beta * id;
+            lux[i * ldn + j] = 0.0f;
+        }
+        for (int i = lane_id(); i < n; i += kWave) {
+            lx[i] = 2.0f * (x[i] - g[i]);
+            lu[i] = 2.0f * e.beta * u[i];
+        }
+        return cost(e, x, u);
+    }
+    static __device__ float final_quad(const EnvLds &e, const float *x, float *lx, float *lxx)
+    {
+        const int n = e.n, ldn = odd_ld(n);
+        const float *g = e.p[0];
+        for (int idx = lane_id(); idx < n * n; idx += kWave) {
+            const int i = idx / n, j = idx - i * n;
+            lxx[i * ldn + j] = (i == j) ? 2.0f : 0.0f;
+        }
+        for (int i = lane_id(); i < n; i += kWave) lx[i] = 2.0f * (x[i] - g[i]);
+        return final_cost(e, x);
+    }
+};
+
+// --------------------------------------------------------------- NAVIGATION ---
+template <> struct Env<TFMPC_ENV_NAVIGATION> {
+    // lambda = prod_z (2 / (1 + exp(-decay_z |x - c_z|)) - 1); also d lambda / d x.   :61-74
+    static __device__ float deceleration(const EnvLds &e, const float *x, float *grad /* [n] regs or null */)
+    {
+        const int n = e.n, Z = e.zones;
+        const float *center = e.p[1], *decay = e.p[2];
+        float lam = 1.0f;
+        for (int z = 0; z < Z; ++z) {
+            float r2 = 0.0f;
+            for (int i = 0; i < n; ++i) { const float dlt = x[i] - center[z * n + i]; r2 = fmaf(dlt, dlt, r2); }
+            const float ex = expf(-decay[z] * sqrtf(r2));
+            lam *= 2.0f / (1.0f + ex) - 1.0f;
+        }
+        if (grad) {
+            for (int i = 0; i < n; ++i) grad[i] = 0.0f;
+            for (int z = 0; z < Z; ++z) {
+                float r2 = 0.0f;
+                for (int i = 0; i < n; ++i) { const float dlt = x[i] - center[z * n + i]; r2 = fmaf(dlt, dlt, r2); }
+                const float r = sqrtf(r2);
+                const float ex = expf(-decay[z] * r);
+                const float h = 2.0f * decay[z] * ex / ((1.0f + ex) * (1.0f + ex));
+                float others = 1.0f;
+                for (int y = 0; y < Z; ++y) {
+                    if (y == z) continue;
+                    float q2 = 0.0f;
+                    for (int i = 0; i < n; ++i) { const float dlt = x[i] - center[y * n + i]; q2 = fmaf(dlt, dlt, q2); }
+                    others *= 2.0f / (1.0f + expf(-decay[y] * sqrtf(q2))) - 1.0f;
+                }
+                for (int i = 0; i < n; ++i) grad[i] += h * (x[i] - center[z * n + i]) / r * others;
+            }
+        }
+        return lam;
+    }
+    static __device__ void transition(const EnvLds &e, const float *x, const float *u, float *xn)
+    {
+        const float lam = deceleration(e, x, nullptr);
+        for (int i = lane_id(); i < e.n; i += kWave) xn[i] = fmaf(lam, u[i], x[i]);     // :36-43
+    }
+    static __device__ float cost(const EnvLds &e, const float *x, const float *)
+    {
+        return Env<TFMPC_ENV_NAVLQR>::final_cost(e, x);                                  // :50-53
+    }
+    static __device__ float final_cost(const EnvLds &e, const float *x)
+    {
+        return Env<TFMPC_ENV_NAVLQR>::final_cost(e, x);                                  // :56-59
+    }
+    static __device__ float linearize(const EnvLds &e, const float *x, const float *u, float *fx, float *fu,
+                                      float *lx, float *lu, float *lxx, float *luu, float *lux)
+    {
+        const int n = e.n, ldn = odd_ld(n);
+        const float *g = e.p[0];
+        float grad[8];
+        const float lam = deceleration(e, x, grad);
+        for (int idx = lane_id(); idx < n * n; idx += kWave) {
+            const int i = idx / n, j = idx - i * n;
+            const float id = (i == j) ? 1.0f : 0.0f;
+            fx[i * ldn + j] = id + u[i] * grad[j];          // I + u grad(lambda)^T
+            fu[i * ldn + j] = lam * id;
+            lxx[i * ldn + j] = 2.0f * id;
+            luu[i * ldn + j] = 0.0f;
+            lux[i * ldn + j] = 0.0f;
+        }
+        for (int i = lane_id(); i < n; i += kWave) {
+            lx[i] = 2.0f * (x[i] - g[i]);
+            lu[i] = 0.0f;
+        }
+        return cost(e, x, u);
+    }
+    static __device__ float final_quad(const EnvLds &e, const float *x, float *lx, float *lxx)
+    {
+        return Env<TFMPC_ENV_NAVLQR>::final_quad(e, x, lx, lxx);
+    }
+};
+
+// --------------------------------------------------------------------- HVAC ---
+template <> struct Env<TFMPC_ENV_HVAC> {
+    static constexpr float CAP_AIR = 1.006f, COST_AIR = 1.0f, TEMP_AIR = 40.0f, TIME_DELTA = 1.0f;   // :10-13
+    static constexpr float PENALTY = 20000.0f, SET_POINT_PENALTY = 10.0f;                              // :14-15
+
+    static __device__ void transition(const EnvLds &e, const float *x, const float *u, float *xn)
+    {
+        const int n = e.n;
+        const float *t_out = e.p[0], *t_hall = e.p[1], *k_out = e.p[4], *k_hall = e.p[5], *cap = e.p[6],
+                    *air_max = e.p[7], *G = e.p[8];
+        for (int i = lane_id(); i < n; i += kWave) {
+            const float air = u[i] * air_max[i];                                          // :72
+            const float heating = air * CAP_AIR * (TEMP_AIR - x[i]);                      // :74
+            float between = 0.0f;                                                         // :131-139
+            for (int j = 0; j < n; ++j) between = fmaf(-G[i * n + j], x[i] - x[j], between);
+            const float outside = k_out[i] * (t_out[i] - x[i]);                           // :143-144
+            const float hall = k_hall[i] * (t_hall[i] - x[i]);                            // :148-149
+            xn[i] = x[i] + TIME_DELTA / cap[i] * (heating + between + outside + hall);    // :80-88
+        }
+    }
+    static __device__ float penalties(const EnvLds &e, const float *x, int i)
+    {
+        const float lo = e.p[2][i], hi = e.p[3][i];
+        const float oob = PENALTY * (fmaxf(0.0f, lo - x[i]) + fmaxf(0.0f, x[i] - hi));   // :97-100
+        const float sp = SET_POINT_PENALTY * fabsf((lo + hi) / 2 - x[i]);                 // :101-105
+        return oob + sp;
+    }
+    static __device__ float cost(const EnvLds &e, const float *x, const float *u)
+    {
+        float part = 0.0f;
+        for (int i = lane_id(); i < e.n; i += kWave) part += COST_AIR * (u[i] * e.p[7][i]) + penalties(e, x, i);
+        return wave_sum(part);                                                            // :107-110
+    }
+    static __device__ float final_cost(const EnvLds &e, const float *x)
+    {
+        float part = 0.0f;
+        for (int i = lane_id(); i < e.n; i += kWave) part += penalties(e, x, i);
+        return wave_sum(part);                                                            // :112-129
+    }
+    static __device__ void cost_grad_x(const EnvLds &e, const float *x, float *lx)
+    {
+        for (int i = lane_id(); i < e.n; i += kWave) {
+            const float lo = e.p[2][i], hi = e.p[3][i];
+            lx[i] = PENALTY * (-(lo > x[i] ? 1.0f : 0.0f) + (x[i] > hi ? 1.0f : 0.0f))
+                    - SET_POINT_PENALTY * signf((lo + hi) / 2 - x[i]);
+        }
+    }
+    static __device__ float linearize(const EnvLds &e, const float *x, const float *u, float *fx, float *fu,
+                                      float *lx, float *lu, float *lxx, float *luu, float *lux)
+    {
+        const int n = e.n, ldn = odd_ld(n);
+        const float *k_out = e.p[4], *k_hall = e.p[5], *cap = e.p[6], *air_max = e.p[7], *G = e.p[8];
+        for (int idx = lane_id(); idx < n * n; idx += kWave) {
+            const int i = idx / n, j = idx - i * n;
+            const float dtc = TIME_DELTA / cap[i];
+            float v = dtc * G[i * n + j];
+            float d = 0.0f;
+            if (i == j) {
+                float gsum = 0.0f;
+                for (int k = 0; k < n; ++k) gsum += G[i * n + k];
+                v = 1.0f + dtc * (G[i * n + i] - u[i] * air_max[i] * CAP_AIR - gsum - k_out[i] - k_hall[i]);
+                d = dtc * air_max[i] * CAP_AIR * (TEMP_AIR - x[i]);
+            }
+            fx[i * ldn + j] = v;
+            fu[i * ldn + j] = d;
+            lxx[i * ldn + j] = 0.0f;
+            luu[i * ldn + j] = 0.0f;
+            lux[i * ldn + j] = 0.0f;
+        }
+        cost_grad_x(e, x, lx);
+        for (int i = lane_id(); i < n; i += kWave) lu[i] = COST_AIR * air_max[i];
+        return cost(e, x, u);
+    }
+    static __device__ float final_quad(const EnvLds &e, const float *x, float *lx, float *lxx)
+    {
+        const int n = e.n, ldn = odd_ld(n);
+        for (int idx = lane_id(); idx < n * n; idx += kWave) lxx[(idx / n) * ldn + idx % n] = 0.0f;
+        cost_grad_x(e, x, lx);
+        return final_cost(e, x);
+    }
+};
+
+// ---------------------------------------------------------------- RESERVOIR ---
+template <> struct Env<TFMPC_ENV_RESERVOIR> {
+    static __device__ void transition(const EnvLds &e, const float *x, const float *u, float *xn)
+    {
+        const int n = e.n;
+        const float *cap = e.p[0], *rain = e.p[6], *D = e.p[7];
+        for (int i = lane_id(); i < n; i += kWave) {
+            float inflow = 0.0f;                                                          // :91  D^T (u*x)
+            for (int j = 0; j < n; ++j) inflow = fmaf(D[j * n + i], u[j] * x[j], inflow);
+            const float vaporated = 0.5f * sinf(x[i] / cap[i]) * x[i];                    // :87
+            xn[i] = x[i] + rain[i] + inflow - vaporated - u[i] * x[i];                    // :56-60
+        }
+    }
+    static __device__ float cost(const EnvLds &e, const float *x, const float *)
+    {
+        float part = 0.0f;
+        for (int i = lane_id(); i < e.n; i += kWave) {
+            const float lo = e.p[1][i], hi = e.p[2][i];
+            const float c1 = -e.p[3][i] * fmaxf(0.0f, lo - x[i]);                         // :70
+            const float c2 = -e.p[4][i] * fmaxf(0.0f, x[i] - hi);                         // :71
+            const float c3 = -e.p[5][i] * fabsf((lo + hi) / 2.0f - x[i]);                 // :72
+            part += c1 + c2 + c3;
+        }
+        return wave_sum(part);
+    }
+    static __device__ float final_cost(const EnvLds &e, const float *x) { return cost(e, x, nullptr); }   // :81-83
+    static __device__ void cost_grad_x(const EnvLds &e, const float *x, float *lx)
+    {
+        for (int i = lane_id(); i < e.n; i += kWave) {
+            const float lo = e.p[1][i], hi = e.p[2][i];
+            const float LP = -e.p[3][i], HP = -e.p[4][i], SP = -e.p[5][i];
+            lx[i] = -LP * (lo > x[i] ? 1.0f : 0.0f) + HP * (x[i] > hi ? 1.0f : 0.0f) - SP * signf((lo + hi) / 2.0f - x[i]);
+        }
+    }
+    static __device__ float linearize(const EnvLds &e, const float *x, const float *u, float *fx, float *fu,
+                                      float *lx, float *lu, float *lxx, float *luu, float *lux)
+    {
+        const int n = e.n, ldn = odd_ld(n);
+        const float *cap = e.p[0], *D = e.p[7];
+        for (int idx = lane_id(); idx < n * n; idx += kWave) {
+            const int i = idx / n, j = idx - i * n;
+            float a = D[j * n + i] * u[j];          // D^T diag(u)
+            float b = D[j * n + i] * x[j];          // D^T diag(x)
+            if (i == j) {
+                const float r = x[i] / cap[i];
+                a += 1.0f - 0.5f * (cosf(r) * r + sinf(r)) - u[i];
+                b -= x[i];
+            }
+            fx[i * ldn + j] = a;
+            fu[i * ldn + j] = b;
+            lxx[i * ldn + j] = 0.0f;
+            luu[i * ldn + j] = 0.0f;
+            lux[i * ldn + j] = 0.0f;
+        }
+        cost_grad_x(e, x, lx);
+        for (int i = lane_id(); i < n; i += kWave) lu[i] = 0.0f;
+        return cost(e, x, u);
+    }
+    static __device__ float final_quad(const EnvLds &e, const float *x, float *lx, float *lxx)
+    {
+        const int n = e.n, ldn = odd_ld(n);
+        for (int idx = lane_id(); idx < n * n; idx += kWave) lxx[(idx / n) * ldn + idx % n] = 0.0f;
+        cost_grad_x(e, x, lx);
+        return final_cost(e, x);
+    }
+};
+
+}  // namespace tfmpc

@@ -33,6 +33,39 @@ _SIGNATURES = {
 }
 
 
+ENV_LQ, ENV_NAVLQR, ENV_NAVIGATION, ENV_HVAC, ENV_RESERVOIR = range(5)
+ENV_MAX_PARAMS = 10
+MAX_ALPHAS = 16
+
+
+class TfmpcEnv(ctypes.Structure):
+    """``struct TfmpcEnv`` of include/tfmpc_hip.h."""
+    _fields_ = [("kind", ctypes.c_int32), ("n", ctypes.c_int32), ("m", ctypes.c_int32),
+                ("n_zones", ctypes.c_int32), ("bounded", ctypes.c_int32),
+                ("reserved0", ctypes.c_int32), ("reserved1", ctypes.c_int32), ("reserved2", ctypes.c_int32),
+                ("low", ctypes.c_void_p), ("high", ctypes.c_void_p),
+                ("p", ctypes.c_void_p * ENV_MAX_PARAMS), ("stride", ctypes.c_int64 * ENV_MAX_PARAMS),
+                ("scalar", ctypes.c_float * 4)]
+
+
+class TfmpcIlqrConfig(ctypes.Structure):
+    """``struct TfmpcIlqrConfig`` of include/tfmpc_hip.h."""
+    _fields_ = [("atol", ctypes.c_float), ("max_iterations", ctypes.c_int32), ("mu_min", ctypes.c_float),
+                ("delta_0", ctypes.c_float), ("c1", ctypes.c_float), ("n_alphas", ctypes.c_int32),
+                ("alphas", ctypes.c_float * MAX_ALPHAS), ("max_attempts", ctypes.c_int32)]
+
+
+_SIGNATURES.update({
+    "tfmpc_ilqr_rollout_f32": (_I, [_P, _I, _I, _P, _P, _P, _P, _P]),
+    "tfmpc_ilqr_derivatives_f32": (_I, [_P, _I, _I, _P, _P] + [_P] * 13 + [_P]),
+    "tfmpc_ilqr_backward_f32": (_I, [_I, _I, _I, _I] + [_P] * 12 + [_P, _P, _I, _P, _L] + [_P] * 6 + [_P]),
+    "tfmpc_ilqr_forward_f32": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P]),
+    "tfmpc_ilqr_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "tfmpc_ilqr_solve_f32": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "tfmpc_boxqp_f32": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+})
+
+
 def lib_path():
     return _LIB_PATH
 

@@ -1,0 +1,51 @@
+"""n-reservoir water network -- drop-in for the reference's
+``tfmpc/envs/reservoir/__init__.py:9-129`` (deterministic ``cec=True`` rainfall):
+``x' = x + rain + D^T (u x) - 1/2 sin(x / cap) x - u x``, piecewise-linear cost,
+actions in [0, 1]."""
+
+import numpy as np
+
+from tfmpc import _hip
+from tfmpc.envs.diffenv import Box, DiffEnv
+
+
+def _np(a):
+    return np.asarray(a.cpu() if hasattr(a, "cpu") else a, dtype=np.float32)
+
+
+class Reservoir(DiffEnv):
+    kind = _hip.ENV_RESERVOIR
+
+    def __init__(self, max_res_cap, lower_bound, upper_bound, low_penalty, high_penalty, set_point_penalty,
+                 downstream, rain_shape, rain_scale):
+        col = lambda a: _np(a).reshape(-1, 1)
+        self.max_res_cap = col(max_res_cap)
+        self.lower_bound, self.upper_bound = col(lower_bound), col(upper_bound)
+        self.low_penalty, self.high_penalty = col(low_penalty), col(high_penalty)
+        self.set_point_penalty = col(set_point_penalty)
+        self.downstream = _np(downstream)
+        self.rain_shape, self.rain_scale = col(rain_shape), col(rain_scale)
+        n = self.state_size
+        self.obs_space = Box(0.0, self.max_res_cap, (n, 1))
+        self.action_space = Box(0.0, 1.0, (n, 1))
+
+    @property
+    def state_size(self):
+        return len(self.lower_bound)
+
+    @property
+    def action_size(self):
+        return self.state_size
+
+    def _params(self):
+        rain = (self.rain_shape * self.rain_scale).astype(np.float32)          # reservoir/__init__.py:100
+        vec = lambda a: (a[:, 0], 1)
+        return [vec(self.max_res_cap), vec(self.lower_bound), vec(self.upper_bound), vec(self.low_penalty),
+                vec(self.high_penalty), vec(self.set_point_penalty), vec(rain), (self.downstream, 2)]
+
+    @classmethod
+    def load(cls, config):
+        return cls(**{k: np.asarray(v, dtype=np.float32) for k, v in config.items()})
+
+    def __repr__(self):
+        return f"Reservoir({self.state_size})"

@@ -1,0 +1,277 @@
+"""Control-limited iLQR (Tassa, Mansard, Todorov 2014) on MI355X -- drop-in for the
+reference's ``tfmpc/solvers/ilqr.py`` (``iLQR.__init__`` :24-43, ``start`` :53-82,
+``derivatives`` :84-92, ``backward`` :94-172, ``forward`` :174-212, ``solve`` :214-283).
+
+Same class, method and argument names, defaults and return arity as the reference.
+Additions: every tensor may carry one leading batch axis ``B`` of independent problem
+instances; ``start`` / ``solve`` take ``u_init`` / ``seed`` because the reference's
+initial actions come from TensorFlow's RNG (``ilqr.py:70``), which nothing else can
+reproduce.  All arithmetic runs in gfx950 HIP kernels through the C ABI
+(``include/tfmpc_hip.h``); ``solve`` is ONE kernel launch in which each wavefront runs
+its instance's whole iteration loop, so there is no per-iteration host round trip.
+
+Reference quirks kept on purpose: one scalar uniform per
+timestep in ``start`` (Q1); the regularisation bump after a Cholesky failure is local
+to the backward retry (Q2); ``residual < atol`` accepts a step the line search rejected
+(Q3); 11 step sizes (Q4); ``backward`` defaults to ``mu=1.0`` while ``solve`` starts at
+0 (Q5).  Deviation: the rejected-attempt loop is capped (``max_attempts``, status bit
+``ST_MAX_ATTEMPTS``) where the reference would loop forever.
+"""
+
+import ctypes
+import logging
+import os
+
+import numpy as np
+import torch
+
+from tfmpc import _hip
+from tfmpc.envs.diffenv import CostApprox, FinalCostApprox, TransitionApprox
+from tfmpc.utils import trajectory
+
+
+def _f32(a, device):
+    if isinstance(a, torch.Tensor):
+        return a.detach().to(device=device, dtype=torch.float32)
+    return torch.as_tensor(np.asarray(a, dtype=np.float32), device=device)
+
+
+class iLQR:
+
+    def __init__(self, env, **kwargs):
+        self.env = env
+
+        # solve
+        self.atol = kwargs.get("atol", 5e-3)
+        self.max_iterations = kwargs.get("max_iterations", 100)
+        # backward
+        self.mu_min = kwargs.get("mu_min", 1e-6)
+        self.delta_0 = kwargs.get("delta_0", 2.0)
+        # forward
+        self.c1 = kwargs.get("c1", 0.0)
+        self.alpha_min = kwargs.get("alpha_min", 1e-3)
+        # build-only: cap on rejected attempts per solve (the reference has none)
+        self.max_attempts = kwargs.get("max_attempts", 64)
+
+        self._config = kwargs
+        self.last_status = None
+        if "logdir" in self._config:
+            logging.basicConfig(filename=os.path.join(self._config["logdir"], "trace.log"), level=logging.DEBUG)
+
+    # -- bounds (ilqr.py:45-51) --------------------------------------------------------
+    @property
+    def device(self):
+        return self.env._device()
+
+    @property
+    def low(self):
+        return torch.as_tensor(self.env.action_space.low, device=self.device)
+
+    @property
+    def high(self):
+        return torch.as_tensor(self.env.action_space.high, device=self.device)
+
+    # -- helpers --------------------------------------------------------------------------
+    def _alphas(self):
+        return np.geomspace(1.0, self.alpha_min, 11)                       # ilqr.py:322
+
+    def _c_config(self):
+        cfg = _hip.TfmpcIlqrConfig()
+        cfg.atol, cfg.max_iterations = float(self.atol), int(self.max_iterations)
+        cfg.mu_min, cfg.delta_0, cfg.c1 = float(self.mu_min), float(self.delta_0), float(self.c1)
+        alphas = self._alphas()
+        cfg.n_alphas = len(alphas)
+        for i, a in enumerate(alphas):
+            cfg.alphas[i] = float(a)
+        cfg.max_attempts = int(self.max_attempts)
+        return cfg
+
+    def _batch_cols(self, a, size, lead):
+        """[.., size(,1)] with `lead` leading axes besides the optional batch axis ->
+        (contiguous tensor [B, *lead, size], batched?)"""
+        t = _f32(a, self.device)
+        if t.shape[-1] == 1 and t.dim() >= 2 and t.shape[-2] == size:
+            t = t.squeeze(-1)
+        if t.shape[-1] != size or t.dim() not in (lead + 1, lead + 2):
+            raise ValueError(f"bad shape {tuple(np.shape(a))} for a size-{size} vector with {lead} leading axes")
+        batched = t.dim() == lead + 2
+        return (t if batched else t.unsqueeze(0)).contiguous(), batched
+
+    def random_actions(self, T, batch_size=None, seed=None):
+        """``u_t = lo' + r_t (hi' - lo')`` with ONE scalar uniform per step and infinite
+        bounds replaced by -1 / +1 (``ilqr.py:59-70``).  Returns ``[(B,) T, m, 1]``."""
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(int(np.random.randint(0, 2 ** 31 - 1)) if seed is None else int(seed))
+        low, high = self.low.reshape(-1), self.high.reshape(-1)
+        lo = torch.where(torch.isinf(low), -torch.ones_like(low), low)
+        hi = torch.where(torch.isinf(high), torch.ones_like(high), high)
+        r = torch.rand((batch_size or 1, int(T), 1), generator=gen).to(self.device)
+        u = (lo + r * (hi - lo)).unsqueeze(-1)
+        return u if batch_size else u[0]
+
+    # -- ilqr.py:53-82 -----------------------------------------------------------------------
+    def start(self, x0, T, u_init=None, seed=None):
+        lib = _hip.require_gpu()
+        T = int(T)
+        n, m = self.env.state_size, self.env.action_size
+        x0, batched = self._batch_cols(x0, n, 0)
+        B = x0.shape[0]
+        if u_init is None:
+            u_init = self.random_actions(T, B if batched else None, seed)
+        u, ub = self._batch_cols(u_init, m, 1)
+        if ub and not batched:
+            x0, batched, B = x0.expand(u.shape[0], n).contiguous(), True, u.shape[0]
+        u = u.expand(B, T, m).contiguous()
+        env, keep = self.env.c_env()
+        states = torch.empty((B, T + 1, n), device=self.device)
+        costs = torch.empty((B, T + 1), device=self.device)
+        rc = lib.tfmpc_ilqr_rollout_f32(ctypes.byref(env), B, T, _hip.ptr(x0), _hip.ptr(u), _hip.ptr(states),
+                                        _hip.ptr(costs), _hip.stream())
+        _hip.check(rc, "tfmpc_ilqr_rollout_f32")
+        states, actions = states.unsqueeze(-1), u.unsqueeze(-1)
+        return (states, actions, costs) if batched else (states[0], actions[0], costs[0])
+
+    # -- ilqr.py:84-92 -----------------------------------------------------------------------
+    def derivatives(self, states, actions):
+        lib = _hip.require_gpu()
+        n, m = self.env.state_size, self.env.action_size
+        x, batched = self._batch_cols(states, n, 1)
+        u, _ = self._batch_cols(actions, m, 1)
+        B, T = x.shape[0], u.shape[1]
+        if x.shape[1] != T + 1:
+            raise ValueError("states must have one more step than actions")
+        dev = self.device
+        f, f_x, f_u = (torch.empty(s, device=dev) for s in ((B, T, n, 1), (B, T, n, n), (B, T, n, m)))
+        l, l_x, l_u = (torch.empty(s, device=dev) for s in ((B, T), (B, T, n, 1), (B, T, m, 1)))
+        l_xx, l_uu, l_ux, l_xu = (torch.empty(s, device=dev) for s in ((B, T, n, n), (B, T, m, m), (B, T, m, n), (B, T, n, m)))
+        fl, fl_x, fl_xx = (torch.empty(s, device=dev) for s in ((B,), (B, n, 1), (B, n, n)))
+        env, keep = self.env.c_env()
+        outs = (f, f_x, f_u, l, l_x, l_u, l_xx, l_uu, l_ux, l_xu, fl, fl_x, fl_xx)
+        rc = lib.tfmpc_ilqr_derivatives_f32(ctypes.byref(env), B, T, _hip.ptr(x), _hip.ptr(u),
+                                            *[_hip.ptr(o) for o in outs], _hip.stream())
+        _hip.check(rc, "tfmpc_ilqr_derivatives_f32")
+        if not batched:
+            outs = tuple(o[0] for o in outs)
+        return TransitionApprox(*outs[:3]), CostApprox(*outs[3:10]), FinalCostApprox(*outs[10:])
+
+    # -- ilqr.py:94-172 ----------------------------------------------------------------------
+    def backward(self, T, actions, transition_model, cost_model, final_cost_model, mu=1.0):
+        lib = _hip.require_gpu()
+        T = int(T)
+        n, m = self.env.state_size, self.env.action_size
+        dev = self.device
+        u, batched = self._batch_cols(actions, m, 1)
+        B = u.shape[0]
+
+        def mat(a, r, c_):      # [(B,) T, r, c] -> contiguous [B, T, r, c]
+            t = _f32(a, dev)
+            return (t if t.dim() == 4 else t.unsqueeze(0)).reshape(B, T, r, c_).contiguous()
+
+        f_x, f_u = mat(transition_model.f_x, n, n), mat(transition_model.f_u, n, m)
+        l = _f32(cost_model.l, dev).reshape(B, T).contiguous()
+        l_x, l_u = mat(cost_model.l_x, n, 1), mat(cost_model.l_u, m, 1)
+        l_xx, l_uu, l_xu = mat(cost_model.l_xx, n, n), mat(cost_model.l_uu, m, m), mat(cost_model.l_xu, n, m)
+        fl = _f32(final_cost_model.l, dev).reshape(B).contiguous()
+        fl_x = _f32(final_cost_model.l_x, dev).reshape(B, n).contiguous()
+        fl_xx = _f32(final_cost_model.l_xx, dev).reshape(B, n, n).contiguous()
+        mu_t = _f32(mu, dev).reshape(-1).contiguous()
+        if mu_t.numel() not in (1, B):
+            raise ValueError("mu must be a scalar or one value per instance")
+        K = torch.empty((B, T, m, n), device=dev)
+        k = torch.empty((B, T, m, 1), device=dev)
+        J, dV1, dV2 = (torch.empty((B,), device=dev) for _ in range(3))
+        status = torch.zeros((B,), dtype=torch.int32, device=dev)
+        low, high = self.low.reshape(-1).contiguous(), self.high.reshape(-1).contiguous()
+        rc = lib.tfmpc_ilqr_backward_f32(B, n, m, T, _hip.ptr(u), _hip.ptr(f_x), _hip.ptr(f_u), _hip.ptr(l),
+                                         _hip.ptr(l_x), _hip.ptr(l_u), _hip.ptr(l_xx), _hip.ptr(l_uu), _hip.ptr(l_xu),
+                                         _hip.ptr(fl), _hip.ptr(fl_x), _hip.ptr(fl_xx), _hip.ptr(low), _hip.ptr(high),
+                                         int(self.env.action_space.is_bounded()), _hip.ptr(mu_t),
+                                         1 if mu_t.numel() == B and B > 1 else 0,
+                                         _hip.ptr(K), _hip.ptr(k), _hip.ptr(J), _hip.ptr(dV1), _hip.ptr(dV2),
+                                         _hip.ptr(status), _hip.stream())
+        _hip.check(rc, "tfmpc_ilqr_backward_f32")
+        self.last_status = status
+        if not batched:
+            if int(status[0]) & _hip.ST_NOT_PD:     # the reference raises tf.errors.InvalidArgumentError here
+                raise ArithmeticError("iLQR.backward: Q_uu (regularised) is not positive definite")
+            return K[0], k[0], J[0], dV1[0], dV2[0]
+        return K, k, J, dV1, dV2
+
+    # -- ilqr.py:174-212 ---------------------------------------------------------------------
+    def forward(self, x, u, K, k, alpha=1.0):
+        lib = _hip.require_gpu()
+        n, m = self.env.state_size, self.env.action_size
+        dev = self.device
+        xs, batched = self._batch_cols(x, n, 1)
+        us, _ = self._batch_cols(u, m, 1)
+        B, T = xs.shape[0], us.shape[1]
+        Kt = _f32(K, dev)
+        Kt = (Kt if Kt.dim() == 4 else Kt.unsqueeze(0)).expand(B, T, m, n).contiguous()
+        kt, _ = self._batch_cols(k, m, 1)
+        kt = kt.expand(B, T, m).contiguous()
+        al = _f32(alpha, dev).reshape(-1).contiguous()
+        if al.numel() not in (1, B):
+            raise ValueError("alpha must be a scalar or one value per instance")
+        states = torch.empty((B, T + 1, n), device=dev)
+        actions = torch.empty((B, T, m), device=dev)
+        costs = torch.empty((B, T + 1), device=dev)
+        J, residual = torch.empty((B,), device=dev), torch.empty((B,), device=dev)
+        env, keep = self.env.c_env()
+        rc = lib.tfmpc_ilqr_forward_f32(ctypes.byref(env), B, T, _hip.ptr(xs), _hip.ptr(us), _hip.ptr(Kt), _hip.ptr(kt),
+                                        _hip.ptr(al), 1 if al.numel() == B and B > 1 else 0, _hip.ptr(states),
+                                        _hip.ptr(actions), _hip.ptr(costs), _hip.ptr(J), _hip.ptr(residual), _hip.stream())
+        _hip.check(rc, "tfmpc_ilqr_forward_f32")
+        states, actions = states.unsqueeze(-1), actions.unsqueeze(-1)
+        if not batched:
+            return states[0], actions[0], costs[0], J[0], residual[0]
+        return states, actions, costs, J, residual
+
+    # -- fused solve, device tensors in/out -----------------------------------------------------
+    def solve_device(self, x0, T, u_init=None, seed=None, workspace=None):
+        """ONE kernel launch for B whole iLQR solves.  Returns a dict of device tensors:
+        ``states[B,T+1,n,1]``, ``actions[B,T,m,1]``, ``costs[B,T+1]``, ``iterations[B]``
+        (the reference's returned loop index) and ``status[B]``.  Never synchronises."""
+        lib = _hip.require_gpu()
+        T = int(T)
+        n, m = self.env.state_size, self.env.action_size
+        dev = self.device
+        x0, batched = self._batch_cols(x0, n, 0)
+        B = x0.shape[0]
+        if u_init is None:
+            u_init = self.random_actions(T, B if batched else None, seed)
+        u, ub = self._batch_cols(u_init, m, 1)
+        if ub and not batched:
+            x0, batched, B = x0.expand(u.shape[0], n).contiguous(), True, u.shape[0]
+        eb = self.env.env_batch_size()
+        if eb is not None:
+            if batched and eb != B:
+                raise ValueError("x0 batch does not match the env's per-instance parameters")
+            if not batched:
+                x0, batched, B = x0.expand(eb, n).contiguous(), True, eb
+        u = u.expand(B, T, m).contiguous()
+        states = torch.empty((B, T + 1, n), device=dev)
+        actions = torch.empty((B, T, m), device=dev)
+        costs = torch.empty((B, T + 1), device=dev)
+        iterations = torch.zeros((B,), dtype=torch.int32, device=dev)
+        status = torch.zeros((B,), dtype=torch.int32, device=dev)
+        ws_bytes = int(lib.tfmpc_ilqr_workspace_bytes(B, n, m, T))
+        if workspace is None or workspace.numel() * workspace.element_size() < ws_bytes:
+            workspace = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+        env, keep = self.env.c_env()
+        cfg = self._c_config()
+        rc = lib.tfmpc_ilqr_solve_f32(ctypes.byref(env), ctypes.byref(cfg), B, T, _hip.ptr(x0), _hip.ptr(u),
+                                      _hip.ptr(states), _hip.ptr(actions), _hip.ptr(costs), _hip.ptr(iterations),
+                                      _hip.ptr(status), _hip.ptr(workspace),
+                                      workspace.numel() * workspace.element_size(), _hip.stream())
+        _hip.check(rc, "tfmpc_ilqr_solve_f32")
+        self.last_status = status
+        return dict(states=states.unsqueeze(-1), actions=actions.unsqueeze(-1), costs=costs, iterations=iterations,
+                    status=status, batched=batched, workspace=workspace)
+
+    # -- ilqr.py:214-283 ---------------------------------------------------------------------
+    def solve(self, x0, T, show_progress=True, u_init=None, seed=None):
+        out = self.solve_device(x0, T, u_init=u_init, seed=seed)
+        if out["batched"]:
+            return trajectory.Trajectory(out["states"], out["actions"], out["costs"]), out["iterations"].cpu().numpy()
+        traj = trajectory.Trajectory(out["states"][0], out["actions"][0], out["costs"][0])
+        return traj, int(out["iterations"][0])
