@@ -1,8 +1,347 @@
-// lqr_mfma16x8.hip -- placeholder until the MFMA variant lands: reports
-// "unsupported" so the dispatcher uses the generic wave kernel.
+// lqr_mfma16x8.hip -- LQR backward + forward for the BASELINE.json headline shape
+// (state_dim n = 16, action_dim m = 8, any horizon) on gfx950 matrix cores.
+//
+// Replaces tfmpc/solvers/lqr.py:59-166 of the reference for that shape.  One
+// wavefront owns one problem instance for the whole solve.
+//
+// Backward sweep (lqr.py:73-127), per timestep, all in registers:
+//   F~ = [F_x | F_u f 0] (16 x 32) and C~ = [[C, c],[.,0]] (32 x 32, padded) are loaded
+//   once in MFMA operand layout and stay resident for all T steps.
+//   1. W  = V F~            8 x v_mfma_f32_16x16x4_f32   (column 24 of W is V f; += v)
+//   2. Q~ = C~ + F~^T W    16 x mfma                      (Q_xx | Q_xu q_x ; Q_ux | Q_uu q_u)
+//      The accumulator layout of a 16x16x4 MFMA (lane (j, q) holds rows 4q..4q+3 of
+//      column j) IS the B-operand layout of the next MFMA if the contraction index is
+//      enumerated as k = 4q + r (r = k-step): W feeds step 2 and V feeds step 1 with no
+//      data movement, and one register set of F~ serves as B operand in 1 and as
+//      A operand (F~^T) in 2.
+//   3. [Q_uu | q_u | Q_ux] (8 x 25) goes through LDS into "one column per lane, eight
+//      rows in registers" and is eliminated by Gauss-Jordan with v_readlane broadcasts
+//      (general inverse of lqr.py:84-87; Q_uu is SPD, no pivoting) -> K, k.
+//   4. V' = Q_xx + Q_xu K, v' = q_x + Q_xu k   8 x mfma (the Schur-complement form of
+//      lqr.py:97-105, equal to its four-term form in exact arithmetic).
+//   K_t, k_t stream to HBM (row-major, the public K/k layout) for the rollout.
+// Forward rollout (lqr.py:141-155): wave-wide fp32 FMA mat-vecs with F and C rows
+//   resident in registers, x/u exchanged through 96 bytes of LDS, K_t prefetched.
+//
+// fp32 MFMA is an exact fp32 fma chain (MI355X_MICROARCH.md), so numerics are those
+// of fp32 VALU code with a different summation order.
+#include <hip/hip_runtime.h>
+
 #include "lqr_kernels.h"
+#include "wave_ops.h"
 
 namespace tfmpc {
-bool lqr_mfma_supported(int, int) { return false; }
-int lqr_mfma_launch(const LqrArgs &, bool, bool, hipStream_t) { return TFMPC_ERR_UNSUPPORTED; }
+
+namespace {
+
+constexpr int N = 16, M = 8, D = 24;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float readlane(float v, int lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// per-wave LDS slice (floats)
+constexpr int kMs = 0;          // [32 cols][8 rows]  elimination input, column-major
+constexpr int kKs = 256;        // [32 cols][8 rows]  K~ = -Q_uu^-1 [Q_ux | . | q_u], column-major
+constexpr int kZs = 512;        // z = [x(16); u(8)]
+constexpr int kQx = 544;        // q_x staging (16)
+constexpr int kLdsFloats = 560;
+
+template <bool BACKWARD, bool FORWARD, bool VALUE>
+__global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int i = lane & 15, q = lane >> 4;
+    const int T = a.T;
+    const float *Fg = a.F + (size_t)b * a.sF;
+    const float *fg = a.f + (size_t)b * a.sf;
+    const float *Cg = a.C + (size_t)b * a.sC;
+    const float *cg = a.c + (size_t)b * a.sc;
+    float *Kg = a.K + (size_t)b * a.sK;
+    float *kg = a.k + (size_t)b * a.sk;
+    int status = 0;
+
+    if (BACKWARD) {
+        // ---- resident operands ------------------------------------------------------
+        float Fb0[4], Fb1[4];            // F~_c[4q+r][i]
+        f32x4 Cd00, Cd01t, Cd10, Cd11;   // C~[16a+4q+r][16c+i]; Cd01t = (C~ tile (0,1))^T
+        f32x4 vterm;                     // c_x in lanes i == 8 (terminal v)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * q + r;
+            Fb0[r] = Fg[k * D + i];
+            Fb1[r] = (i < M) ? Fg[k * D + N + i] : ((i == M) ? fg[k] : 0.0f);
+            Cd00[r] = Cg[k * D + i];
+            Cd01t[r] = (k < M) ? Cg[i * D + N + k] : ((k == M) ? cg[i] : 0.0f);      // C~[i][16+k]
+            vterm[r] = (i == M) ? cg[k] : 0.0f;
+            const int ku = N + k;        // rows 16..31; only 16..23 exist
+            Cd10[r] = (ku < D) ? Cg[ku * D + i] : 0.0f;
+            Cd11[r] = (ku < D) ? ((i < M) ? Cg[ku * D + N + i] : ((i == M) ? cg[ku] : 0.0f)) : 0.0f;
+        }
+        // terminal value function V = C_xx, v = c_x (lqr.py:67-68): v lives in lanes i == 8
+        f32x4 Vd = Cd00, vd = vterm;
+        float cst = 0.0f;
+        for (int idx = lane; idx < 512; idx += kWave) lds[idx] = 0.0f;   // pad columns stay 0
+        __syncthreads();
+
+        for (int t = T - 1; t >= 0; --t) {
+            // 1. W = V F~ (+ v on column 24)                                  lqr.py:74,77-78
+            f32x4 W0 = {0.f, 0.f, 0.f, 0.f}, W1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                W0 = mfma(Vd[r], Fb0[r], W0);
+                W1 = mfma(Vd[r], Fb1[r], W1);
+            }
+            float fw = 0.0f, fv = 0.0f;
+            if (VALUE) {     // f^T (V f) and f^T v for the const recursion (lqr.py:120)
+                float pw = 0.0f, pv = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pw = fmaf(Fb1[r], W1[r], pw);
+                    pv = fmaf(Fb1[r], vd[r], pv);
+                }
+                fw = wave_sum(i == M ? pw : 0.0f);
+                fv = wave_sum(i == M ? pv : 0.0f);
+            }
+            if (i == M) W1 += vd;
+            // 2. Q~ = C~ + F~^T W                                              lqr.py:75-78
+            // Tile (0,1) is produced TRANSPOSED (operand roles swapped: W_1^T F~_0), which puts
+            // the true Q_xu[i][4q+r] straight into A-operand layout for step 4 and q_x[j] in
+            // lanes q == 2.  Using Q_ux^T in its place would be cheaper still but is unstable:
+            // V is symmetric only up to rounding, and the antisymmetric part must propagate
+            // through the CLOSED loop (Q_xx + Q_xu K == [I;K]^T Q [I;K]), not the open one.
+            f32x4 T00 = Cd00, T01t = Cd01t, T10 = Cd10, T11 = Cd11;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                T00 = mfma(Fb0[r], W0[r], T00);
+                T01t = mfma(W1[r], Fb0[r], T01t);
+                T10 = mfma(Fb1[r], W0[r], T10);
+                T11 = mfma(Fb1[r], W1[r], T11);
+            }
+            if (q == 2) lds[kQx + i] = T01t[0];          // q_x[i] = Q~[i][24]
+            // 3. [Q_ux | Q_uu | q_u] -> column-per-lane layout through LDS
+            if (q < 2) {
+                *reinterpret_cast<f32x4 *>(&lds[kMs + i * 8 + 4 * q]) = T10;
+                if (i <= M) *reinterpret_cast<f32x4 *>(&lds[kMs + (N + i) * 8 + 4 * q]) = T11;
+            }
+            __syncthreads();
+            float Mr[8];
+            {
+                const int c = lane & 31;
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(&lds[kMs + c * 8]);
+                const f32x4 hi = *reinterpret_cast<const f32x4 *>(&lds[kMs + c * 8 + 4]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { Mr[r] = lo[r]; Mr[4 + r] = hi[r]; }
+            }
+            float quk = 0.0f;     // k^T q_u (for const), accumulated from the pivots' view below
+            float qu_saved[8];
+            if (VALUE) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) qu_saved[p] = readlane(Mr[p], 24);
+            }
+            // Gauss-Jordan on rows 0..7; column 16+p of row a holds Q_uu[a][p]   lqr.py:84-87
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const float pv = readlane(Mr[p], N + p);
+                // no pivoting: relies on Q_uu being positive definite (C >= 0, C_uu > 0)
+                if (!(pv > 0.0f)) status |= (pv == 0.0f) ? TFMPC_ST_SINGULAR : TFMPC_ST_NOT_PD;
+                const float inv = 1.0f / pv;
+                Mr[p] *= inv;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (r == p) continue;
+                    const float fct = readlane(Mr[r], N + p);
+                    Mr[r] = fmaf(-fct, Mr[p], Mr[r]);
+                }
+            }
+            if (VALUE) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) quk = fmaf(-readlane(Mr[p], 24), qu_saved[p], quk);   // k^T q_u
+            }
+            // K~ = -M: columns 0..15 = K, column 24 = k
+            if (lane < 32) {
+                f32x4 lo, hi;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { lo[r] = -Mr[r]; hi[r] = -Mr[4 + r]; }
+                *reinterpret_cast<f32x4 *>(&lds[kKs + lane * 8]) = lo;
+                *reinterpret_cast<f32x4 *>(&lds[kKs + lane * 8 + 4]) = hi;
+            }
+            __syncthreads();
+            // 4. V' = Q_xx + Q_xu K ; v' = q_x + Q_xu k (column 24)            lqr.py:97-105
+            f32x4 G0 = {0.f, 0.f, 0.f, 0.f}, G1 = {0.f, 0.f, 0.f, 0.f}, Ax = {0.f, 0.f, 0.f, 0.f};
+            f32x4 T01 = {0.f, 0.f, 0.f, 0.f};             // accumulates v' in column 24 (lanes i == 8)
+            if (q < 2) {
+                G0 = *reinterpret_cast<const f32x4 *>(&lds[kKs + i * 8 + 4 * q]);
+                G1 = *reinterpret_cast<const f32x4 *>(&lds[kKs + (N + i) * 8 + 4 * q]);
+                Ax = T01t;                     // Q_xu[i][4q+r]
+            }
+            if (i == M) T01 = *reinterpret_cast<const f32x4 *>(&lds[kQx + 4 * q]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                T00 = mfma(Ax[r], G0[r], T00);
+                T01 = mfma(Ax[r], G1[r], T01);
+            }
+            Vd = T00;
+            vd = T01;
+            // gains to HBM, row-major K[t][a][j], k[t][a] (the public layout)
+            {
+                const int ka = lane >> 3, jc = lane & 7;
+                float2 kv;
+                kv.x = lds[kKs + (2 * jc) * 8 + ka];
+                kv.y = lds[kKs + (2 * jc + 1) * 8 + ka];
+                *reinterpret_cast<float2 *>(&Kg[(size_t)t * (M * N) + 2 * lane]) = kv;
+                if (lane < M) kg[(size_t)t * M + lane] = lds[kKs + 24 * 8 + lane];
+            }
+            if (VALUE) {
+                // const += 1/2 k^T Q_uu k + k^T q_u + 1/2 f^T V f + f^T v with Q_uu k = -q_u
+                // (lqr.py:113-121); f^T(V f + v) was taken before v entered W.
+                cst += 0.5f * quk + 0.5f * fw + fv;
+                if (a.V) {
+                    float *Vo = a.V + ((size_t)b * T + t) * (N * N);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Vo[(4 * q + r) * N + i] = Vd[r];
+                }
+                if (a.v && i == M) {
+                    float *vo = a.v + ((size_t)b * T + t) * N;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vo[4 * q + r] = vd[r];
+                }
+                if (a.cst && lane == 0) a.cst[(size_t)b * T + t] = cst;
+            }
+            __syncthreads();
+        }
+        if (VALUE && !(cst == cst)) status |= TFMPC_ST_NAN;
+    }
+
+    if (FORWARD) {
+        // ---- resident rows of F and C for the mat-vecs --------------------------------
+        const int fi = lane >> 2, fc = lane & 3;       // F: row fi, columns 6fc..6fc+5
+        const int cr = lane >> 1, ch = lane & 1;       // C: row cr (24 used), columns 12ch..12ch+11
+        float Fr[6], Cr[12];
+        {
+            const float2 *p = reinterpret_cast<const float2 *>(Fg + fi * D + 6 * fc);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { const float2 v = p[j]; Fr[2 * j] = v.x; Fr[2 * j + 1] = v.y; }
+        }
+        const float f_i = fg[fi];
+        const bool crow = cr < D;
+        {
+            const float4 *p = reinterpret_cast<const float4 *>(Cg + (crow ? cr : 0) * D + 12 * ch);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float4 v = p[j];
+                Cr[4 * j] = v.x; Cr[4 * j + 1] = v.y; Cr[4 * j + 2] = v.z; Cr[4 * j + 3] = v.w;
+            }
+        }
+        const float c_r = crow ? cg[cr] : 0.0f;
+        float *xs = a.states + (size_t)b * (T + 1) * N;
+        float *us = a.actions + (size_t)b * T * M;
+        float *cs = a.costs + (size_t)b * (T + 1);
+        const int ka = lane >> 3, jc = lane & 7;       // K: row ka, columns 2jc, 2jc+1
+        float *zs = &lds[kZs];
+        __syncthreads();                               // gains written above are visible
+        if (lane < N) {
+            const float x = a.x0[(size_t)b * N + lane];
+            zs[lane] = x;
+            xs[lane] = x;
+        }
+        float2 Kn = {0.f, 0.f};
+        float kn = 0.0f;
+        if (T > 0) {
+            Kn = *reinterpret_cast<const float2 *>(&Kg[2 * lane]);
+            kn = kg[ka];
+        }
+        __syncthreads();
+
+        // cost of the z currently in LDS: 1/2 z^T C z + c^T z            lqr.py:41-47
+        auto stage_cost = [&]() {
+            float s = 0.0f;
+            const f32x4 *zp = reinterpret_cast<const f32x4 *>(&zs[12 * ch]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const f32x4 z4 = zp[j];
+                s = fmaf(Cr[4 * j], z4[0], s); s = fmaf(Cr[4 * j + 1], z4[1], s);
+                s = fmaf(Cr[4 * j + 2], z4[2], s); s = fmaf(Cr[4 * j + 3], z4[3], s);
+            }
+            s += __shfl_xor(s, 1, kWave);
+            const float zr = crow ? zs[cr] : 0.0f;
+            const float part = (ch == 0) ? zr * fmaf(0.5f, s, c_r) : 0.0f;
+            return wave_sum(part);
+        };
+
+        for (int t = 0; t < T; ++t) {
+            const float2 Kc = Kn;
+            const float kc = kn;
+            if (t + 1 < T) {                           // prefetch the next step's gains
+                Kn = *reinterpret_cast<const float2 *>(&Kg[(size_t)(t + 1) * (M * N) + 2 * lane]);
+                kn = kg[(size_t)(t + 1) * M + ka];
+            }
+            // u = K x + k                                                  lqr.py:143
+            const float2 xv = *reinterpret_cast<const float2 *>(&zs[2 * jc]);
+            float u = fmaf(Kc.x, xv.x, Kc.y * xv.y);
+            u += __shfl_xor(u, 1, kWave);
+            u += __shfl_xor(u, 2, kWave);
+            u += __shfl_xor(u, 4, kWave);
+            u += kc;
+            if (jc == 0) { zs[N + ka] = u; us[(size_t)t * M + ka] = u; }
+            __syncthreads();
+            // x' = F z + f                                                  lqr.py:36-39
+            float xn = 0.0f;
+            {
+                const float2 *zp = reinterpret_cast<const float2 *>(&zs[6 * fc]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float2 z2 = zp[j];
+                    xn = fmaf(Fr[2 * j], z2.x, xn);
+                    xn = fmaf(Fr[2 * j + 1], z2.y, xn);
+                }
+            }
+            xn += __shfl_xor(xn, 1, kWave);
+            xn += __shfl_xor(xn, 2, kWave);
+            xn += f_i;
+            const float cost = stage_cost();
+            if (lane == 0) cs[t] = cost;
+            __syncthreads();
+            if (fc == 0) { zs[fi] = xn; xs[(size_t)(t + 1) * N + fi] = xn; }
+            __syncthreads();
+        }
+        // final cost 1/2 x^T C_xx x + c_x^T x  == stage cost with u = 0     lqr.py:49-57
+        if (lane < M) zs[N + lane] = 0.0f;
+        __syncthreads();
+        const float fcost = stage_cost();
+        if (lane == 0) cs[T] = fcost;
+        if (!(fcost == fcost)) status |= TFMPC_ST_NAN;
+    }
+
+    if (a.status && lane == 0) a.status[b] = status;
+}
+
+template <bool BW, bool FW, bool VAL>
+int launch(const LqrArgs &a, hipStream_t stream)
+{
+    hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL>), dim3(a.B), dim3(kWave), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
+}
+
+}  // namespace
+
+bool lqr_mfma_supported(int n, int m) { return n == N && m == M; }
+
+int lqr_mfma_launch(const LqrArgs &a, bool backward, bool forward, hipStream_t stream)
+{
+    const bool value = a.V || a.v || a.cst;
+    if (backward && forward) return value ? launch<true, true, true>(a, stream) : launch<true, true, false>(a, stream);
+    if (backward) return value ? launch<true, false, true>(a, stream) : launch<true, false, false>(a, stream);
+    return launch<false, true, false>(a, stream);
+}
+
 }  // namespace tfmpc
