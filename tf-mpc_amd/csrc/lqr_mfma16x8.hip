@@ -50,9 +50,22 @@ __device__ __forceinline__ float readlane(float v, int lane)
 // per-wave LDS slice (floats)
 constexpr int kMs = 0;          // [32 cols][8 rows]  elimination input, column-major
 constexpr int kKs = 256;        // [32 cols][8 rows]  K~ = -Q_uu^-1 [Q_ux | . | q_u], column-major
-constexpr int kZs = 512;        // z = [x(16); u(8)]
-constexpr int kQx = 544;        // q_x staging (16)
-constexpr int kLdsFloats = 560;
+constexpr int kXs = 512;        // [16 rows][8]       Q_xu, row-major (A operand of the V update)
+constexpr int kQx = 640;        // q_x staging (16)
+constexpr int kZs = 656;        // rollout chunk: rows z_t = [x_t(16); u_t(8)], stride kZld
+constexpr int kZld = 26;        // even (8-byte aligned rows), 26 n mod 32 distinct for n < 16
+constexpr int kTC = 52;         // timesteps per rollout chunk (T = 50 fits one chunk)
+constexpr int kLdsFloats = kZs + (kTC + 1) * kZld + 6;
+
+// DPP lane exchanges inside a row of 16 lanes (no LDS traffic, folded into the VALU op)
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141; // lane i <-> 7 - i inside each 8-lane half row
 
 template <bool BACKWARD, bool FORWARD, bool VALUE>
 __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
@@ -90,7 +103,8 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
         // terminal value function V = C_xx, v = c_x (lqr.py:67-68): v lives in lanes i == 8
         f32x4 Vd = Cd00, vd = vterm;
         float cst = 0.0f;
-        for (int idx = lane; idx < 512; idx += kWave) lds[idx] = 0.0f;   // pad columns stay 0
+        float min_pivot = 1.0f;
+        for (int idx = lane; idx < kZs; idx += kWave) lds[idx] = 0.0f;   // pad columns stay 0
         __syncthreads();
 
         for (int t = T - 1; t >= 0; --t) {
@@ -115,10 +129,10 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
             if (i == M) W1 += vd;
             // 2. Q~ = C~ + F~^T W                                              lqr.py:75-78
             // Tile (0,1) is produced TRANSPOSED (operand roles swapped: W_1^T F~_0), which puts
-            // the true Q_xu[i][4q+r] straight into A-operand layout for step 4 and q_x[j] in
-            // lanes q == 2.  Using Q_ux^T in its place would be cheaper still but is unstable:
-            // V is symmetric only up to rounding, and the antisymmetric part must propagate
-            // through the CLOSED loop (Q_xx + Q_xu K == [I;K]^T Q [I;K]), not the open one.
+            // the true Q_xu[i][4q+r] in lanes (i, q < 2) and q_x[j] in lanes q == 2.  Using
+            // Q_ux^T in its place would be cheaper still but is unstable: V is symmetric only up
+            // to rounding, and the antisymmetric part must propagate through the CLOSED loop
+            // (Q_xx + Q_xu K == [I;K]^T Q [I;K]), not the open one.
             f32x4 T00 = Cd00, T01t = Cd01t, T10 = Cd10, T11 = Cd11;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -127,11 +141,13 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
                 T10 = mfma(Fb1[r], W0[r], T10);
                 T11 = mfma(Fb1[r], W1[r], T11);
             }
-            if (q == 2) lds[kQx + i] = T01t[0];          // q_x[i] = Q~[i][24]
-            // 3. [Q_ux | Q_uu | q_u] -> column-per-lane layout through LDS
+            // 3. [Q_ux | Q_uu | q_u] -> column-per-lane layout through LDS; Q_xu and q_x staged
             if (q < 2) {
                 *reinterpret_cast<f32x4 *>(&lds[kMs + i * 8 + 4 * q]) = T10;
                 if (i <= M) *reinterpret_cast<f32x4 *>(&lds[kMs + (N + i) * 8 + 4 * q]) = T11;
+                *reinterpret_cast<f32x4 *>(&lds[kXs + i * 8 + 4 * q]) = T01t;
+            } else if (q == 2) {
+                lds[kQx + i] = T01t[0];                  // q_x[i] = Q~[i][24]
             }
             __syncthreads();
             float Mr[8];
@@ -142,19 +158,20 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { Mr[r] = lo[r]; Mr[4 + r] = hi[r]; }
             }
-            float quk = 0.0f;     // k^T q_u (for const), accumulated from the pivots' view below
+            float quk = 0.0f;
             float qu_saved[8];
             if (VALUE) {
 #pragma unroll
                 for (int p = 0; p < 8; ++p) qu_saved[p] = readlane(Mr[p], 24);
             }
             // Gauss-Jordan on rows 0..7; column 16+p of row a holds Q_uu[a][p]   lqr.py:84-87
+            // No pivoting: Q_uu is positive definite whenever C >= 0 and C_uu > 0 (checked below).
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const float pv = readlane(Mr[p], N + p);
-                // no pivoting: relies on Q_uu being positive definite (C >= 0, C_uu > 0)
-                if (!(pv > 0.0f)) status |= (pv == 0.0f) ? TFMPC_ST_SINGULAR : TFMPC_ST_NOT_PD;
-                const float inv = 1.0f / pv;
+                min_pivot = fminf(min_pivot, pv);
+                float inv = __builtin_amdgcn_rcpf(pv);
+                inv = fmaf(fmaf(-pv, inv, 1.0f), inv, inv);       // one Newton step: < 1 ulp
                 Mr[p] *= inv;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
@@ -177,18 +194,16 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
             }
             __syncthreads();
             // 4. V' = Q_xx + Q_xu K ; v' = q_x + Q_xu k (column 24)            lqr.py:97-105
-            f32x4 G0 = {0.f, 0.f, 0.f, 0.f}, G1 = {0.f, 0.f, 0.f, 0.f}, Ax = {0.f, 0.f, 0.f, 0.f};
+            //    contraction over the 8 actions as 2 k-steps: a = 4s + q
             f32x4 T01 = {0.f, 0.f, 0.f, 0.f};             // accumulates v' in column 24 (lanes i == 8)
-            if (q < 2) {
-                G0 = *reinterpret_cast<const f32x4 *>(&lds[kKs + i * 8 + 4 * q]);
-                G1 = *reinterpret_cast<const f32x4 *>(&lds[kKs + (N + i) * 8 + 4 * q]);
-                Ax = T01t;                     // Q_xu[i][4q+r]
-            }
             if (i == M) T01 = *reinterpret_cast<const f32x4 *>(&lds[kQx + 4 * q]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                T00 = mfma(Ax[r], G0[r], T00);
-                T01 = mfma(Ax[r], G1[r], T01);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const float ax = lds[kXs + i * 8 + 4 * s2 + q];            // Q_xu[i][4s+q]
+                const float g0 = lds[kKs + i * 8 + 4 * s2 + q];            // K[4s+q][i]
+                const float g1 = lds[kKs + (N + i) * 8 + 4 * s2 + q];      // K~[4s+q][16+i]
+                T00 = mfma(ax, g0, T00);
+                T01 = mfma(ax, g1, T01);
             }
             Vd = T00;
             vd = T01;
@@ -203,7 +218,7 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
             }
             if (VALUE) {
                 // const += 1/2 k^T Q_uu k + k^T q_u + 1/2 f^T V f + f^T v with Q_uu k = -q_u
-                // (lqr.py:113-121); f^T(V f + v) was taken before v entered W.
+                // (lqr.py:113-121); f^T(V f) and f^T v were taken before v entered W.
                 cst += 0.5f * quk + 0.5f * fw + fv;
                 if (a.V) {
                     float *Vo = a.V + ((size_t)b * T + t) * (N * N);
@@ -219,34 +234,37 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
             }
             __syncthreads();
         }
+        if (!(min_pivot > 0.0f)) status |= (min_pivot == 0.0f) ? TFMPC_ST_SINGULAR : TFMPC_ST_NOT_PD;
         if (VALUE && !(cst == cst)) status |= TFMPC_ST_NAN;
     }
 
     if (FORWARD) {
-        // ---- resident rows of F and C for the mat-vecs --------------------------------
+        // ---- resident operands of the rollout ------------------------------------------
         const int fi = lane >> 2, fc = lane & 3;       // F: row fi, columns 6fc..6fc+5
-        const int cr = lane >> 1, ch = lane & 1;       // C: row cr (24 used), columns 12ch..12ch+11
-        float Fr[6], Cr[12];
+        const int ka = lane >> 3, jc = lane & 7;       // K: row ka, columns 2jc, 2jc+1
+        float Fr[6];
         {
             const float2 *p = reinterpret_cast<const float2 *>(Fg + fi * D + 6 * fc);
 #pragma unroll
             for (int j = 0; j < 3; ++j) { const float2 v = p[j]; Fr[2 * j] = v.x; Fr[2 * j + 1] = v.y; }
         }
         const float f_i = fg[fi];
-        const bool crow = cr < D;
-        {
-            const float4 *p = reinterpret_cast<const float4 *>(Cg + (crow ? cr : 0) * D + 12 * ch);
+        // cost post-pass operands: A = C (2 row tiles x 6 k-steps, k = 4s + q), c in D layout
+        float Ca0[6], Ca1[6];
+        f32x4 cq0, cq1;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const float4 v = p[j];
-                Cr[4 * j] = v.x; Cr[4 * j + 1] = v.y; Cr[4 * j + 2] = v.z; Cr[4 * j + 3] = v.w;
-            }
+        for (int s2 = 0; s2 < 6; ++s2) {
+            Ca0[s2] = Cg[i * D + 4 * s2 + q];
+            Ca1[s2] = (i < M) ? Cg[(N + i) * D + 4 * s2 + q] : 0.0f;
         }
-        const float c_r = crow ? cg[cr] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            cq0[r] = cg[4 * q + r];
+            cq1[r] = (q < 2) ? cg[N + 4 * q + r] : 0.0f;
+        }
         float *xs = a.states + (size_t)b * (T + 1) * N;
         float *us = a.actions + (size_t)b * T * M;
         float *cs = a.costs + (size_t)b * (T + 1);
-        const int ka = lane >> 3, jc = lane & 7;       // K: row ka, columns 2jc, 2jc+1
         float *zs = &lds[kZs];
         __syncthreads();                               // gains written above are visible
         if (lane < N) {
@@ -262,64 +280,85 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
         }
         __syncthreads();
 
-        // cost of the z currently in LDS: 1/2 z^T C z + c^T z            lqr.py:41-47
-        auto stage_cost = [&]() {
-            float s = 0.0f;
-            const f32x4 *zp = reinterpret_cast<const f32x4 *>(&zs[12 * ch]);
+        // costs of rows [0, rows) of the chunk buffer: 1/2 z^T C z + c^T z  (lqr.py:41-47)
+        // as C Z on the matrix cores, 16 timesteps per tile.
+        auto chunk_costs = [&](int rows, float *out) {
+            for (int nt = 0; nt * 16 < rows; ++nt) {
+                const int row = (16 * nt + i < rows) ? 16 * nt + i : rows - 1;    // stay inside the chunk
+                const float *zrow = zs + row * kZld;
+                f32x4 D0 = {0.f, 0.f, 0.f, 0.f}, D1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const f32x4 z4 = zp[j];
-                s = fmaf(Cr[4 * j], z4[0], s); s = fmaf(Cr[4 * j + 1], z4[1], s);
-                s = fmaf(Cr[4 * j + 2], z4[2], s); s = fmaf(Cr[4 * j + 3], z4[3], s);
+                for (int s2 = 0; s2 < 6; ++s2) {
+                    const float bz = zrow[4 * s2 + q];
+                    D0 = mfma(Ca0[s2], bz, D0);
+                    D1 = mfma(Ca1[s2], bz, D1);
+                }
+                float part = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    part = fmaf(zrow[4 * q + r], fmaf(0.5f, D0[r], cq0[r]), part);
+                    if (q < 2) part = fmaf(zrow[N + 4 * q + r], fmaf(0.5f, D1[r], cq1[r]), part);
+                }
+                part += __shfl_xor(part, 16, kWave);
+                part += __shfl_xor(part, 32, kWave);
+                if (q == 0 && 16 * nt + i < rows) out[16 * nt + i] = part;
             }
-            s += __shfl_xor(s, 1, kWave);
-            const float zr = crow ? zs[cr] : 0.0f;
-            const float part = (ch == 0) ? zr * fmaf(0.5f, s, c_r) : 0.0f;
-            return wave_sum(part);
         };
 
-        for (int t = 0; t < T; ++t) {
-            const float2 Kc = Kn;
-            const float kc = kn;
-            if (t + 1 < T) {                           // prefetch the next step's gains
-                Kn = *reinterpret_cast<const float2 *>(&Kg[(size_t)(t + 1) * (M * N) + 2 * lane]);
-                kn = kg[(size_t)(t + 1) * M + ka];
-            }
-            // u = K x + k                                                  lqr.py:143
-            const float2 xv = *reinterpret_cast<const float2 *>(&zs[2 * jc]);
-            float u = fmaf(Kc.x, xv.x, Kc.y * xv.y);
-            u += __shfl_xor(u, 1, kWave);
-            u += __shfl_xor(u, 2, kWave);
-            u += __shfl_xor(u, 4, kWave);
-            u += kc;
-            if (jc == 0) { zs[N + ka] = u; us[(size_t)t * M + ka] = u; }
-            __syncthreads();
-            // x' = F z + f                                                  lqr.py:36-39
-            float xn = 0.0f;
-            {
-                const float2 *zp = reinterpret_cast<const float2 *>(&zs[6 * fc]);
+        for (int t0 = 0; t0 < T; t0 += kTC) {
+            const int tc = (T - t0 < kTC) ? (T - t0) : kTC;
+            for (int tt = 0; tt < tc; ++tt) {
+                const int t = t0 + tt;
+                float *zt = zs + tt * kZld;
+                const float2 Kc = Kn;
+                const float kc = kn;
+                if (t + 1 < T) {                       // prefetch the next step's gains
+                    Kn = *reinterpret_cast<const float2 *>(&Kg[(size_t)(t + 1) * (M * N) + 2 * lane]);
+                    kn = kg[(size_t)(t + 1) * M + ka];
+                }
+                // u = K x + k                                              lqr.py:143
+                const float2 xv = *reinterpret_cast<const float2 *>(&zt[2 * jc]);
+                float u = fmaf(Kc.x, xv.x, Kc.y * xv.y);
+                u += dpp<kDppXor1>(u);
+                u += dpp<kDppXor2>(u);
+                u += dpp<kDppHalfMirror>(u);
+                u += kc;
+                if (jc == 0) zt[N + ka] = u;
+                __syncthreads();
+                // x' = F z + f                                              lqr.py:36-39
+                float xn = 0.0f;
+                const float2 *zp = reinterpret_cast<const float2 *>(&zt[6 * fc]);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const float2 z2 = zp[j];
                     xn = fmaf(Fr[2 * j], z2.x, xn);
                     xn = fmaf(Fr[2 * j + 1], z2.y, xn);
                 }
+                xn += dpp<kDppXor1>(xn);
+                xn += dpp<kDppXor2>(xn);
+                xn += f_i;
+                if (fc == 0) zt[kZld + fi] = xn;
+                __syncthreads();
             }
-            xn += __shfl_xor(xn, 1, kWave);
-            xn += __shfl_xor(xn, 2, kWave);
-            xn += f_i;
-            const float cost = stage_cost();
-            if (lane == 0) cs[t] = cost;
+            // chunk epilogue: stage costs on the matrix cores, bulk coalesced stores
+            chunk_costs(tc, cs + t0);
+            for (int idx = lane; idx < tc * N; idx += kWave)
+                xs[(size_t)(t0 + 1) * N + idx] = zs[(1 + idx / N) * kZld + (idx & (N - 1))];
+            for (int idx = lane; idx < tc * M; idx += kWave)
+                us[(size_t)t0 * M + idx] = zs[(idx / M) * kZld + N + (idx & (M - 1))];
             __syncthreads();
-            if (fc == 0) { zs[fi] = xn; xs[(size_t)(t + 1) * N + fi] = xn; }
+            if (lane < N) zs[lane] = zs[tc * kZld + lane];      // carry x into row 0 of the next chunk
             __syncthreads();
         }
-        // final cost 1/2 x^T C_xx x + c_x^T x  == stage cost with u = 0     lqr.py:49-57
+        // final cost 1/2 x^T C_xx x + c_x^T x == stage cost with u = 0      lqr.py:49-57
         if (lane < M) zs[N + lane] = 0.0f;
         __syncthreads();
-        const float fcost = stage_cost();
-        if (lane == 0) cs[T] = fcost;
-        if (!(fcost == fcost)) status |= TFMPC_ST_NAN;
+        chunk_costs(1, cs + T);
+        __syncthreads();
+        if (lane == 0) {
+            const float fcost = cs[T];
+            if (!(fcost == fcost)) status |= TFMPC_ST_NAN;
+        }
     }
 
     if (a.status && lane == 0) a.status[b] = status;
