@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
         // terminal value function V = C_xx, v = c_x (lqr.py:67-68): v lives in lanes i == 8
         f32x4 Vd = Cd00, vd = vterm;
         float cst = 0.0f;
-        float min_pivot = 1.0f;
+        int min_pivot_bits = 0x3f800000;     // smallest pivot seen, as float bits (int order == float order for >= 0)
         for (int idx = lane; idx < kZs; idx += kWave) lds[idx] = 0.0f;   // pad columns stay 0
         __syncthreads();
 
@@ -168,10 +168,9 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
             // No pivoting: Q_uu is positive definite whenever C >= 0 and C_uu > 0 (checked below).
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-                const float pv = readlane(Mr[p], N + p);
-                min_pivot = fminf(min_pivot, pv);
-                float inv = __builtin_amdgcn_rcpf(pv);
-                inv = fmaf(fmaf(-pv, inv, 1.0f), inv, inv);       // one Newton step: < 1 ulp
+                const int pvb = __builtin_amdgcn_readlane(__builtin_bit_cast(int, Mr[p]), N + p);
+                min_pivot_bits = min(min_pivot_bits, pvb);         // scalar; sign bit set <=> pivot < 0
+                const float inv = __builtin_amdgcn_rcpf(__builtin_bit_cast(float, pvb));   // 1 ulp
                 Mr[p] *= inv;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
@@ -234,7 +233,7 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
             }
             __syncthreads();
         }
-        if (!(min_pivot > 0.0f)) status |= (min_pivot == 0.0f) ? TFMPC_ST_SINGULAR : TFMPC_ST_NOT_PD;
+        if (min_pivot_bits <= 0) status |= (min_pivot_bits == 0) ? TFMPC_ST_SINGULAR : TFMPC_ST_NOT_PD;
         if (VALUE && !(cst == cst)) status |= TFMPC_ST_NAN;
     }
 
