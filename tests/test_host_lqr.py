@@ -41,6 +41,7 @@ def test_kernel_choice_and_workspace_queries():
     lib = _hip.load()
     assert lib.tfmpc_version() >= 100
     assert lib.tfmpc_lqr_kernel_name(3, 2, 10) == b"generic_wave"
+    assert lib.tfmpc_lqr_kernel_name(16, 8, 50) == b"mfma_16x8"        # BASELINE headline shape
     assert lib.tfmpc_lqr_kernel_name(200, 200, 10) == b"unsupported"
     assert lib.tfmpc_lqr_workspace_bytes(4, 16, 8, 50) == 4 * 50 * 8 * 17 * 4
 
