@@ -84,6 +84,8 @@ template <int KIND> struct Env;
 
 // ----------------------------------------------------------------------- LQ ---
 template <> struct Env<TFMPC_ENV_LQ> {
+    // true iff every second derivative of cost and final cost is identically zero
+    static constexpr bool kPiecewiseLinearCost = false;
     // x' = F [x;u] + f                                               lqr.py:36-39
     static __device__ void transition(const EnvLds &e, const float *x, const float *u, float *xn)
     {
@@ -171,6 +173,8 @@ template <> struct Env<TFMPC_ENV_LQ> {
 
 // ------------------------------------------------------------------- NAVLQR ---
 template <> struct Env<TFMPC_ENV_NAVLQR> {
+    // true iff every second derivative of cost and final cost is identically zero
+    static constexpr bool kPiecewiseLinearCost = false;
     static __device__ void transition(const EnvLds &e, const float *x, const float *u, float *xn)
     {
         for (int i = lane_id(); i < e.n; i += kWave) xn[i] = x[i] + u[i];            // :32
@@ -231,6 +235,8 @@ template <> struct Env<TFMPC_ENV_NAVLQR> {
 
 // --------------------------------------------------------------- NAVIGATION ---
 template <> struct Env<TFMPC_ENV_NAVIGATION> {
+    // true iff every second derivative of cost and final cost is identically zero
+    static constexpr bool kPiecewiseLinearCost = false;
     // lambda = prod_z (2 / (1 + exp(-decay_z |x - c_z|)) - 1); also d lambda / d x.   :61-74
     static __device__ float deceleration(const EnvLds &e, const float *x, float *grad /* [n] regs or null */)
     {
@@ -306,6 +312,8 @@ template <> struct Env<TFMPC_ENV_NAVIGATION> {
 
 // --------------------------------------------------------------------- HVAC ---
 template <> struct Env<TFMPC_ENV_HVAC> {
+    // true iff every second derivative of cost and final cost is identically zero
+    static constexpr bool kPiecewiseLinearCost = true;
     static constexpr float CAP_AIR = 1.006f, COST_AIR = 1.0f, TEMP_AIR = 40.0f, TIME_DELTA = 1.0f;   // :10-13
     static constexpr float PENALTY = 20000.0f, SET_POINT_PENALTY = 10.0f;                              // :14-15
 
@@ -351,8 +359,9 @@ template <> struct Env<TFMPC_ENV_HVAC> {
                     - SET_POINT_PENALTY * signf((lo + hi) / 2 - x[i]);
         }
     }
-    static __device__ float linearize(const EnvLds &e, const float *x, const float *u, float *fx, float *fu,
-                                      float *lx, float *lu, float *lxx, float *luu, float *lux)
+    // f_x, f_u and l_x, l_u only (first-order model; what the adjoint backward pass needs)
+    static __device__ float linearize1(const EnvLds &e, const float *x, const float *u, float *fx, float *fu,
+                                       float *lx, float *lu)
     {
         const int n = e.n, ldn = odd_ld(n);
         const float *k_out = e.p[4], *k_hall = e.p[5], *cap = e.p[6], *air_max = e.p[7], *G = e.p[8];
@@ -369,13 +378,25 @@ template <> struct Env<TFMPC_ENV_HVAC> {
             }
             fx[i * ldn + j] = v;
             fu[i * ldn + j] = d;
-            lxx[i * ldn + j] = 0.0f;
-            luu[i * ldn + j] = 0.0f;
-            lux[i * ldn + j] = 0.0f;
         }
         cost_grad_x(e, x, lx);
         for (int i = lane_id(); i < n; i += kWave) lu[i] = COST_AIR * air_max[i];
         return cost(e, x, u);
+    }
+    static __device__ float linearize(const EnvLds &e, const float *x, const float *u, float *fx, float *fu,
+                                      float *lx, float *lu, float *lxx, float *luu, float *lux)
+    {
+        const int n = e.n, ldn = odd_ld(n);
+        for (int idx = lane_id(); idx < n * n; idx += kWave) {
+            const int o = (idx / n) * ldn + idx % n;
+            lxx[o] = 0.0f; luu[o] = 0.0f; lux[o] = 0.0f;
+        }
+        return linearize1(e, x, u, fx, fu, lx, lu);
+    }
+    static __device__ float final_grad(const EnvLds &e, const float *x, float *lx)
+    {
+        cost_grad_x(e, x, lx);
+        return final_cost(e, x);
     }
     static __device__ float final_quad(const EnvLds &e, const float *x, float *lx, float *lxx)
     {
@@ -388,6 +409,8 @@ template <> struct Env<TFMPC_ENV_HVAC> {
 
 // ---------------------------------------------------------------- RESERVOIR ---
 template <> struct Env<TFMPC_ENV_RESERVOIR> {
+    // true iff every second derivative of cost and final cost is identically zero
+    static constexpr bool kPiecewiseLinearCost = true;
     static __device__ void transition(const EnvLds &e, const float *x, const float *u, float *xn)
     {
         const int n = e.n;
@@ -420,8 +443,8 @@ template <> struct Env<TFMPC_ENV_RESERVOIR> {
             lx[i] = -LP * (lo > x[i] ? 1.0f : 0.0f) + HP * (x[i] > hi ? 1.0f : 0.0f) - SP * signf((lo + hi) / 2.0f - x[i]);
         }
     }
-    static __device__ float linearize(const EnvLds &e, const float *x, const float *u, float *fx, float *fu,
-                                      float *lx, float *lu, float *lxx, float *luu, float *lux)
+    static __device__ float linearize1(const EnvLds &e, const float *x, const float *u, float *fx, float *fu,
+                                       float *lx, float *lu)
     {
         const int n = e.n, ldn = odd_ld(n);
         const float *cap = e.p[0], *D = e.p[7];
@@ -436,13 +459,25 @@ template <> struct Env<TFMPC_ENV_RESERVOIR> {
             }
             fx[i * ldn + j] = a;
             fu[i * ldn + j] = b;
-            lxx[i * ldn + j] = 0.0f;
-            luu[i * ldn + j] = 0.0f;
-            lux[i * ldn + j] = 0.0f;
         }
         cost_grad_x(e, x, lx);
         for (int i = lane_id(); i < n; i += kWave) lu[i] = 0.0f;
         return cost(e, x, u);
+    }
+    static __device__ float linearize(const EnvLds &e, const float *x, const float *u, float *fx, float *fu,
+                                      float *lx, float *lu, float *lxx, float *luu, float *lux)
+    {
+        const int n = e.n, ldn = odd_ld(n);
+        for (int idx = lane_id(); idx < n * n; idx += kWave) {
+            const int o = (idx / n) * ldn + idx % n;
+            lxx[o] = 0.0f; luu[o] = 0.0f; lux[o] = 0.0f;
+        }
+        return linearize1(e, x, u, fx, fu, lx, lu);
+    }
+    static __device__ float final_grad(const EnvLds &e, const float *x, float *lx)
+    {
+        cost_grad_x(e, x, lx);
+        return final_cost(e, x);
     }
     static __device__ float final_quad(const EnvLds &e, const float *x, float *lx, float *lxx)
     {

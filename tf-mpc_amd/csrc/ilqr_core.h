@@ -59,6 +59,27 @@ __device__ inline float *ilqr_carve(IlqrSmem &s, float *p, int n, int m)
     return p;
 }
 
+// Reduced LDS slice for envs whose cost Hessians vanish identically (HVAC, Reservoir):
+// the backward pass is then the adjoint recursion below and needs no n x n Q terms.
+__host__ __device__ inline size_t ilqr_adjoint_smem_floats(int n, int m)
+{
+    const size_t ldn = odd_ld(n), ldm = odd_ld(m);
+    return n * ldn + n * ldm + 6 * (size_t)n + 5 * (size_t)m + (size_t)m * ldn;
+}
+
+__device__ inline float *ilqr_carve_adjoint(IlqrSmem &s, float *p, int n, int m)
+{
+    s = IlqrSmem{};
+    s.n = n; s.m = m;
+    s.ldn = odd_ld(n); s.ldm = odd_ld(m); s.width = m + 1 + n; s.lda = odd_ld(s.width);
+    s.fx = p; p += n * s.ldn;   s.fu = p; p += n * s.ldm;
+    s.lx = p; p += n;  s.Vx = p; p += n;  s.Qx = p; p += n;
+    s.xv = p; p += n;  s.xn = p; p += n;  s.xh = p; p += n;
+    s.lu = p; p += m;  s.Qu = p; p += m;  s.k = p; p += m;  s.uv = p; p += m;  s.uh = p; p += m;
+    s.K = p; p += m * s.ldn;        // only touched by forward_pass<KIND, true>
+    return p;
+}
+
 // ------------------------------------------------------------------ box-QP ----
 // 1/2 x^T H x + q^T x for x in LDS (optimization.py:8-11).
 __device__ inline float qp_objective(const float *H, int ld, const float *q, const float *x, int m)
@@ -307,6 +328,55 @@ __device__ inline BackwardResult backward_pass(IlqrSmem &s, Provider &prov, int 
     return r;
 }
 
+// Backward pass of ilqr.py:94-172 when l_xx = l_uu = l_ux = 0 and l^f_xx = 0 and the action
+// box is bounded: V_xx stays exactly 0, the controller is always the bang-bang branch
+// (ilqr.py:140-141), K_t = 0, and what is left is the adjoint (costate) recursion
+//   Q_x = l_x + f_x^T V_x,  Q_u = l_u + f_u^T V_x,  k = Q_u >= 0 ? low - u : high - u,  V_x <- Q_x.
+// Bit-identical to backward_pass on such envs (every dropped term is an exact zero).
+template <int KIND>
+__device__ inline BackwardResult backward_pass_adjoint(IlqrSmem &s, const EnvLds &e, int T, const float *xhat,
+                                                       const float *uhat, float *kg)
+{
+    const int n = s.n, m = s.m, ldn = s.ldn, ldm = s.ldm, lane = lane_id();
+    BackwardResult r{0.0f, 0.0f, 0.0f, 0.0f, 0, 0};
+    for (int i = lane; i < n; i += kWave) s.xh[i] = xhat[(size_t)T * n + i];
+    wsync();
+    r.J = Env<KIND>::final_grad(e, s.xh, s.Vx);
+    float gsum = 0.0f;
+    wsync();
+    for (int t = T - 1; t >= 0; --t) {
+        for (int i = lane; i < n; i += kWave) s.xh[i] = xhat[(size_t)t * n + i];
+        for (int a = lane; a < m; a += kWave) s.uh[a] = uhat[(size_t)t * m + a];
+        wsync();
+        const float l = Env<KIND>::linearize1(e, s.xh, s.uh, s.fx, s.fu, s.lx, s.lu);
+        wsync();
+        float p1 = 0.0f, gmax = 0.0f;
+        for (int i = lane; i < n + m; i += kWave) {
+            if (i < n) {
+                float acc = s.lx[i];
+                for (int kk = 0; kk < n; ++kk) acc = fmaf(s.fx[kk * ldn + i], s.Vx[kk], acc);
+                s.Qx[i] = acc;
+            } else {
+                const int a = i - n;
+                float acc = s.lu[a];
+                for (int kk = 0; kk < n; ++kk) acc = fmaf(s.fu[kk * ldm + a], s.Vx[kk], acc);
+                const float kt = (acc >= 0.0f) ? (e.low[a] - s.uh[a]) : (e.high[a] - s.uh[a]);
+                kg[(size_t)t * m + a] = kt;
+                p1 = fmaf(kt, acc, p1);
+                gmax = fmaxf(gmax, fabsf(kt) / (fabsf(s.uh[a]) + 1.0f));
+            }
+        }
+        r.J += l;
+        r.dV1 += wave_sum(p1);
+        gsum += wave_max(gmax);
+        wsync();
+        for (int i = lane; i < n; i += kWave) s.Vx[i] = s.Qx[i];
+        wsync();
+    }
+    r.g_norm = T > 0 ? gsum / (float)T : 0.0f;
+    return r;
+}
+
 // ------------------------------------------------------------ rollouts --------
 // Open-loop rollout under given actions (iLQR.start, ilqr.py:53-82).
 template <int KIND>
@@ -334,7 +404,7 @@ __device__ inline void rollout_pass(IlqrSmem &s, const EnvLds &e, int T, const f
 }
 
 // Closed-loop rollout with step alpha (iLQR.forward, ilqr.py:174-212).
-template <int KIND>
+template <int KIND, bool HAS_K = true>
 __device__ inline void forward_pass(IlqrSmem &s, const EnvLds &e, int T, float alpha, const float *xhat,
                                     const float *uhat, const float *Kg, const float *kg, float *states,
                                     float *actions, float *costs, float &J_out, float &residual_out)
@@ -343,14 +413,14 @@ __device__ inline void forward_pass(IlqrSmem &s, const EnvLds &e, int T, float a
     for (int i = lane; i < n; i += kWave) { const float x = xhat[i]; s.xv[i] = x; states[i] = x; }
     float J = 0.0f, resid = 0.0f;
     for (int t = 0; t < T; ++t) {
-        load_matrix(s.K, ldn, Kg + (size_t)t * m * n, m, n);
+        if (HAS_K) load_matrix(s.K, ldn, Kg + (size_t)t * m * n, m, n);
         for (int a = lane; a < m; a += kWave) { s.k[a] = kg[(size_t)t * m + a]; s.uh[a] = uhat[(size_t)t * m + a]; }
         for (int i = lane; i < n; i += kWave) s.xh[i] = xhat[(size_t)t * n + i];
         wsync();
         float rmax = 0.0f;
         for (int a = lane; a < m; a += kWave) {
             float du = alpha * s.k[a];                                                   // :193-194
-            for (int j = 0; j < n; ++j) du = fmaf(s.K[a * ldn + j], s.xv[j] - s.xh[j], du);
+            if (HAS_K) for (int j = 0; j < n; ++j) du = fmaf(s.K[a * ldn + j], s.xv[j] - s.xh[j], du);
             const float u = fminf(fmaxf(s.uh[a] + du, e.low[a]), e.high[a]);             // :196-197
             s.uv[a] = u;
             actions[(size_t)t * m + a] = u;

@@ -178,8 +178,9 @@ __global__ __launch_bounds__(kWave) void ilqr_solve_kernel(TfmpcEnv env, TfmpcIl
 {
     extern __shared__ float smem[];
     const int b = blockIdx.x, n = env.n, m = env.m, T = a.T, lane = lane_id();
+    constexpr bool kAdjoint = Env<KIND>::kPiecewiseLinearCost;   // HVAC / Reservoir: V_xx == 0 always
     IlqrSmem s;
-    float *p = ilqr_carve(s, smem, n, m);
+    float *p = kAdjoint ? ilqr_carve_adjoint(s, smem, n, m) : ilqr_carve(s, smem, n, m);
     EnvLds e;
     env_load(e, env, b, p);
     wsync();
@@ -205,7 +206,8 @@ __global__ __launch_bounds__(kWave) void ilqr_solve_kernel(TfmpcEnv env, TfmpcIl
             float mu_l = mu, delta_l = delta;
             BackwardResult r;
             for (int retry = 0;; ++retry) {
-                r = backward_pass(s, prov, T, mu_l, bounded, e.low, e.high, Kg, kg);
+                if constexpr (kAdjoint) r = backward_pass_adjoint<KIND>(s, e, T, xhat, uhat, kg);
+                else r = backward_pass(s, prov, T, mu_l, bounded, e.low, e.high, Kg, kg);
                 status |= r.flags;
                 if (!r.failed) break;
                 status |= TFMPC_ST_NOT_PD;
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(kWave) void ilqr_solve_kernel(TfmpcEnv env, TfmpcIl
             for (int ai = 0; ai < cfg.n_alphas; ++ai) {
                 const float alpha = cfg.alphas[ai];
                 float J;
-                forward_pass<KIND>(s, e, T, alpha, xhat, uhat, Kg, kg, xc, uc, cc, J, residual);
+                forward_pass<KIND, !kAdjoint>(s, e, T, alpha, xhat, uhat, Kg, kg, xc, uc, cc, J, residual);
                 const float delta_J = -alpha * (r.dV1 + alpha * r.dV2);    // :339
                 const float dcost = r.J - J;
                 const float z = (delta_J > 0.0f) ? dcost / delta_J : signf(dcost);   // :342-346
@@ -290,6 +292,14 @@ __global__ __launch_bounds__(kWave) void boxqp_kernel(int m, const float *H, con
 static size_t ilqr_smem_bytes(int kind, int n, int m, int zones)
 {
     return (ilqr_smem_floats(n, m) + env_lds_floats(kind, n, m, zones) + 2 * (size_t)m) * sizeof(float);
+}
+
+// the fused solve of HVAC / Reservoir uses the adjoint backward pass and a reduced LDS slice
+static size_t ilqr_solve_smem_bytes(int kind, int n, int m, int zones)
+{
+    const bool adjoint = kind == TFMPC_ENV_HVAC || kind == TFMPC_ENV_RESERVOIR;
+    const size_t core = adjoint ? ilqr_adjoint_smem_floats(n, m) : ilqr_smem_floats(n, m);
+    return (core + env_lds_floats(kind, n, m, zones) + 2 * (size_t)m) * sizeof(float);
 }
 
 static int check_env(const TfmpcEnv *env)
@@ -438,7 +448,7 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
     a.wsx = w; w += (size_t)B * (T + 1) * n;
     a.wsu = w; w += (size_t)B * T * m;
     a.wsc = w;
-    const size_t smem = ilqr_smem_bytes(env->kind, n, m, env->n_zones);
+    const size_t smem = ilqr_solve_smem_bytes(env->kind, n, m, env->n_zones);
     hipStream_t st = static_cast<hipStream_t>(stream);
     TFMPC_DISPATCH_KIND(env->kind, {
         auto kern = ilqr_solve_kernel<KIND>;
