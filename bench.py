@@ -52,6 +52,26 @@ def lqr_bytes_per_solve(n, m, T):
     return 4 * (n * d + n + d * d + d + n) + 4 * ((T + 1) * n + T * m + (T + 1))
 
 
+def measured_traffic(kernel, batch):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/*_pmc_summary.json, collected with tools/pmc_passes.sh on this same command:
+    separate --pmc passes, FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes).
+    bench.py cannot run rocprofv3 on itself, so the number is read back, scaled per instance."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if kernel.split("_")[0] in d.get("kernel", "") and "hbm_bytes_per_launch" in d:
+            best = d
+    if best is None:
+        return None
+    per_instance = best["hbm_bytes_per_launch"]["total_corrected"] / float(best.get("batch_per_launch", BATCH))
+    return per_instance * batch
+
+
 def cpu_baseline(n, m, T, target_seconds=12.0):
     """The oracle's C port of the reference equations, OpenMP over instances on all
     host cores, on a bounded sample of the same workload."""
@@ -168,7 +188,8 @@ def main():
                        "kernel": kernel},
             "timestep_iterations_per_s": value * T,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": measured_traffic(kernel, B),
+                         "traffic_unit": "HBM bytes per launch (PMC, profiles/)",
                          "kernel_ms": kernel_ms, "algorithmic_flop_per_iteration": lqr_flops_per_solve(n, m, T),
                          "algorithmic_bytes_per_iteration": lqr_bytes_per_solve(n, m, T),
                          "hbm_frac_at_algorithmic_bytes": lqr_bytes_per_solve(n, m, T) * B / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
