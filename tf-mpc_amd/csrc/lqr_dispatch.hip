@@ -18,6 +18,19 @@ bool want_mfma(int n, int m)
     return lqr_mfma_supported(n, m);
 }
 
+// lane-per-instance pays once there are enough instances to fill lanes; below that the
+// wave-per-instance kernel has the shorter critical path.  TFMPC_LQR_KERNEL=lane|generic forces.
+constexpr int kLaneMinBatch = 32;
+
+bool want_lane(int n, int m, int B)
+{
+    if (!lqr_lane_supported(n, m)) return false;
+    const char *force = std::getenv("TFMPC_LQR_KERNEL");
+    if (force && std::strcmp(force, "generic") == 0) return false;
+    if (force && std::strcmp(force, "lane") == 0) return true;
+    return B >= kLaneMinBatch;
+}
+
 int check_common(int B, int n, int m, int T, const void *F, const void *f, const void *C, const void *c)
 {
     if (B < 0 || n <= 0 || m <= 0 || T < 0) return TFMPC_ERR_ARG;
@@ -31,6 +44,7 @@ int run(const LqrArgs &a, bool bw, bool fw, void *stream)
     if (a.B == 0) return TFMPC_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (want_mfma(a.n, a.m)) return lqr_mfma_launch(a, bw, fw, s);
+    if (want_lane(a.n, a.m, a.B)) return lqr_lane_launch(a, bw, fw, s);
     return lqr_generic_launch(a, bw, fw, s);
 }
 
@@ -45,6 +59,7 @@ const char *tfmpc_lqr_kernel_name(int n, int m, int T)
     (void)T;
     if (n <= 0 || m <= 0) return "invalid";
     if (want_mfma(n, m)) return "mfma_16x8";
+    if (lqr_lane_supported(n, m)) return "lane (batch >= 32) / generic_wave";
     if (lqr_generic_smem_bytes(n, m) > kMaxLdsBytes) return "unsupported";
     return "generic_wave";
 }

@@ -28,6 +28,10 @@ struct LqrArgs {
 size_t lqr_generic_smem_bytes(int n, int m);
 int lqr_generic_launch(const LqrArgs &a, bool backward, bool forward, hipStream_t stream);
 
+// Lane-per-instance variant for tiny shapes, n + m <= 6 (lqr_lane.hip).
+bool lqr_lane_supported(int n, int m);
+int lqr_lane_launch(const LqrArgs &a, bool backward, bool forward, hipStream_t stream);
+
 // MFMA variant for the BASELINE.json headline shape (lqr_mfma16x8.hip).
 bool lqr_mfma_supported(int n, int m);
 int lqr_mfma_launch(const LqrArgs &a, bool backward, bool forward, hipStream_t stream);
