@@ -1,0 +1,93 @@
+"""Lane-per-instance fused iLQR solve (2-D navigation envs): every instance must land where
+the wave-per-instance kernel and the oracle land.  Both device paths implement the same
+equations; their fp32 summation orders differ, so trajectories agree to fp32 accuracy and
+discrete line-search decisions may flip on a few instances of the nonlinear env."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import problems
+from oracle import envs_ref, ilqr_ref
+from tfmpc import _hip
+from tfmpc.envs.lqr.navigation import NavigationLQR
+from tfmpc.envs.navigation import Navigation
+from tfmpc.solvers.ilqr import iLQR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def force_kernel():
+    old = os.environ.get("TFMPC_ILQR_KERNEL")
+
+    def set_(name):
+        if name is None:
+            os.environ.pop("TFMPC_ILQR_KERNEL", None)
+        else:
+            os.environ["TFMPC_ILQR_KERNEL"] = name
+    yield set_
+    set_(old)
+
+
+def _solve_both(force_kernel, solver, x0, T, u0):
+    out = {}
+    for kern in ("lane", "wave"):
+        force_kernel(kern)
+        out[kern] = solver.solve_device(x0, T, u_init=u0)
+        torch.cuda.synchronize()
+    return out["lane"], out["wave"]
+
+
+@pytest.mark.parametrize("beta,bounds", [(0.0, None), (5.0, None), (0.0, (-1.0, 1.0)), (5.0, (-1.0, 1.0))])
+def test_lane_equals_wave_on_linear_navigation(force_kernel, beta, bounds):
+    rng = np.random.default_rng(11)
+    B, T = 150, 10
+    goals = rng.uniform(-10, 10, size=(B, 2, 1)).astype(np.float32)
+    low, high = bounds if bounds else (None, None)
+    solver = iLQR(NavigationLQR(goals, beta, low, high))
+    x0 = rng.normal(size=(B, 2, 1)).astype(np.float32)
+    u0 = solver.random_actions(T, B, seed=3)
+    lane, wave = _solve_both(force_kernel, solver, x0, T, u0)
+    assert int((lane["status"] & ~_hip.ST_QP_MAXITER).sum()) == 0
+    assert torch.equal(lane["iterations"], wave["iterations"])
+    for key in ("states", "actions", "costs"):
+        scale = float(wave[key].abs().max())
+        assert float((lane[key] - wave[key]).abs().max()) <= 2e-4 * scale, key
+    # and against the fp64 oracle on a few instances
+    for b in (0, 77, 149):
+        o = ilqr_ref.ILQRRef(envs_ref.NavigationLQR(goals[b], beta, low, high))
+        x, u, c, it = o.solve(x0[b], T, u_init=u0[b].cpu().numpy())
+        assert it == int(lane["iterations"][b])
+        assert np.abs(lane["states"][b, ..., 0].cpu().numpy() - x).max() <= 1e-3 * max(np.abs(x).max(), 1.0)
+        assert abs(float(lane["costs"][b].sum()) - c.sum()) <= 1e-3 * abs(c.sum())
+
+
+def test_lane_tracks_wave_and_oracle_on_nonlinear_navigation(force_kernel):
+    cfg = problems.NAV_CONFIG
+    solver = iLQR(Navigation.load(cfg))
+    rng = np.random.default_rng(5)
+    B, T = 128, 20
+    x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
+    u0 = solver.random_actions(T, B, seed=9)
+    lane, wave = _solve_both(force_kernel, solver, x0, T, u0)
+    assert int((lane["status"] & (_hip.ST_NAN | _hip.ST_MAX_ATTEMPTS)).sum()) == 0
+    tl, tw = lane["costs"].sum(dim=1), wave["costs"].sum(dim=1)
+    rel = ((tl - tw).abs() / tw.abs().clamp_min(1e-3)).cpu().numpy()
+    assert np.median(rel) <= 1e-4 and np.quantile(rel, 0.9) <= 2e-2          # a few flipped line searches
+    same_iters = float((lane["iterations"] == wave["iterations"]).float().mean())
+    assert same_iters >= 0.7
+    oenv = envs_ref.Navigation(cfg["goal"], cfg["deceleration"]["center"], cfg["deceleration"]["decay"], cfg["low"],
+                               cfg["high"], dtype=np.float32)
+    for b in (0, 64, 127):
+        o = ilqr_ref.ILQRRef(oenv, dtype=np.float32)
+        x, u, c, it = o.solve(x0[b], T, u_init=u0[b].cpu().numpy())
+        assert abs(float(tl[b]) - c.sum()) <= 2e-2 * abs(c.sum())
+    # returned trajectories obey the env exactly as computed by the (wave) env kernels
+    env = solver.env
+    st, ac = lane["states"], lane["actions"]
+    for t in (0, 9, 19):
+        nxt = env.transition(st[:, t], ac[:, t], batch=True)
+        assert torch.equal(nxt, st[:, t + 1])

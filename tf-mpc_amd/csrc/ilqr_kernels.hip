@@ -4,10 +4,20 @@
 // instance throughout; see ilqr_core.h for the per-step arithmetic.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "ilqr_core.h"
 #include "lqr_kernels.h"
 
 namespace tfmpc {
+
+// lane-per-instance fused solve for tiny envs (ilqr_lane.hip)
+bool ilqr_lane_supported(const TfmpcEnv &env);
+int ilqr_lane_solve_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, int B, int T, const float *x0,
+                           const float *u_init, float *states, float *actions, float *costs, int32_t *iterations,
+                           int32_t *status, float *wsK, float *wsk, float *wsx, float *wsu, float *wsc,
+                           hipStream_t stream);
 
 // ---- model providers for backward_pass ------------------------------------------
 template <int KIND>
@@ -448,8 +458,18 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
     a.wsx = w; w += (size_t)B * (T + 1) * n;
     a.wsu = w; w += (size_t)B * T * m;
     a.wsc = w;
-    const size_t smem = ilqr_solve_smem_bytes(env->kind, n, m, env->n_zones);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    {
+        // tiny 2-D envs: one lane per instance once the batch fills lanes (ilqr_lane.hip);
+        // TFMPC_ILQR_KERNEL=lane|wave forces the choice (tests, A/B timing)
+        const char *force = std::getenv("TFMPC_ILQR_KERNEL");
+        const bool forced_lane = force && std::strcmp(force, "lane") == 0;
+        const bool forced_wave = force && std::strcmp(force, "wave") == 0;
+        if (ilqr_lane_supported(*env) && !forced_wave && (forced_lane || B >= 32))
+            return ilqr_lane_solve_launch(*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status,
+                                          a.wsK, a.wsk, a.wsx, a.wsu, a.wsc, st);
+    }
+    const size_t smem = ilqr_solve_smem_bytes(env->kind, n, m, env->n_zones);
     TFMPC_DISPATCH_KIND(env->kind, {
         auto kern = ilqr_solve_kernel<KIND>;
         if ((rc = prep(kern, smem)) != TFMPC_OK) return rc;

@@ -1,0 +1,607 @@
+// ilqr_lane.hip -- iLQR.solve (tfmpc/solvers/ilqr.py:214-355) for tiny problems: ONE LANE per
+// problem instance, 64 independent solves per wavefront, each lane running its own iteration
+// loop (lanes whose instance has converged idle until the wave's slowest instance is done).
+// Used by tfmpc_ilqr_solve_f32 for the 2-D navigation envs (BASELINE configs[3]: Navigation,
+// n = m = 2, T = 50, batch 16 384) once the batch is large enough to fill lanes.  Same
+// equations and quirks as the wave-per-instance path (ilqr_core.h); step-local matrices live
+// in registers (small_linalg.h), trajectories and gains in the per-instance HBM slabs.
+#include <hip/hip_runtime.h>
+
+#include "envs.h"
+#include "lqr_kernels.h"
+#include "small_linalg.h"
+
+namespace tfmpc {
+
+using small::Mat;
+
+__device__ __forceinline__ float sgnf(float y) { return (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f); }
+
+// ---- per-lane env models (same closed forms as envs.h) ---------------------------------
+template <int N, int M>
+struct LaneModel {                 // quadratic expansion at one (x, u)
+    Mat<N, N> fx, lxx;
+    Mat<N, M> fu;
+    Mat<M, M> luu;
+    Mat<M, N> lux;
+    float lx[N], lu[M], l;
+};
+
+template <int KIND, int N, int M> struct LaneEnv;
+
+template <int N>
+struct LaneEnv<TFMPC_ENV_NAVLQR, N, N> {                 // envs/lqr/navigation/__init__.py:30-47
+    float goal[N], beta;
+    __device__ void load(const TfmpcEnv &g, int b)
+    {
+#pragma unroll
+        for (int i = 0; i < N; ++i) goal[i] = g.p[0][(size_t)b * g.stride[0] + i];
+        beta = g.scalar[0];
+    }
+    __device__ void transition(const float *x, const float *u, float *xn) const
+    {
+#pragma unroll
+        for (int i = 0; i < N; ++i) xn[i] = x[i] + u[i];
+    }
+    __device__ float final_cost(const float *x) const
+    {
+        float c1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) { const float dx = x[i] - goal[i]; c1 += dx * dx; }
+        return c1;
+    }
+    __device__ float cost(const float *x, const float *u) const
+    {
+        float c2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) c2 += u[i] * u[i];
+        return final_cost(x) + beta * c2;
+    }
+    __device__ void linearize(const float *x, const float *u, LaneModel<N, N> &md) const
+    {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            md.lx[i] = 2.0f * (x[i] - goal[i]);
+            md.lu[i] = 2.0f * beta * u[i];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const float id = (i == j) ? 1.0f : 0.0f;
+                md.fx(i, j) = id; md.fu(i, j) = id;
+                md.lxx(i, j) = 2.0f * id; md.luu(i, j) = 2.0f * beta * id; md.lux(i, j) = 0.0f;
+            }
+        }
+        md.l = cost(x, u);
+    }
+    __device__ float final_quad(const float *x, float *lx, Mat<N, N> &lxx) const
+    {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            lx[i] = 2.0f * (x[i] - goal[i]);
+#pragma unroll
+            for (int j = 0; j < N; ++j) lxx(i, j) = (i == j) ? 2.0f : 0.0f;
+        }
+        return final_cost(x);
+    }
+};
+
+template <int N>
+struct LaneEnv<TFMPC_ENV_NAVIGATION, N, N> {             // envs/navigation/__init__.py:34-74
+    float goal[N];
+    const float *center, *decay;   // shared by the batch (uniform addresses -> scalar loads)
+    int zones;
+    __device__ void load(const TfmpcEnv &g, int b)
+    {
+#pragma unroll
+        for (int i = 0; i < N; ++i) goal[i] = g.p[0][(size_t)b * g.stride[0] + i];
+        center = g.p[1]; decay = g.p[2]; zones = g.n_zones;
+    }
+    __device__ float zone_lambda(const float *x, int z, float *r_out, float *ex_out) const
+    {
+        float r2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) { const float d = x[i] - center[z * N + i]; r2 = fmaf(d, d, r2); }
+        const float r = sqrtf(r2);
+        const float ex = expf(-decay[z] * r);
+        if (r_out) { *r_out = r; *ex_out = ex; }
+        return 2.0f / (1.0f + ex) - 1.0f;
+    }
+    __device__ float deceleration(const float *x, float *grad) const
+    {
+        float lam = 1.0f;
+        for (int z = 0; z < zones; ++z) lam *= zone_lambda(x, z, nullptr, nullptr);
+        if (grad) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) grad[i] = 0.0f;
+            for (int z = 0; z < zones; ++z) {
+                float r, ex;
+                zone_lambda(x, z, &r, &ex);
+                const float h = 2.0f * decay[z] * ex / ((1.0f + ex) * (1.0f + ex));
+                float others = 1.0f;
+                for (int y = 0; y < zones; ++y)
+                    if (y != z) others *= zone_lambda(x, y, nullptr, nullptr);
+#pragma unroll
+                for (int i = 0; i < N; ++i) grad[i] += h * (x[i] - center[z * N + i]) / r * others;
+            }
+        }
+        return lam;
+    }
+    __device__ void transition(const float *x, const float *u, float *xn) const
+    {
+        const float lam = deceleration(x, nullptr);
+#pragma unroll
+        for (int i = 0; i < N; ++i) xn[i] = fmaf(lam, u[i], x[i]);
+    }
+    __device__ float final_cost(const float *x) const
+    {
+        float c1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) { const float dx = x[i] - goal[i]; c1 += dx * dx; }
+        return c1;
+    }
+    __device__ float cost(const float *x, const float *) const { return final_cost(x); }
+    __device__ void linearize(const float *x, const float *u, LaneModel<N, N> &md) const
+    {
+        float grad[N];
+        const float lam = deceleration(x, grad);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            md.lx[i] = 2.0f * (x[i] - goal[i]);
+            md.lu[i] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const float id = (i == j) ? 1.0f : 0.0f;
+                md.fx(i, j) = id + u[i] * grad[j];
+                md.fu(i, j) = lam * id;
+                md.lxx(i, j) = 2.0f * id; md.luu(i, j) = 0.0f; md.lux(i, j) = 0.0f;
+            }
+        }
+        md.l = final_cost(x);
+    }
+    __device__ float final_quad(const float *x, float *lx, Mat<N, N> &lxx) const
+    {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            lx[i] = 2.0f * (x[i] - goal[i]);
+#pragma unroll
+            for (int j = 0; j < N; ++j) lxx(i, j) = (i == j) ? 2.0f : 0.0f;
+        }
+        return final_cost(x);
+    }
+};
+
+// ---- box-QP (tfmpc/utils/optimization.py:6-101) in registers ----------------------------
+template <int M>
+__device__ __forceinline__ float qp_value(const Mat<M, M> &H, const float *q, const float *x)
+{
+    float v = 0.0f;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        float hx = 0.0f;
+#pragma unroll
+        for (int j = 0; j < M; ++j) hx = fmaf(H(i, j), x[j], hx);
+        v += x[i] * (0.5f * hx + q[i]);
+    }
+    return v;
+}
+
+// Solves the free sub-system H_ff y = rhs_f (clamped dimensions become identity rows).
+template <int M, int W>
+__device__ __forceinline__ int solve_free(const Mat<M, M> &H, const bool *fre, const Mat<M, W> &rhs, Mat<M, W> &out)
+{
+    Mat<M, M + W> aug;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) aug(i, j) = (fre[i] && fre[j]) ? H(i, j) : ((i == j) ? 1.0f : 0.0f);
+#pragma unroll
+        for (int j = 0; j < W; ++j) aug(i, M + j) = fre[i] ? rhs(i, j) : 0.0f;
+    }
+    const int bad = small::gauss_jordan<M, W, false>(aug);
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < W; ++j) out(i, j) = aug(i, M + j);
+    return bad;
+}
+
+template <int M>
+__device__ inline int boxqp_lane(const Mat<M, M> &H, const float *q, const float *lo, const float *hi, float *x, bool *fre)
+{
+    const float rtol = 1e-8f, step_dec = 0.6f, min_step = 1e-22f, armijo = 0.1f, eps = 1e-6f;
+    float value = qp_value<M>(H, q, x), old_value = value;
+#pragma unroll
+    for (int i = 0; i < M; ++i) fre[i] = true;
+    for (int it = 0; it < 100; ++it) {
+        if (it > 0 && (old_value - value) < rtol * fabsf(old_value)) return 0;
+        old_value = value;
+        float g[M];
+        int n_free = 0;
+        float gn = 0.0f;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            float gi = q[i];
+#pragma unroll
+            for (int j = 0; j < M; ++j) gi = fmaf(H(i, j), x[j], gi);
+            g[i] = gi;
+            const bool clamped = (fabsf(x[i] - lo[i]) < eps && gi > 0.0f) || (fabsf(hi[i] - x[i]) < eps && gi < 0.0f);
+            fre[i] = !clamped;
+            if (!clamped) { n_free += 1; gn = fmaf(gi, gi, gn); }
+        }
+        Mat<M, 1> gc, sol;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            float s = q[i];
+#pragma unroll
+            for (int j = 0; j < M; ++j) s = fmaf(H(i, j), fre[j] ? 0.0f : x[j], s);
+            gc(i, 0) = s;
+        }
+        if (solve_free<M, 1>(H, fre, gc, sol)) return (it == 0) ? TFMPC_ST_NOT_PD : 0;
+        if (n_free == 0) return 0;
+        if (sqrtf(gn) < eps) return 0;
+        float srch[M], sdotg = 0.0f;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            srch[i] = fre[i] ? (-sol(i, 0) - x[i]) : 0.0f;
+            sdotg = fmaf(srch[i], g[i], sdotg);
+        }
+        if (sdotg >= 0.0f) return 0;
+        float step = 1.0f, xc[M], vc;
+        for (;;) {
+#pragma unroll
+            for (int i = 0; i < M; ++i) xc[i] = fminf(fmaxf(fmaf(step, srch[i], x[i]), lo[i]), hi[i]);
+            vc = qp_value<M>(H, q, xc);
+            if (!((vc - old_value) / (step * sdotg) < armijo)) break;
+            step *= step_dec;
+            if (step < min_step) {
+#pragma unroll
+                for (int i = 0; i < M; ++i) xc[i] = fminf(fmaxf(fmaf(step, srch[i], x[i]), lo[i]), hi[i]);
+                vc = qp_value<M>(H, q, xc);
+                break;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < M; ++i) x[i] = xc[i];
+        value = vc;
+    }
+    return TFMPC_ST_QP_MAXITER;
+}
+
+// ---- the solve ------------------------------------------------------------------------
+struct LaneBackward { float J, dV1, dV2, g_norm; int failed, flags; };
+
+struct SolveArgsLane {
+    int B, T;
+    const float *x0, *u_init;
+    float *states, *actions, *costs;
+    int32_t *iterations, *status;
+    float *wsK, *wsk, *wsx, *wsu, *wsc;
+};
+
+template <int KIND, int N, int M>
+__device__ inline LaneBackward backward_lane(const LaneEnv<KIND, N, M> &env, int T, float mu, bool bounded,
+                                             const float *low, const float *high, const float *xhat,
+                                             const float *uhat, float *Kg, float *kg)
+{
+    LaneBackward r{0.0f, 0.0f, 0.0f, 0.0f, 0, 0};
+    float Vx[N];
+    Mat<N, N> Vxx;
+    {
+        float xT[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) xT[i] = xhat[(size_t)T * N + i];
+        r.J = env.final_quad(xT, Vx, Vxx);                                  // ilqr.py:101-104
+    }
+    float gsum = 0.0f;
+    for (int t = T - 1; t >= 0; --t) {
+        float x[N], u[M];
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = xhat[(size_t)t * N + i];
+#pragma unroll
+        for (int a = 0; a < M; ++a) u[a] = uhat[(size_t)t * M + a];
+        LaneModel<N, M> md;
+        env.linearize(x, u, md);
+        float Qx[N], Qu[M];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {                                       // :122
+            float s = md.lx[i];
+#pragma unroll
+            for (int k = 0; k < N; ++k) s = fmaf(md.fx(k, i), Vx[k], s);
+            Qx[i] = s;
+        }
+#pragma unroll
+        for (int a = 0; a < M; ++a) {                                       // :123
+            float s = md.lu[a];
+#pragma unroll
+            for (int k = 0; k < N; ++k) s = fmaf(md.fu(k, a), Vx[k], s);
+            Qu[a] = s;
+        }
+        const Mat<N, N> W1 = small::mul_tn<N, N, N>(md.fx, Vxx);            // :125
+        const Mat<M, N> W2 = small::mul_tn<N, M, N>(md.fu, Vxx);            // :126
+        bool vxx_nonzero = false;
+#pragma unroll
+        for (int i = 0; i < N * N; ++i) vxx_nonzero = vxx_nonzero || (Vxx.a[i] != 0.0f);
+        Mat<N, N> Qxx;
+        Mat<M, M> Quu, Quur;
+        Mat<M, N> Qux, Quxr;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {                                   // :129
+                float s = md.lxx(i, j);
+#pragma unroll
+                for (int k = 0; k < N; ++k) s = fmaf(W1(i, k), md.fx(k, j), s);
+                Qxx(i, j) = s;
+            }
+#pragma unroll
+        for (int a = 0; a < M; ++a) {
+#pragma unroll
+            for (int c = 0; c < M; ++c) {                                   // :130, :133
+                float s = md.luu(a, c), sr = md.luu(a, c);
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    s = fmaf(W2(a, k), md.fu(k, c), s);
+                    sr = fmaf(fmaf(mu, md.fu(k, a), W2(a, k)), md.fu(k, c), sr);
+                }
+                Quu(a, c) = s; Quur(a, c) = sr;
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {                                   // :131, :134
+                float s = md.lux(a, j), sr = md.lux(a, j);
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    s = fmaf(W2(a, k), md.fx(k, j), s);
+                    sr = fmaf(fmaf(mu, md.fu(k, a), W2(a, k)), md.fx(k, j), sr);
+                }
+                Qux(a, j) = s; Quxr(a, j) = sr;
+            }
+        }
+        Mat<M, N> K;
+        float kk[M];
+        if (!bounded) {                                                     // :357-362
+            Mat<M, M + 1 + N> aug;
+#pragma unroll
+            for (int a = 0; a < M; ++a) {
+#pragma unroll
+                for (int c = 0; c < M; ++c) aug(a, c) = Quur(a, c);
+                aug(a, M) = Qu[a];
+#pragma unroll
+                for (int j = 0; j < N; ++j) aug(a, M + 1 + j) = Quxr(a, j);
+            }
+            if (small::gauss_jordan<M, 1 + N, false>(aug)) { r.failed = 1; return r; }
+#pragma unroll
+            for (int a = 0; a < M; ++a) {
+                kk[a] = -aug(a, M);
+#pragma unroll
+                for (int j = 0; j < N; ++j) K(a, j) = -aug(a, M + 1 + j);
+            }
+        } else if (vxx_nonzero) {                                           // :364-387
+            float lo[M], hi[M];
+            bool fre[M];
+#pragma unroll
+            for (int a = 0; a < M; ++a) {
+                lo[a] = low[a] - u[a]; hi[a] = high[a] - u[a];
+                kk[a] = (lo[a] + hi[a]) / 2;
+            }
+            const int rc = boxqp_lane<M>(Quur, Qu, lo, hi, kk, fre);
+            if (rc == TFMPC_ST_NOT_PD) { r.failed = 1; return r; }
+            r.flags |= rc;
+            Mat<M, N> sol;
+            if (solve_free<M, N>(Quur, fre, Quxr, sol)) { r.failed = 1; return r; }
+#pragma unroll
+            for (int a = 0; a < M; ++a)
+#pragma unroll
+                for (int j = 0; j < N; ++j) K(a, j) = fre[a] ? -sol(a, j) : 0.0f;
+        } else {                                                            // :140-141
+#pragma unroll
+            for (int a = 0; a < M; ++a) {
+                kk[a] = (Qu[a] >= 0.0f) ? (low[a] - u[a]) : (high[a] - u[a]);
+#pragma unroll
+                for (int j = 0; j < N; ++j) K(a, j) = 0.0f;
+            }
+        }
+        Mat<N, M> KtQ;                                                      // :147
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int c = 0; c < M; ++c) {
+                float s = 0.0f;
+#pragma unroll
+                for (int a = 0; a < M; ++a) s = fmaf(K(a, i), Quu(a, c), s);
+                KtQ(i, c) = s;
+            }
+        Mat<N, N> Vn;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {                                       // :149-161
+            float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+            for (int a = 0; a < M; ++a) {
+                s1 = fmaf(Qux(a, i), kk[a], s1);
+                s2 = fmaf(K(a, i), Qu[a], s2);
+                s3 = fmaf(KtQ(i, a), kk[a], s3);
+            }
+            Vx[i] = Qx[i] + s1 + s2 + s3;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+#pragma unroll
+                for (int a = 0; a < M; ++a) {
+                    t1 = fmaf(Qux(a, i), K(a, j), t1);
+                    t2 = fmaf(K(a, i), Qux(a, j), t2);
+                    t3 = fmaf(KtQ(i, a), K(a, j), t3);
+                }
+                Vn(i, j) = Qxx(i, j) + t1 + t2 + t3;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) Vxx(i, j) = 0.5f * (Vn(i, j) + Vn(j, i));   // :162
+        float p1 = 0.0f, p2 = 0.0f, gmax = 0.0f;                            // :164-167, :243
+#pragma unroll
+        for (int a = 0; a < M; ++a) {
+            float quk = 0.0f;
+#pragma unroll
+            for (int c = 0; c < M; ++c) quk = fmaf(Quu(a, c), kk[c], quk);
+            p1 = fmaf(kk[a], Qu[a], p1);
+            p2 = fmaf(kk[a], quk, p2);
+            gmax = fmaxf(gmax, fabsf(kk[a]) / (fabsf(u[a]) + 1.0f));
+            kg[(size_t)t * M + a] = kk[a];
+#pragma unroll
+            for (int j = 0; j < N; ++j) Kg[(size_t)t * M * N + a * N + j] = K(a, j);
+        }
+        r.J += md.l;
+        r.dV1 += p1;
+        r.dV2 += 0.5f * p2;
+        gsum += gmax;
+    }
+    r.g_norm = T > 0 ? gsum / (float)T : 0.0f;
+    return r;
+}
+
+template <int KIND, int N, int M>
+__device__ inline void forward_lane(const LaneEnv<KIND, N, M> &env, int T, float alpha, const float *low,
+                                    const float *high, const float *xhat, const float *uhat, const float *Kg,
+                                    const float *kg, float *states, float *actions, float *costs, float &J_out,
+                                    float &res_out)
+{
+    float x[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { x[i] = xhat[i]; states[i] = x[i]; }
+    float J = 0.0f, resid = 0.0f;
+    for (int t = 0; t < T; ++t) {                                           // ilqr.py:192-206
+        float u[M], xn[N];
+#pragma unroll
+        for (int a = 0; a < M; ++a) {
+            float du = alpha * kg[(size_t)t * M + a];
+#pragma unroll
+            for (int j = 0; j < N; ++j) du = fmaf(Kg[(size_t)t * M * N + a * N + j], x[j] - xhat[(size_t)t * N + j], du);
+            u[a] = fminf(fmaxf(uhat[(size_t)t * M + a] + du, low[a]), high[a]);
+            actions[(size_t)t * M + a] = u[a];
+            resid = fmaxf(resid, fabsf(du));
+        }
+        const float c = env.cost(x, u);
+        env.transition(x, u, xn);
+        J += c;
+        costs[t] = c;
+#pragma unroll
+        for (int i = 0; i < N; ++i) { x[i] = xn[i]; states[(size_t)(t + 1) * N + i] = xn[i]; }
+    }
+    const float fc = env.final_cost(x);
+    costs[T] = fc;
+    J_out = J + fc;
+    res_out = resid;
+}
+
+template <int KIND, int N, int M>
+__global__ __launch_bounds__(64) void ilqr_lane_solve_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, SolveArgsLane a)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    const int T = a.T;
+    LaneEnv<KIND, N, M> env;
+    env.load(genv, b);
+    float low[M], high[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) { low[i] = genv.low[i]; high[i] = genv.high[i]; }
+    const bool bounded = genv.bounded != 0;
+
+    float *xhat = a.states + (size_t)b * (T + 1) * N, *uhat = a.actions + (size_t)b * T * M,
+          *chat = a.costs + (size_t)b * (T + 1);
+    float *Kg = a.wsK + (size_t)b * T * M * N, *kg = a.wsk + (size_t)b * T * M;
+    float *xc = a.wsx + (size_t)b * (T + 1) * N, *uc = a.wsu + (size_t)b * T * M, *cc = a.wsc + (size_t)b * (T + 1);
+
+    {   // start (ilqr.py:218)
+        float x[N], xn[N], u[M];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { x[i] = a.x0[(size_t)b * N + i]; xhat[i] = x[i]; }
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int i = 0; i < M; ++i) { u[i] = a.u_init[((size_t)b * T + t) * M + i]; uhat[(size_t)t * M + i] = u[i]; }
+            chat[t] = env.cost(x, u);
+            env.transition(x, u, xn);
+#pragma unroll
+            for (int i = 0; i < N; ++i) { x[i] = xn[i]; xhat[(size_t)(t + 1) * N + i] = xn[i]; }
+        }
+        chat[T] = env.final_cost(x);
+    }
+
+    float mu = 0.0f, delta = 1.0f;
+    int status = 0, attempts = 0, iteration = 0;
+    bool converged = false, give_up = false;
+    for (iteration = 0; iteration < cfg.max_iterations; ++iteration) {
+        for (;;) {
+            float mu_l = mu, delta_l = delta;
+            LaneBackward r;
+            for (int retry = 0;; ++retry) {                                  // :285-315
+                r = backward_lane<KIND, N, M>(env, T, mu_l, bounded, low, high, xhat, uhat, Kg, kg);
+                status |= r.flags;
+                if (!r.failed) break;
+                status |= TFMPC_ST_NOT_PD;
+                delta_l = fmaxf(cfg.delta_0, delta_l * cfg.delta_0);
+                mu_l = fmaxf(cfg.mu_min, mu_l * delta_l);
+                if (retry >= 40) { give_up = true; break; }
+            }
+            if (give_up) break;
+            if (r.g_norm < cfg.atol) { converged = true; break; }            // :243-248
+            bool accept = false;
+            float residual = 0.0f;
+            for (int ai = 0; ai < cfg.n_alphas; ++ai) {                      // :317-355
+                const float alpha = cfg.alphas[ai];
+                float J;
+                forward_lane<KIND, N, M>(env, T, alpha, low, high, xhat, uhat, Kg, kg, xc, uc, cc, J, residual);
+                const float delta_J = -alpha * (r.dV1 + alpha * r.dV2);
+                const float dcost = r.J - J;
+                const float z = (delta_J > 0.0f) ? dcost / delta_J : sgnf(dcost);
+                if (z >= cfg.c1) { accept = true; break; }
+            }
+            const bool small_step = residual < cfg.atol;                    // :253-257
+            if (small_step || accept) {
+                for (int idx = 0; idx < (T + 1) * N; ++idx) xhat[idx] = xc[idx];
+                for (int idx = 0; idx < T * M; ++idx) uhat[idx] = uc[idx];
+                for (int idx = 0; idx <= T; ++idx) chat[idx] = cc[idx];
+            }
+            if (small_step) { converged = true; break; }
+            if (accept) {                                                    // :259-266
+                delta = fminf(1.0f / cfg.delta_0, delta / cfg.delta_0);
+                mu = (mu * delta > cfg.mu_min) ? mu * delta : 0.0f;
+                break;
+            }
+            delta = fmaxf(cfg.delta_0, delta * cfg.delta_0);                 // :267-270
+            mu = fmaxf(cfg.mu_min, mu * delta);
+            if (++attempts >= cfg.max_attempts || !(mu < 1e30f)) { give_up = true; break; }
+        }
+        if (converged || give_up) break;
+    }
+    if (give_up) status |= TFMPC_ST_MAX_ATTEMPTS;
+    if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
+    const float cT = chat[T];
+    if (!(cT == cT)) status |= TFMPC_ST_NAN;
+    a.iterations[b] = iteration;
+    a.status[b] = status;
+}
+
+bool ilqr_lane_supported(const TfmpcEnv &env)
+{
+    if (env.n != 2 || env.m != 2) return false;
+    if (env.kind == TFMPC_ENV_NAVLQR) return true;
+    if (env.kind == TFMPC_ENV_NAVIGATION) return env.stride[1] == 0 && env.stride[2] == 0 && env.n_zones <= 8;
+    return false;
+}
+
+int ilqr_lane_solve_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, int B, int T, const float *x0,
+                           const float *u_init, float *states, float *actions, float *costs, int32_t *iterations,
+                           int32_t *status, float *wsK, float *wsk, float *wsx, float *wsu, float *wsc,
+                           hipStream_t stream)
+{
+    SolveArgsLane a{B, T, x0, u_init, states, actions, costs, iterations, status, wsK, wsk, wsx, wsu, wsc};
+    const dim3 grid((B + 63) / 64), block(64);
+    if (env.kind == TFMPC_ENV_NAVLQR)
+        hipLaunchKernelGGL((ilqr_lane_solve_kernel<TFMPC_ENV_NAVLQR, 2, 2>), grid, block, 0, stream, env, cfg, a);
+    else if (env.kind == TFMPC_ENV_NAVIGATION)
+        hipLaunchKernelGGL((ilqr_lane_solve_kernel<TFMPC_ENV_NAVIGATION, 2, 2>), grid, block, 0, stream, env, cfg, a);
+    else
+        return TFMPC_ERR_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
+}
+
+}  // namespace tfmpc
