@@ -4,8 +4,11 @@
 // Used by tfmpc_ilqr_solve_f32 for the 2-D navigation envs (BASELINE configs[3]: Navigation,
 // n = m = 2, T = 50, batch 16 384) once the batch is large enough to fill lanes.  Same
 // equations and quirks as the wave-per-instance path (ilqr_core.h); step-local matrices live
-// in registers (small_linalg.h), trajectories and gains in the per-instance HBM slabs.
+// in registers (small_linalg.h); the nominal trajectory and the gains live in the wave's LDS
+// ([slot][lane], bank-conflict free) when the horizon fits (T <= 62), else in HBM slabs.
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "envs.h"
 #include "lqr_kernels.h"
@@ -266,6 +269,39 @@ __device__ inline int boxqp_lane(const Mat<M, M> &H, const float *q, const float
     return TFMPC_ST_QP_MAXITER;
 }
 
+// ---- where a lane keeps its nominal trajectory and gains --------------------------------
+// GlobalStore: the instance's HBM slabs (any horizon).  LdsStore: the wave's LDS, laid out
+// [slot][lane] so the 64 lanes of a wave hit 64 different banks; removes the dependent HBM
+// round trip from every step of the backward sweep and of the up-to-11 rollouts.
+template <int N, int M>
+struct GlobalStore {
+    float *xh, *uh, *Kg, *kg;
+    __device__ float x(int t, int i) const { return xh[(size_t)t * N + i]; }
+    __device__ float u(int t, int a) const { return uh[(size_t)t * M + a]; }
+    __device__ float K(int t, int a, int j) const { return Kg[(size_t)t * M * N + a * N + j]; }
+    __device__ float k(int t, int a) const { return kg[(size_t)t * M + a]; }
+    __device__ void set_x(int t, int i, float v) { xh[(size_t)t * N + i] = v; }
+    __device__ void set_u(int t, int a, float v) { uh[(size_t)t * M + a] = v; }
+    __device__ void set_K(int t, int a, int j, float v) { Kg[(size_t)t * M * N + a * N + j] = v; }
+    __device__ void set_k(int t, int a, float v) { kg[(size_t)t * M + a] = v; }
+};
+
+template <int N, int M>
+struct LdsStore {
+    static constexpr int kPerStep = N + M + M * N + M;      // x, u, K, k of one timestep
+    float *base;                                            // wave's LDS + lane
+    __device__ float &at(int t, int off) const { return base[(t * kPerStep + off) * 64]; }
+    __device__ float x(int t, int i) const { return at(t, i); }
+    __device__ float u(int t, int a) const { return at(t, N + a); }
+    __device__ float K(int t, int a, int j) const { return at(t, N + M + a * N + j); }
+    __device__ float k(int t, int a) const { return at(t, N + M + M * N + a); }
+    __device__ void set_x(int t, int i, float v) { at(t, i) = v; }
+    __device__ void set_u(int t, int a, float v) { at(t, N + a) = v; }
+    __device__ void set_K(int t, int a, int j, float v) { at(t, N + M + a * N + j) = v; }
+    __device__ void set_k(int t, int a, float v) { at(t, N + M + M * N + a) = v; }
+    static size_t bytes(int T) { return (size_t)(T + 1) * kPerStep * 64 * sizeof(float); }
+};
+
 // ---- the solve ------------------------------------------------------------------------
 struct LaneBackward { float J, dV1, dV2, g_norm; int failed, flags; };
 
@@ -277,10 +313,9 @@ struct SolveArgsLane {
     float *wsK, *wsk, *wsx, *wsu, *wsc;
 };
 
-template <int KIND, int N, int M>
+template <int KIND, int N, int M, class Store>
 __device__ inline LaneBackward backward_lane(const LaneEnv<KIND, N, M> &env, int T, float mu, bool bounded,
-                                             const float *low, const float *high, const float *xhat,
-                                             const float *uhat, float *Kg, float *kg)
+                                             const float *low, const float *high, Store &st)
 {
     LaneBackward r{0.0f, 0.0f, 0.0f, 0.0f, 0, 0};
     float Vx[N];
@@ -288,16 +323,16 @@ __device__ inline LaneBackward backward_lane(const LaneEnv<KIND, N, M> &env, int
     {
         float xT[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) xT[i] = xhat[(size_t)T * N + i];
+        for (int i = 0; i < N; ++i) xT[i] = st.x(T, i);
         r.J = env.final_quad(xT, Vx, Vxx);                                  // ilqr.py:101-104
     }
     float gsum = 0.0f;
     for (int t = T - 1; t >= 0; --t) {
         float x[N], u[M];
 #pragma unroll
-        for (int i = 0; i < N; ++i) x[i] = xhat[(size_t)t * N + i];
+        for (int i = 0; i < N; ++i) x[i] = st.x(t, i);
 #pragma unroll
-        for (int a = 0; a < M; ++a) u[a] = uhat[(size_t)t * M + a];
+        for (int a = 0; a < M; ++a) u[a] = st.u(t, a);
         LaneModel<N, M> md;
         env.linearize(x, u, md);
         float Qx[N], Qu[M];
@@ -445,9 +480,9 @@ __device__ inline LaneBackward backward_lane(const LaneEnv<KIND, N, M> &env, int
             p1 = fmaf(kk[a], Qu[a], p1);
             p2 = fmaf(kk[a], quk, p2);
             gmax = fmaxf(gmax, fabsf(kk[a]) / (fabsf(u[a]) + 1.0f));
-            kg[(size_t)t * M + a] = kk[a];
+            st.set_k(t, a, kk[a]);
 #pragma unroll
-            for (int j = 0; j < N; ++j) Kg[(size_t)t * M * N + a * N + j] = K(a, j);
+            for (int j = 0; j < N; ++j) st.set_K(t, a, j, K(a, j));
         }
         r.J += md.l;
         r.dV1 += p1;
@@ -458,24 +493,23 @@ __device__ inline LaneBackward backward_lane(const LaneEnv<KIND, N, M> &env, int
     return r;
 }
 
-template <int KIND, int N, int M>
+template <int KIND, int N, int M, class Store>
 __device__ inline void forward_lane(const LaneEnv<KIND, N, M> &env, int T, float alpha, const float *low,
-                                    const float *high, const float *xhat, const float *uhat, const float *Kg,
-                                    const float *kg, float *states, float *actions, float *costs, float &J_out,
-                                    float &res_out)
+                                    const float *high, const Store &st, float *states, float *actions,
+                                    float *costs, float &J_out, float &res_out)
 {
     float x[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) { x[i] = xhat[i]; states[i] = x[i]; }
+    for (int i = 0; i < N; ++i) { x[i] = st.x(0, i); states[i] = x[i]; }
     float J = 0.0f, resid = 0.0f;
     for (int t = 0; t < T; ++t) {                                           // ilqr.py:192-206
         float u[M], xn[N];
 #pragma unroll
         for (int a = 0; a < M; ++a) {
-            float du = alpha * kg[(size_t)t * M + a];
+            float du = alpha * st.k(t, a);
 #pragma unroll
-            for (int j = 0; j < N; ++j) du = fmaf(Kg[(size_t)t * M * N + a * N + j], x[j] - xhat[(size_t)t * N + j], du);
-            u[a] = fminf(fmaxf(uhat[(size_t)t * M + a] + du, low[a]), high[a]);
+            for (int j = 0; j < N; ++j) du = fmaf(st.K(t, a, j), x[j] - st.x(t, j), du);
+            u[a] = fminf(fmaxf(st.u(t, a) + du, low[a]), high[a]);
             actions[(size_t)t * M + a] = u[a];
             resid = fmaxf(resid, fabsf(du));
         }
@@ -492,9 +526,10 @@ __device__ inline void forward_lane(const LaneEnv<KIND, N, M> &env, int T, float
     res_out = resid;
 }
 
-template <int KIND, int N, int M>
+template <int KIND, int N, int M, bool USE_LDS>
 __global__ __launch_bounds__(64) void ilqr_lane_solve_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, SolveArgsLane a)
 {
+    extern __shared__ float lane_lds[];
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= a.B) return;
     const int T = a.T;
@@ -505,22 +540,25 @@ __global__ __launch_bounds__(64) void ilqr_lane_solve_kernel(TfmpcEnv genv, Tfmp
     for (int i = 0; i < M; ++i) { low[i] = genv.low[i]; high[i] = genv.high[i]; }
     const bool bounded = genv.bounded != 0;
 
-    float *xhat = a.states + (size_t)b * (T + 1) * N, *uhat = a.actions + (size_t)b * T * M,
+    float *xout = a.states + (size_t)b * (T + 1) * N, *uout = a.actions + (size_t)b * T * M,
           *chat = a.costs + (size_t)b * (T + 1);
-    float *Kg = a.wsK + (size_t)b * T * M * N, *kg = a.wsk + (size_t)b * T * M;
     float *xc = a.wsx + (size_t)b * (T + 1) * N, *uc = a.wsu + (size_t)b * T * M, *cc = a.wsc + (size_t)b * (T + 1);
+    using Store = typename std::conditional<USE_LDS, LdsStore<N, M>, GlobalStore<N, M>>::type;
+    Store st;
+    if constexpr (USE_LDS) st.base = lane_lds + threadIdx.x;
+    else { st.xh = xout; st.uh = uout; st.Kg = a.wsK + (size_t)b * T * M * N; st.kg = a.wsk + (size_t)b * T * M; }
 
     {   // start (ilqr.py:218)
         float x[N], xn[N], u[M];
 #pragma unroll
-        for (int i = 0; i < N; ++i) { x[i] = a.x0[(size_t)b * N + i]; xhat[i] = x[i]; }
+        for (int i = 0; i < N; ++i) { x[i] = a.x0[(size_t)b * N + i]; st.set_x(0, i, x[i]); }
         for (int t = 0; t < T; ++t) {
 #pragma unroll
-            for (int i = 0; i < M; ++i) { u[i] = a.u_init[((size_t)b * T + t) * M + i]; uhat[(size_t)t * M + i] = u[i]; }
+            for (int i = 0; i < M; ++i) { u[i] = a.u_init[((size_t)b * T + t) * M + i]; st.set_u(t, i, u[i]); }
             chat[t] = env.cost(x, u);
             env.transition(x, u, xn);
 #pragma unroll
-            for (int i = 0; i < N; ++i) { x[i] = xn[i]; xhat[(size_t)(t + 1) * N + i] = xn[i]; }
+            for (int i = 0; i < N; ++i) { x[i] = xn[i]; st.set_x(t + 1, i, xn[i]); }
         }
         chat[T] = env.final_cost(x);
     }
@@ -533,7 +571,7 @@ __global__ __launch_bounds__(64) void ilqr_lane_solve_kernel(TfmpcEnv genv, Tfmp
             float mu_l = mu, delta_l = delta;
             LaneBackward r;
             for (int retry = 0;; ++retry) {                                  // :285-315
-                r = backward_lane<KIND, N, M>(env, T, mu_l, bounded, low, high, xhat, uhat, Kg, kg);
+                r = backward_lane<KIND, N, M>(env, T, mu_l, bounded, low, high, st);
                 status |= r.flags;
                 if (!r.failed) break;
                 status |= TFMPC_ST_NOT_PD;
@@ -548,7 +586,7 @@ __global__ __launch_bounds__(64) void ilqr_lane_solve_kernel(TfmpcEnv genv, Tfmp
             for (int ai = 0; ai < cfg.n_alphas; ++ai) {                      // :317-355
                 const float alpha = cfg.alphas[ai];
                 float J;
-                forward_lane<KIND, N, M>(env, T, alpha, low, high, xhat, uhat, Kg, kg, xc, uc, cc, J, residual);
+                forward_lane<KIND, N, M>(env, T, alpha, low, high, st, xc, uc, cc, J, residual);
                 const float delta_J = -alpha * (r.dV1 + alpha * r.dV2);
                 const float dcost = r.J - J;
                 const float z = (delta_J > 0.0f) ? dcost / delta_J : sgnf(dcost);
@@ -556,9 +594,15 @@ __global__ __launch_bounds__(64) void ilqr_lane_solve_kernel(TfmpcEnv genv, Tfmp
             }
             const bool small_step = residual < cfg.atol;                    // :253-257
             if (small_step || accept) {
-                for (int idx = 0; idx < (T + 1) * N; ++idx) xhat[idx] = xc[idx];
-                for (int idx = 0; idx < T * M; ++idx) uhat[idx] = uc[idx];
-                for (int idx = 0; idx <= T; ++idx) chat[idx] = cc[idx];
+                for (int t = 0; t <= T; ++t) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) st.set_x(t, i, xc[(size_t)t * N + i]);
+                    chat[t] = cc[t];
+                }
+                for (int t = 0; t < T; ++t) {
+#pragma unroll
+                    for (int i = 0; i < M; ++i) st.set_u(t, i, uc[(size_t)t * M + i]);
+                }
             }
             if (small_step) { converged = true; break; }
             if (accept) {                                                    // :259-266
@@ -574,6 +618,16 @@ __global__ __launch_bounds__(64) void ilqr_lane_solve_kernel(TfmpcEnv genv, Tfmp
     }
     if (give_up) status |= TFMPC_ST_MAX_ATTEMPTS;
     if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
+    if constexpr (USE_LDS) {        // the nominal trajectory leaves LDS once, at the end
+        for (int t = 0; t <= T; ++t) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) xout[(size_t)t * N + i] = st.x(t, i);
+        }
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int i = 0; i < M; ++i) uout[(size_t)t * M + i] = st.u(t, i);
+        }
+    }
     const float cT = chat[T];
     if (!(cT == cT)) status |= TFMPC_ST_NAN;
     a.iterations[b] = iteration;
@@ -595,12 +649,25 @@ int ilqr_lane_solve_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, int 
 {
     SolveArgsLane a{B, T, x0, u_init, states, actions, costs, iterations, status, wsK, wsk, wsx, wsu, wsc};
     const dim3 grid((B + 63) / 64), block(64);
-    if (env.kind == TFMPC_ENV_NAVLQR)
-        hipLaunchKernelGGL((ilqr_lane_solve_kernel<TFMPC_ENV_NAVLQR, 2, 2>), grid, block, 0, stream, env, cfg, a);
-    else if (env.kind == TFMPC_ENV_NAVIGATION)
-        hipLaunchKernelGGL((ilqr_lane_solve_kernel<TFMPC_ENV_NAVIGATION, 2, 2>), grid, block, 0, stream, env, cfg, a);
-    else
+    const size_t lds = LdsStore<2, 2>::bytes(T);
+    const bool use_lds = lds <= kMaxLdsBytes;          // T <= 62 at n = m = 2; else HBM slabs
+#define TFMPC_LANE_LAUNCH(KIND_, USE_)                                                                   \
+    do {                                                                                                 \
+        auto kern = ilqr_lane_solve_kernel<KIND_, 2, 2, USE_>;                                           \
+        if (USE_ && lds > 64 * 1024 &&                                                                   \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)     \
+            return TFMPC_ERR_LAUNCH;                                                                     \
+        hipLaunchKernelGGL(kern, grid, block, USE_ ? lds : 0, stream, env, cfg, a);                      \
+    } while (0)
+    if (env.kind == TFMPC_ENV_NAVLQR) {
+        if (use_lds) TFMPC_LANE_LAUNCH(TFMPC_ENV_NAVLQR, true); else TFMPC_LANE_LAUNCH(TFMPC_ENV_NAVLQR, false);
+    } else if (env.kind == TFMPC_ENV_NAVIGATION) {
+        if (use_lds) TFMPC_LANE_LAUNCH(TFMPC_ENV_NAVIGATION, true); else TFMPC_LANE_LAUNCH(TFMPC_ENV_NAVIGATION, false);
+    } else {
         return TFMPC_ERR_UNSUPPORTED;
+    }
+#undef TFMPC_LANE_LAUNCH
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
 }
 
