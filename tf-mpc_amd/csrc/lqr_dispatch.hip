@@ -58,7 +58,7 @@ const char *tfmpc_lqr_kernel_name(int n, int m, int T)
 {
     (void)T;
     if (n <= 0 || m <= 0) return "invalid";
-    if (want_mfma(n, m)) return "mfma_16x8";
+    if (want_mfma(n, m)) return (n == 16 && m == 8) ? "mfma_16x8" : "mfma_16x8 (zero-padded)";
     if (lqr_lane_supported(n, m)) return "lane (batch >= 32) / generic_wave";
     if (lqr_generic_smem_bytes(n, m) > kMaxLdsBytes) return "unsupported";
     return "generic_wave";

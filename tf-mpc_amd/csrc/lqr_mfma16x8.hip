@@ -1,5 +1,6 @@
 // lqr_mfma16x8.hip -- LQR backward + forward for the BASELINE.json headline shape
-// (state_dim n = 16, action_dim m = 8, any horizon) on gfx950 matrix cores.
+// (state_dim n = 16, action_dim m = 8, any horizon) on gfx950 matrix cores; smaller shapes
+// (n <= 16, m <= 8) run through the same kernel zero-padded to 16 x 8 (EXACT = false).
 //
 // Replaces tfmpc/solvers/lqr.py:59-166 of the reference for that shape.  One
 // wavefront owns one problem instance for the whole solve.
@@ -67,7 +68,11 @@ constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
 constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
 constexpr int kDppHalfMirror = 0x141; // lane i <-> 7 - i inside each 8-lane half row
 
-template <bool BACKWARD, bool FORWARD, bool VALUE>
+// EXACT: n == 16 and m == 8 (no guards, vector gain stores).  Otherwise the instance is
+// embedded in the 16 x 8 tile grid: states n..15 and actions m..7 are zero rows/columns of
+// F~ and C~, with a unit diagonal on the padded part of C_uu so the elimination stays regular
+// (the padded gains come out exactly 0).
+template <bool BACKWARD, bool FORWARD, bool VALUE, bool EXACT>
 __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
@@ -75,6 +80,17 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
     const int lane = threadIdx.x;
     const int i = lane & 15, q = lane >> 4;
     const int T = a.T;
+    const int n = EXACT ? N : a.n, m = EXACT ? M : a.m, d = n + m;
+    // padded-index accessors: x index xi in [0,16), u index ui in [0,8)
+    auto Fxx = [&](const float *Fg, int row, int xi) { return (row < n && xi < n) ? Fg[row * d + xi] : 0.0f; };
+    auto Fxu = [&](const float *Fg, int row, int ui) { return (row < n && ui < m) ? Fg[row * d + n + ui] : 0.0f; };
+    // z index zi in [0,24): 0..15 -> x, 16..23 -> u; returns the real row/col of C, c or -1
+    auto zmap = [&](int zi) { return zi < N ? (zi < n ? zi : -1) : (zi - N < m ? n + zi - N : -1); };
+    auto Czz = [&](const float *Cg, int zr, int zc) {
+        const int r = zmap(zr), c_ = zmap(zc);
+        return (r >= 0 && c_ >= 0) ? Cg[r * d + c_] : 0.0f;
+    };
+    auto cz = [&](const float *cg, int zr) { const int r = zmap(zr); return r >= 0 ? cg[r] : 0.0f; };
     const float *Fg = a.F + (size_t)b * a.sF;
     const float *fg = a.f + (size_t)b * a.sf;
     const float *Cg = a.C + (size_t)b * a.sC;
@@ -90,15 +106,30 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
         f32x4 vterm;                     // c_x in lanes i == 8 (terminal v)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int k = 4 * q + r;
-            Fb0[r] = Fg[k * D + i];
-            Fb1[r] = (i < M) ? Fg[k * D + N + i] : ((i == M) ? fg[k] : 0.0f);
-            Cd00[r] = Cg[k * D + i];
-            Cd01t[r] = (k < M) ? Cg[i * D + N + k] : ((k == M) ? cg[i] : 0.0f);      // C~[i][16+k]
-            vterm[r] = (i == M) ? cg[k] : 0.0f;
-            const int ku = N + k;        // rows 16..31; only 16..23 exist
-            Cd10[r] = (ku < D) ? Cg[ku * D + i] : 0.0f;
-            Cd11[r] = (ku < D) ? ((i < M) ? Cg[ku * D + N + i] : ((i == M) ? cg[ku] : 0.0f)) : 0.0f;
+            const int k = 4 * q + r;         // state row of F~ / row of the x-part of C~
+            const int ku = N + k;            // z index of the u-part rows (16..31; 16..23 exist)
+            if (EXACT) {
+                Fb0[r] = Fg[k * D + i];
+                Fb1[r] = (i < M) ? Fg[k * D + N + i] : ((i == M) ? fg[k] : 0.0f);
+                Cd00[r] = Cg[k * D + i];
+                Cd01t[r] = (k < M) ? Cg[i * D + N + k] : ((k == M) ? cg[i] : 0.0f);      // C~[i][16+k]
+                vterm[r] = (i == M) ? cg[k] : 0.0f;
+                Cd10[r] = (ku < D) ? Cg[ku * D + i] : 0.0f;
+                Cd11[r] = (ku < D) ? ((i < M) ? Cg[ku * D + N + i] : ((i == M) ? cg[ku] : 0.0f)) : 0.0f;
+            } else {
+                Fb0[r] = Fxx(Fg, k, i);
+                Fb1[r] = (i < M) ? Fxu(Fg, k, i) : ((i == M && k < n) ? fg[k] : 0.0f);
+                Cd00[r] = Czz(Cg, k, i);
+                Cd01t[r] = (k < M) ? Czz(Cg, i, N + k) : ((k == M) ? cz(cg, i) : 0.0f);
+                vterm[r] = (i == M) ? cz(cg, k) : 0.0f;
+                Cd10[r] = (ku < D) ? Czz(Cg, ku, i) : 0.0f;
+                float c11 = 0.0f;
+                if (ku < D) {
+                    if (i < M) c11 = (k >= m && i == k) ? 1.0f : Czz(Cg, ku, N + i);   // unit diagonal on padded actions
+                    else if (i == M) c11 = cz(cg, ku);
+                }
+                Cd11[r] = c11;
+            }
         }
         // terminal value function V = C_xx, v = c_x (lqr.py:67-68): v lives in lanes i == 8
         f32x4 Vd = Cd00, vd = vterm;
@@ -212,22 +243,30 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
                 float2 kv;
                 kv.x = lds[kKs + (2 * jc) * 8 + ka];
                 kv.y = lds[kKs + (2 * jc + 1) * 8 + ka];
-                *reinterpret_cast<float2 *>(&Kg[(size_t)t * (M * N) + 2 * lane]) = kv;
-                if (lane < M) kg[(size_t)t * M + lane] = lds[kKs + 24 * 8 + lane];
+                if (EXACT) {
+                    *reinterpret_cast<float2 *>(&Kg[(size_t)t * (M * N) + 2 * lane]) = kv;
+                    if (lane < M) kg[(size_t)t * M + lane] = lds[kKs + 24 * 8 + lane];
+                } else {
+                    if (ka < m && 2 * jc < n) Kg[(size_t)t * m * n + ka * n + 2 * jc] = kv.x;
+                    if (ka < m && 2 * jc + 1 < n) Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] = kv.y;
+                    if (lane < m) kg[(size_t)t * m + lane] = lds[kKs + 24 * 8 + lane];
+                }
             }
             if (VALUE) {
                 // const += 1/2 k^T Q_uu k + k^T q_u + 1/2 f^T V f + f^T v with Q_uu k = -q_u
                 // (lqr.py:113-121); f^T(V f) and f^T v were taken before v entered W.
                 cst += 0.5f * quk + 0.5f * fw + fv;
                 if (a.V) {
-                    float *Vo = a.V + ((size_t)b * T + t) * (N * N);
+                    float *Vo = a.V + ((size_t)b * T + t) * (n * n);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Vo[(4 * q + r) * N + i] = Vd[r];
+                    for (int r = 0; r < 4; ++r)
+                        if (EXACT || (4 * q + r < n && i < n)) Vo[(4 * q + r) * n + i] = Vd[r];
                 }
                 if (a.v && i == M) {
-                    float *vo = a.v + ((size_t)b * T + t) * N;
+                    float *vo = a.v + ((size_t)b * T + t) * n;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) vo[4 * q + r] = vd[r];
+                    for (int r = 0; r < 4; ++r)
+                        if (EXACT || 4 * q + r < n) vo[4 * q + r] = vd[r];
                 }
                 if (a.cst && lane == 0) a.cst[(size_t)b * T + t] = cst;
             }
@@ -242,41 +281,61 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
         const int fi = lane >> 2, fc = lane & 3;       // F: row fi, columns 6fc..6fc+5
         const int ka = lane >> 3, jc = lane & 7;       // K: row ka, columns 2jc, 2jc+1
         float Fr[6];
-        {
+        if (EXACT) {
             const float2 *p = reinterpret_cast<const float2 *>(Fg + fi * D + 6 * fc);
 #pragma unroll
             for (int j = 0; j < 3; ++j) { const float2 v = p[j]; Fr[2 * j] = v.x; Fr[2 * j + 1] = v.y; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int zc = 6 * fc + j;
+                Fr[j] = zc < N ? Fxx(Fg, fi, zc) : Fxu(Fg, fi, zc - N);
+            }
         }
-        const float f_i = fg[fi];
+        const float f_i = (EXACT || fi < n) ? fg[fi] : 0.0f;
         // cost post-pass operands: A = C (2 row tiles x 6 k-steps, k = 4s + q), c in D layout
         float Ca0[6], Ca1[6];
         f32x4 cq0, cq1;
 #pragma unroll
         for (int s2 = 0; s2 < 6; ++s2) {
-            Ca0[s2] = Cg[i * D + 4 * s2 + q];
-            Ca1[s2] = (i < M) ? Cg[(N + i) * D + 4 * s2 + q] : 0.0f;
+            if (EXACT) {
+                Ca0[s2] = Cg[i * D + 4 * s2 + q];
+                Ca1[s2] = (i < M) ? Cg[(N + i) * D + 4 * s2 + q] : 0.0f;
+            } else {
+                Ca0[s2] = Czz(Cg, i, 4 * s2 + q);
+                Ca1[s2] = (i < M) ? Czz(Cg, N + i, 4 * s2 + q) : 0.0f;
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            cq0[r] = cg[4 * q + r];
-            cq1[r] = (q < 2) ? cg[N + 4 * q + r] : 0.0f;
+            cq0[r] = EXACT ? cg[4 * q + r] : cz(cg, 4 * q + r);
+            cq1[r] = (q < 2) ? (EXACT ? cg[N + 4 * q + r] : cz(cg, N + 4 * q + r)) : 0.0f;
         }
-        float *xs = a.states + (size_t)b * (T + 1) * N;
-        float *us = a.actions + (size_t)b * T * M;
+        float *xs = a.states + (size_t)b * (T + 1) * n;
+        float *us = a.actions + (size_t)b * T * m;
         float *cs = a.costs + (size_t)b * (T + 1);
         float *zs = &lds[kZs];
         __syncthreads();                               // gains written above are visible
         if (lane < N) {
-            const float x = a.x0[(size_t)b * N + lane];
+            const float x = (EXACT || lane < n) ? a.x0[(size_t)b * n + lane] : 0.0f;
             zs[lane] = x;
-            xs[lane] = x;
+            if (EXACT || lane < n) xs[lane] = x;
         }
+        // gains of step t for this lane: K[ka][2jc], K[ka][2jc+1], k[ka]
+        auto load_gain = [&](int t, float2 &Kv, float &kv) {
+            if (EXACT) {
+                Kv = *reinterpret_cast<const float2 *>(&Kg[(size_t)t * (M * N) + 2 * lane]);
+                kv = kg[(size_t)t * M + ka];
+            } else {
+                const bool row = ka < m;
+                Kv.x = (row && 2 * jc < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc] : 0.0f;
+                Kv.y = (row && 2 * jc + 1 < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] : 0.0f;
+                kv = row ? kg[(size_t)t * m + ka] : 0.0f;
+            }
+        };
         float2 Kn = {0.f, 0.f};
         float kn = 0.0f;
-        if (T > 0) {
-            Kn = *reinterpret_cast<const float2 *>(&Kg[2 * lane]);
-            kn = kg[ka];
-        }
+        if (T > 0) load_gain(0, Kn, kn);
         __syncthreads();
 
         // costs of rows [0, rows) of the chunk buffer: 1/2 z^T C z + c^T z  (lqr.py:41-47)
@@ -311,10 +370,7 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
                 float *zt = zs + tt * kZld;
                 const float2 Kc = Kn;
                 const float kc = kn;
-                if (t + 1 < T) {                       // prefetch the next step's gains
-                    Kn = *reinterpret_cast<const float2 *>(&Kg[(size_t)(t + 1) * (M * N) + 2 * lane]);
-                    kn = kg[(size_t)(t + 1) * M + ka];
-                }
+                if (t + 1 < T) load_gain(t + 1, Kn, kn);      // prefetch the next step's gains
                 // u = K x + k                                              lqr.py:143
                 const float2 xv = *reinterpret_cast<const float2 *>(&zt[2 * jc]);
                 float u = fmaf(Kc.x, xv.x, Kc.y * xv.y);
@@ -341,10 +397,17 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
             }
             // chunk epilogue: stage costs on the matrix cores, bulk coalesced stores
             chunk_costs(tc, cs + t0);
-            for (int idx = lane; idx < tc * N; idx += kWave)
-                xs[(size_t)(t0 + 1) * N + idx] = zs[(1 + idx / N) * kZld + (idx & (N - 1))];
-            for (int idx = lane; idx < tc * M; idx += kWave)
-                us[(size_t)t0 * M + idx] = zs[(idx / M) * kZld + N + (idx & (M - 1))];
+            if (EXACT) {
+                for (int idx = lane; idx < tc * N; idx += kWave)
+                    xs[(size_t)(t0 + 1) * N + idx] = zs[(1 + idx / N) * kZld + (idx & (N - 1))];
+                for (int idx = lane; idx < tc * M; idx += kWave)
+                    us[(size_t)t0 * M + idx] = zs[(idx / M) * kZld + N + (idx & (M - 1))];
+            } else {
+                for (int idx = lane; idx < tc * n; idx += kWave)
+                    xs[(size_t)(t0 + 1) * n + idx] = zs[(1 + idx / n) * kZld + idx % n];
+                for (int idx = lane; idx < tc * m; idx += kWave)
+                    us[(size_t)t0 * m + idx] = zs[(idx / m) * kZld + N + idx % m];
+            }
             __syncthreads();
             if (lane < N) zs[lane] = zs[tc * kZld + lane];      // carry x into row 0 of the next chunk
             __syncthreads();
@@ -366,13 +429,18 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
 template <bool BW, bool FW, bool VAL>
 int launch(const LqrArgs &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL>), dim3(a.B), dim3(kWave), 0, stream, a);
+    if (a.n == N && a.m == M)
+        hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, true>), dim3(a.B), dim3(kWave), 0, stream, a);
+    else
+        hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, false>), dim3(a.B), dim3(kWave), 0, stream, a);
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
 }
 
 }  // namespace
 
-bool lqr_mfma_supported(int n, int m) { return n == N && m == M; }
+// Exact headline shape, or any smaller shape that is still worth a 16 x 8 tile grid (below
+// n + m = 7 the lane-per-instance kernel of lqr_lane.hip takes over).
+bool lqr_mfma_supported(int n, int m) { return n >= 1 && m >= 1 && n <= N && m <= M && n + m > 6; }
 
 int lqr_mfma_launch(const LqrArgs &a, bool backward, bool forward, hipStream_t stream)
 {
