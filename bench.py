@@ -98,6 +98,50 @@ def cpu_baseline(n, m, T, target_seconds=12.0):
             "host_cpus": cores}
 
 
+def dry_run_cpu(args):
+    """Same rank bookkeeping as the real run, gloo instead of RCCL, sleep instead of kernels.
+    The printed line is marked invalid on purpose: it measures nothing."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tfmpc.parallel import gather_trajectories
+    B, n, m, T = 64 + rank, 4, 2, 5            # uneven shards on purpose
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (1 + rank))         # rank 1 is slower: MAX over ranks must pick it up
+    fence()
+    elapsed = time.perf_counter() - t0
+    states = torch.full((B, T + 1, n, 1), float(rank))
+    gathered = gather_trajectories(states, torch.zeros(B, T, m, 1), torch.zeros(B, T + 1)) if world > 1 else None
+    total = torch.tensor([float(B)])
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        dist.all_reduce(total)
+    if rank == 0:
+        line = {"metric": "DRY RUN (no GPU work)", "value": float(total.item()) * args.steps / elapsed, "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "valid": False,
+                "total_instances": int(total.item())}
+        if gathered is not None:
+            line["gathered_states_shape"] = list(gathered[0].shape)
+            line["gathered_rank_of_last_instance"] = float(gathered[0][-1, 0, 0, 0])
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,7 +149,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="instances per GPU (default = BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="TEST ONLY: no GPU work; a fixed-sleep stand-in step drives the multi-rank control flow "
+                         "(barriers, MAX over ranks, the final gather) over gloo so it can be tested without GPUs")
     args = ap.parse_args()
+    if args.dry_run_cpu:
+        return dry_run_cpu(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -161,7 +210,12 @@ def main():
     status_bad = int((out["status"] != 0).sum())
     # the one collective of the path: gather the result trajectories on rank 0 (outside
     # the timed region: it happens once per job, not per step)
-    gathered = gather_trajectories(out["states"], out["actions"], out["costs"]) if world > 1 else None
+    gathered, gather_error = None, None
+    if world > 1:
+        try:
+            gathered = gather_trajectories(out["states"], out["actions"], out["costs"])
+        except Exception as exc:        # the collective is outside the timed region: report, do not lose the line
+            gather_error = repr(exc)
 
     if world > 1:
         tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
@@ -197,6 +251,8 @@ def main():
         }
         if gathered is not None:
             line["gathered_states_shape"] = list(gathered[0].shape)
+        if gather_error is not None:
+            line["gather_error"] = gather_error
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, m, T)
         print(json.dumps(line), flush=True)
