@@ -40,8 +40,10 @@ def test_library_exports_every_declared_symbol():
 def test_kernel_choice_and_workspace_queries():
     lib = _hip.load()
     assert lib.tfmpc_version() >= 100
-    assert lib.tfmpc_lqr_kernel_name(3, 2, 10) == b"generic_wave"
+    assert lib.tfmpc_lqr_kernel_name(3, 2, 10).startswith(b"lane")      # tiny: lane-per-instance (big batches)
     assert lib.tfmpc_lqr_kernel_name(16, 8, 50) == b"mfma_16x8"        # BASELINE headline shape
+    assert lib.tfmpc_lqr_kernel_name(12, 6, 50).startswith(b"mfma_16x8")   # zero-padded into the same tiles
+    assert lib.tfmpc_lqr_kernel_name(32, 32, 10) == b"generic_wave"
     assert lib.tfmpc_lqr_kernel_name(200, 200, 10) == b"unsupported"
     assert lib.tfmpc_lqr_workspace_bytes(4, 16, 8, 50) == 4 * 50 * 8 * 17 * 4
 
