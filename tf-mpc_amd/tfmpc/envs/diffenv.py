@@ -125,10 +125,14 @@ class DiffEnv:
 
     # -- reference protocol ----------------------------------------------------------
     def transition(self, state, action, batch=False, cec=True):
-        if not cec:
-            raise NotImplementedError("stochastic stepping (cec=False) is outside the hot path (SURVEY.md N1)")
         nxt, _, batched = self._step(state, action)
         nxt = nxt.unsqueeze(-1)
+        if not cec:        # stochastic dynamics: deterministic kernel + the env's noise model (gymenv.py)
+            if not hasattr(self, "_noise"):
+                raise NotImplementedError(f"{type(self).__name__} has no stochastic dynamics")
+            if getattr(self, "_generator", None) is None:
+                self.seed(None)
+            nxt = nxt + self._noise(nxt)
         return nxt if batched else nxt[0]
 
     def cost(self, state, action, batch=False):

@@ -7,16 +7,20 @@ import numpy as np
 
 from tfmpc import _hip
 from tfmpc.envs.diffenv import Box, DiffEnv
+from tfmpc.envs.gymenv import GymEnv
 
 
 def _np(a):
     return np.asarray(a.cpu() if hasattr(a, "cpu") else a, dtype=np.float32)
 
 
-class Navigation(DiffEnv):
+class Navigation(DiffEnv, GymEnv):
     kind = _hip.ENV_NAVIGATION
 
+    NOISE_STDDEV = 0.2      # tf.random.truncated_normal(stddev=0.2), navigation/__init__.py:45
+
     def __init__(self, goal, deceleration, low, high):
+        self._gym_init()
         goal = _np(goal)
         if goal.shape[-1] != 1:
             goal = goal[..., None]
@@ -40,6 +44,14 @@ class Navigation(DiffEnv):
 
     def _params(self):
         return [(self.goal[..., 0], 1), (self.deceleration["center"][..., 0], 2), (self.deceleration["decay"], 1)]
+
+    def _noise(self, state):
+        import torch
+        eps = torch.empty_like(state)
+        # TF's truncated normal re-draws samples beyond two standard deviations
+        torch.nn.init.trunc_normal_(eps, mean=0.0, std=self.NOISE_STDDEV, a=-2 * self.NOISE_STDDEV,
+                                    b=2 * self.NOISE_STDDEV, generator=self._generator)
+        return eps
 
     @classmethod
     def load(cls, config):

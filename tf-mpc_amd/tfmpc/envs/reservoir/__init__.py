@@ -7,17 +7,19 @@ import numpy as np
 
 from tfmpc import _hip
 from tfmpc.envs.diffenv import Box, DiffEnv
+from tfmpc.envs.gymenv import GymEnv
 
 
 def _np(a):
     return np.asarray(a.cpu() if hasattr(a, "cpu") else a, dtype=np.float32)
 
 
-class Reservoir(DiffEnv):
+class Reservoir(DiffEnv, GymEnv):
     kind = _hip.ENV_RESERVOIR
 
     def __init__(self, max_res_cap, lower_bound, upper_bound, low_penalty, high_penalty, set_point_penalty,
                  downstream, rain_shape, rain_scale):
+        self._gym_init()
         col = lambda a: _np(a).reshape(-1, 1)
         self.max_res_cap = col(max_res_cap)
         self.lower_bound, self.upper_bound = col(lower_bound), col(upper_bound)
@@ -42,6 +44,21 @@ class Reservoir(DiffEnv):
         vec = lambda a: (a[:, 0], 1)
         return [vec(self.max_res_cap), vec(self.lower_bound), vec(self.upper_bound), vec(self.low_penalty),
                 vec(self.high_penalty), vec(self.set_point_penalty), vec(rain), (self.downstream, 2)]
+
+    def _noise(self, state):
+        # cec=False replaces the mean rainfall shape*scale by a Gamma(shape, rate=1/scale) draw
+        # (reservoir/__init__.py:101-104); the kernel applied the mean, so add (sample - mean)
+        import torch
+        dev = state.device
+        shape = torch.as_tensor(self.rain_shape, device=dev).expand_as(state)
+        scale = torch.as_tensor(self.rain_scale, device=dev).expand_as(state)
+        # torch's gamma sampler takes no generator: derive a seed from the env's generator and
+        # draw inside a forked RNG scope so the global stream is left untouched
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,), generator=self._generator, device=dev).item())
+        with torch.random.fork_rng(devices=[dev] if dev.type == "cuda" else []):
+            torch.manual_seed(seed)
+            sample = torch._standard_gamma(shape) * scale
+        return sample - shape * scale
 
     @classmethod
     def load(cls, config):
