@@ -116,7 +116,9 @@ int tfmpc_lqr_solve_f32(int B, int n, int m, int T,
  * low[m] / high[m]: action bounds (+-inf allowed, shared by the batch); `bounded`
  * is gym's Box.is_bounded(): every bound finite (ilqr.py:136). */
 typedef struct TfmpcEnv {
-    int32_t kind, n, m, n_zones, bounded, reserved0, reserved1, reserved2;
+    int32_t kind, n, m, n_zones, bounded;
+    int32_t any_finite_bound;   /* 1 if any entry of low/high is finite (forward clips, ilqr.py:197) */
+    int32_t reserved1, reserved2;
     const float *low, *high;
     const float *p[TFMPC_ENV_MAX_PARAMS];
     int64_t stride[TFMPC_ENV_MAX_PARAMS];

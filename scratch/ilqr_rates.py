@@ -45,3 +45,8 @@ for kind in ("hvac", "reservoir"):
         env = Reservoir.load(dict(problems.reservoir_config(n, seed=5))); x0 = rng.uniform(50, 75, size=(B, n, 1)).astype(np.float32)
     s = iLQR(env, max_iterations=12); u0 = s.random_actions(T, B, seed=5)
     run(f"cfg5 {kind} n=32", s, x0, T, u0, reps=1)
+# headline shape through the iLQR API on the matrix cores, full batch
+Fb, fb, Cb, cb, xb = problems.make_lqr_batch_fast(65536, 16, 8, seed=1)
+Fb *= 0.25
+s = iLQR(LQEnv(Fb, fb, Cb, cb)); u0 = torch.zeros(65536, 50, 8, 1, device="cuda")
+run("iLQR API, LQ env n=16 m=8 (matrix cores)", s, xb[..., None].astype(np.float32), 50, u0, reps=5)

@@ -195,12 +195,22 @@ def test_fused_solve_matches_golden_and_host_driven_loop(golden, case):
     solver = iLQR(env)
     T = int(G("T"))
     x0, u0 = G("x0")[:, None], G("u_init")[..., None]
-    traj, iteration = solver.solve(x0, T, show_progress=False, u_init=u0)
+    # (a) the fused WAVE kernel == the reference's loop driven over the single kernels, bit for bit
+    # (the LQ env would otherwise take the matrix-core solve kernel, which rounds differently)
+    import os
+    old_force = os.environ.get("TFMPC_ILQR_KERNEL")
+    os.environ["TFMPC_ILQR_KERNEL"] = "wave"
+    try:
+        traj, iteration = solver.solve(x0, T, show_progress=False, u_init=u0)
+    finally:
+        os.environ.pop("TFMPC_ILQR_KERNEL") if old_force is None else os.environ.__setitem__("TFMPC_ILQR_KERNEL", old_force)
     assert int(solver.last_status[0]) & ~_hip.ST_QP_MAXITER == 0
-    # (a) fused kernel == the reference's loop driven over the single kernels, bit for bit
     xh, uh, ch, it_h = _host_driven_solve(solver, x0, T, u0)
     assert iteration == it_h
     assert np.array_equal(traj.states, xh[..., 0].cpu().numpy()) and np.array_equal(traj.costs, ch.cpu().numpy())
+    # default dispatch (matrix cores for lq16x8) is what (b) checks against the oracle
+    traj, iteration = solver.solve(x0, T, show_progress=False, u_init=u0)
+    assert int(solver.last_status[0]) & ~_hip.ST_QP_MAXITER == 0
     # (b) vs the oracle.  On the smooth LQ-type problems: same iteration count and the same
     # trajectory to fp32 accuracy.  On the nonlinear / piecewise-linear envs the 11-point line
     # search takes DISCRETE decisions that flip between fp32 and fp64 (the fp32 CPU restatement

@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "ilqr_core.h"
+#include "ilqr_lq_mfma.h"
 #include "lqr_kernels.h"
 
 namespace tfmpc {
@@ -180,6 +181,7 @@ struct SolveArgs {
     float *states, *actions, *costs;
     int32_t *iterations, *status;
     float *wsK, *wsk, *wsx, *wsu, *wsc;     // per-instance scratch: gains and the candidate trajectory
+    int only_flagged;                       // second-chance launch: solve only instances with kIlqrRetryBit set
 };
 
 // iLQR.solve (ilqr.py:214-283): the whole iteration loop of one instance in one wave.
@@ -188,6 +190,7 @@ __global__ __launch_bounds__(kWave) void ilqr_solve_kernel(TfmpcEnv env, TfmpcIl
 {
     extern __shared__ float smem[];
     const int b = blockIdx.x, n = env.n, m = env.m, T = a.T, lane = lane_id();
+    if (a.only_flagged && !(a.status[b] & kIlqrRetryBit)) return;      // wave-uniform
     constexpr bool kAdjoint = Env<KIND>::kPiecewiseLinearCost;   // HVAC / Reservoir: V_xx == 0 always
     IlqrSmem s;
     float *p = kAdjoint ? ilqr_carve_adjoint(s, smem, n, m) : ilqr_carve(s, smem, n, m);
@@ -468,6 +471,17 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
         if (ilqr_lane_supported(*env) && !forced_wave && (forced_lane || B >= 32))
             return ilqr_lane_solve_launch(*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status,
                                           a.wsK, a.wsk, a.wsx, a.wsu, a.wsc, st);
+    }
+    {
+        // LQ env on the matrix cores (ilqr_lq_mfma.hip); instances it cannot finish (mu > 0 needed)
+        // come back flagged and are re-solved from scratch by the wave kernel right behind it
+        const char *force = std::getenv("TFMPC_ILQR_KERNEL");
+        const bool forced_wave = force && std::strcmp(force, "wave") == 0;
+        if (!forced_wave && ilqr_lq_mfma_supported(*env, T)) {
+            IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk};
+            if ((rc = ilqr_lq_mfma_launch(la, st)) != TFMPC_OK) return rc;
+            a.only_flagged = 1;
+        }
     }
     const size_t smem = ilqr_solve_smem_bytes(env->kind, n, m, env->n_zones);
     TFMPC_DISPATCH_KIND(env->kind, {

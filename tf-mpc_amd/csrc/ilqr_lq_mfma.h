@@ -1,0 +1,31 @@
+// ilqr_lq_mfma.h -- launch interface of the matrix-core iLQR solve for the LQ env
+// (ilqr_lq_mfma.hip).  Internal; the public contract is include/tfmpc_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tfmpc_hip.h"
+
+namespace tfmpc {
+
+// Internal status bit: "this instance needs the generic wave kernel" (non-PD Q_uu or a fully
+// rejected line search, i.e. regularisation mu > 0).  Cleared by the second-chance launch and
+// never visible to the caller.
+constexpr int kIlqrRetryBit = 0x4000;
+
+struct IlqrLqArgs {
+    TfmpcEnv env;
+    TfmpcIlqrConfig cfg;
+    int B, T;
+    const float *x0, *u_init;
+    float *states, *actions, *costs;
+    int32_t *iterations, *status;
+    float *wsK, *wsk;
+};
+
+size_t ilqr_lq_mfma_lds_bytes(int T);
+bool ilqr_lq_mfma_supported(const TfmpcEnv &env, int T);
+int ilqr_lq_mfma_launch(const IlqrLqArgs &a, hipStream_t stream);
+
+}  // namespace tfmpc

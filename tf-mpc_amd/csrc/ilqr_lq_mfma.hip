@@ -1,0 +1,418 @@
+// ilqr_lq_mfma.hip -- iLQR.solve (tfmpc/solvers/ilqr.py:214-355) on the matrix cores for the
+// time-invariant LQ env (ENV_LQ: x' = F z + f, cost 1/2 z^T C z + c^T z -- tfmpc/solvers/lqr.py
+// :36-57 seen through the DiffEnv protocol) with unbounded actions, n <= 16, m <= 8: the
+// BASELINE.json headline shape driven through the iLQR API instead of LQR.solve.
+//
+// One wavefront = one instance for its whole iteration loop.  With mu = 0 the regularised
+// backward pass of ilqr.py:94-172 is the Riccati recursion of lqr_mfma16x8.hip with the affine
+// column carrying (l_z(t) + F^T V_x) instead of (c + F^T(V f + v)); K = -Q_uu^-1 Q_ux makes the
+// four-term updates collapse to V_xx' = Q_xx + Q_xu K, V_x' = Q_x + Q_xu k and dV2 = -dV1/2.
+// So per timestep: 28 MFMA + the readlane Gauss-Jordan, exactly as in the LQR kernel.  The
+// cost gradients l_z(t) = C_s z_t + c of the whole nominal trajectory are one C Z product on
+// the matrix cores before the sweep, and the stage costs of every rollout another one after
+// it.  Nominal and candidate trajectories live in LDS (swapped on accept, never copied).
+//
+// Whatever this kernel does not implement -- a non-PD Q_uu (would need mu > 0, ilqr.py:305-309)
+// or a line search that rejects all 11 steps (ilqr.py:267-270) -- it reports by setting
+// kRetryBit in status[b]; the dispatcher then runs the generic wave kernel over exactly those
+// instances ("second-chance launch", no host round trip).
+#include <hip/hip_runtime.h>
+
+#include "ilqr_lq_mfma.h"
+#include "wave_ops.h"
+
+namespace tfmpc {
+
+namespace {
+
+constexpr int N = 16, M = 8, D = 24;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float readlane(float v, int lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141;
+
+constexpr int kMs = 0, kKs = 256, kXs = 512, kQx = 640, kDyn = 656;   // fixed part of the LDS slice
+constexpr int kZld = 26;
+
+__device__ __forceinline__ float sgn(float y) { return (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f); }
+
+__global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int i = lane & 15, q = lane >> 4;
+    const int T = a.T, Tp = T + 1;
+    const int n = a.env.n, m = a.env.m, d = n + m;
+    const TfmpcIlqrConfig &cfg = a.cfg;
+
+    // dynamic LDS: gains' k and Q_u per step, two trajectory buffers, two cost buffers
+    float *kbuf = lds + kDyn;                    // [T][8]
+    float *qubuf = kbuf + T * M;                 // [T][8]
+    float *bufA = qubuf + T * M;                 // [(T+1)][26]
+    float *bufB = bufA + Tp * kZld;
+    float *costA = bufB + Tp * kZld;             // [T+1]
+    float *costB = costA + ((Tp + 3) & ~3);
+
+    const float *Fg = a.env.p[0] + (size_t)b * a.env.stride[0];
+    const float *fg = a.env.p[1] + (size_t)b * a.env.stride[1];
+    const float *Cg = a.env.p[2] + (size_t)b * a.env.stride[2];
+    const float *cg = a.env.p[3] + (size_t)b * a.env.stride[3];
+    float *Kg = a.wsK + (size_t)b * T * m * n;
+    float *kg = a.wsk + (size_t)b * T * m;
+
+    // padded-index accessors (x index in [0,16), u index in [0,8), z index in [0,24))
+    auto Fxx = [&](int row, int xi) { return (row < n && xi < n) ? Fg[row * d + xi] : 0.0f; };
+    auto Fxu = [&](int row, int ui) { return (row < n && ui < m) ? Fg[row * d + n + ui] : 0.0f; };
+    auto zmap = [&](int zi) { return zi < N ? (zi < n ? zi : -1) : (zi - N < m ? n + zi - N : -1); };
+    auto Cs = [&](int zr, int zc) {            // symmetric part of C (gradient / Hessian of the cost)
+        const int r = zmap(zr), c_ = zmap(zc);
+        return (r >= 0 && c_ >= 0) ? 0.5f * (Cg[r * d + c_] + Cg[c_ * d + r]) : 0.0f;
+    };
+    auto cz = [&](int zr) { const int r = zmap(zr); return r >= 0 ? cg[r] : 0.0f; };
+
+    // ---- operands resident in registers for the whole solve ------------------------------
+    float Fb0[4], Fb1[4];
+    f32x4 Cd00, Cd01t, Cd10, Cd11;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = 4 * q + r, ku = N + k;
+        Fb0[r] = Fxx(k, i);
+        Fb1[r] = (i < M) ? Fxu(k, i) : 0.0f;                     // no f column: the affine slot carries V_x
+        Cd00[r] = Cs(k, i);
+        Cd01t[r] = (k < M) ? Cs(i, N + k) : 0.0f;                // (q == 2, r == 0) <- l_x(t)[i] per step
+        Cd10[r] = (ku < D) ? Cs(ku, i) : 0.0f;
+        float c11 = 0.0f;
+        if (ku < D && i < M) c11 = (k >= m && i == k) ? 1.0f : Cs(ku, N + i);
+        Cd11[r] = c11;                                           // lanes i == 8, q < 2 <- l_u(t) per step
+    }
+    const int fi = lane >> 2, fc = lane & 3;       // F rows for x' = F z + f
+    const int ka = lane >> 3, jc = lane & 7;       // K rows for du = K dx
+    float Fr[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int zc = 6 * fc + j;
+        Fr[j] = zc < N ? Fxx(fi, zc) : Fxu(fi, zc - N);
+    }
+    const float f_i = fi < n ? fg[fi] : 0.0f;
+    float Ca0[6], Ca1[6];                          // A operand of C Z (k = 4s + q)
+    f32x4 cq0, cq1;
+#pragma unroll
+    for (int s2 = 0; s2 < 6; ++s2) {
+        Ca0[s2] = Cs(i, 4 * s2 + q);
+        Ca1[s2] = (i < M) ? Cs(N + i, 4 * s2 + q) : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        cq0[r] = cz(4 * q + r);
+        cq1[r] = (q < 2) ? cz(N + 4 * q + r) : 0.0f;
+    }
+    for (int idx = lane; idx < kDyn; idx += kWave) lds[idx] = 0.0f;
+
+    // C Z on the matrix cores over rows [0, rows) of Z, 16 timesteps per tile.
+    //   GRAD: L[t] = C_s z_t + c (cost gradient, diffenv.py:40-42);  else cost[t] = 1/2 z^T C z + c^T z
+    auto cz_pass = [&](const float *Z, int rows, float *out, bool grad) {
+        for (int nt = 0; nt * 16 < rows; ++nt) {
+            const int t = 16 * nt + i;
+            const float *zrow = Z + ((t < rows) ? t : rows - 1) * kZld;
+            f32x4 D0 = {0.f, 0.f, 0.f, 0.f}, D1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 6; ++s2) {
+                const float bz = zrow[4 * s2 + q];
+                D0 = mfma(Ca0[s2], bz, D0);
+                D1 = mfma(Ca1[s2], bz, D1);
+            }
+            if (grad) {
+                if (t < rows) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        out[t * kZld + 4 * q + r] = D0[r] + cq0[r];
+                        if (q < 2) out[t * kZld + N + 4 * q + r] = D1[r] + cq1[r];
+                    }
+                }
+            } else {
+                float part = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    part = fmaf(zrow[4 * q + r], fmaf(0.5f, D0[r], cq0[r]), part);
+                    if (q < 2) part = fmaf(zrow[N + 4 * q + r], fmaf(0.5f, D1[r], cq1[r]), part);
+                }
+                part += __shfl_xor(part, 16, kWave);
+                part += __shfl_xor(part, 32, kWave);
+                if (q == 0 && t < rows) out[t] = part;
+            }
+        }
+    };
+    auto sum_costs = [&](const float *cbuf) {
+        float p = 0.0f;
+        for (int idx = lane; idx < Tp; idx += kWave) p += cbuf[idx];
+        return wave_sum(p);
+    };
+
+    // ---- start (ilqr.py:218): roll the env under the injected actions --------------------
+    float *nom = bufA, *cand = bufB, *cnom = costA, *ccand = costB;
+    if (lane < N) nom[lane] = (lane < n) ? a.x0[(size_t)b * n + lane] : 0.0f;
+    for (int idx = lane; idx < T * M; idx += kWave) {
+        const int t = idx >> 3, ua = idx & 7;
+        nom[t * kZld + N + ua] = (ua < m) ? a.u_init[((size_t)b * T + t) * m + ua] : 0.0f;
+    }
+    if (lane < M) nom[T * kZld + N + lane] = 0.0f;
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const float *zt = nom + t * kZld;
+        float xn = 0.0f;
+        const float2 *zp = reinterpret_cast<const float2 *>(&zt[6 * fc]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float2 z2 = zp[j];
+            xn = fmaf(Fr[2 * j], z2.x, xn);
+            xn = fmaf(Fr[2 * j + 1], z2.y, xn);
+        }
+        xn += dpp<kDppXor1>(xn);
+        xn += dpp<kDppXor2>(xn);
+        xn += f_i;
+        if (fc == 0) nom[(t + 1) * kZld + fi] = xn;
+        __syncthreads();
+    }
+    cz_pass(nom, Tp, cnom, false);
+    __syncthreads();
+
+    int status = 0, iteration = 0;
+    bool converged = false, retry = false;
+    for (iteration = 0; iteration < cfg.max_iterations; ++iteration) {
+        // ---- derivatives (ilqr.py:234): l_z(t) for the whole nominal trajectory -------------
+        float *Lz = cand;
+        cz_pass(nom, Tp, Lz, true);
+        __syncthreads();
+        const float J_hat = sum_costs(cnom);                       // ilqr.py:104,164
+
+        // ---- backward (ilqr.py:94-172 with mu = 0) -------------------------------------------
+        f32x4 Vd = Cd00, vd = {0.f, 0.f, 0.f, 0.f};
+        if (i == M) vd = *reinterpret_cast<const f32x4 *>(&Lz[T * kZld + 4 * q]);     // V_x = l_x^f
+        int min_pivot_bits = 0x3f800000;
+        for (int t = T - 1; t >= 0; --t) {
+            f32x4 W0 = {0.f, 0.f, 0.f, 0.f}, W1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                W0 = mfma(Vd[r], Fb0[r], W0);
+                W1 = mfma(Vd[r], Fb1[r], W1);
+            }
+            if (i == M) W1 += vd;                                  // affine column: V_x
+            f32x4 T00 = Cd00, T01t = Cd01t, T10 = Cd10, T11 = Cd11;
+            if (q == 2) T01t[0] = Lz[t * kZld + i];                                     // l_x(t)
+            if (i == M && q < 2) T11 = *reinterpret_cast<const f32x4 *>(&Lz[t * kZld + N + 4 * q]);   // l_u(t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                T00 = mfma(Fb0[r], W0[r], T00);                    // Q_xx                 :129
+                T01t = mfma(W1[r], Fb0[r], T01t);                  // Q_xu | Q_x (transposed tile)
+                T10 = mfma(Fb1[r], W0[r], T10);                    // Q_ux                 :131
+                T11 = mfma(Fb1[r], W1[r], T11);                    // Q_uu | Q_u           :130,123
+            }
+            if (q < 2) {
+                *reinterpret_cast<f32x4 *>(&lds[kMs + i * 8 + 4 * q]) = T10;
+                if (i <= M) *reinterpret_cast<f32x4 *>(&lds[kMs + (N + i) * 8 + 4 * q]) = T11;
+                *reinterpret_cast<f32x4 *>(&lds[kXs + i * 8 + 4 * q]) = T01t;
+            } else if (q == 2) {
+                lds[kQx + i] = T01t[0];                            // Q_x[i]               :122
+            }
+            __syncthreads();
+            float Mr[8];
+            {
+                const int c = lane & 31;
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(&lds[kMs + c * 8]);
+                const f32x4 hi = *reinterpret_cast<const f32x4 *>(&lds[kMs + c * 8 + 4]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { Mr[r] = lo[r]; Mr[4 + r] = hi[r]; }
+            }
+            if (lane == 24) {                                      // Q_u(t) for dV1 (column 24 before elimination)
+                f32x4 lo, hi;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { lo[r] = Mr[r]; hi[r] = Mr[4 + r]; }
+                *reinterpret_cast<f32x4 *>(&qubuf[t * M]) = lo;
+                *reinterpret_cast<f32x4 *>(&qubuf[t * M + 4]) = hi;
+            }
+            // [k | K] = -Q_uu^-1 [Q_u | Q_ux]: Gauss-Jordan; a non-positive pivot is the Cholesky
+            // failure of ilqr.py:358                                                  :357-362
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int pvb = __builtin_amdgcn_readlane(__builtin_bit_cast(int, Mr[p]), N + p);
+                min_pivot_bits = min(min_pivot_bits, pvb);
+                const float inv = __builtin_amdgcn_rcpf(__builtin_bit_cast(float, pvb));
+                Mr[p] *= inv;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (r == p) continue;
+                    const float fct = readlane(Mr[r], N + p);
+                    Mr[r] = fmaf(-fct, Mr[p], Mr[r]);
+                }
+            }
+            if (lane < 32) {
+                f32x4 lo, hi;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { lo[r] = -Mr[r]; hi[r] = -Mr[4 + r]; }
+                *reinterpret_cast<f32x4 *>(&lds[kKs + lane * 8]) = lo;
+                *reinterpret_cast<f32x4 *>(&lds[kKs + lane * 8 + 4]) = hi;
+                if (lane == 24) {
+                    *reinterpret_cast<f32x4 *>(&kbuf[t * M]) = lo;
+                    *reinterpret_cast<f32x4 *>(&kbuf[t * M + 4]) = hi;
+                }
+            }
+            __syncthreads();
+            // V_xx' = Q_xx + Q_xu K, V_x' = Q_x + Q_xu k                              :149-161
+            f32x4 T01 = {0.f, 0.f, 0.f, 0.f};
+            if (i == M) T01 = *reinterpret_cast<const f32x4 *>(&lds[kQx + 4 * q]);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const float ax = lds[kXs + i * 8 + 4 * s2 + q];
+                const float g0 = lds[kKs + i * 8 + 4 * s2 + q];
+                const float g1 = lds[kKs + (N + i) * 8 + 4 * s2 + q];
+                T00 = mfma(ax, g0, T00);
+                T01 = mfma(ax, g1, T01);
+            }
+            Vd = T00;
+            vd = T01;
+            {   // gains to HBM, row-major K[t][a][j] (guarded for padded shapes)
+                const float kx = lds[kKs + (2 * jc) * 8 + ka], ky = lds[kKs + (2 * jc + 1) * 8 + ka];
+                if (ka < m && 2 * jc < n) Kg[(size_t)t * m * n + ka * n + 2 * jc] = kx;
+                if (ka < m && 2 * jc + 1 < n) Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] = ky;
+                if (lane < m) kg[(size_t)t * m + lane] = lds[kKs + 24 * 8 + lane];
+            }
+            __syncthreads();
+        }
+        if (min_pivot_bits <= 0) { status |= TFMPC_ST_NOT_PD; retry = true; break; }   // needs mu > 0
+        // dV1 = sum k^T Q_u (:166), dV2 = 1/2 sum k^T Q_uu k = -dV1/2 at mu = 0 (:167),
+        // g_norm = mean_t max_a |k| / (|u_hat| + 1) (:243)
+        float dV1, g_norm;
+        {
+            float p1 = 0.0f, gs = 0.0f;
+            for (int base = 0; base < T * M; base += kWave) {
+                const int idx = base + lane;
+                float ratio = 0.0f;
+                if (idx < T * M) {
+                    const int t = idx >> 3, ua = idx & 7;
+                    const float kv = kbuf[idx];
+                    p1 = fmaf(kv, qubuf[idx], p1);
+                    ratio = fabsf(kv) / (fabsf(nom[t * kZld + N + ua]) + 1.0f);
+                }
+                ratio = fmaxf(ratio, dpp<kDppXor1>(ratio));
+                ratio = fmaxf(ratio, dpp<kDppXor2>(ratio));
+                ratio = fmaxf(ratio, dpp<kDppHalfMirror>(ratio));
+                if ((lane & 7) == 0 && idx < T * M) gs += ratio;
+            }
+            dV1 = wave_sum(p1);
+            g_norm = T > 0 ? wave_sum(gs) / (float)T : 0.0f;
+        }
+        const float dV2 = -0.5f * dV1;
+        if (g_norm < cfg.atol) { converged = true; break; }        // :243-248
+
+        // ---- forward / line search (ilqr.py:317-355, :174-212) -----------------------------------
+        bool accept = false;
+        float residual = 0.0f;
+        for (int ai = 0; ai < cfg.n_alphas; ++ai) {
+            const float alpha = cfg.alphas[ai];
+            if (lane < N) cand[lane] = nom[lane];
+            if (lane < M) cand[T * kZld + N + lane] = 0.0f;
+            float rmax = 0.0f;
+            __syncthreads();
+            for (int t = 0; t < T; ++t) {
+                const float *zh = nom + t * kZld;
+                float *zt = cand + t * kZld;
+                const bool row = ka < m;
+                const float Kx = (row && 2 * jc < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc] : 0.0f;
+                const float Ky = (row && 2 * jc + 1 < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] : 0.0f;
+                const float2 xv = *reinterpret_cast<const float2 *>(&zt[2 * jc]);
+                const float2 xh = *reinterpret_cast<const float2 *>(&zh[2 * jc]);
+                float du = fmaf(Kx, xv.x - xh.x, Ky * (xv.y - xh.y));              // K (x - x_hat)  :193-194
+                du += dpp<kDppXor1>(du);
+                du += dpp<kDppXor2>(du);
+                du += dpp<kDppHalfMirror>(du);
+                du = fmaf(alpha, kbuf[t * M + ka], du);
+                rmax = fmaxf(rmax, fabsf(du));                                     // :206
+                if (jc == 0) zt[N + ka] = zh[N + ka] + du;                         // unbounded: clip is the identity
+                __syncthreads();
+                float xn = 0.0f;
+                const float2 *zp = reinterpret_cast<const float2 *>(&zt[6 * fc]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float2 z2 = zp[j];
+                    xn = fmaf(Fr[2 * j], z2.x, xn);
+                    xn = fmaf(Fr[2 * j + 1], z2.y, xn);
+                }
+                xn += dpp<kDppXor1>(xn);
+                xn += dpp<kDppXor2>(xn);
+                xn += f_i;
+                if (fc == 0) zt[kZld + fi] = xn;
+                __syncthreads();
+            }
+            residual = wave_max(rmax);
+            cz_pass(cand, Tp, ccand, false);
+            __syncthreads();
+            const float J = sum_costs(ccand);
+            const float delta_J = -alpha * (dV1 + alpha * dV2);                    // :339
+            const float dcost = J_hat - J;
+            const float z = (delta_J > 0.0f) ? dcost / delta_J : sgn(dcost);       // :342-346
+            if (z >= cfg.c1) { accept = true; break; }                             // :351-353
+        }
+        const bool small_step = residual < cfg.atol;                              // :253-257
+        if (small_step || accept) {                                                // swap nominal <-> candidate
+            float *tz = nom; nom = cand; cand = tz;
+            float *tcst = cnom; cnom = ccand; ccand = tcst;
+        }
+        if (small_step) { converged = true; break; }
+        if (!accept) { retry = true; break; }                                      // would raise mu (:267-270)
+        // accepted with mu = 0: delta shrinks, mu stays 0 (:259-266)
+    }
+    if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
+    (void)converged;
+
+    // ---- results: the nominal trajectory leaves LDS once ----------------------------------------
+    __syncthreads();
+    float *xs = a.states + (size_t)b * Tp * n, *us = a.actions + (size_t)b * T * m, *cs = a.costs + (size_t)b * Tp;
+    for (int idx = lane; idx < Tp * n; idx += kWave) xs[idx] = nom[(idx / n) * kZld + idx % n];
+    for (int idx = lane; idx < T * m; idx += kWave) us[idx] = nom[(idx / m) * kZld + N + idx % m];
+    for (int idx = lane; idx < Tp; idx += kWave) cs[idx] = cnom[idx];
+    if (lane == 0) {
+        const float cT = cnom[T];
+        if (!(cT == cT)) status |= TFMPC_ST_NAN;
+        if (retry) status |= kIlqrRetryBit;
+        a.iterations[b] = iteration;
+        a.status[b] = status;
+    }
+}
+
+}  // namespace
+
+size_t ilqr_lq_mfma_lds_bytes(int T)
+{
+    const size_t Tp = T + 1;
+    return (kDyn + 2 * (size_t)T * M + 2 * Tp * kZld + 2 * ((Tp + 3) & ~(size_t)3) + 8) * sizeof(float);
+}
+
+bool ilqr_lq_mfma_supported(const TfmpcEnv &env, int T)
+{
+    // any_finite_bound: forward() clips against every finite bound even when the box as a whole
+    // is not "bounded" (ilqr.py:197 vs :136); this kernel implements no clip at all
+    return env.kind == TFMPC_ENV_LQ && !env.bounded && !env.any_finite_bound && env.n <= N && env.m <= M && env.n + env.m > 6 && T >= 1 &&
+           ilqr_lq_mfma_lds_bytes(T) <= 40 * 1024;      // keep >= 4 waves per CU
+}
+
+int ilqr_lq_mfma_launch(const IlqrLqArgs &a, hipStream_t stream)
+{
+    const size_t lds = ilqr_lq_mfma_lds_bytes(a.T);
+    hipLaunchKernelGGL(ilqr_lq_mfma_kernel, dim3(a.B), dim3(kWave), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
+}
+
+}  // namespace tfmpc

@@ -42,7 +42,7 @@ class TfmpcEnv(ctypes.Structure):
     """``struct TfmpcEnv`` of include/tfmpc_hip.h."""
     _fields_ = [("kind", ctypes.c_int32), ("n", ctypes.c_int32), ("m", ctypes.c_int32),
                 ("n_zones", ctypes.c_int32), ("bounded", ctypes.c_int32),
-                ("reserved0", ctypes.c_int32), ("reserved1", ctypes.c_int32), ("reserved2", ctypes.c_int32),
+                ("any_finite_bound", ctypes.c_int32), ("reserved1", ctypes.c_int32), ("reserved2", ctypes.c_int32),
                 ("low", ctypes.c_void_p), ("high", ctypes.c_void_p),
                 ("p", ctypes.c_void_p * ENV_MAX_PARAMS), ("stride", ctypes.c_int64 * ENV_MAX_PARAMS),
                 ("scalar", ctypes.c_float * 4)]

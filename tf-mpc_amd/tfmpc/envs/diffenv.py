@@ -77,6 +77,8 @@ class DiffEnv:
         env.kind, env.n, env.m = int(self.kind), int(self.state_size), int(self.action_size)
         env.n_zones = int(self.n_zones)
         env.bounded = int(self.action_space.is_bounded())
+        env.any_finite_bound = int(bool(np.any(np.isfinite(self.action_space.low)) or
+                                        np.any(np.isfinite(self.action_space.high))))
         keep = []
         low = _f32(self.action_space.low.reshape(-1), dev)
         high = _f32(self.action_space.high.reshape(-1), dev)
