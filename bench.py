@@ -72,6 +72,31 @@ def measured_traffic(kernel, batch):
     return per_instance * batch
 
 
+def ilqr_api_rate(n, m, T, B, reps=5):
+    """Secondary number (not `value`): the same shape driven through tfmpc.solvers.ilqr.iLQR.solve
+    on the LQ env (whole iteration loops in one launch, matrix-core kernel).  F is scaled to
+    spectral radius ~1: iLQR's OPEN-LOOP start rollout of a rho ~ 5 system overflows fp32 long
+    before T = 50, in any implementation.  Iterations counted = reference loop index + 1."""
+    import problems
+    from tfmpc.envs.lq import LQEnv
+    from tfmpc.solvers.ilqr import iLQR
+    F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=4321)
+    solver = iLQR(LQEnv(0.25 * F, f, C, c))
+    x0 = torch.as_tensor(x0[..., None].astype(np.float32), device="cuda")
+    u0 = torch.zeros(B, T, m, 1, device="cuda")
+    out = solver.solve_device(x0, T, u_init=u0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = solver.solve_device(x0, T, u_init=u0, workspace=out["workspace"])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    its = float((out["iterations"].double() + 1).sum())
+    return {"iterations_per_s": its / dt, "ms_per_batch": dt * 1e3, "mean_iterations": its / B,
+            "flagged_instances": int((out["status"] != 0).sum()),
+            "workload": f"iLQR.solve on LQEnv(0.25 F, f, C, c), n={n} m={m} T={T} B={B}, zero initial actions"}
+
+
 def cpu_baseline(n, m, T, target_seconds=12.0):
     """The oracle's C port of the reference equations, OpenMP over instances on all
     host cores, on a bounded sample of the same workload."""
@@ -255,6 +280,8 @@ def main():
             line["gather_error"] = gather_error
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, m, T)
+        if world == 1:
+            line["extra"] = {"ilqr_api": ilqr_api_rate(n, m, T, B)}
         print(json.dumps(line), flush=True)
 
     if world > 1:
