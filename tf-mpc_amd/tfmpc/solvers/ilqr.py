@@ -109,10 +109,17 @@ class iLQR:
         u = (lo + r * (hi - lo)).unsqueeze(-1)
         return u if batch_size else u[0]
 
+    @property
+    def _generic_env(self):
+        """True for envs given as Python/torch functions (tfmpc.envs.torchenv.TorchEnv)."""
+        return getattr(self.env, "kind", None) is None
+
     # -- ilqr.py:53-82 -----------------------------------------------------------------------
     def start(self, x0, T, u_init=None, seed=None):
         lib = _hip.require_gpu()
         T = int(T)
+        if self._generic_env:
+            return self._start_torch(x0, T, u_init, seed)
         n, m = self.env.state_size, self.env.action_size
         x0, batched = self._batch_cols(x0, n, 0)
         B = x0.shape[0]
@@ -134,6 +141,13 @@ class iLQR:
     # -- ilqr.py:84-92 -----------------------------------------------------------------------
     def derivatives(self, states, actions):
         lib = _hip.require_gpu()
+        if self._generic_env:
+            xs = _f32(states, self.device)
+            us = _f32(actions, self.device)
+            tdim = xs.dim() - 3
+            return (self.env.get_linear_transition(xs.narrow(tdim, 0, xs.shape[tdim] - 1), us),
+                    self.env.get_quadratic_cost(xs.narrow(tdim, 0, xs.shape[tdim] - 1), us),
+                    self.env.get_quadratic_final_cost(xs.select(tdim, xs.shape[tdim] - 1)))
         n, m = self.env.state_size, self.env.action_size
         x, batched = self._batch_cols(states, n, 1)
         u, _ = self._batch_cols(actions, m, 1)
@@ -202,6 +216,8 @@ class iLQR:
         lib = _hip.require_gpu()
         n, m = self.env.state_size, self.env.action_size
         dev = self.device
+        if self._generic_env:
+            return self._forward_torch(x, u, K, k, alpha)
         xs, batched = self._batch_cols(x, n, 1)
         us, _ = self._batch_cols(u, m, 1)
         B, T = xs.shape[0], us.shape[1]
@@ -242,6 +258,8 @@ class iLQR:
         u, ub = self._batch_cols(u_init, m, 1)
         if ub and not batched:
             x0, batched, B = x0.expand(u.shape[0], n).contiguous(), True, u.shape[0]
+        if self._generic_env:
+            return self._solve_host_driven(x0, u.expand(B, T, m).contiguous(), batched)
         eb = self.env.env_batch_size()
         if eb is not None:
             if batched and eb != B:
@@ -275,3 +293,140 @@ class iLQR:
             return trajectory.Trajectory(out["states"], out["actions"], out["costs"]), out["iterations"].cpu().numpy()
         traj = trajectory.Trajectory(out["states"][0], out["actions"][0], out["costs"][0])
         return traj, int(out["iterations"][0])
+
+
+    # ===== generic (torch-function) envs: SURVEY.md §8f N2 ============================================
+    # The reference's loop (ilqr.py:214-283) driven from the host over a whole batch: derivatives by
+    # torch.func, the Riccati backward pass in the HIP kernel, rollouts as batched torch ops.  Every
+    # instance carries its own (mu, delta, iteration, converged) exactly like the fused device kernels.
+    def _rollout_torch(self, x0, u):
+        """x0[R,n], u[R,T,m] -> states[R,T+1,n], costs[R,T+1]"""
+        T = u.shape[1]
+        xs, cs, x = [x0], [], x0
+        for t in range(T):
+            nx, c = self.env.step_flat(x, u[:, t])
+            xs.append(nx)
+            cs.append(c)
+            x = nx
+        cs.append(self.env.final_cost_flat(x))
+        return torch.stack(xs, dim=1), torch.stack(cs, dim=1)
+
+    def _start_torch(self, x0, T, u_init, seed):
+        n, m = self.env.state_size, self.env.action_size
+        x0, batched = self._batch_cols(x0, n, 0)
+        B = x0.shape[0]
+        if u_init is None:
+            u_init = self.random_actions(T, B if batched else None, seed)
+        u, ub = self._batch_cols(u_init, m, 1)
+        if ub and not batched:
+            x0, batched, B = x0.expand(u.shape[0], n).contiguous(), True, u.shape[0]
+        u = u.expand(B, T, m).contiguous()
+        states, costs = self._rollout_torch(x0, u)
+        states, actions = states.unsqueeze(-1), u.unsqueeze(-1)
+        return (states, actions, costs) if batched else (states[0], actions[0], costs[0])
+
+    def _line_search_rollouts(self, xh, uh, K, k, alphas):
+        """All step sizes at once: xh[B,T+1,n], uh[B,T,m], K[B,T,m,n], k[B,T,m], alphas[A] ->
+        states[B,A,T+1,n], actions[B,A,T,m], costs[B,A,T+1], residual[B,A] (ilqr.py:174-212)."""
+        B, T, m = uh.shape
+        A, n = alphas.numel(), xh.shape[-1]
+        low, high = self.low.reshape(-1), self.high.reshape(-1)
+        x = xh[:, None, 0].expand(B, A, n).reshape(B * A, n)
+        xs, us, cs = [x], [], []
+        resid = torch.zeros(B * A, device=xh.device)
+        for t in range(T):
+            dx = x.reshape(B, A, n) - xh[:, None, t]
+            du = alphas[None, :, None] * k[:, None, t] + torch.einsum("bij,baj->bai", K[:, t], dx)
+            ua = torch.minimum(torch.maximum(uh[:, None, t] + du, low), high).reshape(B * A, m)
+            nx, c = self.env.step_flat(x, ua)
+            resid = torch.maximum(resid, du.abs().amax(dim=-1).reshape(B * A))
+            us.append(ua)
+            cs.append(c)
+            xs.append(nx)
+            x = nx
+        cs.append(self.env.final_cost_flat(x))
+        shape = lambda lst, w: torch.stack(lst, dim=1).reshape(B, A, len(lst), *( (w,) if w else ()))
+        return shape(xs, n), shape(us, m), shape(cs, 0), resid.reshape(B, A)
+
+    def _forward_torch(self, x, u, K, k, alpha):
+        n, m = self.env.state_size, self.env.action_size
+        xs, batched = self._batch_cols(x, n, 1)
+        us, _ = self._batch_cols(u, m, 1)
+        B, T = xs.shape[0], us.shape[1]
+        Kt = _f32(K, self.device)
+        Kt = (Kt if Kt.dim() == 4 else Kt.unsqueeze(0)).expand(B, T, m, n)
+        kt, _ = self._batch_cols(k, m, 1)
+        al = _f32(alpha, self.device).reshape(-1)
+        st, ac, co, res = self._line_search_rollouts(xs, us, Kt, kt.expand(B, T, m), al[:1])
+        st, ac, co, res = st[:, 0].unsqueeze(-1), ac[:, 0].unsqueeze(-1), co[:, 0], res[:, 0]
+        J = co.sum(dim=1)
+        return (st, ac, co, J, res) if batched else (st[0], ac[0], co[0], J[0], res[0])
+
+    def _solve_host_driven(self, x0, u, batched):
+        dev = self.device
+        B, T, m = u.shape
+        alphas = torch.as_tensor(self._alphas(), dtype=torch.float32, device=dev)
+        A = alphas.numel()
+        xh, ch = self._rollout_torch(x0, u)
+        uh = u.clone()
+        mu = torch.zeros(B, device=dev)
+        delta = torch.ones(B, device=dev)
+        active = torch.ones(B, dtype=torch.bool, device=dev)
+        iterations = torch.zeros(B, dtype=torch.int32, device=dev)
+        status = torch.zeros(B, dtype=torch.int32, device=dev)
+        attempts = torch.zeros(B, dtype=torch.int32, device=dev)
+        d0, mu_min = float(self.delta_0), float(self.mu_min)
+        ar = torch.arange(B, device=dev)
+        for it in range(int(self.max_iterations)):
+            if not bool(active.any()):
+                break
+            iterations[active] = it
+            tm, cm, fm = self.derivatives(xh.unsqueeze(-1), uh.unsqueeze(-1))
+            J_hat = ch.sum(dim=1)
+            pending = active.clone()                       # still inside the `while True` of ilqr.py:238
+            converged = torch.zeros_like(active)
+            while bool(pending.any()):
+                mu_l, delta_l = mu.clone(), delta.clone()   # _backward's local retry (ilqr.py:285-315)
+                for _ in range(64):
+                    K, k, _, dV1, dV2 = self.backward(T, uh.unsqueeze(-1), tm, cm, fm, mu=mu_l)
+                    failed = ((self.last_status & _hip.ST_NOT_PD) != 0) & pending
+                    if not bool(failed.any()):
+                        break
+                    status[failed] |= _hip.ST_NOT_PD
+                    delta_l = torch.where(failed, torch.clamp(delta_l * d0, min=d0), delta_l)
+                    mu_l = torch.where(failed, torch.clamp(mu_l * delta_l, min=mu_min), mu_l)
+                if K.dim() == 3:
+                    K, k, dV1, dV2 = K.unsqueeze(0), k.unsqueeze(0), dV1.reshape(1), dV2.reshape(1)
+                k = k[..., 0]
+                g_norm = (k.abs() / (uh.abs() + 1.0)).amax(dim=2).mean(dim=1)          # ilqr.py:243
+                conv_g = pending & (g_norm < self.atol)
+                ls = pending & ~conv_g
+                xs, us, cs, res = self._line_search_rollouts(xh, uh, K, k, alphas)
+                J = cs.sum(dim=2)                                                        # [B, A]
+                delta_J = -alphas[None] * (dV1[:, None] + alphas[None] * dV2[:, None])   # :339
+                dcost = J_hat[:, None] - J
+                z = torch.where(delta_J > 0, dcost / delta_J, torch.sign(dcost))         # :342-346
+                ok = z >= self.c1
+                accepted = ok.any(dim=1)
+                chosen = torch.where(accepted, ok.float().argmax(dim=1), torch.full_like(ar, A - 1))
+                small = res[ar, chosen] < self.atol                                      # :253-257
+                take = ls & (small | accepted)
+                xh = torch.where(take[:, None, None], xs[ar, chosen], xh)
+                uh = torch.where(take[:, None, None], us[ar, chosen], uh)
+                ch = torch.where(take[:, None], cs[ar, chosen], ch)
+                acc = ls & accepted & ~small                                             # :259-266
+                delta = torch.where(acc, torch.clamp(delta / d0, max=1.0 / d0), delta)
+                mu = torch.where(acc, torch.where(mu * delta > mu_min, mu * delta, torch.zeros_like(mu)), mu)
+                rej = ls & ~accepted & ~small                                            # :267-270
+                delta = torch.where(rej, torch.clamp(delta * d0, min=d0), delta)
+                mu = torch.where(rej, torch.clamp(mu * delta, min=mu_min), mu)
+                attempts = attempts + rej.int()
+                capped = rej & (attempts >= int(self.max_attempts))
+                status[capped] |= _hip.ST_MAX_ATTEMPTS
+                converged |= conv_g | (ls & small) | capped
+                pending = rej & ~capped
+            active = active & ~converged
+        status[~torch.isfinite(ch[:, -1])] |= _hip.ST_NAN
+        self.last_status = status
+        return dict(states=xh.unsqueeze(-1), actions=uh.unsqueeze(-1), costs=ch, iterations=iterations, status=status,
+                    batched=batched, workspace=None)
