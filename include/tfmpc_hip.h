@@ -137,6 +137,9 @@ typedef struct TfmpcIlqrConfig {
     float alphas[TFMPC_MAX_ALPHAS];
     int32_t max_attempts;   /* cap on rejected backward/line-search attempts per solve (the
                                reference loops without bound, ilqr.py:238-270) */
+    int32_t storage_bf16;   /* 1: trajectories and gains kept in HBM are rounded to bf16 on every store
+                               (arithmetic stays fp32) -- the storage-precision sweep of BASELINE
+                               configs[4]; honoured by the wave-per-instance solve kernel */
 } TfmpcIlqrConfig;
 
 /* iLQR.start (ilqr.py:53-82) with the random actions injected: roll the env from

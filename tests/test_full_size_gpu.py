@@ -82,3 +82,22 @@ def test_cfg5_n32_horizon100_batch_32768(kind):
     assert not K.any() and not bool(Kg.any())                                              # F6: K == 0
     assert np.array_equal(kg.cpu().numpy() == (0.0 - us), k == (0.0 - us))                  # same bang-bang pattern
     assert abs(float(Jg) - float(J)) <= 1e-4 * abs(float(J))
+
+
+def test_bf16_storage_mode_is_a_bounded_perturbation_on_hvac():
+    """BASELINE configs[4] "fp32 vs bf16": rounding stored trajectories / gains to bf16 (fp32
+    arithmetic) must perturb, not break, the solve (full sweep: tools/bf16_sweep.py)."""
+    n, T, B = 32, 100, 256
+    env = HVAC.load(dict(problems.hvac_config(n, seed=5)))
+    x0 = (10.0 + np.random.default_rng(5).normal(0, 1.0, size=(B, n, 1))).astype(np.float32)
+    u0 = iLQR(env).random_actions(T, B, seed=5)
+    outs = {}
+    for mode in (False, True):
+        outs[mode] = iLQR(env, max_iterations=1, storage_bf16=mode).solve_device(x0, T, u_init=u0)
+    torch.cuda.synchronize()
+    a, b = outs[False]["states"], outs[True]["states"]
+    rel = ((a - b).abs().reshape(B, -1).amax(1) / a.abs().reshape(B, -1).amax(1)).cpu().numpy()
+    assert 1e-4 < np.median(rel) < 5e-2 and rel.max() < 0.2        # bf16 has 8 significant bits
+    # stored values really are bf16-representable
+    bits = b.contiguous().view(torch.int32)
+    assert int((bits & 0xFFFF).abs().sum()) == 0

@@ -14,6 +14,7 @@ namespace tfmpc {
 
 struct IlqrSmem {
     int n, m, ldn, ldm, lda, width;
+    int bf16;                                        // 1: HBM stores of trajectories / gains round to bf16
     float *fx, *fu, *lx, *lu, *lxx, *luu, *lux;      // model at step t (lux holds l_xu^T)
     float *Vx, *Vxx, *W1, *W2;                       // value terms, f_x^T V_xx, f_u^T V_xx
     float *Qx, *Qu, *Qxx, *Quu, *Qux, *Quur, *Quxr;  // Q terms and their regularised twins
@@ -22,6 +23,16 @@ struct IlqrSmem {
     float *xv, *uv, *xn, *xh, *uh;                   // state/action scratch
     float *qx, *qg, *qs, *qc, *qlo, *qhi, *qfree, *qgc;   // box-QP vectors
 };
+
+// Value as it would read back from a bf16 slab (round to nearest even on the fp32 bits); identity
+// in the default fp32-storage mode.  Only what goes to HBM is rounded, never the registers / LDS.
+__device__ __forceinline__ float stq(const IlqrSmem &s, float v)
+{
+    if (!s.bf16) return v;
+    unsigned u = __float_as_uint(v);
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+    return __uint_as_float(u);
+}
 
 __host__ __device__ inline size_t ilqr_smem_floats(int n, int m)
 {
@@ -39,7 +50,7 @@ __host__ __device__ inline size_t ilqr_smem_floats(int n, int m)
 
 __device__ inline float *ilqr_carve(IlqrSmem &s, float *p, int n, int m)
 {
-    s.n = n; s.m = m;
+    s.n = n; s.m = m; s.bf16 = 0;
     s.ldn = odd_ld(n); s.ldm = odd_ld(m); s.width = m + 1 + n; s.lda = odd_ld(s.width);
     const int ldn = s.ldn, ldm = s.ldm;
     s.fx = p; p += n * ldn;   s.fu = p; p += n * ldm;
@@ -70,7 +81,7 @@ __host__ __device__ inline size_t ilqr_adjoint_smem_floats(int n, int m)
 __device__ inline float *ilqr_carve_adjoint(IlqrSmem &s, float *p, int n, int m)
 {
     s = IlqrSmem{};
-    s.n = n; s.m = m;
+    s.n = n; s.m = m; s.bf16 = 0;
     s.ldn = odd_ld(n); s.ldm = odd_ld(m); s.width = m + 1 + n; s.lda = odd_ld(s.width);
     s.fx = p; p += n * s.ldn;   s.fu = p; p += n * s.ldm;
     s.lx = p; p += n;  s.Vx = p; p += n;  s.Qx = p; p += n;
@@ -315,8 +326,8 @@ __device__ inline BackwardResult backward_pass(IlqrSmem &s, Provider &prov, int 
         r.dV2 += 0.5f * wave_sum(p2);
         gsum += wave_max(gmax);
         // gains out
-        for (int idx = lane; idx < m * n; idx += kWave) Kg[(size_t)t * m * n + idx] = s.K[(idx / n) * ldn + idx % n];
-        for (int a = lane; a < m; a += kWave) kg[(size_t)t * m + a] = s.k[a];
+        for (int idx = lane; idx < m * n; idx += kWave) Kg[(size_t)t * m * n + idx] = stq(s, s.K[(idx / n) * ldn + idx % n]);
+        for (int a = lane; a < m; a += kWave) kg[(size_t)t * m + a] = stq(s, s.k[a]);
         wsync();
         for (int idx = lane; idx < n * n; idx += kWave) {                                 // :162
             const int i = idx / n, j = idx - i * n;
@@ -361,7 +372,7 @@ __device__ inline BackwardResult backward_pass_adjoint(IlqrSmem &s, const EnvLds
                 float acc = s.lu[a];
                 for (int kk = 0; kk < n; ++kk) acc = fmaf(s.fu[kk * ldm + a], s.Vx[kk], acc);
                 const float kt = (acc >= 0.0f) ? (e.low[a] - s.uh[a]) : (e.high[a] - s.uh[a]);
-                kg[(size_t)t * m + a] = kt;
+                kg[(size_t)t * m + a] = stq(s, kt);
                 p1 = fmaf(kt, acc, p1);
                 gmax = fmaxf(gmax, fabsf(kt) / (fabsf(s.uh[a]) + 1.0f));
             }
@@ -384,19 +395,19 @@ __device__ inline void rollout_pass(IlqrSmem &s, const EnvLds &e, int T, const f
                                     float *states, float *costs, float *actions_out)
 {
     const int n = s.n, m = s.m, lane = lane_id();
-    for (int i = lane; i < n; i += kWave) { const float x = x0[i]; s.xv[i] = x; states[i] = x; }
+    for (int i = lane; i < n; i += kWave) { const float x = x0[i]; s.xv[i] = x; states[i] = stq(s, x); }
     for (int t = 0; t < T; ++t) {
         for (int a = lane; a < m; a += kWave) {
             const float u = actions[(size_t)t * m + a];
             s.uv[a] = u;
-            if (actions_out) actions_out[(size_t)t * m + a] = u;
+            if (actions_out) actions_out[(size_t)t * m + a] = stq(s, u);
         }
         wsync();
         const float c = Env<KIND>::cost(e, s.xv, s.uv);
         Env<KIND>::transition(e, s.xv, s.uv, s.xn);
         if (lane == 0) costs[t] = c;
         wsync();
-        for (int i = lane; i < n; i += kWave) { const float x = s.xn[i]; s.xv[i] = x; states[(size_t)(t + 1) * n + i] = x; }
+        for (int i = lane; i < n; i += kWave) { const float x = s.xn[i]; s.xv[i] = x; states[(size_t)(t + 1) * n + i] = stq(s, x); }
     }
     wsync();
     const float fc = Env<KIND>::final_cost(e, s.xv);
@@ -410,7 +421,7 @@ __device__ inline void forward_pass(IlqrSmem &s, const EnvLds &e, int T, float a
                                     float *actions, float *costs, float &J_out, float &residual_out)
 {
     const int n = s.n, m = s.m, ldn = s.ldn, lane = lane_id();
-    for (int i = lane; i < n; i += kWave) { const float x = xhat[i]; s.xv[i] = x; states[i] = x; }
+    for (int i = lane; i < n; i += kWave) { const float x = xhat[i]; s.xv[i] = x; states[i] = stq(s, x); }
     float J = 0.0f, resid = 0.0f;
     for (int t = 0; t < T; ++t) {
         if (HAS_K) load_matrix(s.K, ldn, Kg + (size_t)t * m * n, m, n);
@@ -423,7 +434,7 @@ __device__ inline void forward_pass(IlqrSmem &s, const EnvLds &e, int T, float a
             if (HAS_K) for (int j = 0; j < n; ++j) du = fmaf(s.K[a * ldn + j], s.xv[j] - s.xh[j], du);
             const float u = fminf(fmaxf(s.uh[a] + du, e.low[a]), e.high[a]);             // :196-197
             s.uv[a] = u;
-            actions[(size_t)t * m + a] = u;
+            actions[(size_t)t * m + a] = stq(s, u);
             rmax = fmaxf(rmax, fabsf(du));
         }
         resid = fmaxf(resid, wave_max(rmax));                                            // :206
@@ -433,7 +444,7 @@ __device__ inline void forward_pass(IlqrSmem &s, const EnvLds &e, int T, float a
         J += c;                                                                          // :205
         if (lane == 0) costs[t] = c;
         wsync();
-        for (int i = lane; i < n; i += kWave) { const float x = s.xn[i]; s.xv[i] = x; states[(size_t)(t + 1) * n + i] = x; }
+        for (int i = lane; i < n; i += kWave) { const float x = s.xn[i]; s.xv[i] = x; states[(size_t)(t + 1) * n + i] = stq(s, x); }
     }
     wsync();
     const float fc = Env<KIND>::final_cost(e, s.xv);                                     // :208-210

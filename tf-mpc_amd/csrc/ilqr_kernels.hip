@@ -194,6 +194,7 @@ __global__ __launch_bounds__(kWave) void ilqr_solve_kernel(TfmpcEnv env, TfmpcIl
     constexpr bool kAdjoint = Env<KIND>::kPiecewiseLinearCost;   // HVAC / Reservoir: V_xx == 0 always
     IlqrSmem s;
     float *p = kAdjoint ? ilqr_carve_adjoint(s, smem, n, m) : ilqr_carve(s, smem, n, m);
+    s.bf16 = cfg.storage_bf16;
     EnvLds e;
     env_load(e, env, b, p);
     wsync();
@@ -468,7 +469,7 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
         const char *force = std::getenv("TFMPC_ILQR_KERNEL");
         const bool forced_lane = force && std::strcmp(force, "lane") == 0;
         const bool forced_wave = force && std::strcmp(force, "wave") == 0;
-        if (ilqr_lane_supported(*env) && !forced_wave && (forced_lane || B >= 32))
+        if (ilqr_lane_supported(*env) && !forced_wave && !cfg->storage_bf16 && (forced_lane || B >= 32))
             return ilqr_lane_solve_launch(*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status,
                                           a.wsK, a.wsk, a.wsx, a.wsu, a.wsc, st);
     }
@@ -477,7 +478,7 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
         // come back flagged and are re-solved from scratch by the wave kernel right behind it
         const char *force = std::getenv("TFMPC_ILQR_KERNEL");
         const bool forced_wave = force && std::strcmp(force, "wave") == 0;
-        if (!forced_wave && ilqr_lq_mfma_supported(*env, T)) {
+        if (!forced_wave && !cfg->storage_bf16 && ilqr_lq_mfma_supported(*env, T)) {
             IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk};
             if ((rc = ilqr_lq_mfma_launch(la, st)) != TFMPC_OK) return rc;
             a.only_flagged = 1;

@@ -52,7 +52,8 @@ class TfmpcIlqrConfig(ctypes.Structure):
     """``struct TfmpcIlqrConfig`` of include/tfmpc_hip.h."""
     _fields_ = [("atol", ctypes.c_float), ("max_iterations", ctypes.c_int32), ("mu_min", ctypes.c_float),
                 ("delta_0", ctypes.c_float), ("c1", ctypes.c_float), ("n_alphas", ctypes.c_int32),
-                ("alphas", ctypes.c_float * MAX_ALPHAS), ("max_attempts", ctypes.c_int32)]
+                ("alphas", ctypes.c_float * MAX_ALPHAS), ("max_attempts", ctypes.c_int32),
+                ("storage_bf16", ctypes.c_int32)]
 
 
 _SIGNATURES.update({

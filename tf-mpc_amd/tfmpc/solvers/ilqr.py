@@ -52,6 +52,8 @@ class iLQR:
         self.alpha_min = kwargs.get("alpha_min", 1e-3)
         # build-only: cap on rejected attempts per solve (the reference has none)
         self.max_attempts = kwargs.get("max_attempts", 64)
+        # build-only: keep trajectories / gains in HBM at bf16 precision (fp32 arithmetic); wave kernels only
+        self.storage_bf16 = bool(kwargs.get("storage_bf16", False))
 
         self._config = kwargs
         self.last_status = None
@@ -84,6 +86,7 @@ class iLQR:
         for i, a in enumerate(alphas):
             cfg.alphas[i] = float(a)
         cfg.max_attempts = int(self.max_attempts)
+        cfg.storage_bf16 = int(self.storage_bf16)
         return cfg
 
     def _batch_cols(self, a, size, lead):
