@@ -1,0 +1,78 @@
+"""Argument validation of every C-ABI entry point (include/tfmpc_hip.h).  Bad sizes and null
+pointers must come back as TFMPC_ERR_* BEFORE anything touches the GPU, so these calls are safe
+(and meaningful) on a machine without one."""
+
+import ctypes
+
+import pytest
+
+from tfmpc import _hip
+
+ERR_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE = -1, -2, -4
+NULL = None
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _hip.load()
+
+
+def _dummy():
+    """A non-null pointer that is never dereferenced (validation fails first)."""
+    return ctypes.c_void_p(0x1000)
+
+
+def test_lqr_entry_points_reject_bad_arguments(lib):
+    d = _dummy()
+    ops = [d, 0, d, 0, d, 0, d, 0]
+    assert lib.tfmpc_lqr_solve_f32(-1, 3, 2, 5, *ops, d, d, d, d, d, d, d, d, d, d, d, 0, NULL) == ERR_ARG
+    assert lib.tfmpc_lqr_solve_f32(4, 0, 2, 5, *ops, d, d, d, d, d, d, d, d, d, d, d, 0, NULL) == ERR_ARG
+    assert lib.tfmpc_lqr_solve_f32(4, 3, 2, 5, NULL, 0, d, 0, d, 0, d, 0, d, d, d, d, d, d, d, d, d, d, d, 0, NULL) == ERR_ARG
+    assert lib.tfmpc_lqr_solve_f32(4, 3, 2, 5, *ops, NULL, d, d, d, d, d, d, d, d, d, d, 0, NULL) == ERR_ARG      # x0
+    # gains not requested and no workspace -> workspace error, not a crash
+    assert lib.tfmpc_lqr_solve_f32(4, 3, 2, 5, *ops, d, d, d, d, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0, NULL) == ERR_WORKSPACE
+    assert lib.tfmpc_lqr_solve_f32(4, 200, 200, 5, *ops, d, d, d, d, d, d, d, d, d, d, d, 0, NULL) == ERR_UNSUPPORTED
+    assert lib.tfmpc_lqr_backward_f32(4, 3, 2, 5, *ops, NULL, d, d, d, d, d, NULL) == ERR_ARG                     # K required
+    assert lib.tfmpc_lqr_forward_f32(4, 3, 2, 5, *ops, d, 0, d, 0, NULL, d, d, d, NULL) == ERR_ARG                # x0
+    assert lib.tfmpc_lqr_forward_f32(0, 3, 2, 5, *ops, d, 0, d, 0, d, d, d, d, NULL) == 0                         # empty batch is fine
+    assert lib.tfmpc_lqr_workspace_bytes(0, 3, 2, 5) == 0
+
+
+def _env(kind=_hip.ENV_NAVLQR, n=2, m=2, with_params=True):
+    env = _hip.TfmpcEnv()
+    env.kind, env.n, env.m = kind, n, m
+    env.low = env.high = 0x1000
+    if with_params:
+        for i in range(_hip.ENV_MAX_PARAMS):
+            env.p[i] = 0x1000
+    return env
+
+
+def test_ilqr_entry_points_reject_bad_arguments(lib):
+    d = _dummy()
+    cfg = _hip.TfmpcIlqrConfig()
+    cfg.max_iterations, cfg.n_alphas = 10, 11
+    good = _env()
+    byref = ctypes.byref
+    assert lib.tfmpc_ilqr_rollout_f32(NULL, 4, 5, d, d, d, d, NULL) == ERR_ARG
+    assert lib.tfmpc_ilqr_rollout_f32(byref(_env(kind=9)), 4, 5, d, d, d, d, NULL) == ERR_ARG
+    assert lib.tfmpc_ilqr_rollout_f32(byref(_env(n=2, m=3)), 4, 5, d, d, d, d, NULL) == ERR_ARG     # reference envs: m == n
+    assert lib.tfmpc_ilqr_rollout_f32(byref(_env(with_params=False)), 4, 5, d, d, d, d, NULL) == ERR_ARG
+    assert lib.tfmpc_ilqr_rollout_f32(byref(good), 4, 5, NULL, d, d, d, NULL) == ERR_ARG
+    assert lib.tfmpc_ilqr_rollout_f32(byref(good), -4, 5, d, d, d, d, NULL) == ERR_ARG
+    assert lib.tfmpc_ilqr_rollout_f32(byref(_env(kind=_hip.ENV_HVAC, n=300, m=300)), 4, 5, d, d, d, d, NULL) == ERR_UNSUPPORTED
+    assert lib.tfmpc_ilqr_derivatives_f32(byref(good), 4, 5, NULL, d, *([d] * 13), NULL) == ERR_ARG
+    assert lib.tfmpc_ilqr_forward_f32(byref(good), 4, 5, d, d, d, d, NULL, 0, d, d, d, d, d, NULL) == ERR_ARG   # alpha
+    bw = [d] * 12
+    assert lib.tfmpc_ilqr_backward_f32(4, 2, 2, 5, *bw, d, d, 0, NULL, 0, d, d, d, d, d, d, NULL) == ERR_ARG      # mu
+    assert lib.tfmpc_ilqr_backward_f32(4, 0, 2, 5, *bw, d, d, 0, d, 0, d, d, d, d, d, d, NULL) == ERR_ARG
+    bad_cfg = _hip.TfmpcIlqrConfig()
+    bad_cfg.max_iterations, bad_cfg.n_alphas = 10, 99
+    assert lib.tfmpc_ilqr_solve_f32(byref(good), byref(bad_cfg), 4, 5, d, d, d, d, d, d, d, d, 1 << 20, NULL) == ERR_ARG
+    assert lib.tfmpc_ilqr_solve_f32(byref(good), NULL, 4, 5, d, d, d, d, d, d, d, d, 1 << 20, NULL) == ERR_ARG
+    assert lib.tfmpc_ilqr_solve_f32(byref(good), byref(cfg), 4, 5, d, d, d, d, d, d, d, d, 16, NULL) == ERR_WORKSPACE
+    assert lib.tfmpc_ilqr_solve_f32(byref(good), byref(cfg), 4, 5, d, d, d, d, d, NULL, d, d, 1 << 20, NULL) == ERR_ARG   # iterations
+    assert lib.tfmpc_ilqr_workspace_bytes(4, 2, 2, 5) == 4 * (5 * 4 + 5 * 2 + 6 * 2 + 5 * 2 + 6) * 4
+    assert lib.tfmpc_boxqp_f32(4, 0, d, d, d, d, d, d, d, d, NULL) == ERR_ARG
+    assert lib.tfmpc_boxqp_f32(4, 3, NULL, d, d, d, d, d, d, d, NULL) == ERR_ARG
+    assert lib.tfmpc_boxqp_f32(0, 3, d, d, d, d, d, d, d, d, NULL) == 0

@@ -1,4 +1,5 @@
-"""Throughput of the fused iLQR kernel on the BASELINE configs that are not bench lines."""
+"""Throughput of the BASELINE configs that are NOT bench lines (cfg2, cfg4, cfg5) and of the
+headline shape through the iLQR API.  Run on the GPU box: python tools/secondary_rates.py"""
 import sys, time
 sys.path.insert(0, '/root/repo/tf-mpc_amd'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
 import numpy as np, torch, problems
