@@ -174,6 +174,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="instances per GPU (default = BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary iLQR-API measurement (profiling runs)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="TEST ONLY: no GPU work; a fixed-sleep stand-in step drives the multi-rank control flow "
                          "(barriers, MAX over ranks, the final gather) over gloo so it can be tested without GPUs")
@@ -280,7 +281,7 @@ def main():
             line["gather_error"] = gather_error
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, m, T)
-        if world == 1:
+        if world == 1 and not args.no_extra:
             line["extra"] = {"ilqr_api": ilqr_api_rate(n, m, T, B)}
         print(json.dumps(line), flush=True)
 

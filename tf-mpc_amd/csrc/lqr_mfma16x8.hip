@@ -28,6 +28,9 @@
 // of fp32 VALU code with a different summation order.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "lqr_kernels.h"
 #include "wave_ops.h"
 
@@ -46,6 +49,71 @@ __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c)
 __device__ __forceinline__ float readlane(float v, int lane)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// ---- fp32 products on the bf16 matrix cores ("bf16x3") -------------------------------------
+// x = h + m + l with h, m, l bf16 (24 mantissa bits in all).  A 16x16x16 product X Y is evaluated
+// as Xh Yh + Xh Ym + Xm Yh + Xm Ym + Xh Yl + Xl Yh (the dropped terms are below 2^-24 relative),
+// accumulated in fp32 by three v_mfma_f32_16x16x32_bf16, each carrying TWO of the terms in its
+// K = 32: 3 x 16 cycles instead of 4 x 32 for the f32 MFMA, and -- unlike the f32 MFMA, which runs
+// on the vector FMA lanes -- on the matrix pipe proper, so it overlaps other waves' VALU work.
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b)
+{
+    const bf16x2 p = {(__bf16)a, (__bf16)b};                 // v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, p);
+}
+
+struct Split3 { unsigned h01, h23, m01, m23, l01, l23; };
+
+__device__ __forceinline__ Split3 split3(f32x4 x)
+{
+    Split3 s;
+    s.h01 = pack_bf16(x[0], x[1]);
+    s.h23 = pack_bf16(x[2], x[3]);
+    const float r0 = x[0] - __uint_as_float(s.h01 << 16), r1 = x[1] - __uint_as_float(s.h01 & 0xffff0000u);
+    const float r2 = x[2] - __uint_as_float(s.h23 << 16), r3 = x[3] - __uint_as_float(s.h23 & 0xffff0000u);
+    s.m01 = pack_bf16(r0, r1);
+    s.m23 = pack_bf16(r2, r3);
+    s.l01 = pack_bf16(r0 - __uint_as_float(s.m01 << 16), r1 - __uint_as_float(s.m01 & 0xffff0000u));
+    s.l23 = pack_bf16(r2 - __uint_as_float(s.m23 << 16), r3 - __uint_as_float(s.m23 & 0xffff0000u));
+    return s;
+}
+
+// fragments (8 bf16 per lane: k-slots 0..3 = first term rows r, 4..7 = second term rows r)
+struct ConstFrag { u32x4 hm, lh; };          // [h | m], [l | h]   resident operand (F~)
+struct VarFrag { u32x4 hh, mm, hl; };        // [h | h], [m | m], [h | l]   per-step operand (V, W)
+
+__device__ __forceinline__ ConstFrag const_frag(f32x4 x)
+{
+    const Split3 s = split3(x);
+    return ConstFrag{u32x4{s.h01, s.h23, s.m01, s.m23}, u32x4{s.l01, s.l23, s.h01, s.h23}};
+}
+__device__ __forceinline__ VarFrag var_frag(f32x4 x)
+{
+    const Split3 s = split3(x);
+    return VarFrag{u32x4{s.h01, s.h23, s.h01, s.h23}, u32x4{s.m01, s.m23, s.m01, s.m23}, u32x4{s.h01, s.h23, s.l01, s.l23}};
+}
+__device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// acc += Var (as A operand) x Const (as B operand)
+__device__ __forceinline__ f32x4 mm_var_const(const VarFrag &x, const ConstFrag &y, f32x4 acc)
+{
+    acc = mfma_bf(x.hh, y.hm, acc);
+    acc = mfma_bf(x.mm, y.hm, acc);
+    return mfma_bf(x.hl, y.lh, acc);
+}
+// acc += Const (as A operand) x Var (as B operand)
+__device__ __forceinline__ f32x4 mm_const_var(const ConstFrag &y, const VarFrag &x, f32x4 acc)
+{
+    acc = mfma_bf(y.hm, x.hh, acc);
+    acc = mfma_bf(y.hm, x.mm, acc);
+    return mfma_bf(y.lh, x.hl, acc);
 }
 
 // per-wave LDS slice (floats)
@@ -72,7 +140,7 @@ constexpr int kDppHalfMirror = 0x141; // lane i <-> 7 - i inside each 8-lane hal
 // embedded in the 16 x 8 tile grid: states n..15 and actions m..7 are zero rows/columns of
 // F~ and C~, with a unit diagonal on the padded part of C_uu so the elimination stays regular
 // (the padded gains come out exactly 0).
-template <bool BACKWARD, bool FORWARD, bool VALUE, bool EXACT>
+template <bool BACKWARD, bool FORWARD, bool VALUE, bool EXACT, bool BF3>
 __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
@@ -131,6 +199,11 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
                 Cd11[r] = c11;
             }
         }
+        ConstFrag Fc0{}, Fc1{};                  // bf16x3 fragments of F~ (BF3 only)
+        if (BF3) {
+            Fc0 = const_frag(f32x4{Fb0[0], Fb0[1], Fb0[2], Fb0[3]});
+            Fc1 = const_frag(f32x4{Fb1[0], Fb1[1], Fb1[2], Fb1[3]});
+        }
         // terminal value function V = C_xx, v = c_x (lqr.py:67-68): v lives in lanes i == 8
         f32x4 Vd = Cd00, vd = vterm;
         float cst = 0.0f;
@@ -141,10 +214,16 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
         for (int t = T - 1; t >= 0; --t) {
             // 1. W = V F~ (+ v on column 24)                                  lqr.py:74,77-78
             f32x4 W0 = {0.f, 0.f, 0.f, 0.f}, W1 = {0.f, 0.f, 0.f, 0.f};
+            if (BF3) {
+                const VarFrag Vf = var_frag(Vd);
+                W0 = mm_var_const(Vf, Fc0, W0);
+                W1 = mm_var_const(Vf, Fc1, W1);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                W0 = mfma(Vd[r], Fb0[r], W0);
-                W1 = mfma(Vd[r], Fb1[r], W1);
+                for (int r = 0; r < 4; ++r) {
+                    W0 = mfma(Vd[r], Fb0[r], W0);
+                    W1 = mfma(Vd[r], Fb1[r], W1);
+                }
             }
             float fw = 0.0f, fv = 0.0f;
             if (VALUE) {     // f^T (V f) and f^T v for the const recursion (lqr.py:120)
@@ -165,12 +244,20 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
             // to rounding, and the antisymmetric part must propagate through the CLOSED loop
             // (Q_xx + Q_xu K == [I;K]^T Q [I;K]), not the open one.
             f32x4 T00 = Cd00, T01t = Cd01t, T10 = Cd10, T11 = Cd11;
+            if (BF3) {
+                const VarFrag W0f = var_frag(W0), W1f = var_frag(W1);
+                T00 = mm_const_var(Fc0, W0f, T00);
+                T01t = mm_var_const(W1f, Fc0, T01t);
+                T10 = mm_const_var(Fc1, W0f, T10);
+                T11 = mm_const_var(Fc1, W1f, T11);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                T00 = mfma(Fb0[r], W0[r], T00);
-                T01t = mfma(W1[r], Fb0[r], T01t);
-                T10 = mfma(Fb1[r], W0[r], T10);
-                T11 = mfma(Fb1[r], W1[r], T11);
+                for (int r = 0; r < 4; ++r) {
+                    T00 = mfma(Fb0[r], W0[r], T00);
+                    T01t = mfma(W1[r], Fb0[r], T01t);
+                    T10 = mfma(Fb1[r], W0[r], T10);
+                    T11 = mfma(Fb1[r], W1[r], T11);
+                }
             }
             // 3. [Q_ux | Q_uu | q_u] -> column-per-lane layout through LDS; Q_xu and q_x staged
             if (q < 2) {
@@ -426,13 +513,24 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
     if (a.status && lane == 0) a.status[b] = status;
 }
 
+// TFMPC_LQR_MFMA=f32 keeps the two big products of the sweep on the f32 MFMA; the default
+// evaluates them as bf16x3 on the bf16 matrix cores (same fp32-level accuracy, see split3).
+bool use_bf16x3()
+{
+    const char *v = std::getenv("TFMPC_LQR_MFMA");
+    return !(v && std::strcmp(v, "f32") == 0);
+}
+
 template <bool BW, bool FW, bool VAL>
 int launch(const LqrArgs &a, hipStream_t stream)
 {
-    if (a.n == N && a.m == M)
-        hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, true>), dim3(a.B), dim3(kWave), 0, stream, a);
-    else
-        hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, false>), dim3(a.B), dim3(kWave), 0, stream, a);
+    const bool exact = a.n == N && a.m == M;
+    const bool bf3 = BW && use_bf16x3();
+    const dim3 grid(a.B), block(kWave);
+    if (exact && bf3) hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, true, true>), grid, block, 0, stream, a);
+    else if (exact) hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, true, false>), grid, block, 0, stream, a);
+    else if (bf3) hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, false, false>), grid, block, 0, stream, a);
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
 }
 

@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extra"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/stats.log" 2>&1
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" \
