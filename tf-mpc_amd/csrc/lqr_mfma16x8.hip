@@ -84,36 +84,45 @@ __device__ __forceinline__ Split3 split3(f32x4 x)
 }
 
 // fragments (8 bf16 per lane: k-slots 0..3 = first term rows r, 4..7 = second term rows r)
-struct ConstFrag { u32x4 hm, lh; };          // [h | m], [l | h]   resident operand (F~)
-struct VarFrag { u32x4 hh, mm, hl; };        // [h | h], [m | m], [h | l]   per-step operand (V, W)
+//   resident operand Y (F~):   [h|h], [m|m], [h|l]
+//   per-step operand X (V, W): [h|m] (used against [h|h] and [m|m]) and [l|h] (against [h|l]);
+//   both are 4-register windows of ONE 6-register block [l01 l23 h01 h23 m01 m23], so building
+//   them costs no register moves.
+struct ConstFrag { u32x4 hh, mm, hl; };
+using u32x6 = __attribute__((ext_vector_type(6))) unsigned;
+struct VarFrag {
+    u32x6 r;                                               // l01 l23 h01 h23 m01 m23
+    __device__ __forceinline__ u32x4 hm() const { return __builtin_shufflevector(r, r, 2, 3, 4, 5); }
+    __device__ __forceinline__ u32x4 lh() const { return __builtin_shufflevector(r, r, 0, 1, 2, 3); }
+};
 
 __device__ __forceinline__ ConstFrag const_frag(f32x4 x)
 {
     const Split3 s = split3(x);
-    return ConstFrag{u32x4{s.h01, s.h23, s.m01, s.m23}, u32x4{s.l01, s.l23, s.h01, s.h23}};
+    return ConstFrag{u32x4{s.h01, s.h23, s.h01, s.h23}, u32x4{s.m01, s.m23, s.m01, s.m23}, u32x4{s.h01, s.h23, s.l01, s.l23}};
 }
 __device__ __forceinline__ VarFrag var_frag(f32x4 x)
 {
     const Split3 s = split3(x);
-    return VarFrag{u32x4{s.h01, s.h23, s.h01, s.h23}, u32x4{s.m01, s.m23, s.m01, s.m23}, u32x4{s.h01, s.h23, s.l01, s.l23}};
+    return VarFrag{u32x6{s.l01, s.l23, s.h01, s.h23, s.m01, s.m23}};
 }
 __device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-// acc += Var (as A operand) x Const (as B operand)
+// acc += X (as A operand) x Y (as B operand):  Xh Yh + Xm Yh | Xh Ym + Xm Ym | Xl Yh + Xh Yl
 __device__ __forceinline__ f32x4 mm_var_const(const VarFrag &x, const ConstFrag &y, f32x4 acc)
 {
-    acc = mfma_bf(x.hh, y.hm, acc);
-    acc = mfma_bf(x.mm, y.hm, acc);
-    return mfma_bf(x.hl, y.lh, acc);
+    acc = mfma_bf(x.hm(), y.hh, acc);
+    acc = mfma_bf(x.hm(), y.mm, acc);
+    return mfma_bf(x.lh(), y.hl, acc);
 }
-// acc += Const (as A operand) x Var (as B operand)
+// acc += Y (as A operand) x X (as B operand)
 __device__ __forceinline__ f32x4 mm_const_var(const ConstFrag &y, const VarFrag &x, f32x4 acc)
 {
-    acc = mfma_bf(y.hm, x.hh, acc);
-    acc = mfma_bf(y.hm, x.mm, acc);
-    return mfma_bf(y.lh, x.hl, acc);
+    acc = mfma_bf(y.hh, x.hm(), acc);
+    acc = mfma_bf(y.mm, x.hm(), acc);
+    return mfma_bf(y.hl, x.lh(), acc);
 }
 
 // per-wave LDS slice (floats)
