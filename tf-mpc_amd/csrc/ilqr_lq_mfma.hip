@@ -7,7 +7,7 @@
 // backward pass of ilqr.py:94-172 is the Riccati recursion of lqr_mfma16x8.hip with the affine
 // column carrying (l_z(t) + F^T V_x) instead of (c + F^T(V f + v)); K = -Q_uu^-1 Q_ux makes the
 // four-term updates collapse to V_xx' = Q_xx + Q_xu K, V_x' = Q_x + Q_xu k and dV2 = -dV1/2.
-// So per timestep: 28 MFMA + the readlane Gauss-Jordan, exactly as in the LQR kernel.  The
+// So per timestep the same matrix-core products (bf16x3, mfma_bf16x3.h) + readlane Gauss-Jordan as the LQR kernel.  The
 // cost gradients l_z(t) = C_s z_t + c of the whole nominal trajectory are one C Z product on
 // the matrix cores before the sweep, and the stage costs of every rollout another one after
 // it.  Nominal and candidate trajectories live in LDS (swapped on accept, never copied).
@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ilqr_lq_mfma.h"
+#include "mfma_bf16x3.h"
 #include "wave_ops.h"
 
 namespace tfmpc {
@@ -26,7 +27,8 @@ namespace tfmpc {
 namespace {
 
 constexpr int N = 16, M = 8, D = 24;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x4 = bf3::f32x4;
+using namespace bf3;
 
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c)
 {
@@ -119,6 +121,9 @@ __global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
         cq0[r] = cz(4 * q + r);
         cq1[r] = (q < 2) ? cz(N + 4 * q + r) : 0.0f;
     }
+    // bf16x3 fragments of F~ for the two big products of the sweep (mfma_bf16x3.h)
+    const ConstFrag Fc0 = const_frag(f32x4{Fb0[0], Fb0[1], Fb0[2], Fb0[3]});
+    const ConstFrag Fc1 = const_frag(f32x4{Fb1[0], Fb1[1], Fb1[2], Fb1[3]});
     for (int idx = lane; idx < kDyn; idx += kWave) lds[idx] = 0.0f;
 
     // C Z on the matrix cores over rows [0, rows) of Z, 16 timesteps per tile.
@@ -204,21 +209,21 @@ __global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
         int min_pivot_bits = 0x3f800000;
         for (int t = T - 1; t >= 0; --t) {
             f32x4 W0 = {0.f, 0.f, 0.f, 0.f}, W1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                W0 = mfma(Vd[r], Fb0[r], W0);
-                W1 = mfma(Vd[r], Fb1[r], W1);
+            {
+                const VarFrag Vf = var_frag(Vd);
+                W0 = mm_var_const(Vf, Fc0, W0);
+                W1 = mm_var_const(Vf, Fc1, W1);
             }
             if (i == M) W1 += vd;                                  // affine column: V_x
             f32x4 T00 = Cd00, T01t = Cd01t, T10 = Cd10, T11 = Cd11;
             if (q == 2) T01t[0] = Lz[t * kZld + i];                                     // l_x(t)
             if (i == M && q < 2) T11 = *reinterpret_cast<const f32x4 *>(&Lz[t * kZld + N + 4 * q]);   // l_u(t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                T00 = mfma(Fb0[r], W0[r], T00);                    // Q_xx                 :129
-                T01t = mfma(W1[r], Fb0[r], T01t);                  // Q_xu | Q_x (transposed tile)
-                T10 = mfma(Fb1[r], W0[r], T10);                    // Q_ux                 :131
-                T11 = mfma(Fb1[r], W1[r], T11);                    // Q_uu | Q_u           :130,123
+            {
+                const VarFrag W0f = var_frag(W0), W1f = var_frag(W1);
+                T00 = mm_const_var(Fc0, W0f, T00);                 // Q_xx                 :129
+                T01t = mm_var_const(W1f, Fc0, T01t);               // Q_xu | Q_x (transposed tile)
+                T10 = mm_const_var(Fc1, W0f, T10);                 // Q_ux                 :131
+                T11 = mm_const_var(Fc1, W1f, T11);                 // Q_uu | Q_u           :130,123
             }
             if (q < 2) {
                 *reinterpret_cast<f32x4 *>(&lds[kMs + i * 8 + 4 * q]) = T10;
