@@ -32,9 +32,10 @@ def make_lqr_batch(B, n, m, seed0=1000, x0_seed=7):
 
 
 def make_lqr_batch_fast(B, n, m, seed=0):
-    """Timing-only generator with the distributions of ``make_lqr`` (F, f, c ~
-    N(0,1); C = A A^T/d-style SPD with sklearn's spectrum is NOT reproduced --
-    C = U diag(s) U^T with s ~ 1 + U(0,1)·d spread like make_spd_matrix)."""
+    """Fast vectorised generator for timing runs and large-batch tests: F, f, c ~ N(0,1) as in
+    ``make_lqr``; C = U diag(1 + U(0,1)) U^T with U from the SVD of a random Gram matrix -- SPD
+    and well conditioned (eigenvalues in [1, 2]).  It does NOT reproduce ``make_spd_matrix``'s
+    spectrum (0.04 .. n+m); the seeded ``make_lqr_instance`` does and defines the parity cases."""
     rng = np.random.default_rng(seed)
     d = n + m
     F = rng.normal(size=(B, n, d))

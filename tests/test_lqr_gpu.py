@@ -176,6 +176,24 @@ def test_mfma_kernel_on_padded_shapes(n, m):
             (key, np.median(ratios), max(ratios))
 
 
+@pytest.mark.parametrize("scale", [1e-6, 1e-3, 1e3, 1e6])
+def test_mfma_kernel_is_scale_covariant(scale):
+    """Scaling the cost (C, c) by s scales costs and value function by s and leaves the optimal
+    trajectory unchanged.  Exercises the dynamic range of the bf16x3 operand split (bf16 keeps
+    fp32's exponent range, so nothing may overflow, flush or lose relative accuracy)."""
+    B, n, m, T = 64, 16, 8, 30
+    F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=77)
+    F *= 0.4
+    base = LQR(F, f, C, c).solve_device(x0, T)
+    scaled = LQR(F, f, scale * C, scale * c).solve_device(x0, T)
+    torch.cuda.synchronize()
+    assert int(scaled["status"].abs().sum()) == 0
+    for key, factor in (("states", 1.0), ("actions", 1.0), ("costs", scale)):
+        a, b = base[key].double() * factor, scaled[key].double()
+        rel = ((a - b).abs().reshape(B, -1).amax(1) / a.abs().reshape(B, -1).amax(1)).cpu().numpy()
+        assert np.median(rel) <= 2e-5 and rel.max() <= 2e-3, (key, scale, np.median(rel), rel.max())
+
+
 def test_empty_batch_and_unsupported_shape():
     lib = _hip.require_gpu()
     assert lib.tfmpc_lqr_solve_f32(0, 3, 2, 5, *([None, 0] * 4), None, None, None, None, None, None, None, None,

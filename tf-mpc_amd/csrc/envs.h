@@ -322,14 +322,45 @@ template <> struct Env<TFMPC_ENV_HVAC> {
         const int n = e.n;
         const float *t_out = e.p[0], *t_hall = e.p[1], *k_out = e.p[4], *k_hall = e.p[5], *cap = e.p[6],
                     *air_max = e.p[7], *G = e.p[8];
-        for (int i = lane_id(); i < n; i += kWave) {
-            const float air = u[i] * air_max[i];                                          // :72
-            const float heating = air * CAP_AIR * (TEMP_AIR - x[i]);                      // :74
-            float between = 0.0f;                                                         // :131-139
-            for (int j = 0; j < n; ++j) between = fmaf(-G[i * n + j], x[i] - x[j], between);
-            const float outside = k_out[i] * (t_out[i] - x[i]);                           // :143-144
-            const float hall = k_hall[i] * (t_hall[i] - x[i]);                            // :148-149
-            xn[i] = x[i] + TIME_DELTA / cap[i] * (heating + between + outside + hall);    // :80-88
+        // conduction between rooms, sum_j -G[i][j] (x_i - x_j) (:131-139): each row is split over
+        // `parts` adjacent lanes (all 64 lanes busy for n <= 32) and every lane keeps 4 independent
+        // partial sums so the LDS reads pipeline; the column walk is rotated by the row index so the
+        // lanes of a half-wave hit different banks (leading dimension n = 32 would be a 32-way conflict).
+        const int parts = (n <= 16) ? 4 : ((n <= 32) ? 2 : 1);
+        const int lane = lane_id();
+        for (int base = 0; base < n; base += kWave / parts) {
+            const int i = base + lane / parts, part = lane % parts;
+            float between = 0.0f;
+            if (i < n) {
+                const int per = (n + parts - 1) / parts;
+                const int j0 = part * per, j1 = (j0 + per < n) ? j0 + per : n;
+                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+                const float xi = x[i];
+                int jj = j0;
+                for (; jj + 4 <= j1; jj += 4) {
+                    int c0 = jj + i, c1 = jj + 1 + i, c2 = jj + 2 + i, c3 = jj + 3 + i;
+                    c0 -= (c0 >= n) ? n : 0; c1 -= (c1 >= n) ? n : 0; c2 -= (c2 >= n) ? n : 0; c3 -= (c3 >= n) ? n : 0;
+                    s0 = fmaf(-G[i * n + c0], xi - x[c0], s0);
+                    s1 = fmaf(-G[i * n + c1], xi - x[c1], s1);
+                    s2 = fmaf(-G[i * n + c2], xi - x[c2], s2);
+                    s3 = fmaf(-G[i * n + c3], xi - x[c3], s3);
+                }
+                for (; jj < j1; ++jj) {
+                    int c0 = jj + i;
+                    c0 -= (c0 >= n) ? n : 0;
+                    s0 = fmaf(-G[i * n + c0], xi - x[c0], s0);
+                }
+                between = (s0 + s1) + (s2 + s3);
+            }
+            if (parts >= 2) between += __shfl_xor(between, 1, kWave);
+            if (parts >= 4) between += __shfl_xor(between, 2, kWave);
+            if (i < n && part == 0) {
+                const float air = u[i] * air_max[i];                                          // :72
+                const float heating = air * CAP_AIR * (TEMP_AIR - x[i]);                      // :74
+                const float outside = k_out[i] * (t_out[i] - x[i]);                           // :143-144
+                const float hall = k_hall[i] * (t_hall[i] - x[i]);                            // :148-149
+                xn[i] = x[i] + TIME_DELTA / cap[i] * (heating + between + outside + hall);    // :80-88
+            }
         }
     }
     static __device__ float penalties(const EnvLds &e, const float *x, int i)
@@ -415,11 +446,32 @@ template <> struct Env<TFMPC_ENV_RESERVOIR> {
     {
         const int n = e.n;
         const float *cap = e.p[0], *rain = e.p[6], *D = e.p[7];
-        for (int i = lane_id(); i < n; i += kWave) {
-            float inflow = 0.0f;                                                          // :91  D^T (u*x)
-            for (int j = 0; j < n; ++j) inflow = fmaf(D[j * n + i], u[j] * x[j], inflow);
-            const float vaporated = 0.5f * sinf(x[i] / cap[i]) * x[i];                    // :87
-            xn[i] = x[i] + rain[i] + inflow - vaporated - u[i] * x[i];                    // :56-60
+        // inflow_i = sum_j D[j][i] u_j x_j (:91): rows split over `parts` lanes, 4 partial sums per lane
+        const int parts = (n <= 16) ? 4 : ((n <= 32) ? 2 : 1);
+        const int lane = lane_id();
+        for (int base = 0; base < n; base += kWave / parts) {
+            const int i = base + lane / parts, part = lane % parts;
+            float inflow = 0.0f;
+            if (i < n) {
+                const int per = (n + parts - 1) / parts;
+                const int j0 = part * per, j1 = (j0 + per < n) ? j0 + per : n;
+                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+                int j = j0;
+                for (; j + 4 <= j1; j += 4) {
+                    s0 = fmaf(D[j * n + i], u[j] * x[j], s0);
+                    s1 = fmaf(D[(j + 1) * n + i], u[j + 1] * x[j + 1], s1);
+                    s2 = fmaf(D[(j + 2) * n + i], u[j + 2] * x[j + 2], s2);
+                    s3 = fmaf(D[(j + 3) * n + i], u[j + 3] * x[j + 3], s3);
+                }
+                for (; j < j1; ++j) s0 = fmaf(D[j * n + i], u[j] * x[j], s0);
+                inflow = (s0 + s1) + (s2 + s3);
+            }
+            if (parts >= 2) inflow += __shfl_xor(inflow, 1, kWave);
+            if (parts >= 4) inflow += __shfl_xor(inflow, 2, kWave);
+            if (i < n && part == 0) {
+                const float vaporated = 0.5f * sinf(x[i] / cap[i]) * x[i];                    // :87
+                xn[i] = x[i] + rain[i] + inflow - vaporated - u[i] * x[i];                    // :56-60
+            }
         }
     }
     static __device__ float cost(const EnvLds &e, const float *x, const float *)
