@@ -59,8 +59,7 @@ constexpr int kMs = 0;          // [32 cols][8 rows]  elimination input, column-
 constexpr int kKs = 256;        // [32 cols][8 rows]  K~ = -Q_uu^-1 [Q_ux | . | q_u], column-major
 constexpr int kXs = 512;        // [16 rows][8]       Q_xu, row-major (A operand of the V update)
 constexpr int kQx = 640;        // q_x staging (16)
-constexpr int kMul = 656;       // multiplier column of the current pivot (8)
-constexpr int kZs = 664;        // rollout chunk: rows z_t = [x_t(16); u_t(8)], stride kZld
+constexpr int kZs = 656;        // rollout chunk: rows z_t = [x_t(16); u_t(8)], stride kZld
 constexpr int kZld = 26;        // even (8-byte aligned rows), 26 n mod 32 distinct for n < 16
 constexpr int kTC = 52;         // timesteps per rollout chunk (T = 50 fits one chunk)
 constexpr int kLdsFloats = kZs + (kTC + 1) * kZld + 6;
@@ -146,7 +145,7 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
         // terminal value function V = C_xx, v = c_x (lqr.py:67-68): v lives in lanes i == 8
         f32x4 Vd = Cd00, vd = vterm;
         float cst = 0.0f;
-        float min_pivot = 1.0f;
+        int min_pivot_bits = 0x3f800000;     // smallest pivot seen, as float bits (int order == float order for >= 0)
         for (int idx = lane; idx < kZs; idx += kWave) lds[idx] = 0.0f;   // pad columns stay 0
         __syncthreads();
 
@@ -225,25 +224,16 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
             // No pivoting: Q_uu is positive definite whenever C >= 0 and C_uu > 0 (checked below).
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-                // the multiplier column (lane 16+p, 8 registers) goes through LDS and comes back as a
-                // broadcast read: 4 LDS instructions instead of 8 v_readlane on the VALU pipe
-                if (lane == N + p) {
-                    *reinterpret_cast<f32x4 *>(&lds[kMul]) = f32x4{Mr[0], Mr[1], Mr[2], Mr[3]};
-                    *reinterpret_cast<f32x4 *>(&lds[kMul + 4]) = f32x4{Mr[4], Mr[5], Mr[6], Mr[7]};
-                }
-                __syncthreads();
-                const f32x4 flo = *reinterpret_cast<const f32x4 *>(&lds[kMul]);
-                const f32x4 fhi = *reinterpret_cast<const f32x4 *>(&lds[kMul + 4]);
-                const float fct[8] = {flo[0], flo[1], flo[2], flo[3], fhi[0], fhi[1], fhi[2], fhi[3]};
-                min_pivot = fminf(min_pivot, fct[p]);
-                const float inv = __builtin_amdgcn_rcpf(fct[p]);                 // 1 ulp
+                const int pvb = __builtin_amdgcn_readlane(__builtin_bit_cast(int, Mr[p]), N + p);
+                min_pivot_bits = min(min_pivot_bits, pvb);         // scalar; sign bit set <=> pivot < 0
+                const float inv = __builtin_amdgcn_rcpf(__builtin_bit_cast(float, pvb));   // 1 ulp
                 Mr[p] *= inv;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     if (r == p) continue;
-                    Mr[r] = fmaf(-fct[r], Mr[p], Mr[r]);
+                    const float fct = readlane(Mr[r], N + p);
+                    Mr[r] = fmaf(-fct, Mr[p], Mr[r]);
                 }
-                __syncthreads();
             }
             if (VALUE) {
 #pragma unroll
@@ -307,7 +297,7 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
             }
             __syncthreads();
         }
-        if (!(min_pivot > 0.0f)) status |= (min_pivot == 0.0f) ? TFMPC_ST_SINGULAR : TFMPC_ST_NOT_PD;
+        if (min_pivot_bits <= 0) status |= (min_pivot_bits == 0) ? TFMPC_ST_SINGULAR : TFMPC_ST_NOT_PD;
         if (VALUE && !(cst == cst)) status |= TFMPC_ST_NAN;
     }
 
