@@ -176,6 +176,33 @@ def test_mfma_kernel_on_padded_shapes(n, m):
             (key, np.median(ratios), max(ratios))
 
 
+def test_f32_mfma_variant_agrees_with_bf16x3_default():
+    """TFMPC_LQR_MFMA=f32 keeps the sweep's big products on v_mfma_f32_16x16x4_f32; the default
+    evaluates them as bf16x3.  Both are fp32-accurate, so they agree like two fp32 programs."""
+    import os
+    B, n, m, T = 128, 16, 8, 50
+    F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=21)
+    lqr = LQR(F, f, C, c)
+    ref64 = c_oracle.lqr_solve(F, f, C, c, x0, T, dtype=np.float64)
+    outs = {}
+    old = os.environ.get("TFMPC_LQR_MFMA")
+    try:
+        for mode in ("bf16x3", "f32"):
+            os.environ["TFMPC_LQR_MFMA"] = mode
+            outs[mode] = lqr.solve_device(x0, T)
+            torch.cuda.synchronize()
+            assert int(outs[mode]["status"].abs().sum()) == 0
+    finally:
+        os.environ.pop("TFMPC_LQR_MFMA") if old is None else os.environ.__setitem__("TFMPC_LQR_MFMA", old)
+    errs = {}
+    for mode, o in outs.items():
+        got = _np(o["states"]).reshape(ref64["states"].shape)
+        errs[mode] = np.abs(got - ref64["states"]).reshape(B, -1).max(1) / np.abs(ref64["states"]).reshape(B, -1).max(1)
+    # the bf16x3 path is as close to fp64 as the f32-MFMA path (median and tail within 2x)
+    assert np.median(errs["bf16x3"]) <= 2.0 * np.median(errs["f32"]) + 1e-7
+    assert np.quantile(errs["bf16x3"], 0.95) <= 2.0 * np.quantile(errs["f32"], 0.95) + 1e-6
+
+
 @pytest.mark.parametrize("scale", [1e-6, 1e-3, 1e3, 1e6])
 def test_mfma_kernel_is_scale_covariant(scale):
     """Scaling the cost (C, c) by s scales costs and value function by s and leaves the optimal
