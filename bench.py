@@ -97,6 +97,21 @@ def ilqr_api_rate(n, m, T, B, reps=5):
             "workload": f"iLQR.solve on LQEnv(0.25 F, f, C, c), n={n} m={m} T={T} B={B}, zero initial actions"}
 
 
+def numpy_single_instance_rate(n, m, T, instances=24):
+    """The reference's execution model -- one problem at a time, fp32, its operation order -- as
+    the oracle's numpy restatement looped over a few instances on ONE core.
+    Optimistic for the reference: no TensorFlow op-dispatch or graph-tracing overhead."""
+    import problems
+    from oracle import lqr_ref
+    F, f, C, c, x0 = problems.make_lqr_batch_fast(instances, n, m, seed=5)
+    t0 = time.perf_counter()
+    for b in range(instances):
+        lqr_ref.solve(F[b], f[b], C[b], c[b], x0[b], T, dtype=np.float32)
+    dt = time.perf_counter() - t0
+    return {"value": instances / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{instances} instances, numpy fp32 restatement of lqr.py, one at a time"}
+
+
 def cpu_baseline(n, m, T, target_seconds=12.0):
     """The oracle's C port of the reference equations, OpenMP over instances on all
     host cores, on a bounded sample of the same workload."""
@@ -283,6 +298,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(n, m, T)
         if world == 1 and not args.no_extra:
             line["extra"] = {"ilqr_api": ilqr_api_rate(n, m, T, B)}
+            if not args.no_cpu_baseline:
+                line["extra"]["cpu_numpy_single_instance"] = numpy_single_instance_rate(n, m, T)
         print(json.dumps(line), flush=True)
 
     if world > 1:
