@@ -91,3 +91,30 @@ def test_lane_tracks_wave_and_oracle_on_nonlinear_navigation(force_kernel):
     for t in (0, 9, 19):
         nxt = env.transition(st[:, t], ac[:, t], batch=True)
         assert torch.equal(nxt, st[:, t + 1])
+
+
+@pytest.mark.parametrize("kind,B,T", [("navlqr", 203, 12), ("navigation", 131, 50)])
+def test_group_kernel_equals_per_lane_kernel(force_kernel, kind, B, T):
+    """The 16-lanes-per-instance kernel evaluates all line-search step sizes at once and picks
+    the first accepted one (ilqr.py:322-353); the one-lane-per-instance kernel tries them in
+    order.  Same arithmetic, same decisions: outputs must be bit-identical.  B is not a
+    multiple of 4 so the last wave has idle groups."""
+    rng = np.random.default_rng(21)
+    if kind == "navlqr":
+        goals = rng.uniform(-10, 10, size=(B, 2, 1)).astype(np.float32)
+        solver = iLQR(NavigationLQR(goals, 5.0, -1.0, 1.0))
+        x0 = rng.normal(size=(B, 2, 1)).astype(np.float32)
+    else:
+        solver = iLQR(Navigation.load(problems.NAV_CONFIG))
+        x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
+    u0 = solver.random_actions(T, B, seed=2)
+    out = {}
+    for kern in ("lane", "lane1"):
+        force_kernel(kern)
+        out[kern] = solver.solve_device(x0, T, u_init=u0)
+        torch.cuda.synchronize()
+    g, l = out["lane"], out["lane1"]
+    assert torch.equal(g["iterations"], l["iterations"])
+    assert torch.equal(g["status"], l["status"])
+    for key in ("states", "actions", "costs"):
+        assert torch.equal(g[key], l[key]), key

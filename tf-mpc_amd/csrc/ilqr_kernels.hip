@@ -467,7 +467,7 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
         // tiny 2-D envs: one lane per instance once the batch fills lanes (ilqr_lane.hip);
         // TFMPC_ILQR_KERNEL=lane|wave forces the choice (tests, A/B timing)
         const char *force = std::getenv("TFMPC_ILQR_KERNEL");
-        const bool forced_lane = force && std::strcmp(force, "lane") == 0;
+        const bool forced_lane = force && (std::strcmp(force, "lane") == 0 || std::strcmp(force, "lane1") == 0);
         const bool forced_wave = force && std::strcmp(force, "wave") == 0;
         if (ilqr_lane_supported(*env) && !forced_wave && !cfg->storage_bf16 && (forced_lane || B >= 32))
             return ilqr_lane_solve_launch(*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status,

@@ -8,6 +8,8 @@
 // ([slot][lane], bank-conflict free) when the horizon fits (T <= 62), else in HBM slabs.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "envs.h"
@@ -493,14 +495,29 @@ __device__ inline LaneBackward backward_lane(const LaneEnv<KIND, N, M> &env, int
     return r;
 }
 
-template <int KIND, int N, int M, class Store>
+// Where a rollout's trajectory goes: HBM slabs, nowhere (speculative rollouts only need J and
+// the residual), or the group's second nominal buffer.
+template <int N, int M>
+struct GlobalSink {
+    float *xs, *us, *cs;
+    __device__ void x(int t, int i, float v) const { xs[(size_t)t * N + i] = v; }
+    __device__ void u(int t, int a, float v) const { us[(size_t)t * M + a] = v; }
+    __device__ void c(int t, float v) const { cs[t] = v; }
+};
+struct NullSink {
+    __device__ void x(int, int, float) const {}
+    __device__ void u(int, int, float) const {}
+    __device__ void c(int, float) const {}
+};
+
+template <int KIND, int N, int M, class Store, class Sink>
 __device__ inline void forward_lane(const LaneEnv<KIND, N, M> &env, int T, float alpha, const float *low,
-                                    const float *high, const Store &st, float *states, float *actions,
-                                    float *costs, float &J_out, float &res_out)
+                                    const float *high, const Store &st, const Sink &sink, float &J_out,
+                                    float &res_out)
 {
     float x[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) { x[i] = st.x(0, i); states[i] = x[i]; }
+    for (int i = 0; i < N; ++i) { x[i] = st.x(0, i); sink.x(0, i, x[i]); }
     float J = 0.0f, resid = 0.0f;
     for (int t = 0; t < T; ++t) {                                           // ilqr.py:192-206
         float u[M], xn[N];
@@ -510,18 +527,18 @@ __device__ inline void forward_lane(const LaneEnv<KIND, N, M> &env, int T, float
 #pragma unroll
             for (int j = 0; j < N; ++j) du = fmaf(st.K(t, a, j), x[j] - st.x(t, j), du);
             u[a] = fminf(fmaxf(st.u(t, a) + du, low[a]), high[a]);
-            actions[(size_t)t * M + a] = u[a];
+            sink.u(t, a, u[a]);
             resid = fmaxf(resid, fabsf(du));
         }
         const float c = env.cost(x, u);
         env.transition(x, u, xn);
         J += c;
-        costs[t] = c;
+        sink.c(t, c);
 #pragma unroll
-        for (int i = 0; i < N; ++i) { x[i] = xn[i]; states[(size_t)(t + 1) * N + i] = xn[i]; }
+        for (int i = 0; i < N; ++i) { x[i] = xn[i]; sink.x(t + 1, i, xn[i]); }
     }
     const float fc = env.final_cost(x);
-    costs[T] = fc;
+    sink.c(T, fc);
     J_out = J + fc;
     res_out = resid;
 }
@@ -586,7 +603,7 @@ __global__ __launch_bounds__(64) void ilqr_lane_solve_kernel(TfmpcEnv genv, Tfmp
             for (int ai = 0; ai < cfg.n_alphas; ++ai) {                      // :317-355
                 const float alpha = cfg.alphas[ai];
                 float J;
-                forward_lane<KIND, N, M>(env, T, alpha, low, high, st, xc, uc, cc, J, residual);
+                forward_lane<KIND, N, M>(env, T, alpha, low, high, st, GlobalSink<N, M>{xc, uc, cc}, J, residual);
                 const float delta_J = -alpha * (r.dV1 + alpha * r.dV2);
                 const float dcost = r.J - J;
                 const float z = (delta_J > 0.0f) ? dcost / delta_J : sgnf(dcost);
@@ -634,6 +651,141 @@ __global__ __launch_bounds__(64) void ilqr_lane_solve_kernel(TfmpcEnv genv, Tfmp
     a.status[b] = status;
 }
 
+// ---- group-per-instance variant: speculative PARALLEL line search ---------------------------
+// 16 lanes own one instance (4 instances per wave).  Everything that is sequential in the
+// reference runs redundantly on all 16 lanes (same data, same control flow, so no broadcast is
+// needed), but the 11 line-search rollouts of ilqr.py:322 run AT ONCE, one step size per lane;
+// the first accepted one is picked with a ballot -- exactly the reference's "first alpha that
+// passes" -- and that rollout is replayed once into the other nominal buffer.  An iteration costs
+// backward + 2 rollouts of latency instead of backward + up to 11.
+template <int N, int M>
+struct GroupStore {
+    static constexpr int kGroups = 4;
+    float *base;                 // wave's LDS + group index; slot stride = kGroups
+    int T, cur;                  // cur: which nominal buffer is live
+    __device__ int xoff(int buf) const { return buf * ((T + 1) * N + T * M); }
+    __device__ int koff() const { return 2 * ((T + 1) * N + T * M); }
+    __device__ float &at(int slot) const { return base[slot * kGroups]; }
+    __device__ float x(int t, int i) const { return at(xoff(cur) + t * N + i); }
+    __device__ float u(int t, int a) const { return at(xoff(cur) + (T + 1) * N + t * M + a); }
+    __device__ float K(int t, int a, int j) const { return at(koff() + t * M * N + a * N + j); }
+    __device__ float k(int t, int a) const { return at(koff() + T * M * N + t * M + a); }
+    __device__ void set_x(int t, int i, float v) { at(xoff(cur) + t * N + i) = v; }
+    __device__ void set_u(int t, int a, float v) { at(xoff(cur) + (T + 1) * N + t * M + a) = v; }
+    __device__ void set_K(int t, int a, int j, float v) { at(koff() + t * M * N + a * N + j) = v; }
+    __device__ void set_k(int t, int a, float v) { at(koff() + T * M * N + t * M + a) = v; }
+    static size_t bytes(int T) { return (size_t)(2 * ((T + 1) * N + T * M) + T * M * N + T * M) * kGroups * sizeof(float); }
+};
+
+template <int N, int M>
+struct GroupReplaySink {        // replay of the chosen rollout: other nominal buffer + costs to HBM
+    GroupStore<N, M> st;
+    float *chat;
+    bool leader;
+    __device__ void x(int t, int i, float v) const { st.at(st.xoff(st.cur ^ 1) + t * N + i) = v; }
+    __device__ void u(int t, int a, float v) const { st.at(st.xoff(st.cur ^ 1) + (st.T + 1) * N + t * M + a) = v; }
+    __device__ void c(int t, float v) const { if (leader) chat[t] = v; }
+};
+
+template <int KIND, int N, int M>
+__global__ __launch_bounds__(64) void ilqr_group_solve_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, SolveArgsLane a)
+{
+    extern __shared__ float lane_lds[];
+    constexpr int G = 16;
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    const int b = blockIdx.x * GroupStore<N, M>::kGroups + grp;
+    if (b >= a.B) return;                           // whole group leaves together
+    const int T = a.T;
+    LaneEnv<KIND, N, M> env;
+    env.load(genv, b);
+    float low[M], high[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) { low[i] = genv.low[i]; high[i] = genv.high[i]; }
+    const bool bounded = genv.bounded != 0;
+    const bool leader = gl == 0;
+    float *xout = a.states + (size_t)b * (T + 1) * N, *uout = a.actions + (size_t)b * T * M,
+          *chat = a.costs + (size_t)b * (T + 1);
+    GroupStore<N, M> st{lane_lds + grp, T, 0};
+
+    {   // start (ilqr.py:218), redundantly on every lane of the group
+        float x[N], xn[N], u[M];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { x[i] = a.x0[(size_t)b * N + i]; st.set_x(0, i, x[i]); }
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int i = 0; i < M; ++i) { u[i] = a.u_init[((size_t)b * T + t) * M + i]; st.set_u(t, i, u[i]); }
+            const float c = env.cost(x, u);
+            if (leader) chat[t] = c;
+            env.transition(x, u, xn);
+#pragma unroll
+            for (int i = 0; i < N; ++i) { x[i] = xn[i]; st.set_x(t + 1, i, xn[i]); }
+        }
+        const float fc = env.final_cost(x);
+        if (leader) chat[T] = fc;
+    }
+
+    const int my_alpha_idx = (gl < cfg.n_alphas) ? gl : cfg.n_alphas - 1;
+    const float my_alpha = cfg.alphas[my_alpha_idx];
+    float mu = 0.0f, delta = 1.0f;
+    int status = 0, attempts = 0, iteration = 0;
+    bool converged = false, give_up = false;
+    for (iteration = 0; iteration < cfg.max_iterations; ++iteration) {
+        for (;;) {
+            float mu_l = mu, delta_l = delta;
+            LaneBackward r;
+            for (int retry = 0;; ++retry) {                                  // :285-315
+                r = backward_lane<KIND, N, M>(env, T, mu_l, bounded, low, high, st);
+                status |= r.flags;
+                if (!r.failed) break;
+                status |= TFMPC_ST_NOT_PD;
+                delta_l = fmaxf(cfg.delta_0, delta_l * cfg.delta_0);
+                mu_l = fmaxf(cfg.mu_min, mu_l * delta_l);
+                if (retry >= 40) { give_up = true; break; }
+            }
+            if (give_up) break;
+            if (r.g_norm < cfg.atol) { converged = true; break; }            // :243-248
+            // all step sizes at once, one per lane (ilqr.py:322-353)
+            float J, residual;
+            forward_lane<KIND, N, M>(env, T, my_alpha, low, high, st, NullSink{}, J, residual);
+            const float delta_J = -my_alpha * (r.dV1 + my_alpha * r.dV2);
+            const float dcost = r.J - J;
+            const float z = (delta_J > 0.0f) ? dcost / delta_J : sgnf(dcost);
+            const bool ok = gl < cfg.n_alphas && z >= cfg.c1;
+            const unsigned mask = (unsigned)((__ballot(ok) >> (grp * G)) & 0xFFFFu);
+            const bool accept = mask != 0;
+            const int chosen = accept ? (__ffs(mask) - 1) : cfg.n_alphas - 1;     // first accepted, else the last tried
+            const float res_chosen = __shfl(residual, grp * G + chosen, 64);
+            const bool small_step = res_chosen < cfg.atol;                   // :253-257
+            if (small_step || accept) {
+                float J2, r2;
+                forward_lane<KIND, N, M>(env, T, cfg.alphas[chosen], low, high, st,
+                                         GroupReplaySink<N, M>{st, chat, leader}, J2, r2);
+                st.cur ^= 1;
+            }
+            if (small_step) { converged = true; break; }
+            if (accept) {                                                    // :259-266
+                delta = fminf(1.0f / cfg.delta_0, delta / cfg.delta_0);
+                mu = (mu * delta > cfg.mu_min) ? mu * delta : 0.0f;
+                break;
+            }
+            delta = fmaxf(cfg.delta_0, delta * cfg.delta_0);                 // :267-270
+            mu = fmaxf(cfg.mu_min, mu * delta);
+            if (++attempts >= cfg.max_attempts || !(mu < 1e30f)) { give_up = true; break; }
+        }
+        if (converged || give_up) break;
+    }
+    if (give_up) status |= TFMPC_ST_MAX_ATTEMPTS;
+    if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
+    for (int idx = gl; idx < (T + 1) * N; idx += G) xout[idx] = st.at(st.xoff(st.cur) + idx);
+    for (int idx = gl; idx < T * M; idx += G) uout[idx] = st.at(st.xoff(st.cur) + (T + 1) * N + idx);
+    if (leader) {
+        const float cT = chat[T];
+        if (!(cT == cT)) status |= TFMPC_ST_NAN;
+        a.iterations[b] = iteration;
+        a.status[b] = status;
+    }
+}
+
 bool ilqr_lane_supported(const TfmpcEnv &env)
 {
     if (env.n != 2 || env.m != 2) return false;
@@ -648,6 +800,21 @@ int ilqr_lane_solve_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, int 
                            hipStream_t stream)
 {
     SolveArgsLane a{B, T, x0, u_init, states, actions, costs, iterations, status, wsK, wsk, wsx, wsu, wsc};
+    {
+        const char *force = std::getenv("TFMPC_ILQR_KERNEL");
+        const bool per_lane = force && std::strcmp(force, "lane1") == 0;
+        const size_t glds = GroupStore<2, 2>::bytes(T);
+        if (!per_lane && glds <= 64 * 1024) {
+            const dim3 ggrid((B + 3) / 4), gblock(64);
+            if (env.kind == TFMPC_ENV_NAVLQR)
+                hipLaunchKernelGGL((ilqr_group_solve_kernel<TFMPC_ENV_NAVLQR, 2, 2>), ggrid, gblock, glds, stream, env, cfg, a);
+            else if (env.kind == TFMPC_ENV_NAVIGATION)
+                hipLaunchKernelGGL((ilqr_group_solve_kernel<TFMPC_ENV_NAVIGATION, 2, 2>), ggrid, gblock, glds, stream, env, cfg, a);
+            else
+                return TFMPC_ERR_UNSUPPORTED;
+            return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
+        }
+    }
     const dim3 grid((B + 63) / 64), block(64);
     const size_t lds = LdsStore<2, 2>::bytes(T);
     const bool use_lds = lds <= kMaxLdsBytes;          // T <= 62 at n = m = 2; else HBM slabs
