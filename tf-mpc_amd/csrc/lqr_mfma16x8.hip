@@ -41,6 +41,7 @@ namespace {
 
 constexpr int N = 16, M = 8, D = 24;
 using f32x4 = bf3::f32x4;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c)
 {
@@ -57,10 +58,9 @@ using namespace bf3;      // bf16x3 product helpers (mfma_bf16x3.h)
 // per-wave LDS slice (floats)
 constexpr int kMs = 0;          // [32 cols][8 rows]  elimination input, column-major
 constexpr int kKs = 256;        // [32 cols][8 rows]  K~ = -Q_uu^-1 [Q_ux | . | q_u], column-major
-constexpr int kXs = 512;        // [16 rows][8]       Q_xu, row-major (A operand of the V update)
-constexpr int kQx = 640;        // q_x staging (16)
-constexpr int kZs = 656;        // rollout chunk: rows z_t = [x_t(16); u_t(8)], stride kZld
+constexpr int kZs = 512;        // rollout chunk: rows z_t = [x_t(16); u_t(8)], stride kZld (sweep: V' transpose staging)
 constexpr int kZld = 26;        // even (8-byte aligned rows), 26 n mod 32 distinct for n < 16
+constexpr int kVtLd = 20;        // V' transpose staging [16 cols][kVtLd] inside the rollout buffer
 constexpr int kTC = 52;         // timesteps per rollout chunk (T = 50 fits one chunk)
 constexpr int kLdsFloats = kZs + (kTC + 1) * kZld + 6;
 
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
     if (BACKWARD) {
         // ---- resident operands ------------------------------------------------------
         float Fb0[4], Fb1[4];            // F~_c[4q+r][i]
-        f32x4 Cd00, Cd01t, Cd10, Cd11;   // C~[16a+4q+r][16c+i]; Cd01t = (C~ tile (0,1))^T
+        f32x4 Cd00, Cd01, Cd10, Cd11;    // C~[16a+4q+r][16c+i]
         f32x4 vterm;                     // c_x in lanes i == 8 (terminal v)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
                 Fb0[r] = Fg[k * D + i];
                 Fb1[r] = (i < M) ? Fg[k * D + N + i] : ((i == M) ? fg[k] : 0.0f);
                 Cd00[r] = Cg[k * D + i];
-                Cd01t[r] = (k < M) ? Cg[i * D + N + k] : ((k == M) ? cg[i] : 0.0f);      // C~[i][16+k]
+                Cd01[r] = (i < M) ? Cg[k * D + N + i] : ((i == M) ? cg[k] : 0.0f);       // C~[k][16+i]
                 vterm[r] = (i == M) ? cg[k] : 0.0f;
                 Cd10[r] = (ku < D) ? Cg[ku * D + i] : 0.0f;
                 Cd11[r] = (ku < D) ? ((i < M) ? Cg[ku * D + N + i] : ((i == M) ? cg[ku] : 0.0f)) : 0.0f;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
                 Fb0[r] = Fxx(Fg, k, i);
                 Fb1[r] = (i < M) ? Fxu(Fg, k, i) : ((i == M && k < n) ? fg[k] : 0.0f);
                 Cd00[r] = Czz(Cg, k, i);
-                Cd01t[r] = (k < M) ? Czz(Cg, i, N + k) : ((k == M) ? cz(cg, i) : 0.0f);
+                Cd01[r] = (i < M) ? Czz(Cg, k, N + i) : ((i == M) ? cz(cg, k) : 0.0f);
                 vterm[r] = (i == M) ? cz(cg, k) : 0.0f;
                 Cd10[r] = (ku < D) ? Czz(Cg, ku, i) : 0.0f;
                 float c11 = 0.0f;
@@ -147,6 +147,10 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
         float cst = 0.0f;
         int min_pivot_bits = 0x3f800000;     // smallest pivot seen, as float bits (int order == float order for >= 0)
         for (int idx = lane; idx < kZs; idx += kWave) lds[idx] = 0.0f;   // pad columns stay 0
+        constexpr int kZero = kMs + 25 * 8;      // columns 25..31 of the elimination input are never written
+        constexpr int kQx = kMs + 28 * 8;        // q_x staging in pad columns 28, 29
+        const int t01_src = (i == M) ? kQx + 4 * q : kZero;
+        const int g1_src = (i == M) ? kKs + (N + M) * 8 + q : kZero + q;
         __syncthreads();
 
         for (int t = T - 1; t >= 0; --t) {
@@ -174,25 +178,23 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
                 fw = wave_sum(i == M ? pw : 0.0f);
                 fv = wave_sum(i == M ? pv : 0.0f);
             }
-            if (i == M) W1 += vd;
+            W1 += vd;                            // vd is zero outside lanes i == 8 (see step 4)
             // 2. Q~ = C~ + F~^T W                                              lqr.py:75-78
-            // Tile (0,1) is produced TRANSPOSED (operand roles swapped: W_1^T F~_0), which puts
-            // the true Q_xu[i][4q+r] in lanes (i, q < 2) and q_x[j] in lanes q == 2.  Using
-            // Q_ux^T in its place would be cheaper still but is unstable: V is symmetric only up
-            // to rounding, and the antisymmetric part must propagate through the CLOSED loop
-            // (Q_xx + Q_xu K == [I;K]^T Q [I;K]), not the open one.
-            f32x4 T00 = Cd00, T01t = Cd01t, T10 = Cd10, T11 = Cd11;
+            // V is kept exactly symmetric (step 4), so Q_xu is taken as Q_ux^T below and tile (0,1)
+            // is only needed for its column 24, q_x -- which lands in lanes i == 8 in the layout v'
+            // accumulates in.
+            f32x4 T00 = Cd00, T01 = Cd01, T10 = Cd10, T11 = Cd11;
             if (BF3) {
                 const VarFrag W0f = var_frag(W0), W1f = var_frag(W1);
                 T00 = mm_const_var(Fc0, W0f, T00);
-                T01t = mm_var_const(W1f, Fc0, T01t);
+                T01 = mm_const_var(Fc0, W1f, T01);
                 T10 = mm_const_var(Fc1, W0f, T10);
                 T11 = mm_const_var(Fc1, W1f, T11);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     T00 = mfma(Fb0[r], W0[r], T00);
-                    T01t = mfma(W1[r], Fb0[r], T01t);
+                    T01 = mfma(Fb0[r], W1[r], T01);
                     T10 = mfma(Fb1[r], W0[r], T10);
                     T11 = mfma(Fb1[r], W1[r], T11);
                 }
@@ -201,67 +203,101 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
             if (q < 2) {
                 *reinterpret_cast<f32x4 *>(&lds[kMs + i * 8 + 4 * q]) = T10;
                 if (i <= M) *reinterpret_cast<f32x4 *>(&lds[kMs + (N + i) * 8 + 4 * q]) = T11;
-                *reinterpret_cast<f32x4 *>(&lds[kXs + i * 8 + 4 * q]) = T01t;
-            } else if (q == 2) {
-                lds[kQx + i] = T01t[0];                  // q_x[i] = Q~[i][24]
             }
+            if (i == M) *reinterpret_cast<f32x4 *>(&lds[kQx + 4 * q]) = T01;       // q_x rows 4q..4q+3
             __syncthreads();
-            float Mr[8];
+            // rows (2k, 2k+1) share a register pair so that one v_pk_fma_f32 updates both
+            f32x2 M2[4];
             {
                 const int c = lane & 31;
                 const f32x4 lo = *reinterpret_cast<const f32x4 *>(&lds[kMs + c * 8]);
                 const f32x4 hi = *reinterpret_cast<const f32x4 *>(&lds[kMs + c * 8 + 4]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { Mr[r] = lo[r]; Mr[4 + r] = hi[r]; }
+                M2[0] = f32x2{lo[0], lo[1]}; M2[1] = f32x2{lo[2], lo[3]};
+                M2[2] = f32x2{hi[0], hi[1]}; M2[3] = f32x2{hi[2], hi[3]};
             }
             float quk = 0.0f;
             float qu_saved[8];
             if (VALUE) {
 #pragma unroll
-                for (int p = 0; p < 8; ++p) qu_saved[p] = readlane(Mr[p], 24);
+                for (int p = 0; p < 8; ++p) qu_saved[p] = readlane(M2[p >> 1][p & 1], 24);
             }
-            // Gauss-Jordan on rows 0..7; column 16+p of row a holds Q_uu[a][p]   lqr.py:84-87
-            // No pivoting: Q_uu is positive definite whenever C >= 0 and C_uu > 0 (checked below).
+            // -Q_uu^-1 [Q_ux | q_u] (lqr.py:84-87) by an LDL^T elimination that reads only the upper
+            // triangle of Q_uu (column 16+s of row p, p <= s), like the Cholesky it stands for:
+            //   forward   row_s -= L[s][p] row_p (s > p),  L[s][p] = row_p[16+s] / d_p  by symmetry of the
+            //             Schur complement -- so ONE v_readlane per multiplier serves both sweeps;
+            //   backward  X_p = row_p / d_p - sum_{s>p} L[s][p] X_s.
+            // nl[s][p] = -L[s][p] are wave-uniform scalars (SGPRs); the sign of the result is folded
+            // into the pivot reciprocal.  Q_uu > 0 whenever C >= 0 and C_uu > 0 (pivots checked below).
+            float nl[8][8];
+            f32x2 N2[4];
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-                const int pvb = __builtin_amdgcn_readlane(__builtin_bit_cast(int, Mr[p]), N + p);
-                min_pivot_bits = min(min_pivot_bits, pvb);         // scalar; sign bit set <=> pivot < 0
-                const float inv = __builtin_amdgcn_rcpf(__builtin_bit_cast(float, pvb));   // 1 ulp
-                Mr[p] *= inv;
+                const int pp = p >> 1, ps = p & 1;
+                const float Mp = M2[pp][ps];
+                const int pvb = __builtin_amdgcn_readlane(__builtin_bit_cast(int, Mp), N + p);
+                // smallest pivot so far, on the scalar unit; sign bit set <=> pivot < 0
+                asm("s_min_i32 %0, %0, %1" : "+s"(min_pivot_bits) : "s"(pvb) : "scc");
+                const float ninv = __builtin_amdgcn_rcpf(-__builtin_bit_cast(float, pvb));   // 1 ulp
+                const float Mn = Mp * ninv;                      // -row_p / d_p
+                N2[pp][ps] = Mn;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    if (r == p) continue;
-                    const float fct = readlane(Mr[r], N + p);
-                    Mr[r] = fmaf(-fct, Mr[p], Mr[r]);
-                }
+                for (int s2 = p + 1; s2 < 8; ++s2) nl[s2][p] = readlane(Mn, N + s2);
+                if (ps == 0) M2[pp][1] = fmaf(nl[p + 1][p], Mp, M2[pp][1]);
+                const f32x2 Mpp = {Mp, Mp};
+#pragma unroll
+                for (int k = pp + 1; k < 4; ++k)
+                    M2[k] = __builtin_elementwise_fma(f32x2{nl[2 * k][p], nl[2 * k + 1][p]}, Mpp, M2[k]);
             }
+#pragma unroll
+            for (int s2 = 7; s2 >= 1; --s2) {
+                const float Ns = N2[s2 >> 1][s2 & 1];
+                const f32x2 Nss = {Ns, Ns};
+                if (s2 & 1) N2[s2 >> 1][0] = fmaf(nl[s2][s2 - 1], Ns, N2[s2 >> 1][0]);
+#pragma unroll
+                for (int k = 0; k < (s2 >> 1); ++k)
+                    N2[k] = __builtin_elementwise_fma(f32x2{nl[s2][2 * k], nl[s2][2 * k + 1]}, Nss, N2[k]);
+            }
+            float Mr[8];                                          // rows of K~ = -Q_uu^-1 [Q_ux | . | q_u]
+#pragma unroll
+            for (int r = 0; r < 8; ++r) Mr[r] = N2[r >> 1][r & 1];
             if (VALUE) {
 #pragma unroll
-                for (int p = 0; p < 8; ++p) quk = fmaf(-readlane(Mr[p], 24), qu_saved[p], quk);   // k^T q_u
+                for (int p = 0; p < 8; ++p) quk = fmaf(readlane(Mr[p], 24), qu_saved[p], quk);   // k^T q_u
             }
-            // K~ = -M: columns 0..15 = K, column 24 = k
+            // K~: columns 0..15 = K, column 24 = k
             if (lane < 32) {
                 f32x4 lo, hi;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { lo[r] = -Mr[r]; hi[r] = -Mr[4 + r]; }
+                for (int r = 0; r < 4; ++r) { lo[r] = Mr[r]; hi[r] = Mr[4 + r]; }
                 *reinterpret_cast<f32x4 *>(&lds[kKs + lane * 8]) = lo;
                 *reinterpret_cast<f32x4 *>(&lds[kKs + lane * 8 + 4]) = hi;
             }
             __syncthreads();
             // 4. V' = Q_xx + Q_xu K ; v' = q_x + Q_xu k (column 24)            lqr.py:97-105
             //    contraction over the 8 actions as 2 k-steps: a = 4s + q
-            f32x4 T01 = {0.f, 0.f, 0.f, 0.f};             // accumulates v' in column 24 (lanes i == 8)
-            if (i == M) T01 = *reinterpret_cast<const f32x4 *>(&lds[kQx + 4 * q]);
+            //    vacc accumulates v' on q_x in column 24 (lanes i == 8); every other lane reads its
+            //    operands from the always-zero pad columns, so the next v is 0 there.
+            f32x4 vacc = *reinterpret_cast<const f32x4 *>(&lds[t01_src]);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const float ax = lds[kXs + i * 8 + 4 * s2 + q];            // Q_xu[i][4s+q]
+                const float ax = lds[kMs + i * 8 + 4 * s2 + q];            // Q_xu[i][4s+q] = Q_ux[4s+q][i]
                 const float g0 = lds[kKs + i * 8 + 4 * s2 + q];            // K[4s+q][i]
-                const float g1 = lds[kKs + (N + i) * 8 + 4 * s2 + q];      // K~[4s+q][16+i]
+                const float g1 = lds[g1_src + 4 * s2];                     // K~[4s+q][24] in lanes i == 8
                 T00 = mfma(ax, g0, T00);
-                T01 = mfma(ax, g1, T01);
+                vacc = mfma(ax, g1, vacc);
             }
-            Vd = T00;
-            vd = T01;
+            // V' <- (V' + V'^T) / 2 (transpose through LDS).  The elimination above reads only the
+            // upper triangle of Q_uu; that is consistent only while V carries no antisymmetric part
+            // (otherwise the part it ignores, F_u^T a F_u, is missing from the closed-loop product
+            // and the rounding-level asymmetry of V grows like |F_u K|^2 per step).
+            {
+                float *vt = &lds[kZs];                    // rollout buffer, idle during the sweep
+                *reinterpret_cast<f32x4 *>(&vt[i * kVtLd + 4 * q]) = T00;
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Vd[r] = 0.5f * (T00[r] + vt[(4 * q + r) * kVtLd + i]);
+            }
+            vd = vacc;
             // gains to HBM, row-major K[t][a][j], k[t][a] (the public layout)
             {
                 const int ka = lane >> 3, jc = lane & 7;
