@@ -108,7 +108,8 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
     if (BACKWARD) {
         // ---- resident operands ------------------------------------------------------
         float Fb0[4], Fb1[4];            // F~_c[4q+r][i]
-        f32x4 Cd00, Cd01, Cd10, Cd11;    // C~[16a+4q+r][16c+i]
+        f32x4 Cd00, Cd11;                // C~[16a+4q+r][16c+i]
+        f32x4 Cd01t;                     // rows 0..7: C_ux, row 8: c_x  (= (C~ tile (0,1))^T)
         f32x4 vterm;                     // c_x in lanes i == 8 (terminal v)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -118,17 +119,15 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
                 Fb0[r] = Fg[k * D + i];
                 Fb1[r] = (i < M) ? Fg[k * D + N + i] : ((i == M) ? fg[k] : 0.0f);
                 Cd00[r] = Cg[k * D + i];
-                Cd01[r] = (i < M) ? Cg[k * D + N + i] : ((i == M) ? cg[k] : 0.0f);       // C~[k][16+i]
+                Cd01t[r] = (k < M) ? Cg[(N + k) * D + i] : ((k == M) ? cg[i] : 0.0f);     // C~[16+k][i] | c_x
                 vterm[r] = (i == M) ? cg[k] : 0.0f;
-                Cd10[r] = (ku < D) ? Cg[ku * D + i] : 0.0f;
                 Cd11[r] = (ku < D) ? ((i < M) ? Cg[ku * D + N + i] : ((i == M) ? cg[ku] : 0.0f)) : 0.0f;
             } else {
                 Fb0[r] = Fxx(Fg, k, i);
                 Fb1[r] = (i < M) ? Fxu(Fg, k, i) : ((i == M && k < n) ? fg[k] : 0.0f);
                 Cd00[r] = Czz(Cg, k, i);
-                Cd01[r] = (i < M) ? Czz(Cg, k, N + i) : ((i == M) ? cz(cg, k) : 0.0f);
+                Cd01t[r] = (k < M) ? Czz(Cg, N + k, i) : ((k == M) ? cz(cg, i) : 0.0f);
                 vterm[r] = (i == M) ? cz(cg, k) : 0.0f;
-                Cd10[r] = (ku < D) ? Czz(Cg, ku, i) : 0.0f;
                 float c11 = 0.0f;
                 if (ku < D) {
                     if (i < M) c11 = (k >= m && i == k) ? 1.0f : Czz(Cg, ku, N + i);   // unit diagonal on padded actions
@@ -180,31 +179,30 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
             }
             W1 += vd;                            // vd is zero outside lanes i == 8 (see step 4)
             // 2. Q~ = C~ + F~^T W                                              lqr.py:75-78
-            // V is kept exactly symmetric (step 4), so Q_xu is taken as Q_ux^T below and tile (0,1)
-            // is only needed for its column 24, q_x -- which lands in lanes i == 8 in the layout v'
-            // accumulates in.
-            f32x4 T00 = Cd00, T01 = Cd01, T10 = Cd10, T11 = Cd11;
+            // Three tiles: Q_xx = F_x^T W_0; [Q_uu | q_u] = F~_1^T W_1; and W_1^T F_x, whose rows
+            // 0..7 are Q_ux (= F_u^T V F_x: V is kept exactly symmetric, step 4, so this equals the
+            // F~_1^T W_0 tile that is no longer computed) and whose row 8 is q_x^T = (V f + v)^T F_x.
+            f32x4 T00 = Cd00, T01t = Cd01t, T11 = Cd11;
             if (BF3) {
                 const VarFrag W0f = var_frag(W0), W1f = var_frag(W1);
                 T00 = mm_const_var(Fc0, W0f, T00);
-                T01 = mm_const_var(Fc0, W1f, T01);
-                T10 = mm_const_var(Fc1, W0f, T10);
+                T01t = mm_var_const(W1f, Fc0, T01t);
                 T11 = mm_const_var(Fc1, W1f, T11);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     T00 = mfma(Fb0[r], W0[r], T00);
-                    T01 = mfma(Fb0[r], W1[r], T01);
-                    T10 = mfma(Fb1[r], W0[r], T10);
+                    T01t = mfma(W1[r], Fb0[r], T01t);
                     T11 = mfma(Fb1[r], W1[r], T11);
                 }
             }
             // 3. [Q_ux | Q_uu | q_u] -> column-per-lane layout through LDS; Q_xu and q_x staged
             if (q < 2) {
-                *reinterpret_cast<f32x4 *>(&lds[kMs + i * 8 + 4 * q]) = T10;
+                *reinterpret_cast<f32x4 *>(&lds[kMs + i * 8 + 4 * q]) = T01t;                    // Q_ux[4q+r][i]
                 if (i <= M) *reinterpret_cast<f32x4 *>(&lds[kMs + (N + i) * 8 + 4 * q]) = T11;
+            } else if (q == 2) {
+                lds[kQx + i] = T01t[0];                                                          // q_x[i]
             }
-            if (i == M) *reinterpret_cast<f32x4 *>(&lds[kQx + 4 * q]) = T01;       // q_x rows 4q..4q+3
             __syncthreads();
             // rows (2k, 2k+1) share a register pair so that one v_pk_fma_f32 updates both
             f32x2 M2[4];
