@@ -7,7 +7,7 @@
 // backward pass of ilqr.py:94-172 is the Riccati recursion of lqr_mfma16x8.hip with the affine
 // column carrying (l_z(t) + F^T V_x) instead of (c + F^T(V f + v)); K = -Q_uu^-1 Q_ux makes the
 // four-term updates collapse to V_xx' = Q_xx + Q_xu K, V_x' = Q_x + Q_xu k and dV2 = -dV1/2.
-// So per timestep the same matrix-core products (bf16x3, mfma_bf16x3.h) + readlane Gauss-Jordan as the LQR kernel.  The
+// So per timestep the same matrix-core products (bf16x3, mfma_bf16x3.h) + LDL^T solve (wave_ldlt8.h) as the LQR kernel.  The
 // cost gradients l_z(t) = C_s z_t + c of the whole nominal trajectory are one C Z product on
 // the matrix cores before the sweep, and the stage costs of every rollout another one after
 // it.  Nominal and candidate trajectories live in LDS (swapped on accept, never copied).
@@ -20,6 +20,7 @@
 
 #include "ilqr_lq_mfma.h"
 #include "mfma_bf16x3.h"
+#include "wave_ldlt8.h"
 #include "wave_ops.h"
 
 namespace tfmpc {
@@ -45,7 +46,10 @@ __device__ __forceinline__ float dpp(float v)
 }
 constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141;
 
-constexpr int kMs = 0, kKs = 256, kXs = 512, kQx = 640, kDyn = 656;   // fixed part of the LDS slice
+// fixed part of the LDS slice: elimination input [32 cols][8] (pad columns: 25.. always zero, 28-29 Q_x
+// staging), gains K~ [32 cols][8], V_xx transpose staging [16][kVtLd]
+constexpr int kMs = 0, kKs = 256, kVt = 512, kVtLd = 20, kDyn = kVt + 16 * kVtLd;
+constexpr int kZero = kMs + 25 * 8, kQx = kMs + 28 * 8;
 constexpr int kZld = 26;
 
 __device__ __forceinline__ float sgn(float y) { return (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f); }
@@ -87,15 +91,14 @@ __global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
 
     // ---- operands resident in registers for the whole solve ------------------------------
     float Fb0[4], Fb1[4];
-    f32x4 Cd00, Cd01t, Cd10, Cd11;
+    f32x4 Cd00, Cd01t, Cd11;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int k = 4 * q + r, ku = N + k;
         Fb0[r] = Fxx(k, i);
         Fb1[r] = (i < M) ? Fxu(k, i) : 0.0f;                     // no f column: the affine slot carries V_x
         Cd00[r] = Cs(k, i);
-        Cd01t[r] = (k < M) ? Cs(i, N + k) : 0.0f;                // (q == 2, r == 0) <- l_x(t)[i] per step
-        Cd10[r] = (ku < D) ? Cs(ku, i) : 0.0f;
+        Cd01t[r] = (k < M) ? Cs(N + k, i) : 0.0f;                // rows 0..7: C_ux; (q == 2, r == 0) <- l_x(t)[i] per step
         float c11 = 0.0f;
         if (ku < D && i < M) c11 = (k >= m && i == k) ? 1.0f : Cs(ku, N + i);
         Cd11[r] = c11;                                           // lanes i == 8, q < 2 <- l_u(t) per step
@@ -125,6 +128,8 @@ __global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
     const ConstFrag Fc0 = const_frag(f32x4{Fb0[0], Fb0[1], Fb0[2], Fb0[3]});
     const ConstFrag Fc1 = const_frag(f32x4{Fb1[0], Fb1[1], Fb1[2], Fb1[3]});
     for (int idx = lane; idx < kDyn; idx += kWave) lds[idx] = 0.0f;
+    const int t01_src = (i == M) ? kQx + 4 * q : kZero;
+    const int g1_src = (i == M) ? kKs + (N + M) * 8 + q : kZero + q;
 
     // C Z on the matrix cores over rows [0, rows) of Z, 16 timesteps per tile.
     //   GRAD: L[t] = C_s z_t + c (cost gradient, diffenv.py:40-42);  else cost[t] = 1/2 z^T C z + c^T z
@@ -214,59 +219,45 @@ __global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
                 W0 = mm_var_const(Vf, Fc0, W0);
                 W1 = mm_var_const(Vf, Fc1, W1);
             }
-            if (i == M) W1 += vd;                                  // affine column: V_x
-            f32x4 T00 = Cd00, T01t = Cd01t, T10 = Cd10, T11 = Cd11;
+            W1 += vd;                                              // affine column: V_x (vd is 0 outside lanes i == 8)
+            // Three tiles: Q_xx; [Q_uu | Q_u]; and W_1^T F_x whose rows 0..7 are Q_ux (V_xx is kept
+            // exactly symmetric, ilqr.py:149-162) and whose row 8 is Q_x^T.
+            f32x4 T00 = Cd00, T01t = Cd01t, T11 = Cd11;
             if (q == 2) T01t[0] = Lz[t * kZld + i];                                     // l_x(t)
             if (i == M && q < 2) T11 = *reinterpret_cast<const f32x4 *>(&Lz[t * kZld + N + 4 * q]);   // l_u(t)
             {
                 const VarFrag W0f = var_frag(W0), W1f = var_frag(W1);
                 T00 = mm_const_var(Fc0, W0f, T00);                 // Q_xx                 :129
-                T01t = mm_var_const(W1f, Fc0, T01t);               // Q_xu | Q_x (transposed tile)
-                T10 = mm_const_var(Fc1, W0f, T10);                 // Q_ux                 :131
+                T01t = mm_var_const(W1f, Fc0, T01t);               // Q_ux | Q_x           :131,122
                 T11 = mm_const_var(Fc1, W1f, T11);                 // Q_uu | Q_u           :130,123
             }
             if (q < 2) {
-                *reinterpret_cast<f32x4 *>(&lds[kMs + i * 8 + 4 * q]) = T10;
+                *reinterpret_cast<f32x4 *>(&lds[kMs + i * 8 + 4 * q]) = T01t;
                 if (i <= M) *reinterpret_cast<f32x4 *>(&lds[kMs + (N + i) * 8 + 4 * q]) = T11;
-                *reinterpret_cast<f32x4 *>(&lds[kXs + i * 8 + 4 * q]) = T01t;
             } else if (q == 2) {
                 lds[kQx + i] = T01t[0];                            // Q_x[i]               :122
             }
             __syncthreads();
-            float Mr[8];
+            f32x2 M2[4];
             {
                 const int c = lane & 31;
                 const f32x4 lo = *reinterpret_cast<const f32x4 *>(&lds[kMs + c * 8]);
                 const f32x4 hi = *reinterpret_cast<const f32x4 *>(&lds[kMs + c * 8 + 4]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { Mr[r] = lo[r]; Mr[4 + r] = hi[r]; }
+                M2[0] = f32x2{lo[0], lo[1]}; M2[1] = f32x2{lo[2], lo[3]};
+                M2[2] = f32x2{hi[0], hi[1]}; M2[3] = f32x2{hi[2], hi[3]};
             }
             if (lane == 24) {                                      // Q_u(t) for dV1 (column 24 before elimination)
-                f32x4 lo, hi;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { lo[r] = Mr[r]; hi[r] = Mr[4 + r]; }
-                *reinterpret_cast<f32x4 *>(&qubuf[t * M]) = lo;
-                *reinterpret_cast<f32x4 *>(&qubuf[t * M + 4]) = hi;
+                *reinterpret_cast<f32x4 *>(&qubuf[t * M]) = f32x4{M2[0][0], M2[0][1], M2[1][0], M2[1][1]};
+                *reinterpret_cast<f32x4 *>(&qubuf[t * M + 4]) = f32x4{M2[2][0], M2[2][1], M2[3][0], M2[3][1]};
             }
-            // [k | K] = -Q_uu^-1 [Q_u | Q_ux]: Gauss-Jordan; a non-positive pivot is the Cholesky
-            // failure of ilqr.py:358                                                  :357-362
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int pvb = __builtin_amdgcn_readlane(__builtin_bit_cast(int, Mr[p]), N + p);
-                min_pivot_bits = min(min_pivot_bits, pvb);
-                const float inv = __builtin_amdgcn_rcpf(__builtin_bit_cast(float, pvb));
-                Mr[p] *= inv;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    if (r == p) continue;
-                    const float fct = readlane(Mr[r], N + p);
-                    Mr[r] = fmaf(-fct, Mr[p], Mr[r]);
-                }
-            }
+            // [K | k] = -Q_uu^-1 [Q_ux | Q_u]; a non-positive pivot is the Cholesky failure of
+            // ilqr.py:358                                                              :357-362
+            float Mr[8];
+            ldlt8_solve_neg(M2, Mr, min_pivot_bits);
             if (lane < 32) {
                 f32x4 lo, hi;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { lo[r] = -Mr[r]; hi[r] = -Mr[4 + r]; }
+                for (int r = 0; r < 4; ++r) { lo[r] = Mr[r]; hi[r] = Mr[4 + r]; }
                 *reinterpret_cast<f32x4 *>(&lds[kKs + lane * 8]) = lo;
                 *reinterpret_cast<f32x4 *>(&lds[kKs + lane * 8 + 4]) = hi;
                 if (lane == 24) {
@@ -276,18 +267,23 @@ __global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
             }
             __syncthreads();
             // V_xx' = Q_xx + Q_xu K, V_x' = Q_x + Q_xu k                              :149-161
-            f32x4 T01 = {0.f, 0.f, 0.f, 0.f};
-            if (i == M) T01 = *reinterpret_cast<const f32x4 *>(&lds[kQx + 4 * q]);
+            // (Q_xu = Q_ux^T; vacc accumulates V_x' on Q_x in lanes i == 8, the other lanes read
+            // always-zero pad columns so the next V_x is 0 there)
+            f32x4 vacc = *reinterpret_cast<const f32x4 *>(&lds[t01_src]);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const float ax = lds[kXs + i * 8 + 4 * s2 + q];
+                const float ax = lds[kMs + i * 8 + 4 * s2 + q];
                 const float g0 = lds[kKs + i * 8 + 4 * s2 + q];
-                const float g1 = lds[kKs + (N + i) * 8 + 4 * s2 + q];
+                const float g1 = lds[g1_src + 4 * s2];
                 T00 = mfma(ax, g0, T00);
-                T01 = mfma(ax, g1, T01);
+                vacc = mfma(ax, g1, vacc);
             }
-            Vd = T00;
-            vd = T01;
+            // V_xx <- (V_xx + V_xx^T) / 2                                             :158-162
+            *reinterpret_cast<f32x4 *>(&lds[kVt + i * kVtLd + 4 * q]) = T00;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Vd[r] = 0.5f * (T00[r] + lds[kVt + (4 * q + r) * kVtLd + i]);
+            vd = vacc;
             {   // gains to HBM, row-major K[t][a][j] (guarded for padded shapes)
                 const float kx = lds[kKs + (2 * jc) * 8 + ka], ky = lds[kKs + (2 * jc + 1) * 8 + ka];
                 if (ka < m && 2 * jc < n) Kg[(size_t)t * m * n + ka * n + 2 * jc] = kx;

@@ -33,6 +33,7 @@
 
 #include "lqr_kernels.h"
 #include "mfma_bf16x3.h"
+#include "wave_ldlt8.h"
 #include "wave_ops.h"
 
 namespace tfmpc {
@@ -41,7 +42,6 @@ namespace {
 
 constexpr int N = 16, M = 8, D = 24;
 using f32x4 = bf3::f32x4;
-using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c)
 {
@@ -219,45 +219,9 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
 #pragma unroll
                 for (int p = 0; p < 8; ++p) qu_saved[p] = readlane(M2[p >> 1][p & 1], 24);
             }
-            // -Q_uu^-1 [Q_ux | q_u] (lqr.py:84-87) by an LDL^T elimination that reads only the upper
-            // triangle of Q_uu (column 16+s of row p, p <= s), like the Cholesky it stands for:
-            //   forward   row_s -= L[s][p] row_p (s > p),  L[s][p] = row_p[16+s] / d_p  by symmetry of the
-            //             Schur complement -- so ONE v_readlane per multiplier serves both sweeps;
-            //   backward  X_p = row_p / d_p - sum_{s>p} L[s][p] X_s.
-            // nl[s][p] = -L[s][p] are wave-uniform scalars (SGPRs); the sign of the result is folded
-            // into the pivot reciprocal.  Q_uu > 0 whenever C >= 0 and C_uu > 0 (pivots checked below).
-            float nl[8][8];
-            f32x2 N2[4];
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int pp = p >> 1, ps = p & 1;
-                const float Mp = M2[pp][ps];
-                const int pvb = __builtin_amdgcn_readlane(__builtin_bit_cast(int, Mp), N + p);
-                // smallest pivot so far, on the scalar unit; sign bit set <=> pivot < 0
-                asm("s_min_i32 %0, %0, %1" : "+s"(min_pivot_bits) : "s"(pvb) : "scc");
-                const float ninv = __builtin_amdgcn_rcpf(-__builtin_bit_cast(float, pvb));   // 1 ulp
-                const float Mn = Mp * ninv;                      // -row_p / d_p
-                N2[pp][ps] = Mn;
-#pragma unroll
-                for (int s2 = p + 1; s2 < 8; ++s2) nl[s2][p] = readlane(Mn, N + s2);
-                if (ps == 0) M2[pp][1] = fmaf(nl[p + 1][p], Mp, M2[pp][1]);
-                const f32x2 Mpp = {Mp, Mp};
-#pragma unroll
-                for (int k = pp + 1; k < 4; ++k)
-                    M2[k] = __builtin_elementwise_fma(f32x2{nl[2 * k][p], nl[2 * k + 1][p]}, Mpp, M2[k]);
-            }
-#pragma unroll
-            for (int s2 = 7; s2 >= 1; --s2) {
-                const float Ns = N2[s2 >> 1][s2 & 1];
-                const f32x2 Nss = {Ns, Ns};
-                if (s2 & 1) N2[s2 >> 1][0] = fmaf(nl[s2][s2 - 1], Ns, N2[s2 >> 1][0]);
-#pragma unroll
-                for (int k = 0; k < (s2 >> 1); ++k)
-                    N2[k] = __builtin_elementwise_fma(f32x2{nl[s2][2 * k], nl[s2][2 * k + 1]}, Nss, N2[k]);
-            }
-            float Mr[8];                                          // rows of K~ = -Q_uu^-1 [Q_ux | . | q_u]
-#pragma unroll
-            for (int r = 0; r < 8; ++r) Mr[r] = N2[r >> 1][r & 1];
+            // K~ = -Q_uu^-1 [Q_ux | . | q_u]   (lqr.py:84-87; LDL^T on the upper triangle, wave_ldlt8.h)
+            float Mr[8];
+            ldlt8_solve_neg(M2, Mr, min_pivot_bits);
             if (VALUE) {
 #pragma unroll
                 for (int p = 0; p < 8; ++p) quk = fmaf(readlane(Mr[p], 24), qu_saved[p], quk);   // k^T q_u
