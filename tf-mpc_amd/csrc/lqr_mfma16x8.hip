@@ -315,7 +315,7 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
                 Fr[j] = zc < N ? Fxx(Fg, fi, zc) : Fxu(Fg, fi, zc - N);
             }
         }
-        const float f_i = (EXACT || fi < n) ? fg[fi] : 0.0f;
+        const float f_part = (fc == 0 && (EXACT || fi < n)) ? fg[fi] : 0.0f;     // f enters one of the four partial sums
         // cost post-pass operands: A = C (2 row tiles x 6 k-steps, k = 4s + q), c in D layout
         float Ca0[6], Ca1[6];
         f32x4 cq0, cq1;
@@ -401,10 +401,10 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
                 u += dpp<kDppXor2>(u);
                 u += dpp<kDppHalfMirror>(u);
                 u += kc;
-                if (jc == 0) zt[N + ka] = u;
+                zt[N + ka] = u;                      // all eight lanes of the row hold the same sum
                 __syncthreads();
                 // x' = F z + f                                              lqr.py:36-39
-                float xn = 0.0f;
+                float xn = f_part;
                 const float2 *zp = reinterpret_cast<const float2 *>(&zt[6 * fc]);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
@@ -414,8 +414,7 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
                 }
                 xn += dpp<kDppXor1>(xn);
                 xn += dpp<kDppXor2>(xn);
-                xn += f_i;
-                if (fc == 0) zt[kZld + fi] = xn;
+                zt[kZld + fi] = xn;                  // likewise: the four lanes of row fi agree
                 __syncthreads();
             }
             // chunk epilogue: stage costs on the matrix cores, bulk coalesced stores
