@@ -352,8 +352,8 @@ template <> struct Env<TFMPC_ENV_HVAC> {
                 }
                 between = (s0 + s1) + (s2 + s3);
             }
-            if (parts >= 2) between += __shfl_xor(between, 1, kWave);
-            if (parts >= 4) between += __shfl_xor(between, 2, kWave);
+            if (parts >= 2) between += quad_xor1(between);
+            if (parts >= 4) between += quad_xor2(between);
             if (i < n && part == 0) {
                 const float air = u[i] * air_max[i];                                          // :72
                 const float heating = air * CAP_AIR * (TEMP_AIR - x[i]);                      // :74
@@ -466,8 +466,8 @@ template <> struct Env<TFMPC_ENV_RESERVOIR> {
                 for (; j < j1; ++j) s0 = fmaf(D[j * n + i], u[j] * x[j], s0);
                 inflow = (s0 + s1) + (s2 + s3);
             }
-            if (parts >= 2) inflow += __shfl_xor(inflow, 1, kWave);
-            if (parts >= 4) inflow += __shfl_xor(inflow, 2, kWave);
+            if (parts >= 2) inflow += quad_xor1(inflow);
+            if (parts >= 4) inflow += quad_xor2(inflow);
             if (i < n && part == 0) {
                 const float vaporated = 0.5f * sinf(x[i] / cap[i]) * x[i];                    // :87
                 xn[i] = x[i] + rain[i] + inflow - vaporated - u[i] * x[i];                    // :56-60

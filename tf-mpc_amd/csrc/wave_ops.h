@@ -18,19 +18,44 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 // Fence between cross-lane producer/consumer phases of one wave.
 __device__ __forceinline__ void wsync() { __syncthreads(); }
 
+// Full-wave reductions on the vector unit's DPP cross-lane paths (no LDS traffic: `__shfl_xor`
+// compiles to ds_bpermute_b32 on gfx950, six dependent LDS-crossbar round trips per reduction).
+// Four butterfly steps inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 fold the four
+// rows into lane 63, which a v_readlane hands back as a wave-uniform value.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_move(float old, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xF, false));
+}
+constexpr int kDppQuadXor1 = 0xB1, kDppQuadXor2 = 0x4E, kDppRowHalfMirror = 0x141, kDppRowMirror = 0x140,
+              kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
+    v += dpp_move<kDppQuadXor1>(0.0f, v);
+    v += dpp_move<kDppQuadXor2>(0.0f, v);
+    v += dpp_move<kDppRowHalfMirror>(0.0f, v);
+    v += dpp_move<kDppRowMirror>(0.0f, v);                 // every lane: sum of its row of 16
+    v += dpp_move<kDppRowBcast15, 0xA>(0.0f, v);           // rows 1, 3 += row 0, 2
+    v += dpp_move<kDppRowBcast31, 0xC>(0.0f, v);           // rows 2, 3 += rows 0..1
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
-    return v;
+    v = fmaxf(v, dpp_move<kDppQuadXor1>(v, v));
+    v = fmaxf(v, dpp_move<kDppQuadXor2>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowHalfMirror>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowMirror>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowBcast15, 0xA>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowBcast31, 0xC>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+
+// sum / exchange over groups of 2 or 4 adjacent lanes (a quad)
+__device__ __forceinline__ float quad_xor1(float v) { return dpp_move<kDppQuadXor1>(0.0f, v); }
+__device__ __forceinline__ float quad_xor2(float v) { return dpp_move<kDppQuadXor2>(0.0f, v); }
 
 // Odd leading dimension: a column walk (stride ld) then touches every LDS bank.
 __host__ __device__ __forceinline__ int odd_ld(int x) { return x | 1; }
