@@ -34,6 +34,7 @@ struct EnvLds {
     float beta;
     const float *p[TFMPC_ENV_MAX_PARAMS];
     const float *low, *high;   // [m]
+    const float *aux;          // per-instance constants derived once per kernel (env_aux_len floats)
 };
 
 __host__ __device__ inline int env_param_len(int kind, int i, int n, int m, int zones)
@@ -49,9 +50,20 @@ __host__ __device__ inline int env_param_len(int kind, int i, int n, int m, int 
     return 0;
 }
 
+// Derived constants kept beside the parameters so that no per-timestep code recomputes them:
+//   HVAC       dtc[n] = TIME_DELTA / cap, gsum[n] = sum_k G[i][k], A[n][ldn] = dtc[i] * G[i][j]
+//   Reservoir  Dp[n][ldn] = D with an odd leading dimension (row walks across lanes hit every bank)
+__host__ __device__ inline int env_aux_len(int kind, int n)
+{
+    const int ldn = n | 1;
+    if (kind == TFMPC_ENV_HVAC) return 2 * n + n * ldn;
+    if (kind == TFMPC_ENV_RESERVOIR) return n * ldn;
+    return 0;
+}
+
 __host__ __device__ inline size_t env_lds_floats(int kind, int n, int m, int zones)
 {
-    size_t s = 2 * (size_t)m;
+    size_t s = 2 * (size_t)m + env_aux_len(kind, n);
     for (int i = 0; i < TFMPC_ENV_MAX_PARAMS; ++i) s += env_param_len(kind, i, n, m, zones);
     return s;
 }
@@ -75,7 +87,33 @@ __device__ inline float *env_load(EnvLds &e, const TfmpcEnv &g, int b, float *ba
     float *lo = p, *hi = p + g.m;
     for (int j = lane; j < g.m; j += kWave) { lo[j] = g.low[j]; hi[j] = g.high[j]; }
     e.low = lo; e.high = hi;
-    return p + 2 * g.m;
+    p += 2 * g.m;
+    float *aux = p;
+    e.aux = aux;
+    const int n = g.n, ldn = n | 1;
+    if (g.kind == TFMPC_ENV_HVAC) {
+        wsync();
+        const float *cap = e.p[6], *G = e.p[8];
+        float *dtc = aux, *gsum = aux + n, *A = aux + 2 * n;
+        for (int i = lane; i < n; i += kWave) {
+            dtc[i] = 1.0f / cap[i];                  // TIME_DELTA / cap, TIME_DELTA = 1 (hvac :13)
+            float gs = 0.0f;
+            for (int k = 0; k < n; ++k) gs += G[i * n + k];
+            gsum[i] = gs;
+        }
+        for (int idx = lane; idx < n * n; idx += kWave) {
+            const int i = idx / n, j = idx - i * n;
+            A[i * ldn + j] = (1.0f / cap[i]) * G[idx];
+        }
+    } else if (g.kind == TFMPC_ENV_RESERVOIR) {
+        wsync();
+        const float *D = e.p[7];
+        for (int idx = lane; idx < n * n; idx += kWave) {
+            const int i = idx / n, j = idx - i * n;
+            aux[i * ldn + j] = D[idx];
+        }
+    }
+    return p + env_aux_len(g.kind, n);
 }
 
 __device__ __forceinline__ float signf(float y) { return (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f); }
@@ -390,23 +428,51 @@ template <> struct Env<TFMPC_ENV_HVAC> {
                     - SET_POINT_PENALTY * signf((lo + hi) / 2 - x[i]);
         }
     }
+    // d x'_i / d x_i and d x'_i / d u_i (the only state-dependent entries of f_x, f_u)      :69-89
+    static __device__ __forceinline__ float fx_diag(const EnvLds &e, const float *u, int i)
+    {
+        const int n = e.n;
+        const float *k_out = e.p[4], *k_hall = e.p[5], *air_max = e.p[7], *G = e.p[8];
+        const float dtc = e.aux[i], gsum = e.aux[n + i];
+        return 1.0f + dtc * (G[i * n + i] - u[i] * air_max[i] * CAP_AIR - gsum - k_out[i] - k_hall[i]);
+    }
+    static __device__ __forceinline__ float fu_diag(const EnvLds &e, const float *x, int i)
+    {
+        return e.aux[i] * e.p[7][i] * CAP_AIR * (TEMP_AIR - x[i]);
+    }
+    // Q_x[i] = l_x[i] + sum_k f_x[k][i] V_x[k] and Q_u[a] = l_u[a] + sum_k f_u[k][a] V_x[k] with the
+    // entries of f_x, f_u formed on the fly, in the summation order of the dense path (k ascending;
+    // f_u is diagonal, its exact-zero terms are skipped)
+    static __device__ float adjoint_qx(const EnvLds &e, const float *x, const float *u, const float *Vx, float lx_i, int i)
+    {
+        const int n = e.n, ldn = odd_ld(n);
+        const float *A = e.aux + 2 * n;
+        const float diag = fx_diag(e, u, i);
+        float acc = lx_i;
+        for (int kk = 0; kk < n; ++kk) acc = fmaf((kk == i) ? diag : A[kk * ldn + i], Vx[kk], acc);
+        return acc;
+    }
+    static __device__ float adjoint_qu(const EnvLds &e, const float *x, const float *u, const float *Vx, int a)
+    {
+        return fmaf(fu_diag(e, x, a), Vx[a], COST_AIR * e.p[7][a]);
+    }
+    static __device__ __forceinline__ float cost_grad_x_i(const EnvLds &e, const float *x, int i)
+    {
+        const float lo = e.p[2][i], hi = e.p[3][i];
+        return PENALTY * (-(lo > x[i] ? 1.0f : 0.0f) + (x[i] > hi ? 1.0f : 0.0f)) - SET_POINT_PENALTY * signf((lo + hi) / 2 - x[i]);
+    }
     // f_x, f_u and l_x, l_u only (first-order model; what the adjoint backward pass needs)
     static __device__ float linearize1(const EnvLds &e, const float *x, const float *u, float *fx, float *fu,
                                        float *lx, float *lu)
     {
         const int n = e.n, ldn = odd_ld(n);
-        const float *k_out = e.p[4], *k_hall = e.p[5], *cap = e.p[6], *air_max = e.p[7], *G = e.p[8];
+        const float *air_max = e.p[7];
+        const float *A = e.aux + 2 * n;
         for (int idx = lane_id(); idx < n * n; idx += kWave) {
             const int i = idx / n, j = idx - i * n;
-            const float dtc = TIME_DELTA / cap[i];
-            float v = dtc * G[i * n + j];
+            float v = A[i * ldn + j];                                     // dtc_i * G[i][j]
             float d = 0.0f;
-            if (i == j) {
-                float gsum = 0.0f;
-                for (int k = 0; k < n; ++k) gsum += G[i * n + k];
-                v = 1.0f + dtc * (G[i * n + i] - u[i] * air_max[i] * CAP_AIR - gsum - k_out[i] - k_hall[i]);
-                d = dtc * air_max[i] * CAP_AIR * (TEMP_AIR - x[i]);
-            }
+            if (i == j) { v = fx_diag(e, u, i); d = fu_diag(e, x, i); }
             fx[i * ldn + j] = v;
             fu[i * ldn + j] = d;
         }
@@ -494,6 +560,43 @@ template <> struct Env<TFMPC_ENV_RESERVOIR> {
             const float LP = -e.p[3][i], HP = -e.p[4][i], SP = -e.p[5][i];
             lx[i] = -LP * (lo > x[i] ? 1.0f : 0.0f) + HP * (x[i] > hi ? 1.0f : 0.0f) - SP * signf((lo + hi) / 2.0f - x[i]);
         }
+    }
+    // Q_x[j] = l_x[j] + sum_k f_x[k][j] V_x[k], Q_u[a] = sum_k f_u[k][a] V_x[k] with
+    // f_x[k][j] = D[j][k] u_j (+ evaporation/outflow term on the diagonal), f_u[k][a] = D[a][k] x_a
+    // (- x_a on the diagonal) formed on the fly from row j (a) of D, in the dense path's order
+    static __device__ float adjoint_qx(const EnvLds &e, const float *x, const float *u, const float *Vx, float lx_j, int j)
+    {
+        const int n = e.n, ldn = odd_ld(n);
+        const float *Drow = e.aux + j * ldn;
+        const float uj = u[j];
+        const float r = x[j] / e.p[0][j];
+        const float diag_extra = 1.0f - 0.5f * (cosf(r) * r + sinf(r)) - uj;
+        float acc = lx_j;
+        for (int kk = 0; kk < n; ++kk) {
+            float a = Drow[kk] * uj;
+            if (kk == j) a += diag_extra;
+            acc = fmaf(a, Vx[kk], acc);
+        }
+        return acc;
+    }
+    static __device__ float adjoint_qu(const EnvLds &e, const float *x, const float *u, const float *Vx, int a_)
+    {
+        const int n = e.n, ldn = odd_ld(n);
+        const float *Drow = e.aux + a_ * ldn;
+        const float xa = x[a_];
+        float acc = 0.0f;
+        for (int kk = 0; kk < n; ++kk) {
+            float bb = Drow[kk] * xa;
+            if (kk == a_) bb -= xa;
+            acc = fmaf(bb, Vx[kk], acc);
+        }
+        return acc;
+    }
+    static __device__ __forceinline__ float cost_grad_x_i(const EnvLds &e, const float *x, int i)
+    {
+        const float lo = e.p[1][i], hi = e.p[2][i];
+        const float LP = -e.p[3][i], HP = -e.p[4][i], SP = -e.p[5][i];
+        return -LP * (lo > x[i] ? 1.0f : 0.0f) + HP * (x[i] > hi ? 1.0f : 0.0f) - SP * signf((lo + hi) / 2.0f - x[i]);
     }
     static __device__ float linearize1(const EnvLds &e, const float *x, const float *u, float *fx, float *fu,
                                        float *lx, float *lu)

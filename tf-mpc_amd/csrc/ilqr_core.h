@@ -74,8 +74,7 @@ __device__ inline float *ilqr_carve(IlqrSmem &s, float *p, int n, int m)
 // the backward pass is then the adjoint recursion below and needs no n x n Q terms.
 __host__ __device__ inline size_t ilqr_adjoint_smem_floats(int n, int m)
 {
-    const size_t ldn = odd_ld(n), ldm = odd_ld(m);
-    return n * ldn + n * ldm + 6 * (size_t)n + 5 * (size_t)m + (size_t)m * ldn;
+    return 6 * (size_t)n + 5 * (size_t)m;        // vectors only: f_x, f_u are never materialised, K == 0
 }
 
 __device__ inline float *ilqr_carve_adjoint(IlqrSmem &s, float *p, int n, int m)
@@ -83,11 +82,9 @@ __device__ inline float *ilqr_carve_adjoint(IlqrSmem &s, float *p, int n, int m)
     s = IlqrSmem{};
     s.n = n; s.m = m; s.bf16 = 0;
     s.ldn = odd_ld(n); s.ldm = odd_ld(m); s.width = m + 1 + n; s.lda = odd_ld(s.width);
-    s.fx = p; p += n * s.ldn;   s.fu = p; p += n * s.ldm;
     s.lx = p; p += n;  s.Vx = p; p += n;  s.Qx = p; p += n;
     s.xv = p; p += n;  s.xn = p; p += n;  s.xh = p; p += n;
     s.lu = p; p += m;  s.Qu = p; p += m;  s.k = p; p += m;  s.uv = p; p += m;  s.uh = p; p += m;
-    s.K = p; p += m * s.ldn;        // only touched by forward_pass<KIND, true>
     return p;
 }
 
@@ -355,22 +352,37 @@ __device__ inline BackwardResult backward_pass_adjoint(IlqrSmem &s, const EnvLds
     r.J = Env<KIND>::final_grad(e, s.xh, s.Vx);
     float gsum = 0.0f;
     wsync();
+    // The nominal trajectory streams in from the HBM workspace one step ahead of its use (each lane
+    // keeps the next step's element in a register), and f_x, f_u are never materialised: the env
+    // forms the entries it needs on the fly (Env<KIND>::adjoint_qx / adjoint_qu), in the summation
+    // order of the dense path.
+    const bool one_pass = n + m <= kWave;           // lane i < n: state i; lane n + a: action a
+    float x_next = 0.0f, u_next = 0.0f;
+    if (one_pass && T > 0) {
+        if (lane < n) x_next = xhat[(size_t)(T - 1) * n + lane];
+        else if (lane < n + m) u_next = uhat[(size_t)(T - 1) * m + (lane - n)];
+    }
     for (int t = T - 1; t >= 0; --t) {
-        for (int i = lane; i < n; i += kWave) s.xh[i] = xhat[(size_t)t * n + i];
-        for (int a = lane; a < m; a += kWave) s.uh[a] = uhat[(size_t)t * m + a];
+        if (one_pass) {
+            if (lane < n) s.xh[lane] = x_next;
+            else if (lane < n + m) s.uh[lane - n] = u_next;
+            if (t > 0) {
+                if (lane < n) x_next = xhat[(size_t)(t - 1) * n + lane];
+                else if (lane < n + m) u_next = uhat[(size_t)(t - 1) * m + (lane - n)];
+            }
+        } else {
+            for (int i = lane; i < n; i += kWave) s.xh[i] = xhat[(size_t)t * n + i];
+            for (int a = lane; a < m; a += kWave) s.uh[a] = uhat[(size_t)t * m + a];
+        }
         wsync();
-        const float l = Env<KIND>::linearize1(e, s.xh, s.uh, s.fx, s.fu, s.lx, s.lu);
-        wsync();
+        const float l = Env<KIND>::cost(e, s.xh, s.uh);
         float p1 = 0.0f, gmax = 0.0f;
         for (int i = lane; i < n + m; i += kWave) {
             if (i < n) {
-                float acc = s.lx[i];
-                for (int kk = 0; kk < n; ++kk) acc = fmaf(s.fx[kk * ldn + i], s.Vx[kk], acc);
-                s.Qx[i] = acc;
+                s.Qx[i] = Env<KIND>::adjoint_qx(e, s.xh, s.uh, s.Vx, Env<KIND>::cost_grad_x_i(e, s.xh, i), i);
             } else {
                 const int a = i - n;
-                float acc = s.lu[a];
-                for (int kk = 0; kk < n; ++kk) acc = fmaf(s.fu[kk * ldm + a], s.Vx[kk], acc);
+                const float acc = Env<KIND>::adjoint_qu(e, s.xh, s.uh, s.Vx, a);
                 const float kt = (acc >= 0.0f) ? (e.low[a] - s.uh[a]) : (e.high[a] - s.uh[a]);
                 kg[(size_t)t * m + a] = stq(s, kt);
                 p1 = fmaf(kt, acc, p1);
