@@ -50,21 +50,21 @@ __host__ __device__ inline int env_param_len(int kind, int i, int n, int m, int 
     return 0;
 }
 
-// Derived constants kept beside the parameters so that no per-timestep code recomputes them:
-//   HVAC       dtc[n] = TIME_DELTA / cap, gsum[n] = sum_k G[i][k], A[n][ldn] = dtc[i] * G[i][j]
-//   Reservoir  Dp[n][ldn] = D with an odd leading dimension (row walks across lanes hit every bank)
-__host__ __device__ inline int env_aux_len(int kind, int n)
+// The n x n matrix parameter of HVAC (adjacency G, p[8]) and Reservoir (downstream D, p[7]) is kept
+// in LDS with an ODD leading dimension ldn = n | 1: rows walked across lanes then hit every bank.
+__host__ __device__ inline int env_matrix_param(int kind)
 {
-    const int ldn = n | 1;
-    if (kind == TFMPC_ENV_HVAC) return 2 * n + n * ldn;
-    if (kind == TFMPC_ENV_RESERVOIR) return n * ldn;
-    return 0;
+    return kind == TFMPC_ENV_HVAC ? 8 : (kind == TFMPC_ENV_RESERVOIR ? 7 : -1);
 }
+// Constants derived once per kernel so that no per-timestep code recomputes them:
+//   HVAC  dtc[n] = TIME_DELTA / cap, gsum[n] = sum_k G[i][k]
+__host__ __device__ inline int env_aux_len(int kind, int n) { return kind == TFMPC_ENV_HVAC ? 2 * n : 0; }
 
 __host__ __device__ inline size_t env_lds_floats(int kind, int n, int m, int zones)
 {
     size_t s = 2 * (size_t)m + env_aux_len(kind, n);
-    for (int i = 0; i < TFMPC_ENV_MAX_PARAMS; ++i) s += env_param_len(kind, i, n, m, zones);
+    for (int i = 0; i < TFMPC_ENV_MAX_PARAMS; ++i)
+        s += (i == env_matrix_param(kind)) ? (size_t)n * (n | 1) : (size_t)env_param_len(kind, i, n, m, zones);
     return s;
 }
 
@@ -74,14 +74,20 @@ __device__ inline float *env_load(EnvLds &e, const TfmpcEnv &g, int b, float *ba
 {
     const int lane = lane_id();
     e.n = g.n; e.m = g.m; e.zones = g.n_zones; e.beta = g.scalar[0];
+    const int n = g.n, ldn = n | 1, mat = env_matrix_param(g.kind);
     float *p = base;
     for (int i = 0; i < TFMPC_ENV_MAX_PARAMS; ++i) {
         const int len = env_param_len(g.kind, i, g.n, g.m, g.n_zones);
         e.p[i] = p;
         if (len > 0) {
             const float *src = g.p[i] + (size_t)b * g.stride[i];
-            for (int j = lane; j < len; j += kWave) p[j] = src[j];
-            p += len;
+            if (i == mat) {
+                for (int j = lane; j < len; j += kWave) p[(j / n) * ldn + j % n] = src[j];
+                p += n * ldn;
+            } else {
+                for (int j = lane; j < len; j += kWave) p[j] = src[j];
+                p += len;
+            }
         }
     }
     float *lo = p, *hi = p + g.m;
@@ -90,27 +96,15 @@ __device__ inline float *env_load(EnvLds &e, const TfmpcEnv &g, int b, float *ba
     p += 2 * g.m;
     float *aux = p;
     e.aux = aux;
-    const int n = g.n, ldn = n | 1;
     if (g.kind == TFMPC_ENV_HVAC) {
         wsync();
         const float *cap = e.p[6], *G = e.p[8];
-        float *dtc = aux, *gsum = aux + n, *A = aux + 2 * n;
+        float *dtc = aux, *gsum = aux + n;
         for (int i = lane; i < n; i += kWave) {
             dtc[i] = 1.0f / cap[i];                  // TIME_DELTA / cap, TIME_DELTA = 1 (hvac :13)
             float gs = 0.0f;
-            for (int k = 0; k < n; ++k) gs += G[i * n + k];
+            for (int k = 0; k < n; ++k) gs += G[i * ldn + k];
             gsum[i] = gs;
-        }
-        for (int idx = lane; idx < n * n; idx += kWave) {
-            const int i = idx / n, j = idx - i * n;
-            A[i * ldn + j] = (1.0f / cap[i]) * G[idx];
-        }
-    } else if (g.kind == TFMPC_ENV_RESERVOIR) {
-        wsync();
-        const float *D = e.p[7];
-        for (int idx = lane; idx < n * n; idx += kWave) {
-            const int i = idx / n, j = idx - i * n;
-            aux[i * ldn + j] = D[idx];
         }
     }
     return p + env_aux_len(g.kind, n);
@@ -357,7 +351,7 @@ template <> struct Env<TFMPC_ENV_HVAC> {
 
     static __device__ void transition(const EnvLds &e, const float *x, const float *u, float *xn)
     {
-        const int n = e.n;
+        const int n = e.n, ldg = odd_ld(n);
         const float *t_out = e.p[0], *t_hall = e.p[1], *k_out = e.p[4], *k_hall = e.p[5], *cap = e.p[6],
                     *air_max = e.p[7], *G = e.p[8];
         // conduction between rooms, sum_j -G[i][j] (x_i - x_j) (:131-139): each row is split over
@@ -378,15 +372,15 @@ template <> struct Env<TFMPC_ENV_HVAC> {
                 for (; jj + 4 <= j1; jj += 4) {
                     int c0 = jj + i, c1 = jj + 1 + i, c2 = jj + 2 + i, c3 = jj + 3 + i;
                     c0 -= (c0 >= n) ? n : 0; c1 -= (c1 >= n) ? n : 0; c2 -= (c2 >= n) ? n : 0; c3 -= (c3 >= n) ? n : 0;
-                    s0 = fmaf(-G[i * n + c0], xi - x[c0], s0);
-                    s1 = fmaf(-G[i * n + c1], xi - x[c1], s1);
-                    s2 = fmaf(-G[i * n + c2], xi - x[c2], s2);
-                    s3 = fmaf(-G[i * n + c3], xi - x[c3], s3);
+                    s0 = fmaf(-G[i * ldg + c0], xi - x[c0], s0);
+                    s1 = fmaf(-G[i * ldg + c1], xi - x[c1], s1);
+                    s2 = fmaf(-G[i * ldg + c2], xi - x[c2], s2);
+                    s3 = fmaf(-G[i * ldg + c3], xi - x[c3], s3);
                 }
                 for (; jj < j1; ++jj) {
                     int c0 = jj + i;
                     c0 -= (c0 >= n) ? n : 0;
-                    s0 = fmaf(-G[i * n + c0], xi - x[c0], s0);
+                    s0 = fmaf(-G[i * ldg + c0], xi - x[c0], s0);
                 }
                 between = (s0 + s1) + (s2 + s3);
             }
@@ -434,7 +428,7 @@ template <> struct Env<TFMPC_ENV_HVAC> {
         const int n = e.n;
         const float *k_out = e.p[4], *k_hall = e.p[5], *air_max = e.p[7], *G = e.p[8];
         const float dtc = e.aux[i], gsum = e.aux[n + i];
-        return 1.0f + dtc * (G[i * n + i] - u[i] * air_max[i] * CAP_AIR - gsum - k_out[i] - k_hall[i]);
+        return 1.0f + dtc * (G[i * odd_ld(n) + i] - u[i] * air_max[i] * CAP_AIR - gsum - k_out[i] - k_hall[i]);
     }
     static __device__ __forceinline__ float fu_diag(const EnvLds &e, const float *x, int i)
     {
@@ -446,10 +440,10 @@ template <> struct Env<TFMPC_ENV_HVAC> {
     static __device__ float adjoint_qx(const EnvLds &e, const float *x, const float *u, const float *Vx, float lx_i, int i)
     {
         const int n = e.n, ldn = odd_ld(n);
-        const float *A = e.aux + 2 * n;
+        const float *dtc = e.aux, *G = e.p[8];
         const float diag = fx_diag(e, u, i);
         float acc = lx_i;
-        for (int kk = 0; kk < n; ++kk) acc = fmaf((kk == i) ? diag : A[kk * ldn + i], Vx[kk], acc);
+        for (int kk = 0; kk < n; ++kk) acc = fmaf((kk == i) ? diag : dtc[kk] * G[kk * ldn + i], Vx[kk], acc);
         return acc;
     }
     static __device__ float adjoint_qu(const EnvLds &e, const float *x, const float *u, const float *Vx, int a)
@@ -466,11 +460,10 @@ template <> struct Env<TFMPC_ENV_HVAC> {
                                        float *lx, float *lu)
     {
         const int n = e.n, ldn = odd_ld(n);
-        const float *air_max = e.p[7];
-        const float *A = e.aux + 2 * n;
+        const float *air_max = e.p[7], *G = e.p[8];
         for (int idx = lane_id(); idx < n * n; idx += kWave) {
             const int i = idx / n, j = idx - i * n;
-            float v = A[i * ldn + j];                                     // dtc_i * G[i][j]
+            float v = e.aux[i] * G[i * ldn + j];                          // dtc_i * G[i][j]
             float d = 0.0f;
             if (i == j) { v = fx_diag(e, u, i); d = fu_diag(e, x, i); }
             fx[i * ldn + j] = v;
@@ -510,7 +503,7 @@ template <> struct Env<TFMPC_ENV_RESERVOIR> {
     static constexpr bool kPiecewiseLinearCost = true;
     static __device__ void transition(const EnvLds &e, const float *x, const float *u, float *xn)
     {
-        const int n = e.n;
+        const int n = e.n, ldd = odd_ld(n);
         const float *cap = e.p[0], *rain = e.p[6], *D = e.p[7];
         // inflow_i = sum_j D[j][i] u_j x_j (:91): rows split over `parts` lanes, 4 partial sums per lane
         const int parts = (n <= 16) ? 4 : ((n <= 32) ? 2 : 1);
@@ -524,12 +517,12 @@ template <> struct Env<TFMPC_ENV_RESERVOIR> {
                 float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
                 int j = j0;
                 for (; j + 4 <= j1; j += 4) {
-                    s0 = fmaf(D[j * n + i], u[j] * x[j], s0);
-                    s1 = fmaf(D[(j + 1) * n + i], u[j + 1] * x[j + 1], s1);
-                    s2 = fmaf(D[(j + 2) * n + i], u[j + 2] * x[j + 2], s2);
-                    s3 = fmaf(D[(j + 3) * n + i], u[j + 3] * x[j + 3], s3);
+                    s0 = fmaf(D[j * ldd + i], u[j] * x[j], s0);
+                    s1 = fmaf(D[(j + 1) * ldd + i], u[j + 1] * x[j + 1], s1);
+                    s2 = fmaf(D[(j + 2) * ldd + i], u[j + 2] * x[j + 2], s2);
+                    s3 = fmaf(D[(j + 3) * ldd + i], u[j + 3] * x[j + 3], s3);
                 }
-                for (; j < j1; ++j) s0 = fmaf(D[j * n + i], u[j] * x[j], s0);
+                for (; j < j1; ++j) s0 = fmaf(D[j * ldd + i], u[j] * x[j], s0);
                 inflow = (s0 + s1) + (s2 + s3);
             }
             if (parts >= 2) inflow += quad_xor1(inflow);
@@ -567,7 +560,7 @@ template <> struct Env<TFMPC_ENV_RESERVOIR> {
     static __device__ float adjoint_qx(const EnvLds &e, const float *x, const float *u, const float *Vx, float lx_j, int j)
     {
         const int n = e.n, ldn = odd_ld(n);
-        const float *Drow = e.aux + j * ldn;
+        const float *Drow = e.p[7] + j * ldn;
         const float uj = u[j];
         const float r = x[j] / e.p[0][j];
         const float diag_extra = 1.0f - 0.5f * (cosf(r) * r + sinf(r)) - uj;
@@ -582,7 +575,7 @@ template <> struct Env<TFMPC_ENV_RESERVOIR> {
     static __device__ float adjoint_qu(const EnvLds &e, const float *x, const float *u, const float *Vx, int a_)
     {
         const int n = e.n, ldn = odd_ld(n);
-        const float *Drow = e.aux + a_ * ldn;
+        const float *Drow = e.p[7] + a_ * ldn;
         const float xa = x[a_];
         float acc = 0.0f;
         for (int kk = 0; kk < n; ++kk) {
@@ -605,8 +598,8 @@ template <> struct Env<TFMPC_ENV_RESERVOIR> {
         const float *cap = e.p[0], *D = e.p[7];
         for (int idx = lane_id(); idx < n * n; idx += kWave) {
             const int i = idx / n, j = idx - i * n;
-            float a = D[j * n + i] * u[j];          // D^T diag(u)
-            float b = D[j * n + i] * x[j];          // D^T diag(x)
+            float a = D[j * ldn + i] * u[j];        // D^T diag(u)
+            float b = D[j * ldn + i] * x[j];        // D^T diag(x)
             if (i == j) {
                 const float r = x[i] / cap[i];
                 a += 1.0f - 0.5f * (cosf(r) * r + sinf(r)) - u[i];

@@ -6,7 +6,7 @@ from tfmpc.envs.reservoir import Reservoir
 from tfmpc.solvers.ilqr import iLQR
 n, T, B = 32, 100, 8192
 rng = np.random.default_rng(4)
-names = ["bwd load+wait", "bwd linearize1", "bwd matvec+rest", "", "fwd load+wait", "fwd u/clip/max", "fwd cost", "fwd transition", "fwd store"]
+names = ["bwd load+wait", "bwd cost", "bwd adjoint Qx/Qu", "bwd reductions+copy", "fwd load+wait", "fwd u/clip/max", "fwd cost", "fwd transition", "fwd store"]
 for kind in ("hvac", "reservoir"):
     if kind == "hvac":
         env = HVAC.load(dict(problems.hvac_config(n, seed=5))); x0 = np.full((B, n, 1), 10.0, dtype=np.float32)
