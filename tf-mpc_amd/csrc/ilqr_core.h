@@ -435,6 +435,41 @@ __device__ inline void forward_pass(IlqrSmem &s, const EnvLds &e, int T, float a
     const int n = s.n, m = s.m, ldn = s.ldn, lane = lane_id();
     for (int i = lane; i < n; i += kWave) { const float x = xhat[i]; s.xv[i] = x; states[i] = stq(s, x); }
     float J = 0.0f, resid = 0.0f;
+    if constexpr (!HAS_K) {
+        if (n <= kWave && m <= kWave) {
+            // K == 0 (adjoint envs): u_t = clip(u_hat_t + alpha k_t) needs no state feedback, so the
+            // step streams (k_t, u_hat_t) one step ahead in registers, keeps the running max |du| per
+            // lane (one reduction at the end) and ping-pongs the state between two LDS vectors.
+            float *xcur = s.xv, *xnext = s.xn;
+            float k_n = 0.0f, uh_n = 0.0f, rmax = 0.0f;
+            if (lane < m && T > 0) { k_n = kg[lane]; uh_n = uhat[lane]; }
+            for (int t = 0; t < T; ++t) {
+                const float k_c = k_n, uh_c = uh_n;
+                if (lane < m && t + 1 < T) { k_n = kg[(size_t)(t + 1) * m + lane]; uh_n = uhat[(size_t)(t + 1) * m + lane]; }
+                if (lane < m) {
+                    const float du = alpha * k_c;                                            // :193-194
+                    const float u = fminf(fmaxf(uh_c + du, e.low[lane]), e.high[lane]);      // :196-197
+                    s.uv[lane] = u;
+                    actions[(size_t)t * m + lane] = stq(s, u);
+                    rmax = fmaxf(rmax, fabsf(du));
+                }
+                wsync();
+                const float c = Env<KIND>::cost(e, xcur, s.uv);                              // :198
+                Env<KIND>::transition(e, xcur, s.uv, xnext);                                 // :199
+                J += c;                                                                      // :205
+                if (lane == 0) costs[t] = c;
+                wsync();
+                if (lane < n) states[(size_t)(t + 1) * n + lane] = stq(s, xnext[lane]);
+                float *tmp = xcur; xcur = xnext; xnext = tmp;
+            }
+            wsync();
+            const float fc = Env<KIND>::final_cost(e, xcur);                                 // :208-210
+            if (lane == 0) costs[T] = fc;
+            J_out = J + fc;
+            residual_out = wave_max(rmax);                                                   // :206
+            return;
+        }
+    }
     for (int t = 0; t < T; ++t) {
         if (HAS_K) load_matrix(s.K, ldn, Kg + (size_t)t * m * n, m, n);
         for (int a = lane; a < m; a += kWave) { s.k[a] = kg[(size_t)t * m + a]; s.uh[a] = uhat[(size_t)t * m + a]; }
