@@ -1,0 +1,75 @@
+"""Register-resident HVAC / Reservoir solve (tf-mpc_amd/csrc/ilqr_adjoint.hip, 16 < n <= 32) against the
+generic wave-per-instance kernel.  Both implement ilqr.py:214-355 on the bang-bang branch with the same
+operation order, so every output must be BIT-identical -- also on Reservoir, where any rounding
+difference would flip line-search decisions and change trajectories completely."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import problems
+from tfmpc.envs.hvac import HVAC
+from tfmpc.envs.reservoir import Reservoir
+from tfmpc.solvers.ilqr import iLQR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def force_kernel():
+    old = os.environ.get("TFMPC_ILQR_KERNEL")
+
+    def set_(name):
+        if name is None:
+            os.environ.pop("TFMPC_ILQR_KERNEL", None)
+        else:
+            os.environ["TFMPC_ILQR_KERNEL"] = name
+    yield set_
+    set_(old)
+
+
+@pytest.mark.parametrize("kind", ["hvac", "reservoir"])
+@pytest.mark.parametrize("n,T,B", [(32, 24, 70), (21, 13, 9), (17, 7, 5), (30, 40, 33)])
+def test_register_resident_kernel_equals_wave_kernel(force_kernel, kind, n, T, B):
+    rng = np.random.default_rng(100 + n)
+    if kind == "hvac":
+        env = HVAC.load(dict(problems.hvac_config(n, seed=n)))
+        x0 = rng.uniform(5.0, 30.0, size=(B, n, 1)).astype(np.float32)
+    else:
+        env = Reservoir.load(dict(problems.reservoir_config(n, seed=n)))
+        x0 = rng.uniform(20.0, 90.0, size=(B, n, 1)).astype(np.float32)
+    solver = iLQR(env, max_iterations=6)
+    u0 = solver.random_actions(T, B, seed=n)
+    out = {}
+    for kern in (None, "wave"):
+        force_kernel(kern)
+        out[kern] = solver.solve_device(x0, T, u_init=u0)
+        torch.cuda.synchronize()
+    fast, wave = out[None], out["wave"]
+    assert torch.equal(fast["iterations"], wave["iterations"])
+    assert torch.equal(fast["status"], wave["status"])
+    for key in ("states", "actions", "costs"):
+        assert torch.equal(fast[key], wave[key]), key
+    assert bool(torch.isfinite(fast["costs"]).all())
+
+
+def test_per_instance_parameters(force_kernel):
+    """Parameters with a batch stride (every instance its own env) go through the same loads."""
+    n, T, B = 24, 10, 6
+    cfgs = [problems.hvac_config(n, seed=40 + b) for b in range(B)]
+    env = HVAC.load(dict(cfgs[0]))
+    envs = [HVAC.load(dict(c)) for c in cfgs]
+    rng = np.random.default_rng(3)
+    x0 = rng.uniform(5.0, 30.0, size=(B, n, 1)).astype(np.float32)
+    u0 = iLQR(env).random_actions(T, B, seed=1)
+    for b in range(B):
+        single = iLQR(envs[b], max_iterations=4)
+        force_kernel(None)
+        fast = single.solve_device(x0[b:b + 1], T, u_init=u0[b:b + 1])
+        force_kernel("wave")
+        wave = single.solve_device(x0[b:b + 1], T, u_init=u0[b:b + 1])
+        torch.cuda.synchronize()
+        for key in ("states", "actions", "costs"):
+            assert torch.equal(fast[key], wave[key]), (b, key)

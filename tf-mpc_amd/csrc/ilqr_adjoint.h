@@ -1,0 +1,23 @@
+// ilqr_adjoint.h -- launch interface of the register-resident HVAC / Reservoir solve
+// (ilqr_adjoint.hip).  Internal; the public contract is include/tfmpc_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tfmpc_hip.h"
+
+namespace tfmpc {
+
+struct AdjointSolveArgs {
+    int B, T;
+    const float *x0, *u_init;
+    float *states, *actions, *costs;
+    int32_t *iterations, *status;
+    float *wsk, *wsx, *wsu, *wsc;        // gains k[T][m], candidate x[T+1][n], u[T][m], costs[T+1]
+};
+
+bool ilqr_adjoint_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg);
+int ilqr_adjoint_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const AdjointSolveArgs &a, hipStream_t stream);
+
+}  // namespace tfmpc

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "ilqr_adjoint.h"
 #include "ilqr_core.h"
 #include "ilqr_lq_mfma.h"
 #include "lqr_kernels.h"
@@ -482,6 +483,16 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
             IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk};
             if ((rc = ilqr_lq_mfma_launch(la, st)) != TFMPC_OK) return rc;
             a.only_flagged = 1;
+        }
+    }
+    {
+        // HVAC / Reservoir at 16 < n <= 32: register-resident costate kernel (ilqr_adjoint.hip),
+        // bit-identical to the generic wave kernel below (TFMPC_ILQR_KERNEL=wave selects that one)
+        const char *force = std::getenv("TFMPC_ILQR_KERNEL");
+        const bool forced_wave = force && std::strcmp(force, "wave") == 0;
+        if (!forced_wave && ilqr_adjoint_supported(*env, *cfg)) {
+            const AdjointSolveArgs aa{B, T, x0, u_init, states, actions, costs, iterations, status, a.wsk, a.wsx, a.wsu, a.wsc};
+            return ilqr_adjoint_launch(*env, *cfg, aa, st);
         }
     }
     const size_t smem = ilqr_solve_smem_bytes(env->kind, n, m, env->n_zones);
