@@ -82,7 +82,10 @@ template <> struct Lean<TFMPC_ENV_HVAC> {
             return G[it * n + c];
         };
 #pragma unroll
-        for (int j = 0; j < kHalf; ++j) Grow[j] = (j < tail) ? Gat(j) : 0.0f;
+        for (int j = 0; j < kHalf; ++j) {
+            if ((j & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+            Grow[j] = (j < tail) ? Gat(j) : 0.0f;
+        }
 #pragma unroll
         for (int q = 0; q < 3; ++q) Gtail[q] = (tail + q < cnt) ? Gat(tail + q) : 0.0f;
         const bool row = it < n;
@@ -97,7 +100,10 @@ template <> struct Lean<TFMPC_ENV_HVAC> {
         if (st) for (int k = 0; k < n; ++k) gs += G[i * n + k];
         gsum = gs;
 #pragma unroll
-        for (int kk = 0; kk < kMaxN; ++kk) coef[kk] = (st && kk < n) ? (TIME_DELTA / pcap[kk]) * G[kk * n + i] : 0.0f;
+        for (int kk = 0; kk < kMaxN; ++kk) {
+            if ((kk & 3) == 0) __builtin_amdgcn_sched_barrier(0);     // one-time code: keep few loads in flight
+            coef[kk] = (st && kk < n) ? (TIME_DELTA / pcap[kk]) * G[kk * n + i] : 0.0f;
+        }
         const int a = lane - n;
         const bool ac = a >= 0 && a < n;
         dtc_a = ac ? TIME_DELTA / pcap[a] : 0.0f;
@@ -138,6 +144,7 @@ template <> struct Lean<TFMPC_ENV_HVAC> {
         const float *xr = x2 + off;
 #pragma unroll
         for (int gq = 0; gq < kHalf / 4; ++gq) {
+            if (gq == 2) __builtin_amdgcn_sched_barrier(0);
             s0 = fmaf(-Grow[4 * gq], xi - xr[4 * gq], s0);
             s1 = fmaf(-Grow[4 * gq + 1], xi - xr[4 * gq + 1], s1);
             s2 = fmaf(-Grow[4 * gq + 2], xi - xr[4 * gq + 2], s2);
@@ -167,7 +174,10 @@ template <> struct Lean<TFMPC_ENV_HVAC> {
             acc = grad_x(xh[lane]);
             const int me = opaque(lane);
 #pragma unroll
-            for (int kk = 0; kk < kMaxN; ++kk) acc = fmaf((kk == me) ? diag : coef[kk], vx[kk], acc);   // kk >= n: 0 * 0
+            for (int kk = 0; kk < kMaxN; ++kk) {                  // kk >= n: 0 * 0
+                if ((kk & 7) == 0) __builtin_amdgcn_sched_barrier(0);     // 8 V_x values in flight, not 32
+                acc = fmaf((kk == me) ? diag : coef[kk], vx[kk], acc);
+            }
         } else if (lane < 2 * n) {
             const int a = lane - n;
             const float d = dtc_a * am_a * CAP_AIR * (TEMP_AIR - xh[a]);
@@ -200,7 +210,10 @@ template <> struct Lean<TFMPC_ENV_RESERVOIR> {
         if (it >= n) j0 = 0;
         tail = cnt & ~3;
 #pragma unroll
-        for (int j = 0; j < kHalf; ++j) Dcol[j] = (j < tail) ? D[(j0 + j) * n + it] : 0.0f;
+        for (int j = 0; j < kHalf; ++j) {
+            if ((j & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+            Dcol[j] = (j < tail) ? D[(j0 + j) * n + it] : 0.0f;
+        }
 #pragma unroll
         for (int q = 0; q < 3; ++q) Dtail[q] = (tail + q < cnt) ? D[(j0 + tail + q) * n + it] : 0.0f;
         cap_t = (it < n) ? pcap[it] : 1.0f;
@@ -212,7 +225,10 @@ template <> struct Lean<TFMPC_ENV_RESERVOIR> {
         const int rrow = (lane < n) ? lane : lane - n;
         const bool rv = rrow >= 0 && rrow < n && lane < 2 * n;
 #pragma unroll
-        for (int kk = 0; kk < kMaxN; ++kk) Drow[kk] = (rv && kk < n) ? D[rrow * n + kk] : 0.0f;
+        for (int kk = 0; kk < kMaxN; ++kk) {
+            if ((kk & 3) == 0) __builtin_amdgcn_sched_barrier(0);     // one-time code: keep few loads in flight
+            Drow[kk] = (rv && kk < n) ? D[rrow * n + kk] : 0.0f;
+        }
     }
     __device__ float cost(const float *x, const float *) const                            // reservoir :63-79
     {
@@ -237,6 +253,7 @@ template <> struct Lean<TFMPC_ENV_RESERVOIR> {
         const float *xr = x2 + j0, *ur = u + j0;
 #pragma unroll
         for (int gq = 0; gq < kHalf / 4; ++gq) {
+            if (gq == 2) __builtin_amdgcn_sched_barrier(0);
             s0 = fmaf(Dcol[4 * gq], ur[4 * gq] * xr[4 * gq], s0);
             s1 = fmaf(Dcol[4 * gq + 1], ur[4 * gq + 1] * xr[4 * gq + 1], s1);
             s2 = fmaf(Dcol[4 * gq + 2], ur[4 * gq + 2] * xr[4 * gq + 2], s2);
@@ -266,6 +283,7 @@ template <> struct Lean<TFMPC_ENV_RESERVOIR> {
             const int me = opaque(lane);
 #pragma unroll
             for (int kk = 0; kk < kMaxN; ++kk) {                  // kk >= n: 0 * 0
+                if ((kk & 7) == 0) __builtin_amdgcn_sched_barrier(0);     // 8 V_x values in flight, not 32
                 float a = Drow[kk] * uj;
                 if (kk == me) a += diag_extra;
                 acc = fmaf(a, vx[kk], acc);
@@ -276,6 +294,7 @@ template <> struct Lean<TFMPC_ENV_RESERVOIR> {
             const int me = opaque(a_);
 #pragma unroll
             for (int kk = 0; kk < kMaxN; ++kk) {
+                if ((kk & 7) == 0) __builtin_amdgcn_sched_barrier(0);
                 float bb = Drow[kk] * xa;
                 if (kk == me) bb -= xa;
                 acc = fmaf(bb, vx[kk], acc);
@@ -287,8 +306,10 @@ template <> struct Lean<TFMPC_ENV_RESERVOIR> {
 
 struct BackwardOut { float J, dV1, g_norm; };
 
+// 4 waves per SIMD (<= 128 VGPR, ~18 rarely used values in scratch): measured best of 3 / 4 / 5 / 6 on
+// cfg5 (the kernel is latency-bound; below 128 VGPR the spills reach the time loops)
 template <int KIND>
-__global__ __launch_bounds__(kWave) void ilqr_adjoint_solve_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 4))) void ilqr_adjoint_solve_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     const int b = blockIdx.x, lane = lane_id(), n = genv.n, m = n, T = a.T;
@@ -313,7 +334,7 @@ __global__ __launch_bounds__(kWave) void ilqr_adjoint_solve_kernel(TfmpcEnv genv
         float u_n = (lane < m && T > 0) ? next_u(0) : 0.0f;
         for (int t = 0; t < T; ++t) {
             const float u_c = u_n;
-            if (lane < m) { ul[lane] = u_c; us[(size_t)t * m + lane] = u_c; }
+            if (lane < m) { ul[lane] = u_c; (us + (size_t)t * m)[lane] = u_c; }
             if (lane < m && t + 1 < T) u_n = next_u(t + 1);
             wsync();
             const float c = env.cost(xcur, ul);
@@ -321,7 +342,7 @@ __global__ __launch_bounds__(kWave) void ilqr_adjoint_solve_kernel(TfmpcEnv genv
             J += c;
             if (lane == 0) cs[t] = c;
             wsync();
-            if (lane < n) xs[(size_t)(t + 1) * n + lane] = xnext[lane];
+            if (lane < n) (xs + (size_t)(t + 1) * n)[lane] = xnext[lane];
             float *tmp = xcur; xcur = xnext; xnext = tmp;
         }
         wsync();
@@ -335,7 +356,7 @@ __global__ __launch_bounds__(kWave) void ilqr_adjoint_solve_kernel(TfmpcEnv genv
     {
         const float *u0 = a.u_init + (size_t)b * T * m;
         float J;
-        rollout([&](int t) { return u0[(size_t)t * m + lane]; }, xhat, uhat, chat, J);
+        rollout([&](int t) { return (u0 + (size_t)t * m)[lane]; }, xhat, uhat, chat, J);
     }
 
     float mu = 0.0f, delta = 1.0f;
@@ -346,15 +367,15 @@ __global__ __launch_bounds__(kWave) void ilqr_adjoint_solve_kernel(TfmpcEnv genv
             // ---- backward (ilqr.py:94-172 on the bang-bang branch): costate recursion ------------
             BackwardOut r{0.0f, 0.0f, 0.0f};
             {
-                if (lane < n) { const float x = xhat[(size_t)T * n + lane]; xa[lane] = x; xa[n + lane] = x; }
+                if (lane < n) { const float x = (xhat + (size_t)T * n)[lane]; xa[lane] = x; xa[n + lane] = x; }
                 wsync();
                 if (lane < n) vx[lane] = env.grad_x(xa[lane]);                 // V_x = l_x^f
                 r.J = env.final_cost(xa);
                 float gsum = 0.0f;
                 float x_n = 0.0f, u_n = 0.0f;
                 if (T > 0) {
-                    if (lane < n) x_n = xhat[(size_t)(T - 1) * n + lane];
-                    else if (lane < n + m) u_n = uhat[(size_t)(T - 1) * m + al];
+                    if (lane < n) x_n = (xhat + (size_t)(T - 1) * n)[lane];
+                    else if (lane < n + m) u_n = (uhat + (size_t)(T - 1) * m)[al];
                 }
                 wsync();
                 for (int t = T - 1; t >= 0; --t) {
@@ -362,8 +383,8 @@ __global__ __launch_bounds__(kWave) void ilqr_adjoint_solve_kernel(TfmpcEnv genv
                     else if (lane < n + m) ul[al] = u_n;
                     const float uh_a = u_n;                                     // lanes n + a keep u_hat[a]
                     if (t > 0) {
-                        if (lane < n) x_n = xhat[(size_t)(t - 1) * n + lane];
-                        else if (lane < n + m) u_n = uhat[(size_t)(t - 1) * m + al];
+                        if (lane < n) x_n = (xhat + (size_t)(t - 1) * n)[lane];
+                        else if (lane < n + m) u_n = (uhat + (size_t)(t - 1) * m)[al];
                     }
                     wsync();
                     const float l = env.cost(xa, ul);
@@ -371,7 +392,7 @@ __global__ __launch_bounds__(kWave) void ilqr_adjoint_solve_kernel(TfmpcEnv genv
                     float p1 = 0.0f, gmax = 0.0f;
                     if (lane >= n && lane < n + m) {
                         const float kt = (acc >= 0.0f) ? (low_a - uh_a) : (high_a - uh_a);       // :140-141
-                        kg[(size_t)t * m + al] = kt;
+                        (kg + (size_t)t * m)[al] = kt;
                         p1 = fmaf(kt, acc, p1);
                         gmax = fmaxf(gmax, fabsf(kt) / (fabsf(uh_a) + 1.0f));
                     }
@@ -393,9 +414,9 @@ __global__ __launch_bounds__(kWave) void ilqr_adjoint_solve_kernel(TfmpcEnv genv
                 const float alpha = cfg.alphas[ai];
                 float J, rmax = 0.0f;
                 rollout([&](int t) {
-                            const float du = alpha * kg[(size_t)t * m + lane];                   // :193-194
+                            const float du = alpha * (kg + (size_t)t * m)[lane];                   // :193-194
                             rmax = fmaxf(rmax, fabsf(du));
-                            return fminf(fmaxf(uhat[(size_t)t * m + lane] + du, low), high);     // :196-197
+                            return fminf(fmaxf((uhat + (size_t)t * m)[lane] + du, low), high);     // :196-197
                         },
                         xc, uc, cc, J);
                 residual = wave_max(rmax);                                      // :206
