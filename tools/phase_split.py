@@ -35,3 +35,23 @@ def bw():
 t_bwd = timeit(bw)
 print(f"sweep alone (no value outputs) {t_bwd:.3f} ms")
 print(f"fused solve {t_solve:.3f} ms; rollout alone {t_fwd:.3f} ms (includes output allocation)")
+
+# Do a sweep-only launch and a rollout-only launch overlap when they run CONCURRENTLY (two streams)?
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+st1 = ctypes.c_void_p(s1.cuda_stream) if False else None
+import ctypes
+K2, k2 = K.clone(), k.clone()
+states = torch.empty((B, T + 1, n, 1), device="cuda"); actions = torch.empty((B, T, m, 1), device="cuda"); costs = torch.empty((B, T + 1, 1, 1), device="cuda")
+def both():
+    with torch.cuda.stream(s1):
+        rc = lib.tfmpc_lqr_backward_f32(B, n, m, T, *lqr._ptr_args(), _hip.ptr(K), _hip.ptr(k), None, None, None, _hip.ptr(status), ctypes.c_void_p(s1.cuda_stream))
+    with torch.cuda.stream(s2):
+        rc2 = lib.tfmpc_lqr_forward_f32(B, n, m, T, *lqr._ptr_args(), _hip.ptr(K2), K2[0].numel(), _hip.ptr(k2), k2[0].numel(), _hip.ptr(x0),
+                                        _hip.ptr(states), _hip.ptr(actions), _hip.ptr(costs), ctypes.c_void_p(s2.cuda_stream))
+def timeit2(fn, reps=10):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+print(f"sweep and rollout launched concurrently on two streams: {timeit2(both):.3f} ms per pair")
