@@ -73,3 +73,24 @@ def test_per_instance_parameters(force_kernel):
         torch.cuda.synchronize()
         for key in ("states", "actions", "costs"):
             assert torch.equal(fast[key], wave[key]), (b, key)
+
+
+def test_first_iterations_match_the_fp64_oracle_at_n24():
+    """Against the oracle (numpy / torch-autodiff restatement of ilqr.py + hvac/__init__.py), fp64, at a
+    size the register-resident kernel serves.  HVAC is smooth enough that two iterations agree to fp32
+    accuracy: same line-search decisions, trajectories within 1e-4 relative."""
+    from oracle import envs_ref, ilqr_ref
+    n, T = 24, 12
+    cfg = problems.hvac_config(n, seed=7)
+    rng = np.random.default_rng(1)
+    x0 = rng.uniform(5.0, 30.0, size=(n, 1)).astype(np.float32)
+    solver = iLQR(HVAC.load(dict(cfg)), max_iterations=2)
+    u0 = solver.random_actions(T, None, seed=3)
+    traj, iteration = solver.solve(x0, T, show_progress=False, u_init=u0)
+    o = ilqr_ref.ILQRRef(envs_ref.HVAC(**cfg, dtype=np.float64), dtype=np.float64, max_iterations=2)
+    xs, us, cs, it64 = o.solve(x0.astype(np.float64), T, u_init=u0.cpu().numpy().astype(np.float64))
+    assert iteration == it64
+    scale = np.abs(xs).max()
+    assert np.abs(traj.states - xs).max() <= 1e-4 * scale
+    assert np.abs(traj.actions - us).max() <= 1e-4
+    assert abs(traj.total_cost - cs.sum()) <= 1e-4 * abs(cs.sum())
