@@ -326,13 +326,20 @@ __global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
             if (lane < N) cand[lane] = nom[lane];
             if (lane < M) cand[T * kZld + N + lane] = 0.0f;
             float rmax = 0.0f;
+            // gains of step t for this lane, loaded one step ahead (they come back from HBM / Infinity Cache)
+            const bool row = ka < m;
+            auto load_gain = [&](int t, float &gx, float &gy) {
+                gx = (row && 2 * jc < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc] : 0.0f;
+                gy = (row && 2 * jc + 1 < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] : 0.0f;
+            };
+            float Kxn = 0.0f, Kyn = 0.0f;
+            load_gain(0, Kxn, Kyn);
             __syncthreads();
             for (int t = 0; t < T; ++t) {
                 const float *zh = nom + t * kZld;
                 float *zt = cand + t * kZld;
-                const bool row = ka < m;
-                const float Kx = (row && 2 * jc < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc] : 0.0f;
-                const float Ky = (row && 2 * jc + 1 < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] : 0.0f;
+                const float Kx = Kxn, Ky = Kyn;
+                if (t + 1 < T) load_gain(t + 1, Kxn, Kyn);
                 const float2 xv = *reinterpret_cast<const float2 *>(&zt[2 * jc]);
                 const float2 xh = *reinterpret_cast<const float2 *>(&zh[2 * jc]);
                 float du = fmaf(Kx, xv.x - xh.x, Ky * (xv.y - xh.y));              // K (x - x_hat)  :193-194
