@@ -480,7 +480,7 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
         const char *force = std::getenv("TFMPC_ILQR_KERNEL");
         const bool forced_wave = force && std::strcmp(force, "wave") == 0;
         if (!forced_wave && !cfg->storage_bf16 && ilqr_lq_mfma_supported(*env, T)) {
-            IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk};
+            IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk, a.wsu};
             if ((rc = ilqr_lq_mfma_launch(la, st)) != TFMPC_OK) return rc;
             a.only_flagged = 1;
         }

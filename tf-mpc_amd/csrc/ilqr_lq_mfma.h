@@ -21,7 +21,7 @@ struct IlqrLqArgs {
     const float *x0, *u_init;
     float *states, *actions, *costs;
     int32_t *iterations, *status;
-    float *wsK, *wsk;
+    float *wsK, *wsk, *wsq;      // gains K[T][m][n], k[T][m] and Q_u[T][m] scratch (HBM)
 };
 
 size_t ilqr_lq_mfma_lds_bytes(int T);

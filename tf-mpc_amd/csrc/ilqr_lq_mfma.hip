@@ -64,10 +64,9 @@ __global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
     const int n = a.env.n, m = a.env.m, d = n + m;
     const TfmpcIlqrConfig &cfg = a.cfg;
 
-    // dynamic LDS: gains' k and Q_u per step, two trajectory buffers, two cost buffers
-    float *kbuf = lds + kDyn;                    // [T][8]
-    float *qubuf = kbuf + T * M;                 // [T][8]
-    float *bufA = qubuf + T * M;                 // [(T+1)][26]
+    // dynamic LDS: two trajectory buffers, two cost buffers (k_t and Q_u(t) live in the HBM workspace:
+    // 3.2 KB less LDS per wave at T = 50 is two more waves per CU)
+    float *bufA = lds + kDyn;                    // [(T+1)][26]
     float *bufB = bufA + Tp * kZld;
     float *costA = bufB + Tp * kZld;             // [T+1]
     float *costB = costA + ((Tp + 3) & ~3);
@@ -78,6 +77,7 @@ __global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
     const float *cg = a.env.p[3] + (size_t)b * a.env.stride[3];
     float *Kg = a.wsK + (size_t)b * T * m * n;
     float *kg = a.wsk + (size_t)b * T * m;
+    float *qg = a.wsq + (size_t)b * T * m;
 
     // padded-index accessors (x index in [0,16), u index in [0,8), z index in [0,24))
     auto Fxx = [&](int row, int xi) { return (row < n && xi < n) ? Fg[row * d + xi] : 0.0f; };
@@ -246,10 +246,7 @@ __global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
                 M2[0] = f32x2{lo[0], lo[1]}; M2[1] = f32x2{lo[2], lo[3]};
                 M2[2] = f32x2{hi[0], hi[1]}; M2[3] = f32x2{hi[2], hi[3]};
             }
-            if (lane == 24) {                                      // Q_u(t) for dV1 (column 24 before elimination)
-                *reinterpret_cast<f32x4 *>(&qubuf[t * M]) = f32x4{M2[0][0], M2[0][1], M2[1][0], M2[1][1]};
-                *reinterpret_cast<f32x4 *>(&qubuf[t * M + 4]) = f32x4{M2[2][0], M2[2][1], M2[3][0], M2[3][1]};
-            }
+            if (lane < m) qg[(size_t)t * m + lane] = lds[kMs + 24 * 8 + lane];     // Q_u(t) for dV1 (column 24 before elimination)
             // [K | k] = -Q_uu^-1 [Q_ux | Q_u]; a non-positive pivot is the Cholesky failure of
             // ilqr.py:358                                                              :357-362
             float Mr[8];
@@ -260,10 +257,6 @@ __global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
                 for (int r = 0; r < 4; ++r) { lo[r] = Mr[r]; hi[r] = Mr[4 + r]; }
                 *reinterpret_cast<f32x4 *>(&lds[kKs + lane * 8]) = lo;
                 *reinterpret_cast<f32x4 *>(&lds[kKs + lane * 8 + 4]) = hi;
-                if (lane == 24) {
-                    *reinterpret_cast<f32x4 *>(&kbuf[t * M]) = lo;
-                    *reinterpret_cast<f32x4 *>(&kbuf[t * M + 4]) = hi;
-                }
             }
             __syncthreads();
             // V_xx' = Q_xx + Q_xu K, V_x' = Q_x + Q_xu k                              :149-161
@@ -303,8 +296,8 @@ __global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
                 float ratio = 0.0f;
                 if (idx < T * M) {
                     const int t = idx >> 3, ua = idx & 7;
-                    const float kv = kbuf[idx];
-                    p1 = fmaf(kv, qubuf[idx], p1);
+                    const float kv = (ua < m) ? kg[(size_t)t * m + ua] : 0.0f;
+                    p1 = fmaf(kv, (ua < m) ? qg[(size_t)t * m + ua] : 0.0f, p1);
                     ratio = fabsf(kv) / (fabsf(nom[t * kZld + N + ua]) + 1.0f);
                 }
                 ratio = fmaxf(ratio, dpp<kDppXor1>(ratio));
@@ -328,25 +321,26 @@ __global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
             float rmax = 0.0f;
             // gains of step t for this lane, loaded one step ahead (they come back from HBM / Infinity Cache)
             const bool row = ka < m;
-            auto load_gain = [&](int t, float &gx, float &gy) {
+            auto load_gain = [&](int t, float &gx, float &gy, float &gk) {
                 gx = (row && 2 * jc < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc] : 0.0f;
                 gy = (row && 2 * jc + 1 < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] : 0.0f;
+                gk = row ? kg[(size_t)t * m + ka] : 0.0f;
             };
-            float Kxn = 0.0f, Kyn = 0.0f;
-            load_gain(0, Kxn, Kyn);
+            float Kxn = 0.0f, Kyn = 0.0f, kkn = 0.0f;
+            load_gain(0, Kxn, Kyn, kkn);
             __syncthreads();
             for (int t = 0; t < T; ++t) {
                 const float *zh = nom + t * kZld;
                 float *zt = cand + t * kZld;
-                const float Kx = Kxn, Ky = Kyn;
-                if (t + 1 < T) load_gain(t + 1, Kxn, Kyn);
+                const float Kx = Kxn, Ky = Kyn, kk = kkn;
+                if (t + 1 < T) load_gain(t + 1, Kxn, Kyn, kkn);
                 const float2 xv = *reinterpret_cast<const float2 *>(&zt[2 * jc]);
                 const float2 xh = *reinterpret_cast<const float2 *>(&zh[2 * jc]);
                 float du = fmaf(Kx, xv.x - xh.x, Ky * (xv.y - xh.y));              // K (x - x_hat)  :193-194
                 du += dpp<kDppXor1>(du);
                 du += dpp<kDppXor2>(du);
                 du += dpp<kDppHalfMirror>(du);
-                du = fmaf(alpha, kbuf[t * M + ka], du);
+                du = fmaf(alpha, kk, du);
                 rmax = fmaxf(rmax, fabsf(du));                                     // :206
                 if (jc == 0) zt[N + ka] = zh[N + ka] + du;                         // unbounded: clip is the identity
                 __syncthreads();
@@ -405,7 +399,7 @@ __global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
 size_t ilqr_lq_mfma_lds_bytes(int T)
 {
     const size_t Tp = T + 1;
-    return (kDyn + 2 * (size_t)T * M + 2 * Tp * kZld + 2 * ((Tp + 3) & ~(size_t)3) + 8) * sizeof(float);
+    return (kDyn + 2 * Tp * kZld + 2 * ((Tp + 3) & ~(size_t)3) + 8) * sizeof(float);
 }
 
 bool ilqr_lq_mfma_supported(const TfmpcEnv &env, int T)
