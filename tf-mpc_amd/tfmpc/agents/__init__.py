@@ -1,1 +1,4 @@
-from tfmpc.agents.mpc import MPC  # noqa: F401
+"""Receding-horizon controllers over the batched HIP solvers (caller side of the hot path)."""
+from .mpc import MPC
+
+__all__ = ["MPC"]
