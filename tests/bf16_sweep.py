@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Storage-precision sweep of BASELINE configs[4] (iLQR on HVAC / Reservoir, n = m = 32, T = 100):
 trajectories and gains kept in HBM at fp32 vs rounded to bf16 on every store (arithmetic fp32 in
-both), against the fp64 CPU restatement.  Run on the GPU box:  python tools/bf16_sweep.py > profiles/rNN_bf16_sweep.json
+both), against the fp64 CPU restatement.  Run on the GPU box:  python tests/bf16_sweep.py > profiles/rNN_bf16_sweep.json
 
 Two views: (a) after ONE iteration (continuous dependence on the data, before line-search decisions
 can diverge): relative state error vs fp64; (b) after 12 iterations: relative difference of the

@@ -86,7 +86,7 @@ def test_cfg5_n32_horizon100_batch_32768(kind):
 
 def test_bf16_storage_mode_is_a_bounded_perturbation_on_hvac():
     """BASELINE configs[4] "fp32 vs bf16": rounding stored trajectories / gains to bf16 (fp32
-    arithmetic) must perturb, not break, the solve (full sweep: tools/bf16_sweep.py)."""
+    arithmetic) must perturb, not break, the solve (full sweep: tests/bf16_sweep.py)."""
     n, T, B = 32, 100, 256
     env = HVAC.load(dict(problems.hvac_config(n, seed=5)))
     x0 = (10.0 + np.random.default_rng(5).normal(0, 1.0, size=(B, n, 1))).astype(np.float32)
