@@ -345,7 +345,7 @@ template <int KIND>
 __device__ inline BackwardResult backward_pass_adjoint(IlqrSmem &s, const EnvLds &e, int T, const float *xhat,
                                                        const float *uhat, float *kg)
 {
-    const int n = s.n, m = s.m, ldn = s.ldn, ldm = s.ldm, lane = lane_id();
+    const int n = s.n, m = s.m, lane = lane_id();
     BackwardResult r{0.0f, 0.0f, 0.0f, 0.0f, 0, 0};
     for (int i = lane; i < n; i += kWave) s.xh[i] = xhat[(size_t)T * n + i];
     wsync();
