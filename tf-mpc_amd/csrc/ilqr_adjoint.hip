@@ -59,7 +59,7 @@ template <> struct Lean<TFMPC_ENV_HVAC> {
     float Grow[kHalf];                     // G[it][(j0 + j + it) mod n] for j < tail = cnt & ~3, else 0
     float Gtail[3];                        // the cnt & 3 elements after them (else 0)
     float t_out, t_hall, k_out, k_hall, rcap, am_t;      // row it
-    float lo, hi, am;                      // lane i < n: bounds, air_max
+    float lo, hi, mid, am;                 // lane i < n: bounds, their midpoint (lo + hi) / 2, air_max
     float coef[kMaxN];                     // lane i < n: dtc[kk] * G[kk][i]
     float Gii, gsum, dtc_i, k_out_i, k_hall_i;           // lane i < n: the diagonal of f_x
     float dtc_a, am_a;                     // lane n + a: the diagonal of f_u
@@ -94,6 +94,7 @@ template <> struct Lean<TFMPC_ENV_HVAC> {
         const int i = lane;
         const bool st = i < n;
         lo = st ? plo[i] : 0.0f; hi = st ? phi[i] : 0.0f; am = st ? pam[i] : 0.0f;
+        mid = (lo + hi) / 2;
         dtc_i = st ? TIME_DELTA / pcap[i] : 0.0f; k_out_i = st ? pk_out[i] : 0.0f; k_hall_i = st ? pk_hall[i] : 0.0f;
         Gii = st ? G[i * n + i] : 0.0f;
         float gs = 0.0f;
@@ -112,7 +113,7 @@ template <> struct Lean<TFMPC_ENV_HVAC> {
     __device__ __forceinline__ float penalties(float x) const
     {
         const float oob = PENALTY * (fmaxf(0.0f, lo - x) + fmaxf(0.0f, x - hi));      // hvac :97-100
-        const float sp = SET_POINT_PENALTY * fabsf((lo + hi) / 2 - x);                 // :101-105
+        const float sp = SET_POINT_PENALTY * fabsf(mid - x);                 // :101-105
         return oob + sp;
     }
     // stage cost (:91-110) and final cost (:112-129); x, u in LDS
@@ -130,7 +131,7 @@ template <> struct Lean<TFMPC_ENV_HVAC> {
     }
     __device__ __forceinline__ float grad_x(float x) const
     {
-        return PENALTY * (-(lo > x ? 1.0f : 0.0f) + (x > hi ? 1.0f : 0.0f)) - SET_POINT_PENALTY * sgnf((lo + hi) / 2 - x);
+        return PENALTY * (-(lo > x ? 1.0f : 0.0f) + (x > hi ? 1.0f : 0.0f)) - SET_POINT_PENALTY * sgnf(mid - x);
     }
     // x' (:69-89): x is the doubled state vector x2[0..2n), so the rotated walk (j0 + j + it) mod n is
     // x2[off + j]
@@ -193,7 +194,7 @@ template <> struct Lean<TFMPC_ENV_RESERVOIR> {
     float Dcol[kHalf];                     // transition: D[j0 + j][it] for j < tail = cnt & ~3, else 0
     float Dtail[3];                        // the cnt & 3 elements after them (else 0)
     float cap_t, rain_t;                   // row it
-    float cap, lo, hi, LP, HP, SP;         // lane i < n
+    float cap, lo, hi, mid, LP, HP, SP;    // lane i < n (mid = (lo + hi) / 2)
     float Drow[kMaxN];                     // lanes i < n and n + a: D[i][kk] (row i = lane mod n)
 
     __device__ void load(const TfmpcEnv &g, int b)
@@ -221,6 +222,7 @@ template <> struct Lean<TFMPC_ENV_RESERVOIR> {
         const int i = lane;
         const bool st = i < n;
         cap = st ? pcap[i] : 1.0f; lo = st ? plo[i] : 0.0f; hi = st ? phi[i] : 0.0f;
+        mid = (lo + hi) / 2.0f;
         LP = st ? -plp[i] : 0.0f; HP = st ? -php[i] : 0.0f; SP = st ? -psp[i] : 0.0f;
         const int rrow = (lane < n) ? lane : lane - n;
         const bool rv = rrow >= 0 && rrow < n && lane < 2 * n;
@@ -237,7 +239,7 @@ template <> struct Lean<TFMPC_ENV_RESERVOIR> {
             const float xv = x[lane_id()];
             const float c1 = LP * fmaxf(0.0f, lo - xv);
             const float c2 = HP * fmaxf(0.0f, xv - hi);
-            const float c3 = SP * fabsf((lo + hi) / 2.0f - xv);
+            const float c3 = SP * fabsf(mid - xv);
             part_ += c1 + c2 + c3;
         }
         return wave_sum(part_);
@@ -245,7 +247,7 @@ template <> struct Lean<TFMPC_ENV_RESERVOIR> {
     __device__ float final_cost(const float *x) const { return cost(x, nullptr); }         // :81-83
     __device__ __forceinline__ float grad_x(float x) const
     {
-        return -LP * (lo > x ? 1.0f : 0.0f) + HP * (x > hi ? 1.0f : 0.0f) - SP * sgnf((lo + hi) / 2.0f - x);
+        return -LP * (lo > x ? 1.0f : 0.0f) + HP * (x > hi ? 1.0f : 0.0f) - SP * sgnf(mid - x);
     }
     __device__ void transition(const float *x2, const float *u, float *xn2) const          // :47-61, :85-105
     {
