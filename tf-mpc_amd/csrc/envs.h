@@ -441,9 +441,8 @@ template <> struct Env<TFMPC_ENV_HVAC> {
     {
         const int n = e.n, ldn = odd_ld(n);
         const float *dtc = e.aux, *G = e.p[8];
-        const float diag = fx_diag(e, u, i);
-        float acc = lx_i;
-        for (int kk = 0; kk < n; ++kk) acc = fmaf((kk == i) ? diag : dtc[kk] * G[kk * ldn + i], Vx[kk], acc);
+        float acc = fmaf(fx_diag(e, u, i), Vx[i], lx_i);            // diagonal term first (ilqr_core.h backward_pass)
+        for (int kk = 0; kk < n; ++kk) if (kk != i) acc = fmaf(dtc[kk] * G[kk * ldn + i], Vx[kk], acc);
         return acc;
     }
     static __device__ float adjoint_qu(const EnvLds &e, const float *x, const float *u, const float *Vx, int a)
@@ -564,12 +563,8 @@ template <> struct Env<TFMPC_ENV_RESERVOIR> {
         const float uj = u[j];
         const float r = x[j] / e.p[0][j];
         const float diag_extra = 1.0f - 0.5f * (cosf(r) * r + sinf(r)) - uj;
-        float acc = lx_j;
-        for (int kk = 0; kk < n; ++kk) {
-            float a = Drow[kk] * uj;
-            if (kk == j) a += diag_extra;
-            acc = fmaf(a, Vx[kk], acc);
-        }
+        float acc = fmaf(Drow[j] * uj + diag_extra, Vx[j], lx_j);   // diagonal term first (ilqr_core.h backward_pass)
+        for (int kk = 0; kk < n; ++kk) if (kk != j) acc = fmaf(Drow[kk] * uj, Vx[kk], acc);
         return acc;
     }
     static __device__ float adjoint_qu(const EnvLds &e, const float *x, const float *u, const float *Vx, int a_)
@@ -577,12 +572,8 @@ template <> struct Env<TFMPC_ENV_RESERVOIR> {
         const int n = e.n, ldn = odd_ld(n);
         const float *Drow = e.p[7] + a_ * ldn;
         const float xa = x[a_];
-        float acc = 0.0f;
-        for (int kk = 0; kk < n; ++kk) {
-            float bb = Drow[kk] * xa;
-            if (kk == a_) bb -= xa;
-            acc = fmaf(bb, Vx[kk], acc);
-        }
+        float acc = fmaf(Drow[a_] * xa - xa, Vx[a_], 0.0f);         // diagonal term first
+        for (int kk = 0; kk < n; ++kk) if (kk != a_) acc = fmaf(Drow[kk] * xa, Vx[kk], acc);
         return acc;
     }
     static __device__ __forceinline__ float cost_grad_x_i(const EnvLds &e, const float *x, int i)

@@ -60,7 +60,7 @@ template <> struct Lean<TFMPC_ENV_HVAC> {
     float Gtail[3];                        // the cnt & 3 elements after them (else 0)
     float t_out, t_hall, k_out, k_hall, rcap, am_t;      // row it
     float lo, hi, mid, am;                 // lane i < n: bounds, their midpoint (lo + hi) / 2, air_max
-    float coef[kMaxN];                     // lane i < n: dtc[kk] * G[kk][i]
+    float coef[kMaxN];                     // lane i < n: dtc[kk] * G[kk][i], with 0 at kk == i (added separately)
     float Gii, gsum, dtc_i, k_out_i, k_hall_i;           // lane i < n: the diagonal of f_x
     float dtc_a, am_a;                     // lane n + a: the diagonal of f_u
 
@@ -103,7 +103,7 @@ template <> struct Lean<TFMPC_ENV_HVAC> {
 #pragma unroll
         for (int kk = 0; kk < kMaxN; ++kk) {
             if ((kk & 3) == 0) __builtin_amdgcn_sched_barrier(0);     // one-time code: keep few loads in flight
-            coef[kk] = (st && kk < n) ? (TIME_DELTA / pcap[kk]) * G[kk * n + i] : 0.0f;
+            coef[kk] = (st && kk < n && kk != i) ? (TIME_DELTA / pcap[kk]) * G[kk * n + i] : 0.0f;
         }
         const int a = lane - n;
         const bool ac = a >= 0 && a < n;
@@ -172,12 +172,13 @@ template <> struct Lean<TFMPC_ENV_HVAC> {
         float acc = 0.0f;
         if (lane < n) {
             const float diag = 1.0f + dtc_i * (Gii - uh[lane] * am * CAP_AIR - gsum - k_out_i - k_hall_i);
-            acc = grad_x(xh[lane]);
-            const int me = opaque(lane);
+            // diagonal term first, then the column by ascending row: its own diagonal slot holds 0, an
+            // exact no-op (as do the rows >= n: 0 * 0) -- the order of ilqr_core.h backward_pass
+            acc = fmaf(diag, vx[lane], grad_x(xh[lane]));
 #pragma unroll
-            for (int kk = 0; kk < kMaxN; ++kk) {                  // kk >= n: 0 * 0
+            for (int kk = 0; kk < kMaxN; ++kk) {
                 if ((kk & 7) == 0) __builtin_amdgcn_sched_barrier(0);     // 8 V_x values in flight, not 32
-                acc = fmaf((kk == me) ? diag : coef[kk], vx[kk], acc);
+                acc = fmaf(coef[kk], vx[kk], acc);
             }
         } else if (lane < 2 * n) {
             const int a = lane - n;
@@ -195,7 +196,8 @@ template <> struct Lean<TFMPC_ENV_RESERVOIR> {
     float Dtail[3];                        // the cnt & 3 elements after them (else 0)
     float cap_t, rain_t;                   // row it
     float cap, lo, hi, mid, LP, HP, SP;    // lane i < n (mid = (lo + hi) / 2)
-    float Drow[kMaxN];                     // lanes i < n and n + a: D[i][kk] (row i = lane mod n)
+    float Drow[kMaxN];                     // lanes i < n and n + a: D[i][kk] (row i = lane mod n), 0 at kk == i
+    float Dii;                             // D[i][i], added separately
 
     __device__ void load(const TfmpcEnv &g, int b)
     {
@@ -226,10 +228,11 @@ template <> struct Lean<TFMPC_ENV_RESERVOIR> {
         LP = st ? -plp[i] : 0.0f; HP = st ? -php[i] : 0.0f; SP = st ? -psp[i] : 0.0f;
         const int rrow = (lane < n) ? lane : lane - n;
         const bool rv = rrow >= 0 && rrow < n && lane < 2 * n;
+        Dii = rv ? D[rrow * n + rrow] : 0.0f;
 #pragma unroll
         for (int kk = 0; kk < kMaxN; ++kk) {
             if ((kk & 3) == 0) __builtin_amdgcn_sched_barrier(0);     // one-time code: keep few loads in flight
-            Drow[kk] = (rv && kk < n) ? D[rrow * n + kk] : 0.0f;
+            Drow[kk] = (rv && kk < n && kk != rrow) ? D[rrow * n + kk] : 0.0f;
         }
     }
     __device__ float cost(const float *x, const float *) const                            // reservoir :63-79
@@ -281,25 +284,21 @@ template <> struct Lean<TFMPC_ENV_RESERVOIR> {
             const float uj = uh[lane];
             const float r = xh[lane] / cap;
             const float diag_extra = 1.0f - 0.5f * (cosf(r) * r + sinf(r)) - uj;
-            acc = grad_x(xh[lane]);
-            const int me = opaque(lane);
+            // diagonal term first, then the row by ascending column with a zero in the diagonal slot
+            acc = fmaf(Dii * uj + diag_extra, vx[lane], grad_x(xh[lane]));
 #pragma unroll
             for (int kk = 0; kk < kMaxN; ++kk) {                  // kk >= n: 0 * 0
                 if ((kk & 7) == 0) __builtin_amdgcn_sched_barrier(0);     // 8 V_x values in flight, not 32
-                float a = Drow[kk] * uj;
-                if (kk == me) a += diag_extra;
-                acc = fmaf(a, vx[kk], acc);
+                acc = fmaf(Drow[kk] * uj, vx[kk], acc);
             }
         } else if (lane < 2 * n) {
             const int a_ = lane - n;
             const float xa = xh[a_];
-            const int me = opaque(a_);
+            acc = fmaf(Dii * xa - xa, vx[a_], 0.0f);
 #pragma unroll
             for (int kk = 0; kk < kMaxN; ++kk) {
                 if ((kk & 7) == 0) __builtin_amdgcn_sched_barrier(0);
-                float bb = Drow[kk] * xa;
-                if (kk == me) bb -= xa;
-                acc = fmaf(bb, vx[kk], acc);
+                acc = fmaf(Drow[kk] * xa, vx[kk], acc);
             }
         }
         return acc;

@@ -222,8 +222,21 @@ __device__ inline BackwardResult backward_pass(IlqrSmem &s, Provider &prov, int 
         // Q_x, Q_u (:122-123); W1 = f_x^T V_xx, W2 = f_u^T V_xx (:125-126)
         for (int i = lane; i < n + m; i += kWave) {
             float acc;
-            if (i < n) { acc = s.lx[i]; for (int kk = 0; kk < n; ++kk) acc = fmaf(s.fx[kk * ldn + i], s.Vx[kk], acc); s.Qx[i] = acc; }
-            else { const int a = i - n; acc = s.lu[a]; for (int kk = 0; kk < n; ++kk) acc = fmaf(s.fu[kk * ldm + a], s.Vx[kk], acc); s.Qu[a] = acc; }
+            // summation order: the diagonal term first, then the others by ascending row.  (The
+            // register-resident costate kernel keeps column i of f_x in VGPRs with a zero on the
+            // diagonal and adds the state-dependent diagonal entry separately; every path that forms
+            // Q_x, Q_u uses this one order so that they stay bit-identical.)
+            if (i < n) {
+                acc = fmaf(s.fx[i * ldn + i], s.Vx[i], s.lx[i]);
+                for (int kk = 0; kk < n; ++kk) if (kk != i) acc = fmaf(s.fx[kk * ldn + i], s.Vx[kk], acc);
+                s.Qx[i] = acc;
+            } else {
+                const int a = i - n;
+                acc = s.lu[a];
+                if (a < n) acc = fmaf(s.fu[a * ldm + a], s.Vx[a], acc);
+                for (int kk = 0; kk < n; ++kk) if (kk != a) acc = fmaf(s.fu[kk * ldm + a], s.Vx[kk], acc);
+                s.Qu[a] = acc;
+            }
         }
         wave_matmul(n, n, n, [&](int i, int kk) { return s.fx[kk * ldn + i]; }, [&](int kk, int j) { return s.Vxx[kk * ldn + j]; },
                     [](int, int) { return 0.0f; }, [&](int i, int j, float x) { s.W1[i * ldn + j] = x; });

@@ -1,0 +1,18 @@
+"""One HVAC and one Reservoir cfg5 solve (n = m = 32, T = 100, B = 32768, 12 iterations) for profiling:
+rocprofv3 --kernel-trace --pmc ... -- python3 tools/cfg5_once.py"""
+import sys
+sys.path.insert(0, '/root/repo/tf-mpc_amd'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+import numpy as np, torch, problems
+from tfmpc.envs.hvac import HVAC
+from tfmpc.envs.reservoir import Reservoir
+from tfmpc.solvers.ilqr import iLQR
+n, T, B = 32, 100, 32768
+rng = np.random.default_rng(4)
+for kind in ("hvac", "reservoir"):
+    if kind == "hvac":
+        env = HVAC.load(dict(problems.hvac_config(n, seed=5))); x0 = np.full((B, n, 1), 10.0, dtype=np.float32)
+    else:
+        env = Reservoir.load(dict(problems.reservoir_config(n, seed=5))); x0 = rng.uniform(50, 75, size=(B, n, 1)).astype(np.float32)
+    s = iLQR(env, max_iterations=12); u0 = s.random_actions(T, B, seed=5)
+    out = s.solve_device(x0, T, u_init=u0); torch.cuda.synchronize()
+    print(kind, float((out["iterations"].float() + 1).mean()))
