@@ -42,15 +42,20 @@ __device__ __forceinline__ float wave_sum(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Maximum over the wave of NON-NEGATIVE, non-NaN values (every caller reduces |.| quantities built with
+// fmaxf from 0): for those the IEEE order is the unsigned order of the bit patterns, and v_max_u32 takes
+// its DPP operand directly -- one instruction per step instead of move + canonicalise + v_max_f32.
 __device__ __forceinline__ float wave_max(float v)
 {
-    v = fmaxf(v, dpp_move<kDppQuadXor1>(v, v));
-    v = fmaxf(v, dpp_move<kDppQuadXor2>(v, v));
-    v = fmaxf(v, dpp_move<kDppRowHalfMirror>(v, v));
-    v = fmaxf(v, dpp_move<kDppRowMirror>(v, v));
-    v = fmaxf(v, dpp_move<kDppRowBcast15, 0xA>(v, v));
-    v = fmaxf(v, dpp_move<kDppRowBcast31, 0xC>(v, v));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    auto step = [&](auto mv) { const unsigned o = (unsigned)mv; u = u > o ? u : o; };
+    step(__builtin_amdgcn_update_dpp((int)u, (int)u, kDppQuadXor1, 0xF, 0xF, false));
+    step(__builtin_amdgcn_update_dpp((int)u, (int)u, kDppQuadXor2, 0xF, 0xF, false));
+    step(__builtin_amdgcn_update_dpp((int)u, (int)u, kDppRowHalfMirror, 0xF, 0xF, false));
+    step(__builtin_amdgcn_update_dpp((int)u, (int)u, kDppRowMirror, 0xF, 0xF, false));
+    step(__builtin_amdgcn_update_dpp((int)u, (int)u, kDppRowBcast15, 0xA, 0xF, false));
+    step(__builtin_amdgcn_update_dpp((int)u, (int)u, kDppRowBcast31, 0xC, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)u, 63));
 }
 
 // sum / exchange over groups of 2 or 4 adjacent lanes (a quad)
