@@ -104,14 +104,14 @@ __global__ __launch_bounds__(kWave) void lqr_generic_kernel(LqrArgs a)
 
         for (int t = T - 1; t >= 0; --t) {
             // W = F^T V  [d][n]                                        (lqr.py:74)
-            wave_matmul(d, n, n,
+            wave_matmul_blocked(d, n, n,
                         [&](int r, int k) { return s.F[k * ldd + r]; },
                         [&](int k, int j) { return s.V[k * ldn + j]; },
                         [](int, int) { return 0.0f; },
                         [&](int r, int j, float x) { s.W[r * ldn + j] = x; });
             wsync();
             // Q = C + W F ; q = c + W f + F^T v                        (lqr.py:75-78)
-            wave_matmul(d, d, n,
+            wave_matmul_blocked(d, d, n,
                         [&](int r, int k) { return s.W[r * ldn + k]; },
                         [&](int k, int j) { return s.F[k * ldd + j]; },
                         [&](int r, int j) { return s.C[r * ldd + j]; },
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kWave) void lqr_generic_kernel(LqrArgs a)
             }
             wsync();
             // K^T Q_uu  [n][m]                                         (lqr.py:95)
-            wave_matmul(n, m, m,
+            wave_matmul_blocked(n, m, m,
                         [&](int i, int k) { return s.K[k * ldn + i]; },
                         [&](int k, int j) { return s.Q[(n + k) * ldd + n + j]; },
                         [](int, int) { return 0.0f; },
