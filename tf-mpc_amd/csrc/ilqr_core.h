@@ -206,7 +206,17 @@ struct BackwardResult {
 //   float load(int t)  -- fills s.fx, s.fu, s.lx, s.lu, s.lxx, s.luu, s.lux (= l_xu^T), s.uh (= u_hat_t)
 //                         and returns l_t; called by all lanes; no trailing sync needed.
 //   float load_final() -- fills s.Vx (= l_x^f) and s.Vxx (= l_xx^f), returns l^f.
-template <class Provider>
+// BLK: register-blocked matrix products (wave_matmul_blocked).  Worth it from n ~ 12 up, where the
+// products are LDS-issue bound; it costs ~40 VGPRs, i.e. a wave per SIMD on small shapes, so the
+// launchers pick the variant by shape.  Results are bit-identical either way.
+template <bool BLK, class FA, class FB, class FInit, class FOut>
+__device__ __forceinline__ void matmul(int M, int N, int K, FA a, FB b, FInit init, FOut out)
+{
+    if constexpr (BLK) wave_matmul_blocked(M, N, K, a, b, init, out);
+    else wave_matmul(M, N, K, a, b, init, out);
+}
+
+template <bool BLK = false, class Provider>
 __device__ inline BackwardResult backward_pass(IlqrSmem &s, Provider &prov, int T, float mu, bool bounded,
                                                const float *low, const float *high, float *Kg, float *kg)
 {
@@ -238,9 +248,9 @@ __device__ inline BackwardResult backward_pass(IlqrSmem &s, Provider &prov, int 
                 s.Qu[a] = acc;
             }
         }
-        wave_matmul(n, n, n, [&](int i, int kk) { return s.fx[kk * ldn + i]; }, [&](int kk, int j) { return s.Vxx[kk * ldn + j]; },
+        matmul<BLK>(n, n, n, [&](int i, int kk) { return s.fx[kk * ldn + i]; }, [&](int kk, int j) { return s.Vxx[kk * ldn + j]; },
                     [](int, int) { return 0.0f; }, [&](int i, int j, float x) { s.W1[i * ldn + j] = x; });
-        wave_matmul(m, n, n, [&](int a, int kk) { return s.fu[kk * ldm + a]; }, [&](int kk, int j) { return s.Vxx[kk * ldn + j]; },
+        matmul<BLK>(m, n, n, [&](int a, int kk) { return s.fu[kk * ldm + a]; }, [&](int kk, int j) { return s.Vxx[kk * ldn + j]; },
                     [](int, int) { return 0.0f; }, [&](int a, int j, float x) { s.W2[a * ldn + j] = x; });
         // V_xx != 0 test of :137 (before V_xx is overwritten)
         float nzp = 0.0f;
@@ -248,16 +258,16 @@ __device__ inline BackwardResult backward_pass(IlqrSmem &s, Provider &prov, int 
         const bool vxx_nonzero = wave_sum(nzp) > 0.0f;
         wsync();
         // Q_xx, Q_uu, Q_ux (:129-131) and the regularised Q_uu, Q_ux (:127,133-134)
-        wave_matmul(n, n, n, [&](int i, int kk) { return s.W1[i * ldn + kk]; }, [&](int kk, int j) { return s.fx[kk * ldn + j]; },
+        matmul<BLK>(n, n, n, [&](int i, int kk) { return s.W1[i * ldn + kk]; }, [&](int kk, int j) { return s.fx[kk * ldn + j]; },
                     [&](int i, int j) { return s.lxx[i * ldn + j]; }, [&](int i, int j, float x) { s.Qxx[i * ldn + j] = x; });
-        wave_matmul(m, m, n, [&](int a, int kk) { return s.W2[a * ldn + kk]; }, [&](int kk, int b) { return s.fu[kk * ldm + b]; },
+        matmul<BLK>(m, m, n, [&](int a, int kk) { return s.W2[a * ldn + kk]; }, [&](int kk, int b) { return s.fu[kk * ldm + b]; },
                     [&](int a, int b) { return s.luu[a * ldm + b]; }, [&](int a, int b, float x) { s.Quu[a * ldm + b] = x; });
-        wave_matmul(m, n, n, [&](int a, int kk) { return s.W2[a * ldn + kk]; }, [&](int kk, int j) { return s.fx[kk * ldn + j]; },
+        matmul<BLK>(m, n, n, [&](int a, int kk) { return s.W2[a * ldn + kk]; }, [&](int kk, int j) { return s.fx[kk * ldn + j]; },
                     [&](int a, int j) { return s.lux[a * ldn + j]; }, [&](int a, int j, float x) { s.Qux[a * ldn + j] = x; });
-        wave_matmul(m, m, n, [&](int a, int kk) { return fmaf(mu, s.fu[kk * ldm + a], s.W2[a * ldn + kk]); },
+        matmul<BLK>(m, m, n, [&](int a, int kk) { return fmaf(mu, s.fu[kk * ldm + a], s.W2[a * ldn + kk]); },
                     [&](int kk, int b) { return s.fu[kk * ldm + b]; },
                     [&](int a, int b) { return s.luu[a * ldm + b]; }, [&](int a, int b, float x) { s.Quur[a * ldm + b] = x; });
-        wave_matmul(m, n, n, [&](int a, int kk) { return fmaf(mu, s.fu[kk * ldm + a], s.W2[a * ldn + kk]); },
+        matmul<BLK>(m, n, n, [&](int a, int kk) { return fmaf(mu, s.fu[kk * ldm + a], s.W2[a * ldn + kk]); },
                     [&](int kk, int j) { return s.fx[kk * ldn + j]; },
                     [&](int a, int j) { return s.lux[a * ldn + j]; }, [&](int a, int j, float x) { s.Quxr[a * ldn + j] = x; });
         wsync();
@@ -298,7 +308,7 @@ __device__ inline BackwardResult backward_pass(IlqrSmem &s, Provider &prov, int 
         wsync();
 
         // K^T Q_uu (:147)
-        wave_matmul(n, m, m, [&](int i, int a) { return s.K[a * ldn + i]; }, [&](int a, int b) { return s.Quu[a * ldm + b]; },
+        matmul<BLK>(n, m, m, [&](int i, int a) { return s.K[a * ldn + i]; }, [&](int a, int b) { return s.Quu[a * ldm + b]; },
                     [](int, int) { return 0.0f; }, [&](int i, int b, float x) { s.KtQ[i * ldm + b] = x; });
         wsync();
         // V_x (:149-154), V_xx before symmetrisation (:156-161) -> W1

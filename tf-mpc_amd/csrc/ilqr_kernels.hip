@@ -127,6 +127,8 @@ __global__ __launch_bounds__(kWave) void ilqr_derivatives_kernel(TfmpcEnv env, i
     if (o.fl_xx) store_matrix(o.fl_xx + (size_t)b * n * n, s.Vxx, ldn, n, n);
 }
 
+constexpr int kBlockedFrom = 12;         // state dimension from which the register-blocked products pay
+
 struct BackwardArgs {
     int n, m, T, bounded;
     const float *actions, *f_x, *f_u, *l, *l_x, *l_u, *l_xx, *l_uu, *l_xu, *fl, *fl_x, *fl_xx, *low, *high, *mu;
@@ -135,6 +137,7 @@ struct BackwardArgs {
     int32_t *status;
 };
 
+template <bool BLK>
 __global__ __launch_bounds__(kWave) void ilqr_backward_kernel(BackwardArgs a)
 {
     extern __shared__ float smem[];
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(kWave) void ilqr_backward_kernel(BackwardArgs a)
                               a.l_u + bT * m, a.l_xx + bT * n * n, a.l_uu + bT * m * m, a.l_xu + bT * n * m,
                               a.fl + b, a.fl_x + (size_t)b * n, a.fl_xx + (size_t)b * n * n};
     const float mu = a.mu[(size_t)b * a.mu_stride];
-    BackwardResult r = backward_pass(s, prov, T, mu, a.bounded != 0, low, high, a.K + bT * m * n, a.k + bT * m);
+    BackwardResult r = backward_pass<BLK>(s, prov, T, mu, a.bounded != 0, low, high, a.K + bT * m * n, a.k + bT * m);
     if (lane == 0) {
         a.J[b] = r.J; a.dV1[b] = r.dV1; a.dV2[b] = r.dV2;
         if (a.status) a.status[b] = r.flags | (r.failed ? TFMPC_ST_NOT_PD : 0);
@@ -186,7 +189,7 @@ struct SolveArgs {
 };
 
 // iLQR.solve (ilqr.py:214-283): the whole iteration loop of one instance in one wave.
-template <int KIND>
+template <int KIND, bool BLK = false>
 __global__ __launch_bounds__(kWave) void ilqr_solve_kernel(TfmpcEnv env, TfmpcIlqrConfig cfg, SolveArgs a)
 {
     extern __shared__ float smem[];
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(kWave) void ilqr_solve_kernel(TfmpcEnv env, TfmpcIl
             BackwardResult r;
             for (int retry = 0;; ++retry) {
                 if constexpr (kAdjoint) r = backward_pass_adjoint<KIND>(s, e, T, xhat, uhat, kg);
-                else r = backward_pass(s, prov, T, mu_l, bounded, e.low, e.high, Kg, kg);
+                else r = backward_pass<BLK>(s, prov, T, mu_l, bounded, e.low, e.high, Kg, kg);
                 status |= r.flags;
                 if (!r.failed) break;
                 status |= TFMPC_ST_NOT_PD;
@@ -406,11 +409,13 @@ int tfmpc_ilqr_backward_f32(int B, int n, int m, int T, const float *actions, co
     if (T > 0 && (!actions || !f_x || !f_u || !l || !l_x || !l_u || !l_xx || !l_uu || !l_xu || !K || !k)) return TFMPC_ERR_ARG;
     const size_t smem = (ilqr_smem_floats(n, m) + 2 * (size_t)m) * sizeof(float);
     if (smem > kMaxLdsBytes) return TFMPC_ERR_UNSUPPORTED;
-    int rc = prep(ilqr_backward_kernel, smem);
+    const bool blk = n >= kBlockedFrom;
+    int rc = blk ? prep(ilqr_backward_kernel<true>, smem) : prep(ilqr_backward_kernel<false>, smem);
     if (rc != TFMPC_OK) return rc;
     BackwardArgs a{n, m, T, bounded, actions, f_x, f_u, l, l_x, l_u, l_xx, l_uu, l_xu, fl, fl_x, fl_xx, low, high, mu,
                    mu_stride, K, k, J, dV1, dV2, status};
-    hipLaunchKernelGGL(ilqr_backward_kernel, dim3(B), dim3(kWave), smem, static_cast<hipStream_t>(stream), a);
+    if (blk) hipLaunchKernelGGL(ilqr_backward_kernel<true>, dim3(B), dim3(kWave), smem, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(ilqr_backward_kernel<false>, dim3(B), dim3(kWave), smem, static_cast<hipStream_t>(stream), a);
     return launched();
 }
 
@@ -496,6 +501,12 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
         }
     }
     const size_t smem = ilqr_solve_smem_bytes(env->kind, n, m, env->n_zones);
+    if (env->kind == TFMPC_ENV_LQ && n >= kBlockedFrom) {      // the only dense env that comes in large shapes
+        auto kern = ilqr_solve_kernel<TFMPC_ENV_LQ, true>;
+        if ((rc = prep(kern, smem)) != TFMPC_OK) return rc;
+        hipLaunchKernelGGL(kern, dim3(B), dim3(kWave), smem, st, *env, *cfg, a);
+        return launched();
+    }
     TFMPC_DISPATCH_KIND(env->kind, {
         auto kern = ilqr_solve_kernel<KIND>;
         if ((rc = prep(kern, smem)) != TFMPC_OK) return rc;
