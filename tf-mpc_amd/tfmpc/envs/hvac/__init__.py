@@ -55,3 +55,14 @@ class HVAC(DiffEnv):
 
     def __repr__(self):
         return f"HVAC({self.state_size})"
+
+    def __str__(self):
+        """Parameter listing with the reference's fields (``hvac/__init__.py:154-186``)."""
+        row = lambda a, fmt=".3f": "[" + ", ".join(format(float(v), fmt) for v in np.ravel(a)) + "]"
+        bounds = ", ".join(f"[{lo:.3f}, {hi:.3f}]" for lo, hi in zip(np.ravel(self.temp_lower_bound), np.ravel(self.temp_upper_bound)))
+        R = "\n".join(f"[outside={o:.3f}, hall={h:.3f}]" for o, h in zip(np.ravel(self.R_outside), np.ravel(self.R_hall)))
+        fields = [f"temp_bounds=[{bounds}]", f"R=\n{R}", f"R_wall=\n{self.R_wall}", f"capacity={row(self.capacity)}",
+                  f"air_max={row(self.air_max)}", f"adj=\n{self.adj}", f"adj_outside={np.ravel(self.adj_outside).tolist()}",
+                  f"adj_hall={np.ravel(self.adj_hall).tolist()}", f"temp_outside={row(self.temp_outside)}",
+                  f"temp_hall={row(self.temp_hall)}"]
+        return "HVAC(\n" + ",\n".join(fields) + "\n)"

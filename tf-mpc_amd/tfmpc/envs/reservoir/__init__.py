@@ -66,3 +66,9 @@ class Reservoir(DiffEnv, GymEnv):
 
     def __repr__(self):
         return f"Reservoir({self.state_size})"
+
+    def __str__(self):
+        """Bounds, topology and rainfall distributions (``reservoir/__init__.py:110-121``)."""
+        bounds = ", ".join(f"[{lo:.2f}, {hi:.2f}]" for lo, hi in zip(np.ravel(self.lower_bound), np.ravel(self.upper_bound)))
+        rain = ", ".join(f"Gamma(shape={k:.2f}, scale={th:.2f})" for k, th in zip(np.ravel(self.rain_shape), np.ravel(self.rain_scale)))
+        return f"Reservoir(\nbounds={bounds},\ntopology=\n{self.downstream},\nrain={rain})"
