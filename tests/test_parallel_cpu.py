@@ -72,3 +72,11 @@ def test_two_rank_shard_and_gather(tmp_path):
     res = torch.load(out_path)
     assert res["ok"]
     assert res["shapes"] == [(B, T + 1, n, 1), (B, T, m, 1), (B, T + 1)]
+
+
+def test_two_rank_gather_with_an_empty_shard(tmp_path):
+    B, n, m, T = 1, 4, 2, 5            # fewer instances than ranks: rank 1 owns nothing
+    out_path = str(tmp_path / "rank0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), B, n, m, T, out_path), nprocs=2, join=True)
+    res = torch.load(out_path)
+    assert res["ok"] and res["shapes"][0] == (B, T + 1, n, 1)

@@ -31,20 +31,20 @@ def gather_trajectories(states, actions, costs, dst=0, group=None):
         return states, actions, costs
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     b = states.shape[0]
-    per = states[0].numel() + actions[0].numel() + costs[0].numel()
+    ns, na, nc = states.shape[1:].numel(), actions.shape[1:].numel(), costs.shape[1:].numel()   # valid for an empty shard too
+    per = ns + na + nc
     sizes = torch.tensor([b], device=states.device, dtype=torch.int64)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes, group=group)          # 8 bytes per rank; sizes only
     all_b = [int(s.item()) for s in all_sizes]
     bmax = max(all_b)
     packed = torch.zeros((bmax, per), device=states.device, dtype=states.dtype)
-    packed[:b] = torch.cat([states.reshape(b, -1), actions.reshape(b, -1), costs.reshape(b, -1)], dim=1)
+    packed[:b] = torch.cat([states.reshape(b, ns), actions.reshape(b, na), costs.reshape(b, nc)], dim=1)
     recv = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
     dist.gather(packed, recv, dst=dst, group=group)        # the one data-path collective
     if rank != dst:
         return None
     full = torch.cat([r[:nb] for r, nb in zip(recv, all_b)], dim=0)
-    ns, na = states[0].numel(), actions[0].numel()
     B = full.shape[0]
     return (full[:, :ns].reshape(B, *states.shape[1:]), full[:, ns:ns + na].reshape(B, *actions.shape[1:]),
             full[:, ns + na:].reshape(B, *costs.shape[1:]))
