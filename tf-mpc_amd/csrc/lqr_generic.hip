@@ -104,14 +104,14 @@ __global__ __launch_bounds__(kWave) void lqr_generic_kernel(LqrArgs a)
 
         for (int t = T - 1; t >= 0; --t) {
             // W = F^T V  [d][n]                                        (lqr.py:74)
-            wave_matmul_blocked(d, n, n,
+            wave_matmul_mfma(d, n, n,
                         [&](int r, int k) { return s.F[k * ldd + r]; },
                         [&](int k, int j) { return s.V[k * ldn + j]; },
                         [](int, int) { return 0.0f; },
                         [&](int r, int j, float x) { s.W[r * ldn + j] = x; });
             wsync();
             // Q = C + W F ; q = c + W f + F^T v                        (lqr.py:75-78)
-            wave_matmul_blocked(d, d, n,
+            wave_matmul_mfma(d, d, n,
                         [&](int r, int k) { return s.W[r * ldn + k]; },
                         [&](int k, int j) { return s.F[k * ldd + j]; },
                         [&](int r, int j) { return s.C[r * ldd + j]; },
@@ -150,24 +150,23 @@ __global__ __launch_bounds__(kWave) void lqr_generic_kernel(LqrArgs a)
             }
             wsync();
             // K^T Q_uu  [n][m]                                         (lqr.py:95)
-            wave_matmul_blocked(n, m, m,
+            wave_matmul_mfma(n, m, m,
                         [&](int i, int k) { return s.K[k * ldn + i]; },
                         [&](int k, int j) { return s.Q[(n + k) * ldd + n + j]; },
                         [](int, int) { return 0.0f; },
                         [&](int i, int j, float x) { s.KtQ[i * ldm + j] = x; });
             wsync();
             // V' = Q_xx + Q_xu K + K^T Q_ux + K^T Q_uu K               (lqr.py:97-100)
-            for (int idx = lane; idx < n * n; idx += kWave) {
-                const int i = idx / n, j = idx - i * n;
-                float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-                for (int k = 0; k < m; ++k) {
-                    const float Kkj = s.K[k * ldn + j];
-                    s1 = fmaf(s.Q[i * ldd + n + k], Kkj, s1);
-                    s2 = fmaf(s.K[k * ldn + i], s.Q[(n + k) * ldd + j], s2);
-                    s3 = fmaf(s.KtQ[i * ldm + k], Kkj, s3);
-                }
-                s.Vn[i * ldn + j] = s.Q[i * ldd + j] + s1 + s2 + s3;
-            }
+            // as ONE product [Q_xu | K^T | K^T Q_uu] [K ; Q_ux ; K] accumulated onto Q_xx
+            wave_matmul_mfma(n, n, 3 * m,
+                        [&](int i, int k) {
+                            return k < m ? s.Q[i * ldd + n + k] : (k < 2 * m ? s.K[(k - m) * ldn + i] : s.KtQ[i * ldm + (k - 2 * m)]);
+                        },
+                        [&](int k, int j) {
+                            return k < m ? s.K[k * ldn + j] : (k < 2 * m ? s.Q[(n + k - m) * ldd + j] : s.K[(k - 2 * m) * ldn + j]);
+                        },
+                        [&](int i, int j) { return s.Q[i * ldd + j]; },
+                        [&](int i, int j, float x) { s.Vn[i * ldn + j] = x; });
             // v' = q_x + Q_xu k + K^T q_u + K^T Q_uu k                 (lqr.py:102-105)
             for (int i = lane; i < n; i += kWave) {
                 float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;

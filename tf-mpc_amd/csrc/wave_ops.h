@@ -80,6 +80,56 @@ __device__ __forceinline__ void wave_matmul(int M, int N, int K, FA a, FB b, FIn
     }
 }
 
+// Matrix-core variant for large shapes: 16 x 16 output tiles on v_mfma_f32_16x16x4_f32 (fp32 operands, fp32
+// accumulation; the same 64 flop/cycle/SIMD peak as the vector FMAs, but ONE instruction per 1024 multiply-adds and
+// 1.25 operand reads per instruction: four column tiles share each a-operand).  The kernels that use it run one or two
+// waves per SIMD out of LDS and are latency-bound on their instruction count, which this divides by ~8 against the
+// register-blocked loop.  Rows / columns / k beyond the matrix are clamped reads whose products land in discarded
+// outputs (rows, columns) or are zeroed (k).  NOT bit-identical to wave_matmul: the MFMA adds four products per
+// accumulate; a kernel must use one variant for all its launches of a shape.
+using wm_f32x4 = __attribute__((ext_vector_type(4))) float;
+template <class FA, class FB, class FInit, class FOut>
+__device__ __forceinline__ void wave_matmul_mfma(int M, int N, int K, FA a, FB b, FInit init, FOut out)
+{
+    const int lane = lane_id(), li = lane & 15, lq = lane >> 4;
+    for (int i0 = 0; i0 < M; i0 += 16) {
+        const int ia = (i0 + li < M) ? i0 + li : M - 1;
+        int ir[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ir[r] = (i0 + 4 * lq + r < M) ? i0 + 4 * lq + r : M - 1;
+        for (int j0 = 0; j0 < N; j0 += 64) {
+            const int tiles = (N - j0 + 15) >> 4;          // wave-uniform; 4 or fewer column tiles in this pass
+            int jb[4];
+            wm_f32x4 acc[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                jb[c] = (j0 + 16 * c + li < N) ? j0 + 16 * c + li : N - 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[c][r] = init(ir[r], jb[c]);
+            }
+            for (int k0 = 0; k0 < K; k0 += 4) {
+                const bool kin = k0 + lq < K;
+                const int kc = kin ? k0 + lq : K - 1;
+                float av = a(ia, kc);
+                av = kin ? av : 0.0f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c < tiles) {
+                        float bv = b(kc, jb[c]);
+                        bv = kin ? bv : 0.0f;
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[c], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c < tiles && i0 + 4 * lq + r < M && j0 + 16 * c + li < N) out(i0 + 4 * lq + r, j0 + 16 * c + li, acc[c][r]);
+        }
+    }
+}
+
 // Register-blocked variant for the kernels that only ever see large shapes (lqr_generic.hip: n > 16 or m > 8):
 // 4 x 4 (or 2 x 2) outputs per lane and step share their a- and b-operands, which cuts the LDS reads per FMA
 // from 2 to 1/2 (or 1) -- those kernels are LDS-issue bound.  Every output is still its own fma chain over
@@ -185,35 +235,44 @@ __device__ __forceinline__ void store_matrix(float *dst, const float *src, int l
 template <bool PIVOT>
 __device__ __forceinline__ int wave_gauss_jordan(float *aug, int ld, int rows, int width, float *fac, float *prow)
 {
+    // Column per lane: a lane carries its column(s) j = lane, lane + 64, ... through the whole row sweep of a
+    // pivot, so the only cross-lane data are the multipliers fac[i] = aug[i][p] (staged once per pivot, read
+    // back as LDS broadcasts) -- no index divisions and two fences per pivot.  Element arithmetic and pivot
+    // choice are those of the textbook loop: aug[i][j] <- fma(-aug[i][p], aug[piv][j] / aug[piv][p], aug[i][j]).
+    (void)prow;
     const int lane = lane_id();
     int bad = 0;
     for (int p = 0; p < rows; ++p) {
-        int piv = p;
-        if (PIVOT) {
-            float best = fabsf(aug[p * ld + p]);
-            for (int i = p + 1; i < rows; ++i) {
-                const float a = fabsf(aug[i * ld + p]);
-                if (a > best) { best = a; piv = i; }
-            }
-        }
-        const float pv = aug[piv * ld + p];
-        if (PIVOT ? (pv == 0.0f) : !(pv > 0.0f)) bad = 1;
-        const float inv = 1.0f / pv;
-        // stage the (scaled) pivot row and the multiplier column
-        for (int j = lane; j < width; j += kWave) prow[j] = aug[piv * ld + j] * inv;
         for (int i = lane; i < rows; i += kWave) fac[i] = aug[i * ld + p];
         wsync();
-        if (PIVOT && piv != p) {
-            // move row p into slot piv (its multiplier is fac[p])
-            for (int j = lane; j < width; j += kWave) aug[piv * ld + j] = aug[p * ld + j];
-            if (lane == 0) fac[piv] = fac[p];
-            wsync();
+        int piv = p;
+        if (PIVOT) {
+            if (rows <= kWave) {
+                // first row of maximal |entry| among rows p..rows-1, as the sequential scan finds it
+                const bool in = lane >= p && lane < rows;
+                const float mine = in ? fabsf(fac[lane]) : 0.0f;
+                const float best = wave_max(mine);
+                const unsigned long long hit = __ballot(in && mine == best);
+                if (hit) piv = __ffsll((long long)hit) - 1;
+            } else {
+                float best = fabsf(fac[p]);
+                for (int i = p + 1; i < rows; ++i) {
+                    const float a = fabsf(fac[i]);
+                    if (a > best) { best = a; piv = i; }
+                }
+            }
         }
-        const int total = rows * width;
-        for (int idx = lane; idx < total; idx += kWave) {
-            const int i = idx / width;
-            const int j = idx - i * width;
-            aug[i * ld + j] = (i == p) ? prow[j] : fmaf(-fac[i], prow[j], aug[i * ld + j]);
+        const float pv = fac[piv];
+        if (PIVOT ? (pv == 0.0f) : !(pv > 0.0f)) bad = 1;
+        const float inv = 1.0f / pv;
+        for (int j = lane; j < width; j += kWave) {
+            const float pr = aug[piv * ld + j] * inv;            // scaled pivot row, this column
+            if (PIVOT && piv != p) aug[piv * ld + j] = aug[p * ld + j];   // row p moves into slot piv ...
+            for (int i = 0; i < rows; ++i) {
+                const float fi = fac[(PIVOT && i == piv) ? p : i];        // ... and keeps its multiplier
+                const float old = aug[i * ld + j];
+                aug[i * ld + j] = (i == p) ? pr : fmaf(-fi, pr, old);
+            }
         }
         wsync();
     }
