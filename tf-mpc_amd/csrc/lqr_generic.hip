@@ -94,10 +94,7 @@ __global__ __launch_bounds__(kWave) void lqr_generic_kernel(LqrArgs a)
 
     if (BACKWARD) {
         // terminal condition V = C_xx, v = c_x, const = 0              (lqr.py:67-69)
-        for (int idx = lane; idx < n * n; idx += kWave) {
-            const int i = idx / n, j = idx - i * n;
-            s.V[i * ldn + j] = s.C[i * ldd + j];
-        }
+        wave_for_2d(n, n, [&](int i, int j, int) { s.V[i * ldn + j] = s.C[i * ldd + j]; });
         for (int i = lane; i < n; i += kWave) s.v[i] = s.c[i];
         float cst = 0.0f;
         wsync();
@@ -127,22 +124,20 @@ __global__ __launch_bounds__(kWave) void lqr_generic_kernel(LqrArgs a)
             wsync();
             // [Q_uu | q_u | Q_ux] -> Gauss-Jordan -> [I | Q_uu^-1 q_u | Q_uu^-1 Q_ux]
             // (general inverse with row pivoting, lqr.py:84-87)
-            for (int idx = lane; idx < m * s.width; idx += kWave) {
-                const int r = idx / s.width, j = idx - r * s.width;
+            wave_for_2d(m, s.width, [&](int r, int j, int) {
                 float x;
                 if (j < m) x = s.Q[(n + r) * ldd + n + j];
                 else if (j == m) x = s.q[n + r];
                 else x = s.Q[(n + r) * ldd + (j - m - 1)];
                 s.aug[r * lda + j] = x;
-            }
+            });
             wsync();
             if (wave_gauss_jordan<true>(s.aug, lda, m, s.width, s.fac, s.prow)) status |= TFMPC_ST_SINGULAR;
-            for (int idx = lane; idx < m * n; idx += kWave) {
-                const int r = idx / n, j = idx - r * n;
+            wave_for_2d(m, n, [&](int r, int j, int idx) {
                 const float x = -s.aug[r * lda + m + 1 + j];
                 s.K[r * ldn + j] = x;
                 if (Kg) Kg[(size_t)t * m * n + idx] = x;
-            }
+            });
             for (int r = lane; r < m; r += kWave) {
                 const float x = -s.aug[r * lda + m];
                 s.k[r] = x;
@@ -192,12 +187,11 @@ __global__ __launch_bounds__(kWave) void lqr_generic_kernel(LqrArgs a)
             }
             cst += wave_sum(part);
             wsync();
-            for (int idx = lane; idx < n * n; idx += kWave) {
-                const int i = idx / n, j = idx - i * n;
+            wave_for_2d(n, n, [&](int i, int j, int idx) {
                 const float x = s.Vn[i * ldn + j];
                 s.V[i * ldn + j] = x;
                 if (a.V) a.V[((size_t)b * T + t) * n * n + idx] = x;
-            }
+            });
             for (int i = lane; i < n; i += kWave) {
                 const float x = s.vn[i];
                 s.v[i] = x;
@@ -206,6 +200,7 @@ __global__ __launch_bounds__(kWave) void lqr_generic_kernel(LqrArgs a)
             if (a.cst && lane == 0) a.cst[(size_t)b * T + t] = cst;
             wsync();
         }
+
         if (!(cst == cst)) status |= TFMPC_ST_NAN;
     }
 
