@@ -31,6 +31,19 @@ bool want_lane(int n, int m, int B)
     return B >= kLaneMinBatch;
 }
 
+// Workgroup-per-instance kernel from n + m = kBlockFrom up (below that one wave per instance still gets several
+// waves per SIMD out of its LDS slice and needs no barriers).  TFMPC_LQR_KERNEL=block|generic forces.
+constexpr int kBlockFrom = 20;
+
+bool want_block(int n, int m)
+{
+    if (lqr_block_smem_bytes(n, m) > kMaxLdsBytes) return false;
+    const char *force = std::getenv("TFMPC_LQR_KERNEL");
+    if (force && std::strcmp(force, "generic") == 0) return false;
+    if (force && std::strcmp(force, "block") == 0) return true;
+    return n + m >= kBlockFrom;
+}
+
 int check_common(int B, int n, int m, int T, const void *F, const void *f, const void *C, const void *c)
 {
     if (B < 0 || n <= 0 || m <= 0 || T < 0) return TFMPC_ERR_ARG;
@@ -45,6 +58,7 @@ int run(const LqrArgs &a, bool bw, bool fw, void *stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (want_mfma(a.n, a.m)) return lqr_mfma_launch(a, bw, fw, s);
     if (want_lane(a.n, a.m, a.B)) return lqr_lane_launch(a, bw, fw, s);
+    if (want_block(a.n, a.m)) return lqr_block_launch(a, bw, fw, s);
     return lqr_generic_launch(a, bw, fw, s);
 }
 
@@ -61,6 +75,7 @@ const char *tfmpc_lqr_kernel_name(int n, int m, int T)
     if (want_mfma(n, m)) return (n == 16 && m == 8) ? "mfma_16x8" : "mfma_16x8 (zero-padded)";
     if (lqr_lane_supported(n, m)) return "lane (batch >= 32) / generic_wave";
     if (lqr_generic_smem_bytes(n, m) > kMaxLdsBytes) return "unsupported";
+    if (want_block(n, m)) return "block_mfma_f32";
     return "generic_wave";
 }
 

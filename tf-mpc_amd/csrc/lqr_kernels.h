@@ -28,6 +28,10 @@ struct LqrArgs {
 size_t lqr_generic_smem_bytes(int n, int m);
 int lqr_generic_launch(const LqrArgs &a, bool backward, bool forward, hipStream_t stream);
 
+// Workgroup-per-instance variant for large shapes (lqr_block.hip): four waves, products on the f32 matrix cores.
+size_t lqr_block_smem_bytes(int n, int m);
+int lqr_block_launch(const LqrArgs &a, bool backward, bool forward, hipStream_t stream);
+
 // Lane-per-instance variant for tiny shapes, n + m <= 6 (lqr_lane.hip).
 bool lqr_lane_supported(int n, int m);
 int lqr_lane_launch(const LqrArgs &a, bool backward, bool forward, hipStream_t stream);
