@@ -38,7 +38,7 @@ def _problem(B, n, m, seed):
 
 
 @pytest.mark.parametrize("n,m,T", [(32, 16, 12), (24, 24, 8), (17, 9, 15), (33, 3, 6), (20, 1, 9), (5, 19, 7), (48, 16, 4),
-                                   (3, 2, 10), (16, 16, 1)])
+                                   (3, 2, 10), (16, 16, 1), (20, 4, 130)])       # T = 130: three chunks of the cost post-pass
 def test_block_kernel_matches_oracle_and_wave_kernel(force_kernel, n, m, T):
     B = 37
     F, f, C, c, x0 = _problem(B, n, m, seed=97 * n + m)

@@ -35,7 +35,8 @@ constexpr int kBT = kBW * kWave;
 
 struct BlockSmem {
     int ldf, ldv, ldm, lda, width;
-    float *Fa, *Ca, *Vv[2], *Wv, *Qq, *q, *aug, *fac, *prow, *rowp, *Kk, *KtQ, *z, *y, *red, *part;
+    int scratch_floats;
+    float *Fa, *Ca, *Vv[2], *Wv, *Qq, *q, *aug, *fac, *prow, *rowp, *Kk, *KtQ, *z, *y, *red, *part, *scratch;
 };
 
 __host__ __device__ inline size_t block_smem_floats(int n, int m)
@@ -67,6 +68,13 @@ __device__ inline BlockSmem block_carve(float *base, int n, int m)
     float *p = base;
     s.Fa = p; p += n * s.ldf;
     s.Ca = p; p += d * s.ldf;
+    s.Kk = p; p += m * s.ldv;
+    s.z = p; p += d;
+    s.y = p; p += d + n;
+    s.red = p; p += kBW;
+    s.part = p; p += kBT;
+    // from here on: operands of the Riccati sweep only -- the rollout reuses the region for its cost post-pass
+    s.scratch = p;
     s.Vv[0] = p; p += n * s.ldv;
     s.Vv[1] = p; p += n * s.ldv;
     s.Wv = p; p += d * s.ldv;
@@ -76,12 +84,8 @@ __device__ inline BlockSmem block_carve(float *base, int n, int m)
     s.fac = p; p += m;
     s.prow = p; p += s.width;
     s.rowp = p; p += s.width;
-    s.Kk = p; p += m * s.ldv;
     s.KtQ = p; p += n * s.ldm;
-    s.z = p; p += d;
-    s.y = p; p += d + n;
-    s.red = p; p += kBW;
-    s.part = p; p += kBT;
+    s.scratch_floats = (int)(p - s.scratch);
     return s;
 }
 
@@ -257,44 +261,88 @@ __global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             s.z[i] = x;
             xs[i] = x;
         }
-        for (int t = 0; t < T; ++t) {
-            block_for_2d<kBW>(m, n, [&](int r, int j, int idx) { s.Kk[r * ldv + j] = Kr[(size_t)t * m * n + idx]; });
-            for (int r = tid; r < m; r += kBT) s.Kk[r * ldv + n] = kr[(size_t)t * m + r];
+        // The rollout proper is u = K x + k, x' = F z + f per step; the stage costs 1/2 z^T C z + c^T z (lqr.py:41-47)
+        // need no sequencing, so the visited z_t are kept as columns of Z (in the sweep's dead LDS) and priced
+        // afterwards, a chunk of timesteps at a time, as Y = C Z on the matrix cores.  The final cost
+        // 1/2 x^T C_xx x + c_x^T x (lqr.py:49-57) is the same expression at z = [x_T; 0].
+        const int cap = s.scratch_floats / (2 * d);           // columns of Z and of Y that fit (>= 1: the region holds [Q | q])
+        const int ldz = (cap & 1) ? cap : cap - 1;            // odd leading dimension
+        const int tc = T + 1 < ldz ? T + 1 : ldz;             // timesteps per chunk
+        float *Z = s.scratch, *Y = s.scratch + d * ldz;
+        constexpr int kPre = 8;                               // gains of the next step, prefetched into registers
+        const int gains = m * (n + 1);                        // K_t then k_t, as they lie in HBM
+        const bool prefetch = gains <= kPre * kBT;
+        float gain[kPre];
+        int gain_at[kPre];                                    // where each lands in [K | k]
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const int idx = tid + u * kBT;
+            gain_at[u] = idx < m * n ? (idx / n) * ldv + idx % n : (idx - m * n) * ldv + n;
+        }
+        auto fetch_gains = [&](int t) {
+#pragma unroll
+            for (int u = 0; u < kPre; ++u) {
+                const int idx = tid + u * kBT;
+                gain[u] = idx < m * n ? Kr[(size_t)t * m * n + idx] : (idx < gains ? kr[(size_t)t * m + idx - m * n] : 0.0f);
+            }
+        };
+        if (prefetch && T > 0) fetch_gains(0);
+        int nan = 0;
+        for (int t0 = 0; t0 <= T; t0 += tc) {
+            const int cols = (T + 1 - t0 < tc) ? T + 1 - t0 : tc;          // timesteps t0 .. t0 + cols - 1 (T = final state)
+            for (int tt = 0; tt < cols; ++tt) {
+                const int t = t0 + tt;
+                if (t == T) {
+                    for (int r = tid; r < d; r += kBT) Z[r * ldz + tt] = r < n ? s.z[r] : 0.0f;
+                    break;
+                }
+                if (prefetch) {
+#pragma unroll
+                    for (int u = 0; u < kPre; ++u)
+                        if (tid + u * kBT < gains) s.Kk[gain_at[u]] = gain[u];
+                    if (t + 1 < T) fetch_gains(t + 1);
+                } else {
+                    block_for_2d<kBW>(m, n, [&](int r, int j, int idx) { s.Kk[r * ldv + j] = Kr[(size_t)t * m * n + idx]; });
+                    for (int r = tid; r < m; r += kBT) s.Kk[r * ldv + n] = kr[(size_t)t * m + r];
+                }
+                __syncthreads();
+                // u = K x + k                                                (lqr.py:143)
+                block_matvec<kBW>(m, n,
+                            [&](int r, int k) { return s.Kk[r * ldv + k]; },
+                            [&](int k) { return s.z[k]; },
+                            [&](int r) { return s.Kk[r * ldv + n]; }, s.part,
+                            [&](int r, float u) { s.z[n + r] = u; us[(size_t)t * m + r] = u; });
+                // x' = F z + f                                                 (lqr.py:36-39)
+                block_matvec<kBW>(n, d,
+                            [&](int r, int k) { return s.Fa[r * ldf + k]; },
+                            [&](int k) { return s.z[k]; },
+                            [&](int r) { return s.Fa[r * ldf + d]; }, s.part,
+                            [&](int r, float v) { s.y[r] = v; });
+                for (int r = tid; r < d; r += kBT) Z[r * ldz + tt] = s.z[r];
+                __syncthreads();
+                for (int i = tid; i < n; i += kBT) {
+                    const float x = s.y[i];
+                    s.z[i] = x;
+                    xs[(size_t)(t + 1) * n + i] = x;
+                }
+                __syncthreads();
+            }
             __syncthreads();
-            // u = K x + k                                                (lqr.py:143)
-            block_matvec<kBW>(m, n,
-                        [&](int r, int k) { return s.Kk[r * ldv + k]; },
-                        [&](int k) { return s.z[k]; },
-                        [&](int r) { return s.Kk[r * ldv + n]; }, s.part,
-                        [&](int r, float u) { s.z[n + r] = u; us[(size_t)t * m + r] = u; });
-            // y = [C z ; F z]: the cost 1/2 z^T C z + c^T z (lqr.py:41-47) and x' = F z + f (lqr.py:36-39)
-            block_matvec<kBW>(d + n, d,
-                        [&](int r, int k) { return r < d ? s.Ca[r * ldf + k] : s.Fa[(r - d) * ldf + k]; },
-                        [&](int k) { return s.z[k]; },
-                        [&](int r) { return r < d ? 0.0f : s.Fa[(r - d) * ldf + d]; }, s.part,
-                        [&](int r, float v) { s.y[r] = v; });
-            float part = 0.0f;
-            for (int r = tid; r < d; r += kBT) part += s.z[r] * (0.5f * s.y[r] + s.Ca[r * ldf + d]);
-            const float cost = block_sum<kBW>(part, s.red);
-            if (tid == 0) cs[t] = cost;
-            for (int i = tid; i < n; i += kBT) {
-                const float x = s.y[d + i];
-                s.z[i] = x;
-                xs[(size_t)(t + 1) * n + i] = x;
+            block_matmul_mfma<kBW>(d, cols, d,
+                        [&](int r, int k) { return s.Ca[r * ldf + k]; },
+                        [&](int k, int j) { return Z[k * ldz + j]; },
+                        [](int, int) { return 0.0f; },
+                        [&](int r, int j, float v) { Y[r * ldz + j] = v; });
+            __syncthreads();
+            for (int j = tid; j < cols; j += kBT) {
+                float cost = 0.0f;
+                for (int r = 0; r < d; ++r) cost = fmaf(Z[r * ldz + j], fmaf(0.5f, Y[r * ldz + j], s.Ca[r * ldf + d]), cost);
+                cs[t0 + j] = cost;
+                nan |= !(cost == cost);
             }
             __syncthreads();
         }
-        // final cost 1/2 x^T C_xx x + c_x^T x                            (lqr.py:49-57)
-        block_matvec<kBW>(n, n,
-                    [&](int r, int k) { return s.Ca[r * ldf + k]; },
-                    [&](int k) { return s.z[k]; },
-                    [](int) { return 0.0f; }, s.part,
-                    [&](int r, float v) { s.y[r] = v; });
-        float part = 0.0f;
-        for (int r = tid; r < n; r += kBT) part += s.z[r] * (0.5f * s.y[r] + s.Ca[r * ldf + d]);
-        const float last_cost = block_sum<kBW>(part, s.red);
-        if (tid == 0) cs[T] = last_cost;
-        if (!(last_cost == last_cost)) status |= TFMPC_ST_NAN;
+        if (__syncthreads_or(nan)) status |= TFMPC_ST_NAN;
     }
 
     if (a.status && tid == 0) a.status[b] = status;
