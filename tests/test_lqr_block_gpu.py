@@ -69,7 +69,7 @@ def test_block_kernel_is_the_default_for_large_shapes_and_split_equals_fused(for
     lib = _hip.require_gpu()
     assert lib.tfmpc_lqr_kernel_name(32, 16, 10) == b"block_mfma_f32"
     assert lib.tfmpc_lqr_kernel_name(16, 8, 10).startswith(b"mfma_16x8")
-    assert lib.tfmpc_lqr_kernel_name(17, 2, 10) == b"generic_wave"
+    assert lib.tfmpc_lqr_kernel_name(17, 2, 10) == b"block_mfma_f32 (batch <= 2048) / generic_wave"
     B, n, m, T = 21, 28, 12, 9
     F, f, C, c, x0 = _problem(B, n, m, seed=5)
     lqr = LQR(F, f, C, c)

@@ -31,17 +31,21 @@ bool want_lane(int n, int m, int B)
     return B >= kLaneMinBatch;
 }
 
-// Workgroup-per-instance kernel from n + m = kBlockFrom up (below that one wave per instance still gets several
-// waves per SIMD out of its LDS slice and needs no barriers).  TFMPC_LQR_KERNEL=block|generic forces.
-constexpr int kBlockFrom = 20;
+// Workgroup-per-instance kernel (lqr_block.hip) vs wave-per-instance (lqr_generic.hip), measured on MI355X at T = 50
+// (tools/block_vs_wave.py): the block kernel has the shorter critical path at every shape (B = 256: 1.4-3.9x), but it
+// holds 3 workgroups per CU, so once the batch fills the chip the wave kernel's many resident waves win below
+// n + m ~ 28 (B = 8192: 0.4-0.7x there, 1.5-3.4x above).  TFMPC_LQR_KERNEL=block|generic forces.
+constexpr int kBlockFrom = 28;
+constexpr int kBlockMaxSmallBatch = 2048;
 
-bool want_block(int n, int m)
+bool want_block(int n, int m, int B)
 {
     if (lqr_block_smem_bytes(n, m) > kMaxLdsBytes) return false;
     const char *force = std::getenv("TFMPC_LQR_KERNEL");
     if (force && std::strcmp(force, "generic") == 0) return false;
     if (force && std::strcmp(force, "block") == 0) return true;
-    return n + m >= kBlockFrom;
+    if (lqr_lane_supported(n, m)) return false;           // tiny shapes: one wave (or one lane) is already the short path
+    return n + m >= kBlockFrom || B <= kBlockMaxSmallBatch;
 }
 
 int check_common(int B, int n, int m, int T, const void *F, const void *f, const void *C, const void *c)
@@ -58,7 +62,7 @@ int run(const LqrArgs &a, bool bw, bool fw, void *stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (want_mfma(a.n, a.m)) return lqr_mfma_launch(a, bw, fw, s);
     if (want_lane(a.n, a.m, a.B)) return lqr_lane_launch(a, bw, fw, s);
-    if (want_block(a.n, a.m)) return lqr_block_launch(a, bw, fw, s);
+    if (want_block(a.n, a.m, a.B)) return lqr_block_launch(a, bw, fw, s);
     return lqr_generic_launch(a, bw, fw, s);
 }
 
@@ -75,7 +79,8 @@ const char *tfmpc_lqr_kernel_name(int n, int m, int T)
     if (want_mfma(n, m)) return (n == 16 && m == 8) ? "mfma_16x8" : "mfma_16x8 (zero-padded)";
     if (lqr_lane_supported(n, m)) return "lane (batch >= 32) / generic_wave";
     if (lqr_generic_smem_bytes(n, m) > kMaxLdsBytes) return "unsupported";
-    if (want_block(n, m)) return "block_mfma_f32";
+    if (want_block(n, m, 1 << 30)) return "block_mfma_f32";
+    if (want_block(n, m, 1)) return "block_mfma_f32 (batch <= 2048) / generic_wave";
     return "generic_wave";
 }
 

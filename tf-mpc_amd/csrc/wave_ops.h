@@ -211,12 +211,14 @@ __device__ __forceinline__ void wave_for_2d(int rows, int cols, F f)
     const int total = rows * cols;
     int idx = lane_id();
     int i = idx / cols, j = idx - i * cols;
+    if (idx < total) f(i, j, idx);
+    if (total <= kWave) return;                 // the common case for small matrices: no stride bookkeeping at all
     const int di = kWave / cols, dj = kWave - di * cols;
-    for (; idx < total; idx += kWave) {
-        f(i, j, idx);
+    for (idx += kWave; idx < total; idx += kWave) {
         i += di;
         j += dj;
         if (j >= cols) { j -= cols; ++i; }
+        f(i, j, idx);
     }
 }
 
@@ -278,21 +280,12 @@ __device__ __forceinline__ int wave_gauss_jordan(float *aug, int ld, int rows, i
         for (int j = lane; j < width; j += kWave) {
             const float pr = aug[piv * ld + j] * inv;            // scaled pivot row, this column
             if (PIVOT && piv != p) aug[piv * ld + j] = aug[p * ld + j];   // row p moves into slot piv ...
-            // eight rows at a time, every read before the first write: the compiler cannot prove that aug and fac
-            // do not alias, and a read-modify-write per row would serialise on the LDS latency
-            for (int i0 = 0; i0 < rows; i0 += 8) {
-                float fi[8], old[8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const int i = (i0 + r < rows) ? i0 + r : rows - 1;
-                    fi[r] = fac[(PIVOT && i == piv) ? p : i];             // ... and keeps its multiplier
-                    old[r] = aug[i * ld + j];
-                }
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const int i = i0 + r;
-                    if (i < rows) aug[i * ld + j] = (i == p) ? pr : fmaf(-fi[r], pr, old[r]);
-                }
+            // (a chunked read-all-then-write-all row loop is faster for 16+ rows but costs the small systems of the
+            // iLQR kernels 25 %; the large shapes have the block kernel)
+            for (int i = 0; i < rows; ++i) {
+                const float fi = fac[(PIVOT && i == piv) ? p : i];        // ... and keeps its multiplier
+                const float old = aug[i * ld + j];
+                aug[i * ld + j] = (i == p) ? pr : fmaf(-fi, pr, old);
             }
         }
         wsync();
