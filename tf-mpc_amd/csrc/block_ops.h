@@ -53,84 +53,12 @@ __device__ __forceinline__ float block_sum(float v, float *scratch)
     return s;
 }
 
-// out(i, j, init(i, j) + sum_k a(i, k) b(k, j)), i < M, j < N, on v_mfma_f32_16x16x4_f32: a "pass" is one row tile
-// x CT column tiles (one a-operand read feeds CT MFMAs); passes are dealt round-robin to the block's waves.  The
-// steps with all four k in range carry no clamps or masks (plain strided addresses), a last partial step is masked.
-// Rows / columns beyond the matrix are clamped reads whose products land in discarded outputs.
-template <int NW, int CT, class FA, class FB, class FInit, class FOut>
-__device__ __forceinline__ void block_matmul_mfma_ct(int M, int N, int K, FA a, FB b, FInit init, FOut out)
-{
-    using f32x4 = __attribute__((ext_vector_type(4))) float;
-    const int lane = Block<NW>::lane(), li = lane & 15, lq = lane >> 4;
-    const int col_groups = (N + 16 * CT - 1) / (16 * CT), passes = ((M + 15) >> 4) * col_groups;
-    const int Kmain = K & ~3;
-    for (int p = Block<NW>::wave(); p < passes; p += NW) {
-        const int ti = p / col_groups, tj = p - ti * col_groups;
-        const int i0 = 16 * ti, j0 = 16 * CT * tj;
-        const int ia = (i0 + li < M) ? i0 + li : M - 1;
-        int ir[4], jb[CT];
-        f32x4 acc[CT];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ir[r] = (i0 + 4 * lq + r < M) ? i0 + 4 * lq + r : M - 1;
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            jb[c] = (j0 + 16 * c + li < N) ? j0 + 16 * c + li : N - 1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[c][r] = init(ir[r], jb[c]);
-        }
-        // chunks of four k-steps: 4 (1 + CT) operand reads issued back to back (their LDS round trips overlap),
-        // then 4 CT MFMAs; the remaining full steps one at a time
-        int k0 = 0;
-        for (; k0 + 16 <= Kmain; k0 += 16) {
-            float av[4], bv[4][CT];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                av[u] = a(ia, k0 + 4 * u + lq);
-#pragma unroll
-                for (int c = 0; c < CT; ++c) bv[u][c] = b(k0 + 4 * u + lq, jb[c]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int c = 0; c < CT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u][c], acc[c], 0, 0, 0);
-        }
-        for (; k0 < Kmain; k0 += 4) {
-            const float av = a(ia, k0 + lq);
-            float bv[CT];
-#pragma unroll
-            for (int c = 0; c < CT; ++c) bv[c] = b(k0 + lq, jb[c]);
-#pragma unroll
-            for (int c = 0; c < CT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[c], acc[c], 0, 0, 0);
-        }
-        if (Kmain < K) {
-            const bool kin = Kmain + lq < K;
-            const int kc = kin ? Kmain + lq : K - 1;
-            float av = a(ia, kc);
-            av = kin ? av : 0.0f;
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                float bv = b(kc, jb[c]);
-                bv = kin ? bv : 0.0f;
-                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[c], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < CT; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (i0 + 4 * lq + r < M && j0 + 16 * c + li < N) out(i0 + 4 * lq + r, j0 + 16 * c + li, acc[c][r]);
-    }
-}
-
-// Column tiles per pass chosen so that the passes fit the block's waves in one round when they can: these products
-// are bound by the LDS round trip per k-step, not by the MFMA count, so fewer rounds of fatter passes win.
+// block_matmul_mfma<NW>: the pass-based matrix-core product of wave_ops.h (mfma_matmul) with the passes dealt to
+// the block's NW waves.
 template <int NW, class FA, class FB, class FInit, class FOut>
 __device__ __forceinline__ void block_matmul_mfma(int M, int N, int K, FA a, FB b, FInit init, FOut out)
 {
-    const int rt = (M + 15) >> 4, ct = (N + 15) >> 4;
-    if (rt * ct <= NW) block_matmul_mfma_ct<NW, 1>(M, N, K, a, b, init, out);
-    else if (rt * ((ct + 1) >> 1) <= NW) block_matmul_mfma_ct<NW, 2>(M, N, K, a, b, init, out);
-    else block_matmul_mfma_ct<NW, 4>(M, N, K, a, b, init, out);
+    mfma_matmul<NW>(M, N, K, a, b, init, out);
 }
 
 // Gauss-Jordan WITHOUT pivoting of an m x width system, m <= 16, width <= 64, by ONE wave entirely in registers:

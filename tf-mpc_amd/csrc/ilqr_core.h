@@ -206,13 +206,14 @@ struct BackwardResult {
 //   float load(int t)  -- fills s.fx, s.fu, s.lx, s.lu, s.lxx, s.luu, s.lux (= l_xu^T), s.uh (= u_hat_t)
 //                         and returns l_t; called by all lanes; no trailing sync needed.
 //   float load_final() -- fills s.Vx (= l_x^f) and s.Vxx (= l_xx^f), returns l^f.
-// BLK: register-blocked matrix products (wave_matmul_blocked).  Worth it from n ~ 12 up, where the
-// products are LDS-issue bound; it costs ~40 VGPRs, i.e. a wave per SIMD on small shapes, so the
-// launchers pick the variant by shape.  Results are bit-identical either way.
+// BLK: matrix products on the f32 matrix cores (wave_matmul_mfma: 16 x 16 tiles, one instruction per 1024
+// multiply-adds).  Worth it from n ~ 12 up, where the lane-strided products are LDS-issue bound; it costs VGPRs,
+// i.e. a wave per SIMD on small shapes, so the launchers pick the variant by shape (the same variant for every
+// launch of a shape: the MFMA sums four products per accumulate, so the two are not bit-identical).
 template <bool BLK, class FA, class FB, class FInit, class FOut>
 __device__ __forceinline__ void matmul(int M, int N, int K, FA a, FB b, FInit init, FOut out)
 {
-    if constexpr (BLK) wave_matmul_blocked(M, N, K, a, b, init, out);
+    if constexpr (BLK) wave_matmul_mfma(M, N, K, a, b, init, out);
     else wave_matmul(M, N, K, a, b, init, out);
 }
 
