@@ -172,78 +172,6 @@ __device__ __forceinline__ void wave_matmul_mfma(int M, int N, int K, FA a, FB b
     mfma_matmul<1>(M, N, K, a, b, init, out);
 }
 
-// Register-blocked variant for the kernels that only ever see large shapes (lqr_generic.hip: n > 16 or m > 8):
-// 4 x 4 (or 2 x 2) outputs per lane and step share their a- and b-operands, which cuts the LDS reads per FMA
-// from 2 to 1/2 (or 1) -- those kernels are LDS-issue bound.  Every output is still its own fma chain over
-// k = 0..K-1, so the results are bit-identical to wave_matmul.  Not used by the iLQR kernels: the 16
-// accumulators raise their VGPR count from ~125 to ~168, which costs the small-n cases a wave per SIMD.
-template <class FA, class FB, class FInit, class FOut>
-__device__ __forceinline__ void wave_matmul_blocked(int M, int N, int K, FA a, FB b, FInit init, FOut out)
-{
-    if (M * N >= 16 * kWave) {              // 4 x 4 blocks: 8 reads per 16 FMAs
-        const int Mb = (M + 3) >> 2, Nb = (N + 3) >> 2, blocks = Mb * Nb;
-        for (int idx = lane_id(); idx < blocks; idx += kWave) {
-            const int bi = idx / Nb, bj = idx - bi * Nb;
-            int ii[4], jj[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ii[r] = (4 * bi + r < M) ? 4 * bi + r : M - 1;          // clamped: in-bounds operand reads
-                jj[r] = (4 * bj + r < N) ? 4 * bj + r : N - 1;
-            }
-            float s[4][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) s[r][c] = init(ii[r], jj[c]);
-            for (int kk = 0; kk < K; ++kk) {
-                float av[4], bv[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { av[r] = a(ii[r], kk); bv[r] = b(kk, jj[r]); }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) s[r][c] = fmaf(av[r], bv[c], s[r][c]);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (4 * bi + r < M && 4 * bj + c < N) out(4 * bi + r, 4 * bj + c, s[r][c]);
-        }
-        return;
-    }
-    if (M * N >= 4 * kWave) {
-        const int Mb = (M + 1) >> 1, Nb = (N + 1) >> 1, blocks = Mb * Nb;
-        for (int idx = lane_id(); idx < blocks; idx += kWave) {
-            const int bi = idx / Nb, bj = idx - bi * Nb;
-            const int i0 = 2 * bi, j0 = 2 * bj;
-            const bool i1 = i0 + 1 < M, j1 = j0 + 1 < N;
-            const int i1c = i1 ? i0 + 1 : i0, j1c = j1 ? j0 + 1 : j0;       // clamped: in-bounds operand reads
-            float s00 = init(i0, j0), s01 = init(i0, j1c), s10 = init(i1c, j0), s11 = init(i1c, j1c);
-            for (int kk = 0; kk < K; ++kk) {
-                const float a0 = a(i0, kk), a1 = a(i1c, kk), b0 = b(kk, j0), b1 = b(kk, j1c);
-                s00 = fmaf(a0, b0, s00);
-                s01 = fmaf(a0, b1, s01);
-                s10 = fmaf(a1, b0, s10);
-                s11 = fmaf(a1, b1, s11);
-            }
-            out(i0, j0, s00);
-            if (j1) out(i0, j0 + 1, s01);
-            if (i1) out(i0 + 1, j0, s10);
-            if (i1 && j1) out(i0 + 1, j0 + 1, s11);
-        }
-        return;
-    }
-    const int total = M * N;
-    for (int idx = lane_id(); idx < total; idx += kWave) {
-        const int i = idx / N;
-        const int j = idx - i * N;
-        float s = init(i, j);
-        for (int kk = 0; kk < K; ++kk) s = fmaf(a(i, kk), b(kk, j), s);
-        out(i, j, s);
-    }
-}
-
 // f(i, j, idx) for idx = i * cols + j = lane, lane + 64, ... < rows * cols: a row-major [rows][cols] index space
 // dealt round-robin to the lanes, with the (i, j) split carried incrementally -- one integer division per call
 // instead of one per element (a v_rcp-based division is ~25 instructions on gfx950).
