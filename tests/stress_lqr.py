@@ -1,5 +1,6 @@
-"""Randomised parity sweep of the matrix-core LQR kernel against the C oracle (fp64 = truth, fp32 = the
-noise floor of an fp32 implementation in the reference's operation order): shapes n <= 16, m <= 8,
+"""Randomised parity sweep of the LQR kernels against the C oracle (fp64 = truth, fp32 = the
+noise floor of an fp32 implementation in the reference's operation order): shapes n <= 16, m <= 8 (matrix-core
+kernel; `python tests/stress_lqr.py [cases] large` draws n <= 40, m <= 24 instead: block and wave kernels),
 horizons 1..60, well- and ill-conditioned costs (make_spd_matrix-like spectra down to 0.02), unstable F.
 Reports, per case, the device error relative to the fp32 restatement's error.  Run on the GPU box:
 python tests/stress_lqr.py [cases]"""
@@ -10,14 +11,16 @@ from oracle import c_oracle
 from tfmpc.solvers.lqr import LQR
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+large = len(sys.argv) > 2 and sys.argv[2] == "large"
 rng = np.random.default_rng(2024)
 c_oracle.build()
 worst = []
 t_start = time.time()
 for case in range(cases):
     n = int(rng.integers(3, 17)); m = int(rng.integers(1, 9))
+    if large: n = int(rng.integers(6, 41)); m = int(rng.integers(1, 25))
     if n + m <= 6: n = 7 - m
-    T = int(rng.integers(1, 61)); B = int(rng.integers(40, 400))
+    T = int(rng.integers(1, 61)); B = int(rng.integers(40, 400)) if not large else int(rng.choice([3, 40, 300, 2500]))
     d = n + m
     rho = rng.choice([0.5, 1.0, 2.0, 4.0])                      # spectral scale of F
     lam_min = rng.choice([1.0, 0.2, 0.04, 0.02])                 # smallest eigenvalue of C
