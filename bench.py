@@ -97,6 +97,64 @@ def ilqr_api_rate(n, m, T, B, reps=5):
             "workload": f"iLQR.solve on LQEnv(0.25 F, f, C, c), n={n} m={m} T={T} B={B}, zero initial actions"}
 
 
+def other_config_rates():
+    """Secondary numbers (not `value`): the other BASELINE.json configs, one timed launch each after a warm-up --
+    cfg2 navlin LQR (B=4096), cfg4 Navigation iLQR (B=16384), cfg5 HVAC / Reservoir iLQR (n=32, T=100, B=32768,
+    <= 12 iterations), and a dense LQR beyond the headline tile (n=32, m=16, B=8192).  Inputs as in SURVEY.md 8(d)."""
+    import problems
+    from tfmpc.envs import make_lqr_linear_navigation
+    from tfmpc.envs.hvac import HVAC
+    from tfmpc.envs.navigation import Navigation
+    from tfmpc.envs.reservoir import Reservoir
+    from tfmpc.solvers.ilqr import iLQR
+    from tfmpc.solvers.lqr import LQR
+
+    def timed(fn, reps):
+        out = fn(None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn(out["workspace"])
+        torch.cuda.synchronize()
+        return out, (time.perf_counter() - t0) / reps
+
+    def ilqr_line(solver, x0, T, u0, reps):
+        out, dt = timed(lambda ws: solver.solve_device(x0, T, u_init=u0, workspace=ws), reps)
+        its = float((out["iterations"].double() + 1).sum())
+        return {"ms_per_batch": dt * 1e3, "iterations_per_s": its / dt, "mean_iterations": its / x0.shape[0],
+                "flagged_instances": int((out["status"] != 0).sum()), "batch": int(x0.shape[0]), "horizon": T}
+
+    res = {}
+    rng = np.random.default_rng(4)
+    F, f, C, c, x0n, goal = problems.make_navlin_batch(4096, 5.0)
+    lqr = make_lqr_linear_navigation(goal[..., None], 5.0)
+    _, dt = timed(lambda ws: lqr.solve_device(x0n[..., None], 50, workspace=ws), 20)
+    res["cfg2_navlin_lqr"] = {"ms_per_batch": dt * 1e3, "solves_per_s": 4096 / dt, "batch": 4096, "horizon": 50}
+    solver = iLQR(Navigation.load(problems.NAV_CONFIG))
+    x0 = rng.uniform(0, 10, size=(16384, 2, 1)).astype(np.float32)
+    res["cfg4_navigation_ilqr"] = ilqr_line(solver, x0, 50, solver.random_actions(50, 16384, seed=4), 2)
+    for kind in ("hvac", "reservoir"):
+        n, T, B = 32, 100, 32768
+        if kind == "hvac":
+            env, x0 = HVAC.load(dict(problems.hvac_config(n, seed=5))), np.full((B, n, 1), 10.0, dtype=np.float32)
+        else:
+            env, x0 = Reservoir.load(dict(problems.reservoir_config(n, seed=5))), rng.uniform(50, 75, size=(B, n, 1)).astype(np.float32)
+        solver = iLQR(env, max_iterations=12)
+        res[f"cfg5_{kind}_ilqr_n32"] = ilqr_line(solver, x0, T, solver.random_actions(T, B, seed=5), 1)
+    F, f, C, c, x0 = problems.make_lqr_batch_fast(8192, 32, 16, seed=1)
+    big = LQR(0.5 * F, f, C, c)
+    x0d = big._prep_x0(x0)
+    _, dt = timed(lambda ws: big.solve_device(x0d, 50, workspace=ws), 3)
+    res["lqr_n32_m16"] = {"ms_per_batch": dt * 1e3, "solves_per_s": 8192 / dt, "batch": 8192, "horizon": 50,
+                          "kernel": _hip_kernel_name(32, 16, 50)}
+    return res
+
+
+def _hip_kernel_name(n, m, T):
+    from tfmpc import _hip
+    return _hip.require_gpu().tfmpc_lqr_kernel_name(n, m, T).decode()
+
+
 def numpy_single_instance_rate(n, m, T, instances=24):
     """The reference's execution model -- one problem at a time, fp32, its operation order -- as
     the oracle's numpy restatement looped over a few instances on ONE core.
@@ -298,6 +356,10 @@ def main():
             line["cpu_baseline"] = cpu_baseline(n, m, T)
         if world == 1 and not args.no_extra:
             line["extra"] = {"ilqr_api": ilqr_api_rate(n, m, T, B)}
+            try:                                    # secondary numbers must never cost the headline line
+                line["extra"]["other_configs"] = other_config_rates()
+            except Exception as exc:
+                line["extra"]["other_configs_error"] = repr(exc)
             if not args.no_cpu_baseline:
                 line["extra"]["cpu_numpy_single_instance"] = numpy_single_instance_rate(n, m, T)
         print(json.dumps(line), flush=True)
