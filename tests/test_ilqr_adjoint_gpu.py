@@ -31,7 +31,8 @@ def force_kernel():
 
 
 @pytest.mark.parametrize("kind", ["hvac", "reservoir"])
-@pytest.mark.parametrize("n,T,B", [(32, 24, 70), (21, 13, 9), (17, 7, 5), (30, 40, 33), (32, 1, 1), (18, 2, 3)])
+@pytest.mark.parametrize("n,T,B", [(32, 24, 70), (21, 13, 9), (17, 7, 5), (30, 40, 33), (32, 1, 1), (18, 2, 3),
+                                   (16, 9, 7), (12, 11, 4), (6, 20, 40), (4, 15, 33), (2, 5, 3), (3, 1, 2)])
 def test_register_resident_kernel_equals_wave_kernel(force_kernel, kind, n, T, B):
     rng = np.random.default_rng(100 + n)
     if kind == "hvac":

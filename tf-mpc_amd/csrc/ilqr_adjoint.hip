@@ -1,6 +1,7 @@
 // ilqr_adjoint.hip -- iLQR.solve (tfmpc/solvers/ilqr.py:214-355) for the two reference envs whose
 // costs are piecewise linear, HVAC (tfmpc/envs/hvac/__init__.py) and Reservoir
-// (tfmpc/envs/reservoir/__init__.py), at 16 < n = m <= 32: BASELINE.json configs[4].
+// (tfmpc/envs/reservoir/__init__.py), at n = m <= 32: BASELINE.json configs[4] (n = 32)
+// and the reference's own hvac6 / res4 configs.
 //
 // On these envs every cost Hessian is identically zero, V_xx stays exactly 0, the backward pass always
 // takes the bang-bang branch (ilqr.py:140-141, K_t = 0) and what is left of an iteration is the costate
@@ -50,12 +51,15 @@ __device__ __forceinline__ int opaque(int v)
 }
 
 // ---------------------------------------------------------------------------------- HVAC ----
-template <int KIND> struct Lean;
+// SMALL: n <= 16 -- loops stop at the first all-zero group (wave-uniform tests) and HVAC rows are split over four
+// lanes like in the generic kernel; the n > 16 variant carries none of those tests in its time loops.
+template <int KIND, bool SMALL> struct Lean;
 
-template <> struct Lean<TFMPC_ENV_HVAC> {
+template <bool SMALL> struct Lean<TFMPC_ENV_HVAC, SMALL> {
     static constexpr float CAP_AIR = 1.006f, COST_AIR = 1.0f, TEMP_AIR = 40.0f, TIME_DELTA = 1.0f;
     static constexpr float PENALTY = 20000.0f, SET_POINT_PENALTY = 10.0f;
-    int n, it, part, off, tail;            // transition: row it = lane / 2, run [j0, j0 + cnt), off = it + j0
+    int n, it, part, off, tail, per;       // transition: row it = lane / parts, run [j0, j0 + cnt), off = it + j0
+    static constexpr bool quads = SMALL;   // n <= 16: a row is split over FOUR lanes, like the generic kernel does (envs.h)
     float Grow[kHalf];                     // G[it][(j0 + j + it) mod n] for j < tail = cnt & ~3, else 0
     float Gtail[3];                        // the cnt & 3 elements after them (else 0)
     float t_out, t_hall, k_out, k_hall, rcap, am_t;      // row it
@@ -71,8 +75,10 @@ template <> struct Lean<TFMPC_ENV_HVAC> {
         auto P = [&](int i) { return g.p[i] + (size_t)b * g.stride[i]; };
         const float *pt_out = P(0), *pt_hall = P(1), *plo = P(2), *phi = P(3), *pk_out = P(4), *pk_hall = P(5), *pcap = P(6),
                     *pam = P(7), *G = P(8);
-        it = lane >> 1; part = lane & 1;
-        const int per = (n + 1) / 2, j0 = part * per, j1 = (j0 + per < n) ? j0 + per : n;
+        const int parts = quads ? 4 : 2;
+        it = lane / parts; part = lane % parts;
+        per = (n + parts - 1) / parts;
+        const int j0 = part * per, j1 = (j0 + per < n) ? j0 + per : n;
         const int cnt = (it < n && j1 > j0) ? j1 - j0 : 0;
         off = (it < n) ? it + j0 : 0;
         tail = cnt & ~3;
@@ -146,6 +152,7 @@ template <> struct Lean<TFMPC_ENV_HVAC> {
 #pragma unroll
         for (int gq = 0; gq < kHalf / 4; ++gq) {
             if (gq == 2) __builtin_amdgcn_sched_barrier(0);
+            if (SMALL && 4 * gq + 4 > per) break;            // wave-uniform: no run reaches this group of four
             s0 = fmaf(-Grow[4 * gq], xi - xr[4 * gq], s0);
             s1 = fmaf(-Grow[4 * gq + 1], xi - xr[4 * gq + 1], s1);
             s2 = fmaf(-Grow[4 * gq + 2], xi - xr[4 * gq + 2], s2);
@@ -155,6 +162,7 @@ template <> struct Lean<TFMPC_ENV_HVAC> {
         for (int q = 0; q < 3; ++q) s0 = fmaf(-Gtail[q], xi - xr[tail + q], s0);
         float between = (s0 + s1) + (s2 + s3);
         between += quad_xor1(between);
+        if (quads) between += quad_xor2(between);
         if (it < n && part == 0) {
             const float air = u[it] * am_t;                                               // :72
             const float heating = air * CAP_AIR * (TEMP_AIR - xi);                        // :74
@@ -178,6 +186,7 @@ template <> struct Lean<TFMPC_ENV_HVAC> {
 #pragma unroll
             for (int kk = 0; kk < kMaxN; ++kk) {
                 if ((kk & 7) == 0) __builtin_amdgcn_sched_barrier(0);     // 8 V_x values in flight, not 32
+                if (SMALL && (kk & 7) == 0 && kk >= n) break;             // wave-uniform: the rest are 0 * 0
                 acc = fmaf(coef[kk], vx[kk], acc);
             }
         } else if (lane < 2 * n) {
@@ -190,7 +199,7 @@ template <> struct Lean<TFMPC_ENV_HVAC> {
 };
 
 // ----------------------------------------------------------------------------- RESERVOIR ----
-template <> struct Lean<TFMPC_ENV_RESERVOIR> {
+template <bool SMALL> struct Lean<TFMPC_ENV_RESERVOIR, SMALL> {
     int n, it, part, j0, tail;
     float Dcol[kHalf];                     // transition: D[j0 + j][it] for j < tail = cnt & ~3, else 0
     float Dtail[3];                        // the cnt & 3 elements after them (else 0)
@@ -259,6 +268,7 @@ template <> struct Lean<TFMPC_ENV_RESERVOIR> {
 #pragma unroll
         for (int gq = 0; gq < kHalf / 4; ++gq) {
             if (gq == 2) __builtin_amdgcn_sched_barrier(0);
+            if (SMALL && 4 * gq + 4 > (n + 1) / 2) break;    // wave-uniform: no run reaches this group of four
             s0 = fmaf(Dcol[4 * gq], ur[4 * gq] * xr[4 * gq], s0);
             s1 = fmaf(Dcol[4 * gq + 1], ur[4 * gq + 1] * xr[4 * gq + 1], s1);
             s2 = fmaf(Dcol[4 * gq + 2], ur[4 * gq + 2] * xr[4 * gq + 2], s2);
@@ -289,6 +299,7 @@ template <> struct Lean<TFMPC_ENV_RESERVOIR> {
 #pragma unroll
             for (int kk = 0; kk < kMaxN; ++kk) {                  // kk >= n: 0 * 0
                 if ((kk & 7) == 0) __builtin_amdgcn_sched_barrier(0);     // 8 V_x values in flight, not 32
+                if (SMALL && (kk & 7) == 0 && kk >= n) break;
                 acc = fmaf(Drow[kk] * uj, vx[kk], acc);
             }
         } else if (lane < 2 * n) {
@@ -298,6 +309,7 @@ template <> struct Lean<TFMPC_ENV_RESERVOIR> {
 #pragma unroll
             for (int kk = 0; kk < kMaxN; ++kk) {
                 if ((kk & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+                if (SMALL && (kk & 7) == 0 && kk >= n) break;
                 acc = fmaf(Drow[kk] * xa, vx[kk], acc);
             }
         }
@@ -309,12 +321,12 @@ struct BackwardOut { float J, dV1, g_norm; };
 
 // 4 waves per SIMD (<= 128 VGPR, ~18 rarely used values in scratch): measured best of 3 / 4 / 5 / 6 on
 // cfg5 (the kernel is latency-bound; below 128 VGPR the spills reach the time loops)
-template <int KIND>
+template <int KIND, bool SMALL>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 4))) void ilqr_adjoint_solve_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     const int b = blockIdx.x, lane = lane_id(), n = genv.n, m = n, T = a.T;
-    Lean<KIND> env;
+    Lean<KIND, SMALL> env;
     env.load(genv, b);
     float *xa = lds, *xb = lds + kXld, *ul = lds + 2 * kXld, *vx = lds + 2 * kXld + kMaxN;
     for (int idx = lane; idx < kLdsFloats; idx += kWave) lds[idx] = 0.0f;      // entries >= n stay 0 (zero-coefficient reads)
@@ -459,15 +471,21 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 
 bool ilqr_adjoint_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg)
 {
-    return (env.kind == TFMPC_ENV_HVAC || env.kind == TFMPC_ENV_RESERVOIR) && env.n == env.m && env.n > kHalf && env.n <= kMaxN &&
+    return (env.kind == TFMPC_ENV_HVAC || env.kind == TFMPC_ENV_RESERVOIR) && env.n == env.m && env.n >= 2 && env.n <= kMaxN &&
            env.bounded && !cfg.storage_bf16;
 }
 
 int ilqr_adjoint_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const AdjointSolveArgs &a, hipStream_t stream)
 {
     const dim3 grid(a.B), block(kWave);
-    if (env.kind == TFMPC_ENV_HVAC) hipLaunchKernelGGL(ilqr_adjoint_solve_kernel<TFMPC_ENV_HVAC>, grid, block, 0, stream, env, cfg, a);
-    else hipLaunchKernelGGL(ilqr_adjoint_solve_kernel<TFMPC_ENV_RESERVOIR>, grid, block, 0, stream, env, cfg, a);
+    const bool small = env.n <= kHalf;
+    if (env.kind == TFMPC_ENV_HVAC) {
+        if (small) hipLaunchKernelGGL((ilqr_adjoint_solve_kernel<TFMPC_ENV_HVAC, true>), grid, block, 0, stream, env, cfg, a);
+        else hipLaunchKernelGGL((ilqr_adjoint_solve_kernel<TFMPC_ENV_HVAC, false>), grid, block, 0, stream, env, cfg, a);
+    } else {
+        if (small) hipLaunchKernelGGL((ilqr_adjoint_solve_kernel<TFMPC_ENV_RESERVOIR, true>), grid, block, 0, stream, env, cfg, a);
+        else hipLaunchKernelGGL((ilqr_adjoint_solve_kernel<TFMPC_ENV_RESERVOIR, false>), grid, block, 0, stream, env, cfg, a);
+    }
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
 }
 

@@ -1,0 +1,19 @@
+"""Per-iteration latency of one Navigation iLQR instance (cfg4 tail): B small, atol = 0 so every instance runs
+max_iterations.  Bounded (box-QP in the backward pass) vs unbounded actions.  Run on the GPU box."""
+import sys, time
+sys.path.insert(0, '/root/repo/tf-mpc_amd'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+import numpy as np, torch, problems
+from tfmpc.envs.navigation import Navigation
+from tfmpc.solvers.ilqr import iLQR
+
+for label, cfg in (("bounded", problems.NAV_CONFIG), ("unbounded", dict(problems.NAV_CONFIG, low=[[-1e9], [-1e9]], high=[[1e9], [1e9]]))):
+    env = Navigation.load(cfg)
+    for B in (1, 4, 64):
+        s = iLQR(env, atol=0.0, max_iterations=50)
+        rng = np.random.default_rng(4)
+        x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32); u0 = s.random_actions(50, B, seed=4)
+        out = s.solve_device(x0, 50, u_init=u0); torch.cuda.synchronize()
+        t = time.perf_counter(); out = s.solve_device(x0, 50, u_init=u0, workspace=out["workspace"]); torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        its = (out["iterations"].double() + 1).max().item()
+        print(f"{label:9s} B={B:3d}: {dt*1e3:7.2f} ms for {its:.0f} iterations -> {dt/its*1e6:6.1f} us per iteration")

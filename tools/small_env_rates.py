@@ -1,0 +1,20 @@
+"""iLQR on the reference's own small env configs (hvac6.config.json, res4.config.json: n = 6 / 4) at large batch.
+Run on the GPU box."""
+import sys, time
+sys.path.insert(0, '/root/repo/tf-mpc_amd'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+import numpy as np, torch, problems
+from tfmpc.envs.hvac import HVAC
+from tfmpc.envs.reservoir import Reservoir
+from tfmpc.solvers.ilqr import iLQR
+
+rng = np.random.default_rng(0)
+for name, env, x0 in (("hvac6", HVAC.load(dict(problems.HVAC6_CONFIG)), np.array(problems.HVAC6_X0, dtype=np.float32)),
+                      ("res4", Reservoir.load(dict(problems.RES4_CONFIG)), np.array(problems.RES4_X0, dtype=np.float32))):
+    for B, T in ((16384, 100), (65536, 40)):
+        x = (x0[None] * rng.uniform(0.9, 1.1, size=(B, 1, 1))).astype(np.float32)
+        s = iLQR(env, max_iterations=12); u0 = s.random_actions(T, B, seed=1)
+        out = s.solve_device(x, T, u_init=u0); torch.cuda.synchronize()
+        t = time.perf_counter(); out = s.solve_device(x, T, u_init=u0, workspace=out["workspace"]); torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        its = (out["iterations"].double() + 1).sum().item()
+        print(f"{name}: B={B} T={T}: {dt*1e3:.2f} ms, mean iterations {its/B:.1f}, {its/dt:.3e} iterations/s, flagged {(out['status']!=0).sum().item()}")
