@@ -60,11 +60,12 @@ template <bool SMALL> struct Lean<TFMPC_ENV_HVAC, SMALL> {
     static constexpr float PENALTY = 20000.0f, SET_POINT_PENALTY = 10.0f;
     int n, it, part, off, tail, per;       // transition: row it = lane / parts, run [j0, j0 + cnt), off = it + j0
     static constexpr bool quads = SMALL;   // n <= 16: a row is split over FOUR lanes, like the generic kernel does (envs.h)
-    float Grow[kHalf];                     // G[it][(j0 + j + it) mod n] for j < tail = cnt & ~3, else 0
+    static constexpr int kRun = SMALL ? 4 : kHalf, kCols = SMALL ? kHalf : kMaxN;   // longest run of a lane; columns
+    float Grow[kRun];                      // G[it][(j0 + j + it) mod n] for j < tail = cnt & ~3, else 0
     float Gtail[3];                        // the cnt & 3 elements after them (else 0)
     float t_out, t_hall, k_out, k_hall, rcap, am_t;      // row it
     float lo, hi, mid, am;                 // lane i < n: bounds, their midpoint (lo + hi) / 2, air_max
-    float coef[kMaxN];                     // lane i < n: dtc[kk] * G[kk][i], with 0 at kk == i (added separately)
+    float coef[kCols];                     // lane i < n: dtc[kk] * G[kk][i], with 0 at kk == i (added separately)
     float Gii, gsum, dtc_i, k_out_i, k_hall_i;           // lane i < n: the diagonal of f_x
     float dtc_a, am_a;                     // lane n + a: the diagonal of f_u
 
@@ -88,7 +89,7 @@ template <bool SMALL> struct Lean<TFMPC_ENV_HVAC, SMALL> {
             return G[it * n + c];
         };
 #pragma unroll
-        for (int j = 0; j < kHalf; ++j) {
+        for (int j = 0; j < kRun; ++j) {
             if ((j & 3) == 0) __builtin_amdgcn_sched_barrier(0);
             Grow[j] = (j < tail) ? Gat(j) : 0.0f;
         }
@@ -107,7 +108,7 @@ template <bool SMALL> struct Lean<TFMPC_ENV_HVAC, SMALL> {
         if (st) for (int k = 0; k < n; ++k) gs += G[i * n + k];
         gsum = gs;
 #pragma unroll
-        for (int kk = 0; kk < kMaxN; ++kk) {
+        for (int kk = 0; kk < kCols; ++kk) {
             if ((kk & 3) == 0) __builtin_amdgcn_sched_barrier(0);     // one-time code: keep few loads in flight
             coef[kk] = (st && kk < n && kk != i) ? (TIME_DELTA / pcap[kk]) * G[kk * n + i] : 0.0f;
         }
@@ -150,7 +151,7 @@ template <bool SMALL> struct Lean<TFMPC_ENV_HVAC, SMALL> {
         float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
         const float *xr = x2 + off;
 #pragma unroll
-        for (int gq = 0; gq < kHalf / 4; ++gq) {
+        for (int gq = 0; gq < kRun / 4; ++gq) {
             if (gq == 2) __builtin_amdgcn_sched_barrier(0);
             if (SMALL && 4 * gq + 4 > per) break;            // wave-uniform: no run reaches this group of four
             s0 = fmaf(-Grow[4 * gq], xi - xr[4 * gq], s0);
@@ -184,7 +185,7 @@ template <bool SMALL> struct Lean<TFMPC_ENV_HVAC, SMALL> {
             // exact no-op (as do the rows >= n: 0 * 0) -- the order of ilqr_core.h backward_pass
             acc = fmaf(diag, vx[lane], grad_x(xh[lane]));
 #pragma unroll
-            for (int kk = 0; kk < kMaxN; ++kk) {
+            for (int kk = 0; kk < kCols; ++kk) {
                 if ((kk & 7) == 0) __builtin_amdgcn_sched_barrier(0);     // 8 V_x values in flight, not 32
                 if (SMALL && (kk & 7) == 0 && kk >= n) break;             // wave-uniform: the rest are 0 * 0
                 acc = fmaf(coef[kk], vx[kk], acc);
@@ -201,11 +202,12 @@ template <bool SMALL> struct Lean<TFMPC_ENV_HVAC, SMALL> {
 // ----------------------------------------------------------------------------- RESERVOIR ----
 template <bool SMALL> struct Lean<TFMPC_ENV_RESERVOIR, SMALL> {
     int n, it, part, j0, tail;
-    float Dcol[kHalf];                     // transition: D[j0 + j][it] for j < tail = cnt & ~3, else 0
+    static constexpr int kRun = SMALL ? 8 : kHalf, kCols = SMALL ? kHalf : kMaxN;   // longest run of a lane; columns
+    float Dcol[kRun];                      // transition: D[j0 + j][it] for j < tail = cnt & ~3, else 0
     float Dtail[3];                        // the cnt & 3 elements after them (else 0)
     float cap_t, rain_t;                   // row it
     float cap, lo, hi, mid, LP, HP, SP;    // lane i < n (mid = (lo + hi) / 2)
-    float Drow[kMaxN];                     // lanes i < n and n + a: D[i][kk] (row i = lane mod n), 0 at kk == i
+    float Drow[kCols];                     // lanes i < n and n + a: D[i][kk] (row i = lane mod n), 0 at kk == i
     float Dii;                             // D[i][i], added separately
 
     __device__ void load(const TfmpcEnv &g, int b)
@@ -222,7 +224,7 @@ template <bool SMALL> struct Lean<TFMPC_ENV_RESERVOIR, SMALL> {
         if (it >= n) j0 = 0;
         tail = cnt & ~3;
 #pragma unroll
-        for (int j = 0; j < kHalf; ++j) {
+        for (int j = 0; j < kRun; ++j) {
             if ((j & 3) == 0) __builtin_amdgcn_sched_barrier(0);
             Dcol[j] = (j < tail) ? D[(j0 + j) * n + it] : 0.0f;
         }
@@ -239,7 +241,7 @@ template <bool SMALL> struct Lean<TFMPC_ENV_RESERVOIR, SMALL> {
         const bool rv = rrow >= 0 && rrow < n && lane < 2 * n;
         Dii = rv ? D[rrow * n + rrow] : 0.0f;
 #pragma unroll
-        for (int kk = 0; kk < kMaxN; ++kk) {
+        for (int kk = 0; kk < kCols; ++kk) {
             if ((kk & 3) == 0) __builtin_amdgcn_sched_barrier(0);     // one-time code: keep few loads in flight
             Drow[kk] = (rv && kk < n && kk != rrow) ? D[rrow * n + kk] : 0.0f;
         }
@@ -266,7 +268,7 @@ template <bool SMALL> struct Lean<TFMPC_ENV_RESERVOIR, SMALL> {
         float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
         const float *xr = x2 + j0, *ur = u + j0;
 #pragma unroll
-        for (int gq = 0; gq < kHalf / 4; ++gq) {
+        for (int gq = 0; gq < kRun / 4; ++gq) {
             if (gq == 2) __builtin_amdgcn_sched_barrier(0);
             if (SMALL && 4 * gq + 4 > (n + 1) / 2) break;    // wave-uniform: no run reaches this group of four
             s0 = fmaf(Dcol[4 * gq], ur[4 * gq] * xr[4 * gq], s0);
@@ -297,7 +299,7 @@ template <bool SMALL> struct Lean<TFMPC_ENV_RESERVOIR, SMALL> {
             // diagonal term first, then the row by ascending column with a zero in the diagonal slot
             acc = fmaf(Dii * uj + diag_extra, vx[lane], grad_x(xh[lane]));
 #pragma unroll
-            for (int kk = 0; kk < kMaxN; ++kk) {                  // kk >= n: 0 * 0
+            for (int kk = 0; kk < kCols; ++kk) {                  // kk >= n: 0 * 0
                 if ((kk & 7) == 0) __builtin_amdgcn_sched_barrier(0);     // 8 V_x values in flight, not 32
                 if (SMALL && (kk & 7) == 0 && kk >= n) break;
                 acc = fmaf(Drow[kk] * uj, vx[kk], acc);
@@ -307,7 +309,7 @@ template <bool SMALL> struct Lean<TFMPC_ENV_RESERVOIR, SMALL> {
             const float xa = xh[a_];
             acc = fmaf(Dii * xa - xa, vx[a_], 0.0f);
 #pragma unroll
-            for (int kk = 0; kk < kMaxN; ++kk) {
+            for (int kk = 0; kk < kCols; ++kk) {
                 if ((kk & 7) == 0) __builtin_amdgcn_sched_barrier(0);
                 if (SMALL && (kk & 7) == 0 && kk >= n) break;
                 acc = fmaf(Drow[kk] * xa, vx[kk], acc);
@@ -320,9 +322,10 @@ template <bool SMALL> struct Lean<TFMPC_ENV_RESERVOIR, SMALL> {
 struct BackwardOut { float J, dV1, g_norm; };
 
 // 4 waves per SIMD (<= 128 VGPR, ~18 rarely used values in scratch): measured best of 3 / 4 / 5 / 6 on
-// cfg5 (the kernel is latency-bound; below 128 VGPR the spills reach the time loops)
+// cfg5 (the kernel is latency-bound; below 128 VGPR the spills reach the time loops); the n <= 16 variant keeps half the
+// matrix registers and runs 6 waves per SIMD (measured best of 4 / 5 / 6 / 8 on hvac6 and res4)
 template <int KIND, bool SMALL>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 4))) void ilqr_adjoint_solve_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SMALL ? 6 : 4, SMALL ? 6 : 4))) void ilqr_adjoint_solve_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     const int b = blockIdx.x, lane = lane_id(), n = genv.n, m = n, T = a.T;
