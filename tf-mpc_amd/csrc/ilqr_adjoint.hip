@@ -22,6 +22,9 @@
 
 #include <stdint.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "../../include/tfmpc_hip.h"
 #include "ilqr_adjoint.h"
 #include "wave_ops.h"
@@ -50,12 +53,38 @@ __device__ __forceinline__ int opaque(int v)
     return v;
 }
 
+// Reductions over a group of GS = 16 / 32 / 64 adjacent lanes (one instance per group).  Every value these kernels
+// reduce lives in the first 16 lanes of its group, so the row tree of wave_sum / wave_max gives the same bits at any GS.
+template <int GS>
+__device__ __forceinline__ float group_sum(float v)
+{
+    if (GS == kWave) return wave_sum(v);
+    v += dpp_move<kDppQuadXor1>(0.0f, v);
+    v += dpp_move<kDppQuadXor2>(0.0f, v);
+    v += dpp_move<kDppRowHalfMirror>(0.0f, v);
+    v += dpp_move<kDppRowMirror>(0.0f, v);                 // every lane: sum of its row of 16
+    if (GS == 32) v += __shfl_xor(v, 16, kWave);
+    return v;
+}
+template <int GS>
+__device__ __forceinline__ float group_max(float v)      // non-negative, non-NaN inputs (like wave_max)
+{
+    if (GS == kWave) return wave_max(v);
+    v = fmaxf(v, dpp_move<kDppQuadXor1>(0.0f, v));
+    v = fmaxf(v, dpp_move<kDppQuadXor2>(0.0f, v));
+    v = fmaxf(v, dpp_move<kDppRowHalfMirror>(0.0f, v));
+    v = fmaxf(v, dpp_move<kDppRowMirror>(0.0f, v));
+    if (GS == 32) v = fmaxf(v, __shfl_xor(v, 16, kWave));
+    return v;
+}
+
 // ---------------------------------------------------------------------------------- HVAC ----
 // SMALL: n <= 16 -- loops stop at the first all-zero group (wave-uniform tests) and HVAC rows are split over four
 // lanes like in the generic kernel; the n > 16 variant carries none of those tests in its time loops.
-template <int KIND, bool SMALL> struct Lean;
+template <int KIND, bool SMALL, int GS = kWave> struct Lean;      // GS: lanes per instance (lane index = gl)
 
-template <bool SMALL> struct Lean<TFMPC_ENV_HVAC, SMALL> {
+template <bool SMALL, int GS> struct Lean<TFMPC_ENV_HVAC, SMALL, GS> {
+    int gl;                                // lane within the instance's group
     static constexpr float CAP_AIR = 1.006f, COST_AIR = 1.0f, TEMP_AIR = 40.0f, TIME_DELTA = 1.0f;
     static constexpr float PENALTY = 20000.0f, SET_POINT_PENALTY = 10.0f;
     int n, it, part, off, tail, per;       // transition: row it = lane / parts, run [j0, j0 + cnt), off = it + j0
@@ -71,7 +100,7 @@ template <bool SMALL> struct Lean<TFMPC_ENV_HVAC, SMALL> {
 
     __device__ void load(const TfmpcEnv &g, int b)
     {
-        const int lane = lane_id();
+        const int lane = gl = lane_id() % GS;
         n = g.n;
         auto P = [&](int i) { return g.p[i] + (size_t)b * g.stride[i]; };
         const float *pt_out = P(0), *pt_hall = P(1), *plo = P(2), *phi = P(3), *pk_out = P(4), *pk_hall = P(5), *pcap = P(6),
@@ -127,14 +156,14 @@ template <bool SMALL> struct Lean<TFMPC_ENV_HVAC, SMALL> {
     __device__ float cost(const float *x, const float *u) const
     {
         float part_ = 0.0f;
-        if (lane_id() < n) part_ += COST_AIR * (u[lane_id()] * am) + penalties(x[lane_id()]);
-        return wave_sum(part_);
+        if (gl < n) part_ += COST_AIR * (u[gl] * am) + penalties(x[gl]);
+        return group_sum<GS>(part_);
     }
     __device__ float final_cost(const float *x) const
     {
         float part_ = 0.0f;
-        if (lane_id() < n) part_ += penalties(x[lane_id()]);
-        return wave_sum(part_);
+        if (gl < n) part_ += penalties(x[gl]);
+        return group_sum<GS>(part_);
     }
     __device__ __forceinline__ float grad_x(float x) const
     {
@@ -177,7 +206,7 @@ template <bool SMALL> struct Lean<TFMPC_ENV_HVAC, SMALL> {
     // Q_x[i] (lanes < n) and Q_u[a] (lanes n + a) of one backward step; xh, uh, vx in LDS
     __device__ __forceinline__ float adjoint(const float *xh, const float *uh, const float *vx) const
     {
-        const int lane = lane_id();
+        const int lane = gl;
         float acc = 0.0f;
         if (lane < n) {
             const float diag = 1.0f + dtc_i * (Gii - uh[lane] * am * CAP_AIR - gsum - k_out_i - k_hall_i);
@@ -200,7 +229,8 @@ template <bool SMALL> struct Lean<TFMPC_ENV_HVAC, SMALL> {
 };
 
 // ----------------------------------------------------------------------------- RESERVOIR ----
-template <bool SMALL> struct Lean<TFMPC_ENV_RESERVOIR, SMALL> {
+template <bool SMALL, int GS> struct Lean<TFMPC_ENV_RESERVOIR, SMALL, GS> {
+    int gl;                                // lane within the instance's group
     int n, it, part, j0, tail;
     static constexpr int kRun = SMALL ? 8 : kHalf, kCols = SMALL ? kHalf : kMaxN;   // longest run of a lane; columns
     float Dcol[kRun];                      // transition: D[j0 + j][it] for j < tail = cnt & ~3, else 0
@@ -212,7 +242,7 @@ template <bool SMALL> struct Lean<TFMPC_ENV_RESERVOIR, SMALL> {
 
     __device__ void load(const TfmpcEnv &g, int b)
     {
-        const int lane = lane_id();
+        const int lane = gl = lane_id() % GS;
         n = g.n;
         auto P = [&](int i) { return g.p[i] + (size_t)b * g.stride[i]; };
         const float *pcap = P(0), *plo = P(1), *phi = P(2), *plp = P(3), *php = P(4), *psp = P(5), *prain = P(6), *D = P(7);
@@ -249,14 +279,14 @@ template <bool SMALL> struct Lean<TFMPC_ENV_RESERVOIR, SMALL> {
     __device__ float cost(const float *x, const float *) const                            // reservoir :63-79
     {
         float part_ = 0.0f;
-        if (lane_id() < n) {
-            const float xv = x[lane_id()];
+        if (gl < n) {
+            const float xv = x[gl];
             const float c1 = LP * fmaxf(0.0f, lo - xv);
             const float c2 = HP * fmaxf(0.0f, xv - hi);
             const float c3 = SP * fabsf(mid - xv);
             part_ += c1 + c2 + c3;
         }
-        return wave_sum(part_);
+        return group_sum<GS>(part_);
     }
     __device__ float final_cost(const float *x) const { return cost(x, nullptr); }         // :81-83
     __device__ __forceinline__ float grad_x(float x) const
@@ -290,7 +320,7 @@ template <bool SMALL> struct Lean<TFMPC_ENV_RESERVOIR, SMALL> {
     }
     __device__ __forceinline__ float adjoint(const float *xh, const float *uh, const float *vx) const
     {
-        const int lane = lane_id();
+        const int lane = gl;
         float acc = 0.0f;
         if (lane < n) {
             const float uj = uh[lane];
@@ -470,6 +500,171 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SMALL ? 6
     }
 }
 
+// ---- several instances per wavefront (n <= 8) ------------------------------------------------------------------
+// A 6-room HVAC instance keeps 24 of the 64 lanes busy, a 4-reservoir instance 8.  Here a wave carries 64 / GS
+// instances, one per group of GS = 16 or 32 lanes, in lockstep: every tick all groups run one costate recursion, then
+// line-search rounds in which every group still searching rolls out ITS next step size; groups that are finished, or
+// have accepted, keep executing (their stores are masked) until the last group of the wave is done.  Per group the
+// state machine and the arithmetic are those of ilqr_adjoint_solve_kernel (so of the generic wave kernel: bit-identical,
+// which is how this is tested); scalars that were wave-uniform there are group-uniform vector values here.
+// 4 waves per SIMD: measured best of 3 / 4 / 5 / 6 / 8 on hvac6 and res4 (more group state, fewer spills).
+template <int KIND, int GS>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 4))) void ilqr_adjoint_group_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
+{
+    constexpr int G = kWave / GS;
+    __shared__ __attribute__((aligned(16))) float lds[G * kLdsFloats];
+    const int wl = lane_id(), grp = wl / GS, lane = wl % GS, n = genv.n, m = n, T = a.T;
+    const int b_raw = blockIdx.x * G + grp;
+    const bool live = b_raw < a.B;                       // the last wave may carry empty groups: they compute on the
+    const int b = live ? b_raw : a.B - 1;                // last instance's data and store nothing
+    Lean<KIND, true, GS> env;
+    env.load(genv, b);
+    float *slice = lds + grp * kLdsFloats;
+    float *xa = slice, *xb = slice + kXld, *ul = slice + 2 * kXld, *vx = slice + 2 * kXld + kMaxN;
+    for (int idx = wl; idx < G * kLdsFloats; idx += kWave) lds[idx] = 0.0f;
+    wsync();
+    const float low = (lane < m) ? genv.low[lane] : 0.0f, high = (lane < m) ? genv.high[lane] : 0.0f;
+    const int al = lane - n;
+    const float low_a = (al >= 0 && al < m) ? genv.low[al] : 0.0f, high_a = (al >= 0 && al < m) ? genv.high[al] : 0.0f;
+
+    float *xhat = a.states + (size_t)b * (T + 1) * n, *uhat = a.actions + (size_t)b * T * m, *chat = a.costs + (size_t)b * (T + 1);
+    float *kg = a.wsk + (size_t)b * T * m;
+    float *xc = a.wsx + (size_t)b * (T + 1) * n, *uc = a.wsu + (size_t)b * T * m, *cc = a.wsc + (size_t)b * (T + 1);
+
+    // one rollout of every group; `keep` (group-uniform) masks the stores of the trajectory
+    auto rollout = [&](auto next_u, bool from_x0, bool keep, float *xs, float *us, float *cs, float &J_out) {
+        float *xcur = xa, *xnext = xb;
+        if (lane < n) {
+            const float x = from_x0 ? a.x0[(size_t)b * n + lane] : xhat[lane];
+            xcur[lane] = x; xcur[n + lane] = x;
+            if (keep) xs[lane] = x;
+        }
+        float J = 0.0f;
+        float u_n = (lane < m && T > 0) ? next_u(0) : 0.0f;
+        for (int t = 0; t < T; ++t) {
+            const float u_c = u_n;
+            if (lane < m) { ul[lane] = u_c; if (keep) (us + (size_t)t * m)[lane] = u_c; }
+            if (lane < m && t + 1 < T) u_n = next_u(t + 1);
+            wsync();
+            const float c = env.cost(xcur, ul);
+            env.transition(xcur, ul, xnext);
+            J += c;
+            if (lane == 0 && keep) cs[t] = c;
+            wsync();
+            if (lane < n && keep) (xs + (size_t)(t + 1) * n)[lane] = xnext[lane];
+            float *tmp = xcur; xcur = xnext; xnext = tmp;
+        }
+        wsync();
+        const float fc = env.final_cost(xcur);
+        if (lane == 0 && keep) cs[T] = fc;
+        J_out = J + fc;
+        wsync();
+    };
+
+    {
+        const float *u0 = a.u_init + (size_t)b * T * m;
+        float J;
+        rollout([&](int t) { return (u0 + (size_t)t * m)[lane]; }, true, live, xhat, uhat, chat, J);
+    }
+
+    float mu = 0.0f, delta = 1.0f;
+    int status = 0, attempts = 0, iteration = 0;
+    bool done = !live || cfg.max_iterations <= 0;
+    while (__any(!done)) {
+        // ---- backward (ilqr.py:94-172 on the bang-bang branch): costate recursion, all groups ------------
+        BackwardOut r{0.0f, 0.0f, 0.0f};
+        {
+            if (lane < n) { const float x = (xhat + (size_t)T * n)[lane]; xa[lane] = x; xa[n + lane] = x; }
+            wsync();
+            if (lane < n) vx[lane] = env.grad_x(xa[lane]);
+            r.J = env.final_cost(xa);
+            float gsum = 0.0f;
+            float x_n = 0.0f, u_n = 0.0f;
+            if (T > 0) {
+                if (lane < n) x_n = (xhat + (size_t)(T - 1) * n)[lane];
+                else if (lane < n + m) u_n = (uhat + (size_t)(T - 1) * m)[al];
+            }
+            wsync();
+            for (int t = T - 1; t >= 0; --t) {
+                if (lane < n) { xa[lane] = x_n; xa[n + lane] = x_n; }
+                else if (lane < n + m) ul[al] = u_n;
+                const float uh_a = u_n;
+                if (t > 0) {
+                    if (lane < n) x_n = (xhat + (size_t)(t - 1) * n)[lane];
+                    else if (lane < n + m) u_n = (uhat + (size_t)(t - 1) * m)[al];
+                }
+                wsync();
+                const float l = env.cost(xa, ul);
+                const float acc = env.adjoint(xa, ul, vx);
+                float p1 = 0.0f, gmax = 0.0f;
+                if (lane >= n && lane < n + m) {
+                    const float kt = (acc >= 0.0f) ? (low_a - uh_a) : (high_a - uh_a);
+                    if (!done) (kg + (size_t)t * m)[al] = kt;
+                    p1 = fmaf(kt, acc, p1);
+                    gmax = fmaxf(gmax, fabsf(kt) / (fabsf(uh_a) + 1.0f));
+                }
+                r.J += l;
+                r.dV1 += group_sum<GS>(p1);
+                gsum += group_max<GS>(gmax);
+                wsync();
+                if (lane < n) vx[lane] = acc;
+                wsync();
+            }
+            r.g_norm = T > 0 ? gsum / (float)T : 0.0f;
+        }
+        const bool converged_g = !done && r.g_norm < cfg.atol;                 // :243-248
+        wsync();
+        // ---- line search rounds (ilqr.py:317-355): every searching group tries its next step size ------
+        const bool searching = !done && !converged_g;
+        bool accept = false;
+        float residual = 0.0f;
+        for (int ai = 0; ai < cfg.n_alphas && __any(searching && !accept); ++ai) {
+            const float alpha = cfg.alphas[ai];
+            const bool trying = searching && !accept;
+            float J, rmax = 0.0f;
+            rollout([&](int t) {
+                        const float du = alpha * (kg + (size_t)t * m)[lane];
+                        rmax = fmaxf(rmax, fabsf(du));
+                        return fminf(fmaxf((uhat + (size_t)t * m)[lane] + du, low), high);
+                    },
+                    false, trying, xc, uc, cc, J);
+            const float res = group_max<GS>(rmax);
+            const float delta_J = -alpha * (r.dV1 + alpha * 0.0f);
+            const float dcost = r.J - J;
+            const float z = (delta_J > 0.0f) ? dcost / delta_J : sgnf(dcost);
+            if (trying) {
+                residual = res;
+                if (z >= cfg.c1) accept = true;
+            }
+        }
+        const bool small_step = searching && residual < cfg.atol;            // :253-257
+        const bool take = searching && (small_step || accept);
+        {
+            for (int idx = lane; idx < (T + 1) * n; idx += GS) { const float v = xc[idx]; if (take) xhat[idx] = v; }
+            for (int idx = lane; idx < T * m; idx += GS) { const float v = uc[idx]; if (take) uhat[idx] = v; }
+            for (int idx = lane; idx <= T; idx += GS) { const float v = cc[idx]; if (take) chat[idx] = v; }
+            wsync();
+        }
+        if (converged_g || small_step) done = true;                            // converged
+        else if (searching && accept) {                                        // :259-266
+            delta = fminf(1.0f / cfg.delta_0, delta / cfg.delta_0);
+            mu = (mu * delta > cfg.mu_min) ? mu * delta : 0.0f;
+            if (++iteration >= cfg.max_iterations) done = true;
+        } else if (searching) {                                                // :267-270
+            delta = fmaxf(cfg.delta_0, delta * cfg.delta_0);
+            mu = fmaxf(cfg.mu_min, mu * delta);
+            if (++attempts >= cfg.max_attempts || !(mu < 1e30f)) { status |= TFMPC_ST_MAX_ATTEMPTS; done = true; }
+        }
+    }
+    if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
+    if (lane == 0 && live) {
+        const float c0 = chat[T];
+        if (!(c0 == c0)) status |= TFMPC_ST_NAN;
+        a.iterations[b] = iteration;
+        a.status[b] = status;
+    }
+}
+
 }  // namespace
 
 bool ilqr_adjoint_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg)
@@ -480,14 +675,29 @@ bool ilqr_adjoint_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg)
 
 int ilqr_adjoint_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const AdjointSolveArgs &a, hipStream_t stream)
 {
-    const dim3 grid(a.B), block(kWave);
+    const dim3 block(kWave);
     const bool small = env.n <= kHalf;
-    if (env.kind == TFMPC_ENV_HVAC) {
-        if (small) hipLaunchKernelGGL((ilqr_adjoint_solve_kernel<TFMPC_ENV_HVAC, true>), grid, block, 0, stream, env, cfg, a);
-        else hipLaunchKernelGGL((ilqr_adjoint_solve_kernel<TFMPC_ENV_HVAC, false>), grid, block, 0, stream, env, cfg, a);
+    // lanes an instance needs: HVAC splits a row over four lanes (n <= 16), Reservoir over two; both use 2 n lanes for Q_x, Q_u
+    const int lanes = (env.kind == TFMPC_ENV_HVAC && small) ? 4 * env.n : 2 * env.n;
+    const char *force = std::getenv("TFMPC_ILQR_KERNEL");                  // "lean1": one instance per wave (A/B, tests)
+    const bool packed = lanes <= 32 && !(force && std::strcmp(force, "lean1") == 0);
+    if (packed && lanes <= 16) {
+        const dim3 grid((a.B + 3) / 4);
+        if (env.kind == TFMPC_ENV_HVAC) hipLaunchKernelGGL((ilqr_adjoint_group_kernel<TFMPC_ENV_HVAC, 16>), grid, block, 0, stream, env, cfg, a);
+        else hipLaunchKernelGGL((ilqr_adjoint_group_kernel<TFMPC_ENV_RESERVOIR, 16>), grid, block, 0, stream, env, cfg, a);
+    } else if (packed) {
+        const dim3 grid((a.B + 1) / 2);
+        if (env.kind == TFMPC_ENV_HVAC) hipLaunchKernelGGL((ilqr_adjoint_group_kernel<TFMPC_ENV_HVAC, 32>), grid, block, 0, stream, env, cfg, a);
+        else hipLaunchKernelGGL((ilqr_adjoint_group_kernel<TFMPC_ENV_RESERVOIR, 32>), grid, block, 0, stream, env, cfg, a);
     } else {
-        if (small) hipLaunchKernelGGL((ilqr_adjoint_solve_kernel<TFMPC_ENV_RESERVOIR, true>), grid, block, 0, stream, env, cfg, a);
-        else hipLaunchKernelGGL((ilqr_adjoint_solve_kernel<TFMPC_ENV_RESERVOIR, false>), grid, block, 0, stream, env, cfg, a);
+        const dim3 grid(a.B);
+        if (env.kind == TFMPC_ENV_HVAC) {
+            if (small) hipLaunchKernelGGL((ilqr_adjoint_solve_kernel<TFMPC_ENV_HVAC, true>), grid, block, 0, stream, env, cfg, a);
+            else hipLaunchKernelGGL((ilqr_adjoint_solve_kernel<TFMPC_ENV_HVAC, false>), grid, block, 0, stream, env, cfg, a);
+        } else {
+            if (small) hipLaunchKernelGGL((ilqr_adjoint_solve_kernel<TFMPC_ENV_RESERVOIR, true>), grid, block, 0, stream, env, cfg, a);
+            else hipLaunchKernelGGL((ilqr_adjoint_solve_kernel<TFMPC_ENV_RESERVOIR, false>), grid, block, 0, stream, env, cfg, a);
+        }
     }
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
 }
