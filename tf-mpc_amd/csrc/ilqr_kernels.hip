@@ -470,12 +470,14 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
     a.wsc = w;
     hipStream_t st = static_cast<hipStream_t>(stream);
     {
-        // tiny 2-D envs: one lane per instance once the batch fills lanes (ilqr_lane.hip);
-        // TFMPC_ILQR_KERNEL=lane|wave forces the choice (tests, A/B timing)
+        // tiny 2-D envs: 16 lanes per instance with a speculative parallel line search (ilqr_lane.hip) at EVERY batch
+        // size -- also for one instance it has the shorter critical path (Navigation, T = 50, B = 1: 2.3 ms against
+        // 7.2 ms for the wave kernel; tools/small_batch_lane_vs_wave.py).  TFMPC_ILQR_KERNEL=lane|lane1|wave forces.
         const char *force = std::getenv("TFMPC_ILQR_KERNEL");
         const bool forced_lane = force && (std::strcmp(force, "lane") == 0 || std::strcmp(force, "lane1") == 0);
         const bool forced_wave = force && std::strcmp(force, "wave") == 0;
-        if (ilqr_lane_supported(*env) && !forced_wave && !cfg->storage_bf16 && (forced_lane || B >= 32))
+        (void)forced_lane;
+        if (ilqr_lane_supported(*env) && !forced_wave && !cfg->storage_bf16)
             return ilqr_lane_solve_launch(*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status,
                                           a.wsK, a.wsk, a.wsx, a.wsu, a.wsc, st);
     }
