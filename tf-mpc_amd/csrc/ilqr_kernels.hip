@@ -493,7 +493,7 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
         }
     }
     {
-        // HVAC / Reservoir at 16 < n <= 32: register-resident costate kernel (ilqr_adjoint.hip),
+        // HVAC / Reservoir at n <= 32: register-resident costate kernel (ilqr_adjoint.hip),
         // bit-identical to the generic wave kernel below (TFMPC_ILQR_KERNEL=wave selects that one)
         const char *force = std::getenv("TFMPC_ILQR_KERNEL");
         const bool forced_wave = force && std::strcmp(force, "wave") == 0;
