@@ -343,6 +343,9 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_TFLOPS, "traffic": measured_traffic(kernel, B),
                          "traffic_unit": "HBM bytes per launch (PMC, profiles/)",
+                         "traffic_note": "algorithmic bytes + the gain round trip: K_t, k_t (27.2 KB per solve) are produced "
+                                         "backwards and consumed forwards, written once and read once = 3.57 GB per launch "
+                                         "(DESIGN.md section 3.1)",
                          "kernel_ms": kernel_ms, "algorithmic_flop_per_iteration": lqr_flops_per_solve(n, m, T),
                          "algorithmic_bytes_per_iteration": lqr_bytes_per_solve(n, m, T),
                          "hbm_frac_at_algorithmic_bytes": lqr_bytes_per_solve(n, m, T) * B / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
