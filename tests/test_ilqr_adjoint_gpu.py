@@ -86,6 +86,31 @@ def test_packed_instances_finish_at_different_times(force_kernel, kind, n):
         assert torch.equal(out[None][key], out["wave"][key]), key
 
 
+@pytest.mark.parametrize("n,B", [(4, 50), (8, 21), (13, 9), (16, 6), (27, 5)])
+def test_dense_coupling_matrices_sum_in_the_same_order(force_kernel, n, B):
+    """The recipes above give chain topologies (one non-zero per column of `downstream`), for which any summation
+    order is exact.  With DENSE random couplings the register-resident kernels only stay bit-identical to the wave kernel
+    if both split and order the row sums the same way."""
+    T = 12
+    rng = np.random.default_rng(50 + n)
+    cfg = dict(problems.reservoir_config(n, seed=n))
+    cfg["downstream"] = rng.uniform(0.0, 0.3, size=(n, n)).astype(np.float32) * (1.0 - np.eye(n, dtype=np.float32))
+    hcfg = dict(problems.hvac_config(n, seed=n))
+    hcfg["adj"] = np.triu(np.ones((n, n), dtype=bool), 1)                        # every pair of rooms shares a wall
+    for env, x0 in ((Reservoir.load(cfg), rng.uniform(20.0, 90.0, size=(B, n, 1)).astype(np.float32)),
+                    (HVAC.load(hcfg), rng.uniform(5.0, 30.0, size=(B, n, 1)).astype(np.float32))):
+        solver = iLQR(env, max_iterations=5)
+        u0 = solver.random_actions(T, B, seed=n)
+        out = {}
+        for kern in (None, "lean1", "wave"):
+            force_kernel(kern)
+            out[kern] = solver.solve_device(x0, T, u_init=u0)
+            torch.cuda.synchronize()
+        for kern in (None, "lean1"):
+            for key in ("states", "actions", "costs", "iterations", "status"):
+                assert torch.equal(out[kern][key], out["wave"][key]), (type(env).__name__, kern, key)
+
+
 def test_per_instance_parameters(force_kernel):
     """Parameters with a batch stride (every instance its own env) go through the same loads."""
     n, T, B = 24, 10, 6

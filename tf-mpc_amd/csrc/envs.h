@@ -355,10 +355,10 @@ template <> struct Env<TFMPC_ENV_HVAC> {
         const float *t_out = e.p[0], *t_hall = e.p[1], *k_out = e.p[4], *k_hall = e.p[5], *cap = e.p[6],
                     *air_max = e.p[7], *G = e.p[8];
         // conduction between rooms, sum_j -G[i][j] (x_i - x_j) (:131-139): each row is split over
-        // `parts` adjacent lanes (all 64 lanes busy for n <= 32) and every lane keeps 4 independent
+        // `parts` adjacent lanes (all 64 lanes busy at n = 32) and every lane keeps 4 independent
         // partial sums so the LDS reads pipeline; the column walk is rotated by the row index so the
         // lanes of a half-wave hit different banks (leading dimension n = 32 would be a 32-way conflict).
-        const int parts = (n <= 16) ? 4 : ((n <= 32) ? 2 : 1);
+        const int parts = (n <= 32) ? 2 : 1;      // the register-resident kernels (ilqr_adjoint.hip) sum in this order too
         const int lane = lane_id();
         for (int base = 0; base < n; base += kWave / parts) {
             const int i = base + lane / parts, part = lane % parts;
@@ -505,7 +505,7 @@ template <> struct Env<TFMPC_ENV_RESERVOIR> {
         const int n = e.n, ldd = odd_ld(n);
         const float *cap = e.p[0], *rain = e.p[6], *D = e.p[7];
         // inflow_i = sum_j D[j][i] u_j x_j (:91): rows split over `parts` lanes, 4 partial sums per lane
-        const int parts = (n <= 16) ? 4 : ((n <= 32) ? 2 : 1);
+        const int parts = (n <= 32) ? 2 : 1;      // the register-resident kernels (ilqr_adjoint.hip) sum in this order too
         const int lane = lane_id();
         for (int base = 0; base < n; base += kWave / parts) {
             const int i = base + lane / parts, part = lane % parts;

@@ -79,8 +79,8 @@ __device__ __forceinline__ float group_max(float v)      // non-negative, non-Na
 }
 
 // ---------------------------------------------------------------------------------- HVAC ----
-// SMALL: n <= 16 -- loops stop at the first all-zero group (wave-uniform tests) and HVAC rows are split over four
-// lanes like in the generic kernel; the n > 16 variant carries none of those tests in its time loops.
+// SMALL: n <= 16 -- loops stop at the first all-zero group (wave-uniform tests) and half the matrix registers; the
+// n > 16 variant carries none of those tests in its time loops.
 template <int KIND, bool SMALL, int GS = kWave> struct Lean;      // GS: lanes per instance (lane index = gl)
 
 template <bool SMALL, int GS> struct Lean<TFMPC_ENV_HVAC, SMALL, GS> {
@@ -88,8 +88,7 @@ template <bool SMALL, int GS> struct Lean<TFMPC_ENV_HVAC, SMALL, GS> {
     static constexpr float CAP_AIR = 1.006f, COST_AIR = 1.0f, TEMP_AIR = 40.0f, TIME_DELTA = 1.0f;
     static constexpr float PENALTY = 20000.0f, SET_POINT_PENALTY = 10.0f;
     int n, it, part, off, tail, per;       // transition: row it = lane / parts, run [j0, j0 + cnt), off = it + j0
-    static constexpr bool quads = SMALL;   // n <= 16: a row is split over FOUR lanes, like the generic kernel does (envs.h)
-    static constexpr int kRun = SMALL ? 4 : kHalf, kCols = SMALL ? kHalf : kMaxN;   // longest run of a lane; columns
+    static constexpr int kRun = SMALL ? 8 : kHalf, kCols = SMALL ? kHalf : kMaxN;   // longest run of a lane; columns
     float Grow[kRun];                      // G[it][(j0 + j + it) mod n] for j < tail = cnt & ~3, else 0
     float Gtail[3];                        // the cnt & 3 elements after them (else 0)
     float t_out, t_hall, k_out, k_hall, rcap, am_t;      // row it
@@ -105,9 +104,8 @@ template <bool SMALL, int GS> struct Lean<TFMPC_ENV_HVAC, SMALL, GS> {
         auto P = [&](int i) { return g.p[i] + (size_t)b * g.stride[i]; };
         const float *pt_out = P(0), *pt_hall = P(1), *plo = P(2), *phi = P(3), *pk_out = P(4), *pk_hall = P(5), *pcap = P(6),
                     *pam = P(7), *G = P(8);
-        const int parts = quads ? 4 : 2;
-        it = lane / parts; part = lane % parts;
-        per = (n + parts - 1) / parts;
+        it = lane >> 1; part = lane & 1;
+        per = (n + 1) / 2;
         const int j0 = part * per, j1 = (j0 + per < n) ? j0 + per : n;
         const int cnt = (it < n && j1 > j0) ? j1 - j0 : 0;
         off = (it < n) ? it + j0 : 0;
@@ -192,7 +190,6 @@ template <bool SMALL, int GS> struct Lean<TFMPC_ENV_HVAC, SMALL, GS> {
         for (int q = 0; q < 3; ++q) s0 = fmaf(-Gtail[q], xi - xr[tail + q], s0);
         float between = (s0 + s1) + (s2 + s3);
         between += quad_xor1(between);
-        if (quads) between += quad_xor2(between);
         if (it < n && part == 0) {
             const float air = u[it] * am_t;                                               // :72
             const float heating = air * CAP_AIR * (TEMP_AIR - xi);                        // :74
@@ -677,8 +674,8 @@ int ilqr_adjoint_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const A
 {
     const dim3 block(kWave);
     const bool small = env.n <= kHalf;
-    // lanes an instance needs: HVAC splits a row over four lanes (n <= 16), Reservoir over two; both use 2 n lanes for Q_x, Q_u
-    const int lanes = (env.kind == TFMPC_ENV_HVAC && small) ? 4 * env.n : 2 * env.n;
+    // lanes an instance needs: two per row of the transition, and 2 n for Q_x, Q_u
+    const int lanes = 2 * env.n;
     const char *force = std::getenv("TFMPC_ILQR_KERNEL");                  // "lean1": one instance per wave (A/B, tests)
     const bool packed = lanes <= 32 && !(force && std::strcmp(force, "lean1") == 0);
     if (packed && lanes <= 16) {
