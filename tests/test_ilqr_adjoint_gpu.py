@@ -1,5 +1,5 @@
 """Register-resident HVAC / Reservoir solve (tf-mpc_amd/csrc/ilqr_adjoint.hip, n <= 32; for small n several
-instances per wavefront, `TFMPC_ILQR_KERNEL=lean1` forces one) against the generic wave-per-instance kernel.  All implement ilqr.py:214-355 on the bang-bang branch with the same
+instances per wavefront, `TFMPC_ILQR_KERNEL=lean`; `lean1` forces one) against the generic wave-per-instance kernel.  All implement ilqr.py:214-355 on the bang-bang branch with the same
 operation order, so every output must be BIT-identical -- also on Reservoir, where any rounding
 difference would flip line-search decisions and change trajectories completely."""
 
@@ -45,12 +45,12 @@ def test_register_resident_kernel_equals_wave_kernel(force_kernel, kind, n, T, B
     solver = iLQR(env, max_iterations=6)
     u0 = solver.random_actions(T, B, seed=n)
     out = {}
-    for kern in (None, "lean1", "wave"):      # packed where the shape allows it / one instance per wave / generic
+    for kern in ("lean", "lean1", "wave"):    # packed where the shape allows it / one instance per wave / generic
         force_kernel(kern)
         out[kern] = solver.solve_device(x0, T, u_init=u0)
         torch.cuda.synchronize()
     wave = out["wave"]
-    for kern in (None, "lean1"):
+    for kern in ("lean", "lean1"):
         fast = out[kern]
         assert torch.equal(fast["iterations"], wave["iterations"]), kern
         assert torch.equal(fast["status"], wave["status"]), kern
@@ -75,15 +75,15 @@ def test_packed_instances_finish_at_different_times(force_kernel, kind, n):
     solver = iLQR(env, max_iterations=30, atol=0.05)
     u0 = solver.random_actions(T, B, seed=n)
     out = {}
-    for kern in (None, "wave"):
+    for kern in ("lean", "wave"):
         force_kernel(kern)
         out[kern] = solver.solve_device(x0, T, u_init=u0)
         torch.cuda.synchronize()
     its = out["wave"]["iterations"]
     assert len(torch.unique(its)) >= 5, torch.unique(its)          # the scenario does spread the finishing times
-    assert torch.equal(out[None]["iterations"], its) and torch.equal(out[None]["status"], out["wave"]["status"])
+    assert torch.equal(out["lean"]["iterations"], its) and torch.equal(out["lean"]["status"], out["wave"]["status"])
     for key in ("states", "actions", "costs"):
-        assert torch.equal(out[None][key], out["wave"][key]), key
+        assert torch.equal(out["lean"][key], out["wave"][key]), key
 
 
 @pytest.mark.parametrize("n,B", [(4, 50), (8, 21), (13, 9), (16, 6), (27, 5)])
@@ -102,11 +102,11 @@ def test_dense_coupling_matrices_sum_in_the_same_order(force_kernel, n, B):
         solver = iLQR(env, max_iterations=5)
         u0 = solver.random_actions(T, B, seed=n)
         out = {}
-        for kern in (None, "lean1", "wave"):
+        for kern in ("lean", "lean1", "wave"):
             force_kernel(kern)
             out[kern] = solver.solve_device(x0, T, u_init=u0)
             torch.cuda.synchronize()
-        for kern in (None, "lean1"):
+        for kern in ("lean", "lean1"):
             for key in ("states", "actions", "costs", "iterations", "status"):
                 assert torch.equal(out[kern][key], out["wave"][key]), (type(env).__name__, kern, key)
 

@@ -1,0 +1,156 @@
+"""Sixteen instances per wavefront with the coupling-matrix products on the matrix cores
+(tf-mpc_amd/csrc/ilqr_adjoint_mfma.hip; HVAC / Reservoir envs shared by the batch, `TFMPC_ILQR_KERNEL=costate_mfma`,
+the default from B = 16) against the generic wave-per-instance kernel and the fp64 oracle.
+
+Reservoir keeps the wave kernels' operation order and reduction trees, and on a 0/1 `downstream` matrix (every
+reference config) a row of the coupling product is a single exact term: there every output must be BIT-identical, which
+is the only meaningful comparison on this env (any rounding difference flips line-search decisions and changes the
+trajectories completely).  HVAC folds the linear part of the room balance into the matrix, so it agrees to fp32
+rounding until a bang-bang decision flips: most instances to ~1e-7, a few per cent differently but equally good."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import problems
+from tfmpc.envs.hvac import HVAC
+from tfmpc.envs.reservoir import Reservoir
+from tfmpc.solvers.ilqr import iLQR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def force_kernel():
+    old = os.environ.get("TFMPC_ILQR_KERNEL")
+
+    def set_(name):
+        if name is None:
+            os.environ.pop("TFMPC_ILQR_KERNEL", None)
+        else:
+            os.environ["TFMPC_ILQR_KERNEL"] = name
+    yield set_
+    set_(old)
+
+
+def _env(kind, n, B, seed):
+    rng = np.random.default_rng(100 + n)
+    if kind == "hvac":
+        return HVAC.load(dict(problems.hvac_config(n, seed=seed))), rng.uniform(5.0, 30.0, size=(B, n, 1)).astype(np.float32)
+    return Reservoir.load(dict(problems.reservoir_config(n, seed=seed))), rng.uniform(20.0, 90.0, size=(B, n, 1)).astype(np.float32)
+
+
+def _both(force_kernel, solver, x0, T, u0, kernels=("wave", "costate_mfma")):
+    out = {}
+    for kern in kernels:
+        force_kernel(kern)
+        out[kern] = {k: v.clone() for k, v in solver.solve_device(x0, T, u_init=u0).items() if torch.is_tensor(v) and k != "workspace"}
+        torch.cuda.synchronize()
+    return out
+
+
+SHAPES = [(32, 24, 70), (21, 13, 9), (17, 7, 5), (30, 40, 33), (32, 1, 1), (18, 2, 3), (16, 9, 7), (12, 11, 4),
+          (6, 20, 40), (4, 15, 33), (2, 5, 3), (3, 1, 2), (8, 12, 130), (5, 30, 257), (7, 3, 1), (28, 30, 16)]
+
+
+@pytest.mark.parametrize("n,T,B", SHAPES)
+def test_reservoir_is_bit_identical_to_the_wave_kernel(force_kernel, n, T, B):
+    env, x0 = _env("reservoir", n, B, n)
+    solver = iLQR(env, max_iterations=6)
+    u0 = solver.random_actions(T, B, seed=n)
+    out = _both(force_kernel, solver, x0, T, u0)
+    for key in ("iterations", "status", "states", "actions", "costs"):
+        assert torch.equal(out["costate_mfma"][key], out["wave"][key]), key
+    assert bool(torch.isfinite(out["costate_mfma"]["costs"]).all())
+
+
+@pytest.mark.parametrize("n,T,B,iters,atol", [(32, 100, 512, 12, None), (8, 25, 203, 30, 0.05), (20, 25, 100, 30, 0.05)])
+def test_reservoir_columns_finish_at_different_times(force_kernel, n, T, B, iters, atol):
+    """The 16 instances of a wave run in lockstep; columns that converge early (loose atol) keep executing with masked
+    stores, and the nominal / candidate buffers flip per column.  Still bit-identical to the wave kernel."""
+    env, x0 = _env("reservoir", n, B, n)
+    kw = {} if atol is None else {"atol": atol}
+    solver = iLQR(env, max_iterations=iters, **kw)
+    u0 = solver.random_actions(T, B, seed=n)
+    out = _both(force_kernel, solver, x0, T, u0)
+    if atol is not None:
+        assert len(torch.unique(out["wave"]["iterations"])) >= 4       # the scenario does spread the finishing times
+    for key in ("iterations", "status", "states", "actions", "costs"):
+        assert torch.equal(out["costate_mfma"][key], out["wave"][key]), key
+
+
+def test_default_dispatch_takes_the_matrix_core_kernel_from_16_instances(force_kernel):
+    """B >= 16 on a shared env goes to the 16-per-wave kernel without any forcing; per-instance envs and small batches
+    stay on the register-resident kernels (both equal the wave kernel bit for bit on Reservoir)."""
+    env, x0 = _env("reservoir", 24, 40, 3)
+    solver = iLQR(env, max_iterations=5)
+    u0 = solver.random_actions(15, 40, seed=2)
+    out = _both(force_kernel, solver, x0, 15, u0, kernels=("wave", None, "costate_mfma"))
+    for key in ("iterations", "states", "actions", "costs"):
+        assert torch.equal(out[None][key], out["wave"][key]) and torch.equal(out["costate_mfma"][key], out["wave"][key])
+
+
+@pytest.mark.parametrize("n,T,B", SHAPES)
+def test_hvac_tracks_the_wave_kernel(force_kernel, n, T, B):
+    env, x0 = _env("hvac", n, B, n)
+    solver = iLQR(env, max_iterations=6)
+    u0 = solver.random_actions(T, B, seed=n)
+    out = _both(force_kernel, solver, x0, T, u0)
+    w, f = out["wave"], out["costate_mfma"]
+    assert bool(torch.isfinite(f["costs"]).all())
+    assert torch.equal(w["status"], f["status"])
+    rel = ((w["states"] - f["states"]).abs().flatten(1).max(dim=1).values /
+           w["states"].abs().flatten(1).max(dim=1).values)
+    close = rel < 2e-6                                            # fp32 rounding through <= 6 iterations
+    assert float(close.float().mean()) >= 0.9, float(rel.max())   # the rest: a bang-bang decision flipped
+    assert bool((w["iterations"] == f["iterations"])[close].all())
+    tw, tf_ = w["costs"].sum(dim=1), f["costs"].sum(dim=1)
+    assert float(((tw - tf_).abs() / tw.abs()).max()) < 1e-3       # flipped or not, the solutions are equally good
+
+
+def test_hvac_first_iterations_match_the_fp64_oracle_at_n24(force_kernel):
+    """The oracle test of the register-resident kernel (tests/test_ilqr_adjoint_gpu.py), for the 16-per-wave kernel:
+    16 different start states in one wave, each against the fp64 restatement of ilqr.py + hvac/__init__.py."""
+    from oracle import envs_ref, ilqr_ref
+    n, T, B = 24, 12, 16
+    cfg = problems.hvac_config(n, seed=7)
+    rng = np.random.default_rng(1)
+    x0 = rng.uniform(5.0, 30.0, size=(B, n, 1)).astype(np.float32)
+    solver = iLQR(HVAC.load(dict(cfg)), max_iterations=2)
+    u0 = solver.random_actions(T, B, seed=3)
+    force_kernel("costate_mfma")
+    out = solver.solve_device(x0, T, u_init=u0)
+    torch.cuda.synchronize()
+    states, its = out["states"].cpu().numpy()[..., 0], out["iterations"].cpu().numpy()
+    o = ilqr_ref.ILQRRef(envs_ref.HVAC(**cfg, dtype=np.float64), dtype=np.float64, max_iterations=2)
+    for b in (0, 5, 15):
+        xs, us, cs, it64 = o.solve(x0[b].astype(np.float64), T, u_init=u0[b].cpu().numpy().astype(np.float64))
+        assert int(its[b]) == it64
+        assert np.abs(states[b] - xs[..., 0]).max() <= 1e-4 * np.abs(xs).max()
+
+
+@pytest.mark.parametrize("kind", ["hvac", "reservoir"])
+def test_dense_couplings_solve_as_well_as_the_wave_kernel(force_kernel, kind):
+    """Dense random couplings: the matrix-core row sums round differently from the wave kernel's, so trajectories may
+    part ways at a flipped decision -- but the first rollout (no decisions yet) agrees to rounding and the solves end
+    at costs of the same quality."""
+    n, T, B = 27, 12, 64
+    rng = np.random.default_rng(50 + n)
+    if kind == "reservoir":
+        cfg = dict(problems.reservoir_config(n, seed=n))
+        cfg["downstream"] = rng.uniform(0.0, 0.3, size=(n, n)).astype(np.float32) * (1.0 - np.eye(n, dtype=np.float32))
+        env, x0 = Reservoir.load(cfg), rng.uniform(20.0, 90.0, size=(B, n, 1)).astype(np.float32)
+    else:
+        cfg = dict(problems.hvac_config(n, seed=n))
+        cfg["adj"] = np.triu(np.ones((n, n), dtype=bool), 1)
+        env, x0 = HVAC.load(cfg), rng.uniform(5.0, 30.0, size=(B, n, 1)).astype(np.float32)
+    u0 = iLQR(env).random_actions(T, B, seed=n)
+    start = _both(force_kernel, iLQR(env, max_iterations=1, atol=1e9), x0, T, u0)     # "converged" at once: the start rollout
+    rel = (start["wave"]["states"] - start["costate_mfma"]["states"]).abs().max() / start["wave"]["states"].abs().max()
+    assert float(rel) < 2e-6
+    full = _both(force_kernel, iLQR(env, max_iterations=5), x0, T, u0)
+    tw, tf_ = full["wave"]["costs"].sum(dim=1), full["costate_mfma"]["costs"].sum(dim=1)
+    assert bool(torch.isfinite(tf_).all())
+    assert float(tf_.median()) <= float(tw.median()) * 1.05 + 1e-3                # costs are positive on both envs

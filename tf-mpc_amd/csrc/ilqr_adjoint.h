@@ -20,4 +20,9 @@ struct AdjointSolveArgs {
 bool ilqr_adjoint_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg);
 int ilqr_adjoint_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const AdjointSolveArgs &a, hipStream_t stream);
 
+// sixteen instances per wave, coupling-matrix products on the matrix cores (ilqr_adjoint_mfma.hip): envs whose
+// parameters are shared by the whole batch
+bool ilqr_adjoint_mfma_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg);
+int ilqr_adjoint_mfma_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const AdjointSolveArgs &a, hipStream_t stream);
+
 }  // namespace tfmpc

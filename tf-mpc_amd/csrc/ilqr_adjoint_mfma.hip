@@ -1,0 +1,524 @@
+// ilqr_adjoint_mfma.hip -- iLQR.solve (tfmpc/solvers/ilqr.py:214-355) for HVAC (tfmpc/envs/hvac/__init__.py) and
+// Reservoir (tfmpc/envs/reservoir/__init__.py) when the env is SHARED by the batch (every parameter has batch
+// stride 0, which is what the reference's one-env-object API gives): SIXTEEN instances per wavefront, the coupling
+// matrix products on the matrix cores.
+//
+// On these envs the backward pass is the costate recursion (bang-bang branch, ilqr.py:140-141) and every
+// rollout is open loop, so all the dense work of an iteration is  y = M z  with a matrix that is the same for every
+// instance and every timestep: HVAC's wall-conduction matrix G, Reservoir's `downstream` D.  With one instance per
+// wave (ilqr_adjoint.hip) that is a mat-vec per wave and step, ~100 vector instructions and an LDS exchange of x.
+// Here the 16 states of a wave form the matrix X (n x 16) and  Y = M X  is 16 `v_mfma_f32_16x16x4_f32` at n = 32
+// (exact fp32 multiply-adds), with M resident in 16 registers as the A operands and X ALREADY in operand layout:
+//   * lane (j, q) = (lane & 15, lane >> 4) holds rows 16 b + 4 q + r (b < NT, r < 4) of column j = instance j -- the
+//     accumulator layout of the 16x16 tile b -- as registers e = 4 b + r;
+//   * enumerating the contraction as k-step (b, r) = "row 16 b + 4 q + r from lane quarter q", register e of X is the
+//     B operand of k-step e as it stands, and the A operand of output tile a is M[16 a + (lane & 15)][16 b + 4 q + r]:
+//     no LDS, no cross-lane traffic between a step's result and the next step's operand;
+//   * everything else of a step is element-wise on the 4 NT values a lane owns (costs, clipping, the bilinear / sine
+//     terms), with per-row parameters in registers; the only cross-lane work is the column sum of the stage cost and
+//     the column max of the gradient norm (two lane exchanges each).
+// The 16 instances run the reference state machine in lockstep with masked stores (as ilqr_adjoint_group_kernel does
+// for its 2 / 4 groups): one costate sweep, then line-search rounds in which every instance still searching rolls out
+// ITS next step size; the nominal and candidate trajectories ping-pong between the output arrays and the workspace per
+// instance (no copy on acceptance), the gains k_t stream through the workspace.
+//
+// Arithmetic: Reservoir keeps the operation order of the wave kernels for every element-wise expression, the cost
+// reduction tree and the J / value bookkeeping, so on 0/1 `downstream` matrices (every reference config: a row sum is
+// then a single exact term) its results are BIT-identical to theirs -- that is how it is tested.  HVAC folds the linear
+// part of the room balance into the matrix (conduction - row sums - outside / hall conductances) and is compared within
+// fp32 tolerance.  Dense couplings: tolerance as well (the MFMA sums four products per accumulate).
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "../../include/tfmpc_hip.h"
+#include "ilqr_adjoint.h"
+#include "wave_ops.h"
+
+namespace tfmpc {
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kCols = 16;                 // instances per wave
+
+__device__ __forceinline__ float sgnf_(float y) { return (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f); }
+
+// exchange with the lanes that hold the other rows of this column: lane ^ 16, lane ^ 32
+__device__ __forceinline__ float xq16(float v) { return __shfl_xor(v, 16, kWave); }
+__device__ __forceinline__ float xq32(float v) { return __shfl_xor(v, 32, kWave); }
+// sum over the 16 rows of one tile, balanced tree in row order (= the row tree of wave_sum / group_sum)
+__device__ __forceinline__ float tile_sum(float s4)
+{
+    s4 += xq16(s4);
+    s4 += xq32(s4);
+    return s4;
+}
+template <int NT>
+__device__ __forceinline__ float col_sum(const float (&v)[4 * NT])
+{
+    float t = tile_sum((v[0] + v[1]) + (v[2] + v[3]));
+    if (NT == 2) t += tile_sum((v[4] + v[5]) + (v[6] + v[7]));
+    return t;
+}
+template <int NT>
+__device__ __forceinline__ float col_max(const float (&v)[4 * NT])         // non-negative inputs
+{
+    float mx = v[0];
+#pragma unroll
+    for (int e = 1; e < 4 * NT; ++e) mx = fmaxf(mx, v[e]);
+    mx = fmaxf(mx, xq16(mx));
+    mx = fmaxf(mx, xq32(mx));
+    return mx;
+}
+
+template <int NT>
+__device__ __forceinline__ int row_of(int e, int q) { return 16 * (e >> 2) + 4 * q + (e & 3); }
+
+// per-row parameter vector p[0..n) -> this lane's 4 NT rows (rows >= n: dflt)
+template <int NT>
+__device__ __forceinline__ void load_rows(const float *p, int n, int q, float dflt, float (&o)[4 * NT])
+{
+#pragma unroll
+    for (int e = 0; e < 4 * NT; ++e) {
+        const int r = row_of<NT>(e, q);
+        o[e] = (r < n) ? p[r] : dflt;
+    }
+}
+
+// one instance-time vector v[0..n) of a trajectory <-> this lane's rows; VEC: n % 4 == 0 and 16-byte aligned arrays
+template <int NT, bool VEC>
+__device__ __forceinline__ void ldv(const float *p, int n, int q, float (&o)[4 * NT])
+{
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int r0 = 16 * b + 4 * q;
+        if (VEC) {
+            float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (r0 < n) t = *reinterpret_cast<const float4 *>(p + r0);
+            o[4 * b] = t.x; o[4 * b + 1] = t.y; o[4 * b + 2] = t.z; o[4 * b + 3] = t.w;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[4 * b + r] = (r0 + r < n) ? p[r0 + r] : 0.0f;
+        }
+    }
+}
+template <int NT, bool VEC>
+__device__ __forceinline__ void stv(float *p, int n, int q, bool keep, const float (&v)[4 * NT])
+{
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int r0 = 16 * b + 4 * q;
+        if (VEC) {
+            if (keep && r0 < n) *reinterpret_cast<float4 *>(p + r0) = make_float4(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (keep && r0 + r < n) p[r0 + r] = v[4 * b + r];
+        }
+    }
+}
+
+// acc (tile a, this lane's rows) += sum over rows of A[a][.] * z : NT x NT x 4 MFMAs, the NT accumulation chains
+// interleaved (a dependent v_mfma_f32_16x16x4_f32 waits 40 cycles, an independent one issues after 32)
+template <int NT>
+__device__ __forceinline__ void mat_apply(const float (&A)[NT][NT][4], const float (&z)[4 * NT], float (&acc)[4 * NT])
+{
+    f32x4 c[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) c[a] = f32x4{acc[4 * a], acc[4 * a + 1], acc[4 * a + 2], acc[4 * a + 3]};
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int a = 0; a < NT; ++a) c[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[a][b][r], z[4 * b + r], c[a], 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+        acc[4 * a] = c[a][0]; acc[4 * a + 1] = c[a][1]; acc[4 * a + 2] = c[a][2]; acc[4 * a + 3] = c[a][3];
+    }
+}
+
+// A operands of  Y = M Z  for a matrix given element-wise: el(R, C) = M[R][C] (0 outside n x n)
+template <int NT, class F>
+__device__ __forceinline__ void load_operand(int n, int i, int q, F el, float (&A)[NT][NT][4])
+{
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int R = 16 * a + i, C = 16 * b + 4 * q + r;
+                A[a][b][r] = (R < n && C < n) ? el(R, C) : 0.0f;
+            }
+}
+
+template <int KIND, int NT> struct EnvM;
+
+// ---------------------------------------------------------------------------------- HVAC ----
+// x' = x + rcap (heating + [A x + c0])   with  A = G - diag(gsum + k_out + k_hall),  c0 = k_out t_out + k_hall t_hall
+// (hvac/__init__.py:69-89, :131-149);  Q_x = l_x + V_x - u am CAP w + A^T w,  w = rcap V_x;  Q_u = COST am + am CAP (TEMP - x) w
+template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
+    static constexpr int NV = 4 * NT;
+    static constexpr float CAP_AIR = 1.006f, COST_AIR = 1.0f, TEMP_AIR = 40.0f, TIME_DELTA = 1.0f;
+    static constexpr float PENALTY = 20000.0f, SET_POINT_PENALTY = 10.0f;
+    float Af[NT][NT][4], Ab[NT][NT][4];
+    float lo[NV], hi[NV], am[NV], rcap[NV], c0[NV];
+
+    __device__ void load(const TfmpcEnv &g, int i, int q)
+    {
+        const int n = g.n;
+        const float *pt_out = g.p[0], *pt_hall = g.p[1], *plo = g.p[2], *phi = g.p[3], *pk_out = g.p[4], *pk_hall = g.p[5],
+                    *pcap = g.p[6], *pam = g.p[7], *G = g.p[8];
+        auto el = [&](int R, int C) {
+            float v = G[R * n + C];
+            if (R == C) {
+                float gs = 0.0f;
+                for (int k = 0; k < n; ++k) gs += G[R * n + k];
+                v -= gs + pk_out[R] + pk_hall[R];
+            }
+            return v;
+        };
+        load_operand<NT>(n, i, q, el, Af);
+        load_operand<NT>(n, i, q, [&](int R, int C) { return el(C, R); }, Ab);
+        load_rows<NT>(plo, n, q, 0.0f, lo);
+        load_rows<NT>(phi, n, q, 0.0f, hi);
+        load_rows<NT>(pam, n, q, 0.0f, am);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const int r = row_of<NT>(e, q);
+            rcap[e] = (r < n) ? TIME_DELTA / pcap[r] : 0.0f;
+            c0[e] = (r < n) ? pk_out[r] * pt_out[r] + pk_hall[r] * pt_hall[r] : 0.0f;
+        }
+    }
+    __device__ __forceinline__ float penalties(float x, int e) const
+    {
+        const float mid = (lo[e] + hi[e]) / 2;
+        const float oob = PENALTY * (fmaxf(0.0f, lo[e] - x) + fmaxf(0.0f, x - hi[e]));      // hvac :97-100
+        const float sp = SET_POINT_PENALTY * fabsf(mid - x);                              // :101-105
+        return oob + sp;
+    }
+    __device__ __forceinline__ float stage_cost(float x, float u, int e) const { return COST_AIR * (u * am[e]) + penalties(x, e); }
+    __device__ __forceinline__ float final_cost(float x, int e) const { return penalties(x, e); }
+    __device__ __forceinline__ float grad_x(float x, int e) const
+    {
+        const float mid = (lo[e] + hi[e]) / 2;
+        return PENALTY * (-(lo[e] > x ? 1.0f : 0.0f) + (x > hi[e] ? 1.0f : 0.0f)) - SET_POINT_PENALTY * sgnf_(mid - x);
+    }
+    __device__ __forceinline__ void step(const float (&x)[NV], const float (&u)[NV], float (&xn)[NV]) const
+    {
+        float acc[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) acc[e] = c0[e];
+        mat_apply<NT>(Af, x, acc);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const float air = u[e] * am[e];                                               // :72
+            const float heating = air * CAP_AIR * (TEMP_AIR - x[e]);                      // :74
+            xn[e] = x[e] + rcap[e] * (heating + acc[e]);                                  // :80-88
+        }
+    }
+    __device__ __forceinline__ void adjoint(const float (&xh)[NV], const float (&uh)[NV], const float (&vx)[NV],
+                                            float (&Qx)[NV], float (&Qu)[NV]) const
+    {
+        float w[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            w[e] = rcap[e] * vx[e];
+            Qx[e] = fmaf(-(uh[e] * am[e] * CAP_AIR), w[e], grad_x(xh[e], e) + vx[e]);
+        }
+        mat_apply<NT>(Ab, w, Qx);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const float d = rcap[e] * am[e] * CAP_AIR * (TEMP_AIR - xh[e]);
+            Qu[e] = fmaf(d, vx[e], COST_AIR * am[e]);
+        }
+    }
+};
+
+// ----------------------------------------------------------------------------- RESERVOIR ----
+// element-wise expressions in the order of ilqr_adjoint.hip / envs.h (reservoir/__init__.py:47-105)
+template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
+    static constexpr int NV = 4 * NT;
+    float Af[NT][NT][4], Ab[NT][NT][4];              // D^T (inflow = D^T (u x)), D without its diagonal
+    float cap[NV], lo[NV], hi[NV], LP[NV], HP[NV], SP[NV], rain[NV], Dii[NV];
+
+    __device__ void load(const TfmpcEnv &g, int i, int q)
+    {
+        const int n = g.n;
+        const float *pcap = g.p[0], *plo = g.p[1], *phi = g.p[2], *plp = g.p[3], *php = g.p[4], *psp = g.p[5], *prain = g.p[6],
+                    *D = g.p[7];
+        load_operand<NT>(n, i, q, [&](int R, int C) { return D[C * n + R]; }, Af);
+        load_operand<NT>(n, i, q, [&](int R, int C) { return (R == C) ? 0.0f : D[R * n + C]; }, Ab);
+        load_rows<NT>(pcap, n, q, 1.0f, cap);
+        load_rows<NT>(plo, n, q, 0.0f, lo);
+        load_rows<NT>(phi, n, q, 0.0f, hi);
+        load_rows<NT>(prain, n, q, 0.0f, rain);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const int r = row_of<NT>(e, q);
+            const bool st = r < n;
+            LP[e] = st ? -plp[r] : 0.0f; HP[e] = st ? -php[r] : 0.0f; SP[e] = st ? -psp[r] : 0.0f;
+            Dii[e] = st ? D[r * n + r] : 0.0f;
+        }
+    }
+    __device__ __forceinline__ float stage_cost(float x, float, int e) const               // reservoir :63-79
+    {
+        const float mid = (lo[e] + hi[e]) / 2.0f;
+        const float c1 = LP[e] * fmaxf(0.0f, lo[e] - x);
+        const float c2 = HP[e] * fmaxf(0.0f, x - hi[e]);
+        const float c3 = SP[e] * fabsf(mid - x);
+        return c1 + c2 + c3;
+    }
+    __device__ __forceinline__ float final_cost(float x, int e) const { return stage_cost(x, 0.0f, e); }     // :81-83
+    __device__ __forceinline__ float grad_x(float x, int e) const
+    {
+        const float mid = (lo[e] + hi[e]) / 2.0f;
+        return -LP[e] * (lo[e] > x ? 1.0f : 0.0f) + HP[e] * (x > hi[e] ? 1.0f : 0.0f) - SP[e] * sgnf_(mid - x);
+    }
+    __device__ __forceinline__ void step(const float (&x)[NV], const float (&u)[NV], float (&xn)[NV]) const
+    {
+        float z[NV], inflow[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) { z[e] = u[e] * x[e]; inflow[e] = 0.0f; }
+        mat_apply<NT>(Af, z, inflow);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const float xi = x[e];
+            const float vaporated = 0.5f * sinf(xi / cap[e]) * xi;                        // :87
+            xn[e] = xi + rain[e] + inflow[e] - vaporated - u[e] * xi;                     // :56-60
+        }
+    }
+    __device__ __forceinline__ void adjoint(const float (&xh)[NV], const float (&uh)[NV], const float (&vx)[NV],
+                                            float (&Qx)[NV], float (&Qu)[NV]) const
+    {
+        float Y[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) Y[e] = 0.0f;
+        mat_apply<NT>(Ab, vx, Y);                                                         // sum_{k != i} D[i][k] V_x[k]
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const float uj = uh[e], xa = xh[e];
+            const float r = xa / cap[e];
+            const float diag_extra = 1.0f - 0.5f * (cosf(r) * r + sinf(r)) - uj;
+            Qx[e] = fmaf(uj, Y[e], fmaf(Dii[e] * uj + diag_extra, vx[e], grad_x(xa, e)));
+            Qu[e] = fmaf(xa, Y[e], fmaf(Dii[e] * xa - xa, vx[e], 0.0f));
+        }
+    }
+};
+
+template <int KIND, int NT, bool VEC>
+__global__ __launch_bounds__(kWave) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
+{
+    constexpr int NV = 4 * NT;
+    const int lane = lane_id(), j = lane & 15, q = lane >> 4, n = genv.n, m = n, T = a.T;
+    const int b_raw = blockIdx.x * kCols + j;
+    const bool live = b_raw < a.B;                       // the last wave may carry empty columns: they compute on the
+    const size_t b = live ? b_raw : a.B - 1;             // last instance's data and store nothing
+    EnvM<KIND, NT> env;
+    env.load(genv, j, q);
+    float alow[NV], ahigh[NV];
+    load_rows<NT>(genv.low, m, q, 0.0f, alow);
+    load_rows<NT>(genv.high, m, q, 0.0f, ahigh);
+
+    // trajectories of this column: [0] the output arrays, [1] the workspace; the nominal one is [flip]
+    float *const xbuf[2] = {a.states + b * (T + 1) * n, a.wsx + b * (T + 1) * n};
+    float *const ubuf[2] = {a.actions + b * T * m, a.wsu + b * T * m};
+    float *const cbuf[2] = {a.costs + b * (T + 1), a.wsc + b * (T + 1)};
+    float *const kg = a.wsk + b * T * m;
+    const float *const x0p = a.x0 + b * n;
+    int flip = 0;
+
+    // One rollout of every column from x0.  SEARCH: u_t = clip(u_hat_t + alpha k_t) (ilqr.py:193-197), else the
+    // injected start actions (:53-82).  Inputs of step t + 1 are requested before step t is computed.
+    auto rollout = [&](auto search, float alpha, const float *uh, bool keep, float *xs, float *us, float *cs, float &J_out,
+                       float &res_out) {
+        constexpr bool SEARCH = decltype(search)::value;
+        float x[NV], ur[NV], kr[NV], rmax[NV];
+        ldv<NT, VEC>(x0p, n, q, x);
+        stv<NT, VEC>(xs, n, q, keep, x);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) { rmax[e] = 0.0f; kr[e] = 0.0f; ur[e] = 0.0f; }
+        if (T > 0) {
+            ldv<NT, VEC>(uh, m, q, ur);
+            if (SEARCH) ldv<NT, VEC>(kg, m, q, kr);
+        }
+        float J = 0.0f;
+        for (int t = 0; t < T; ++t) {
+            float u[NV];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) {
+                if (SEARCH) {
+                    const float du = alpha * kr[e];
+                    rmax[e] = fmaxf(rmax[e], fabsf(du));
+                    u[e] = fminf(fmaxf(ur[e] + du, alow[e]), ahigh[e]);
+                } else {
+                    u[e] = ur[e];
+                }
+            }
+            if (t + 1 < T) {
+                ldv<NT, VEC>(uh + (size_t)(t + 1) * m, m, q, ur);
+                if (SEARCH) ldv<NT, VEC>(kg + (size_t)(t + 1) * m, m, q, kr);
+            }
+            float cp[NV], xn[NV];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) cp[e] = env.stage_cost(x[e], u[e], e);
+            const float c = col_sum<NT>(cp);
+            env.step(x, u, xn);
+            J += c;
+            stv<NT, VEC>(us + (size_t)t * m, m, q, keep, u);
+            stv<NT, VEC>(xs + (size_t)(t + 1) * n, n, q, keep, xn);
+            if (keep && q == 0) cs[t] = c;
+#pragma unroll
+            for (int e = 0; e < NV; ++e) x[e] = xn[e];
+        }
+        float cp[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) cp[e] = env.final_cost(x[e], e);
+        const float fc = col_sum<NT>(cp);
+        if (keep && q == 0) cs[T] = fc;
+        J_out = J + fc;
+        res_out = col_max<NT>(rmax);
+        wsync();                 // costs are written by lane quarter 0 and read by all four in the next sweep
+    };
+
+    {
+        float J, res;
+        rollout(std::false_type{}, 0.0f, a.u_init + b * T * m, live, xbuf[0], ubuf[0], cbuf[0], J, res);
+    }
+
+    float mu = 0.0f, delta = 1.0f;
+    int status = 0, attempts = 0, iteration = 0;
+    bool done = !live || cfg.max_iterations <= 0;
+    while (__any(!done)) {
+        float *const xhat = xbuf[flip], *const uhat = ubuf[flip], *const chat = cbuf[flip];
+        float *const xc = xbuf[flip ^ 1], *const uc = ubuf[flip ^ 1], *const cc = cbuf[flip ^ 1];
+        // ---- backward (ilqr.py:94-172 on the bang-bang branch): costate recursion, all columns ------------
+        float rJ, dV1, g_norm;
+        {
+            float vx[NV], xr[NV], ur[NV], xT[NV], p1[NV];
+            ldv<NT, VEC>(xhat + (size_t)T * n, n, q, xT);
+#pragma unroll
+            for (int e = 0; e < NV; ++e) { vx[e] = env.grad_x(xT[e], e); p1[e] = 0.0f; xr[e] = 0.0f; ur[e] = 0.0f; }    // V_x = l_x^f
+            rJ = chat[T];                                    // the stage costs of the nominal trajectory are the l_t
+            float gsum = 0.0f, l_n = 0.0f;
+            if (T > 0) {
+                ldv<NT, VEC>(xhat + (size_t)(T - 1) * n, n, q, xr);
+                ldv<NT, VEC>(uhat + (size_t)(T - 1) * m, m, q, ur);
+                l_n = chat[T - 1];
+            }
+            for (int t = T - 1; t >= 0; --t) {
+                float xh[NV], uh[NV];
+#pragma unroll
+                for (int e = 0; e < NV; ++e) { xh[e] = xr[e]; uh[e] = ur[e]; }
+                const float l = l_n;
+                if (t > 0) {
+                    ldv<NT, VEC>(xhat + (size_t)(t - 1) * n, n, q, xr);
+                    ldv<NT, VEC>(uhat + (size_t)(t - 1) * m, m, q, ur);
+                    l_n = chat[t - 1];
+                }
+                float Qx[NV], Qu[NV], kt[NV], gm[NV];
+                env.adjoint(xh, uh, vx, Qx, Qu);
+#pragma unroll
+                for (int e = 0; e < NV; ++e) {
+                    kt[e] = (Qu[e] >= 0.0f) ? (alow[e] - uh[e]) : (ahigh[e] - uh[e]);           // :140-141
+                    p1[e] = fmaf(kt[e], Qu[e], p1[e]);
+                    gm[e] = fabsf(kt[e]) / (fabsf(uh[e]) + 1.0f);
+                    vx[e] = Qx[e];                                                              // V_x <- Q_x
+                }
+                stv<NT, VEC>(kg + (size_t)t * m, m, q, !done, kt);
+                rJ += l;
+                gsum += col_max<NT>(gm);
+            }
+            dV1 = col_sum<NT>(p1);
+            g_norm = T > 0 ? gsum / (float)T : 0.0f;
+        }
+        const bool converged_g = !done && g_norm < cfg.atol;                   // :243-248
+        // ---- line search rounds (ilqr.py:317-355): every searching column tries its next step size ------
+        const bool searching = !done && !converged_g;
+        bool accept = false;
+        float residual = 0.0f;
+        for (int ai = 0; ai < cfg.n_alphas && __any(searching && !accept); ++ai) {
+            const float alpha = cfg.alphas[ai];
+            const bool trying = searching && !accept;
+            float J, res;
+            rollout(std::true_type{}, alpha, uhat, trying, xc, uc, cc, J, res);
+            const float delta_J = -alpha * (dV1 + alpha * 0.0f);               // :339 (dV2 == 0 here)
+            const float dcost = rJ - J;
+            const float z = (delta_J > 0.0f) ? dcost / delta_J : sgnf_(dcost); // :342-346
+            if (trying) {
+                residual = res;
+                if (z >= cfg.c1) accept = true;                                // :351-353
+            }
+        }
+        const bool small_step = searching && residual < cfg.atol;              // :253-257
+        if (searching && (small_step || accept)) flip ^= 1;                    // the candidate becomes the nominal
+        if (converged_g || small_step) done = true;                            // converged
+        else if (searching && accept) {                                        // :259-266
+            delta = fminf(1.0f / cfg.delta_0, delta / cfg.delta_0);
+            mu = (mu * delta > cfg.mu_min) ? mu * delta : 0.0f;
+            if (++iteration >= cfg.max_iterations) done = true;
+        } else if (searching) {                                                // :267-270
+            delta = fmaxf(cfg.delta_0, delta * cfg.delta_0);
+            mu = fmaxf(cfg.mu_min, mu * delta);
+            if (++attempts >= cfg.max_attempts || !(mu < 1e30f)) { status |= TFMPC_ST_MAX_ATTEMPTS; done = true; }
+        }
+    }
+    // columns whose final nominal trajectory sits in the workspace: copy it out (rows of this lane)
+    {
+        const bool mv = live && flip;
+        for (int t = 0; t <= T; ++t) {
+            float v[NV];
+            ldv<NT, VEC>(xbuf[1] + (size_t)t * n, n, q, v);
+            stv<NT, VEC>(xbuf[0] + (size_t)t * n, n, q, mv, v);
+            if (t < T) {
+                ldv<NT, VEC>(ubuf[1] + (size_t)t * m, m, q, v);
+                stv<NT, VEC>(ubuf[0] + (size_t)t * m, m, q, mv, v);
+            }
+            if (q == 0) { const float c = cbuf[1][t]; if (mv) cbuf[0][t] = c; }
+        }
+    }
+    if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
+    if (q == 0 && live) {
+        const float cT = cbuf[flip][T];
+        if (!(cT == cT)) status |= TFMPC_ST_NAN;
+        a.iterations[b] = iteration;
+        a.status[b] = status;
+    }
+}
+
+}  // namespace
+
+bool ilqr_adjoint_mfma_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg)
+{
+    if (!ilqr_adjoint_supported(env, cfg)) return false;
+    for (int i = 0; i < TFMPC_ENV_MAX_PARAMS; ++i)
+        if (env.p[i] && env.stride[i] != 0) return false;          // the coupling matrix must be the batch's, not the instance's
+    return true;
+}
+
+int ilqr_adjoint_mfma_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const AdjointSolveArgs &a, hipStream_t stream)
+{
+    const dim3 block(kWave), grid((a.B + kCols - 1) / kCols);
+    auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const bool vec = env.n % 4 == 0 && aligned(a.x0) && aligned(a.u_init) && aligned(a.states) && aligned(a.actions) &&
+                     aligned(a.wsk) && aligned(a.wsx) && aligned(a.wsu);
+    const bool two = env.n > 16;
+#define TFMPC_LAUNCH_AM(KIND)                                                                                                  \
+    do {                                                                                                                       \
+        if (two && vec) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, 2, true>), grid, block, 0, stream, env, cfg, a);     \
+        else if (two) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, 2, false>), grid, block, 0, stream, env, cfg, a);      \
+        else if (vec) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, 1, true>), grid, block, 0, stream, env, cfg, a);       \
+        else hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, 1, false>), grid, block, 0, stream, env, cfg, a);               \
+    } while (0)
+    if (env.kind == TFMPC_ENV_HVAC) TFMPC_LAUNCH_AM(TFMPC_ENV_HVAC);
+    else TFMPC_LAUNCH_AM(TFMPC_ENV_RESERVOIR);
+#undef TFMPC_LAUNCH_AM
+    return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
+}
+
+}  // namespace tfmpc

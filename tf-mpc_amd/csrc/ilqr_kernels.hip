@@ -127,6 +127,7 @@ __global__ __launch_bounds__(kWave) void ilqr_derivatives_kernel(TfmpcEnv env, i
     if (o.fl_xx) store_matrix(o.fl_xx + (size_t)b * n * n, s.Vxx, ldn, n, n);
 }
 
+constexpr int kCostateMfmaMinBatch = 16; // shared-env HVAC / Reservoir batches from this size: 16 instances per wave
 constexpr int kBlockedFrom = 12;         // state dimension from which the register-blocked products pay
 
 struct BackwardArgs {
@@ -499,6 +500,12 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
         const bool forced_wave = force && std::strcmp(force, "wave") == 0;
         if (!forced_wave && ilqr_adjoint_supported(*env, *cfg)) {
             const AdjointSolveArgs aa{B, T, x0, u_init, states, actions, costs, iterations, status, a.wsk, a.wsx, a.wsu, a.wsc};
+            // a batch that shares one env: 16 instances per wave with the coupling-matrix products on the matrix
+            // cores (ilqr_adjoint_mfma.hip); TFMPC_ILQR_KERNEL=costate_mfma forces it, lean / lean1 the kernels above
+            const bool forced_lean = force && (std::strcmp(force, "lean") == 0 || std::strcmp(force, "lean1") == 0);
+            const bool forced_mfma = force && std::strcmp(force, "costate_mfma") == 0;
+            if (!forced_lean && ilqr_adjoint_mfma_supported(*env, *cfg) && (forced_mfma || B >= kCostateMfmaMinBatch))
+                return ilqr_adjoint_mfma_launch(*env, *cfg, aa, st);
             return ilqr_adjoint_launch(*env, *cfg, aa, st);
         }
     }
