@@ -69,7 +69,10 @@ def test_cfg5_n32_horizon100_batch_32768(kind):
     idx = torch.arange(0, B, 512, device=states.device)
     for t in (0, 49, 99):                                                                  # trajectory obeys the env
         nxt = env.transition(states[idx, t].unsqueeze(-1), actions[idx, t].unsqueeze(-1), batch=True)
-        assert torch.equal(nxt[..., 0], states[idx, t + 1])
+        if kind == "reservoir":       # the 16-per-wave solve kernel keeps the env kernel's operation order here
+            assert torch.equal(nxt[..., 0], states[idx, t + 1])
+        else:                         # HVAC: the solve kernel folds the linear terms into the conduction matrix
+            assert float((nxt[..., 0] - states[idx, t + 1]).abs().max()) <= 1e-6 * float(states[idx, t + 1].abs().max())
     # sample parity with the fp32 restatement on the first backward/forward pieces (deterministic part)
     b = 7
     o = ilqr_ref.ILQRRef(oenv, dtype=np.float32)

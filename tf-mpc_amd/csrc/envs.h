@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/tfmpc_hip.h"
+#include "trig.h"
 #include "wave_ops.h"
 
 namespace tfmpc {
@@ -527,7 +528,7 @@ template <> struct Env<TFMPC_ENV_RESERVOIR> {
             if (parts >= 2) inflow += quad_xor1(inflow);
             if (parts >= 4) inflow += quad_xor2(inflow);
             if (i < n && part == 0) {
-                const float vaporated = 0.5f * sinf(x[i] / cap[i]) * x[i];                    // :87
+                const float vaporated = 0.5f * sin_f32(x[i] * (1.0f / cap[i])) * x[i];                    // :87
                 xn[i] = x[i] + rain[i] + inflow - vaporated - u[i] * x[i];                    // :56-60
             }
         }
@@ -561,8 +562,10 @@ template <> struct Env<TFMPC_ENV_RESERVOIR> {
         const int n = e.n, ldn = odd_ld(n);
         const float *Drow = e.p[7] + j * ldn;
         const float uj = u[j];
-        const float r = x[j] / e.p[0][j];
-        const float diag_extra = 1.0f - 0.5f * (cosf(r) * r + sinf(r)) - uj;
+        const float r = x[j] * (1.0f / e.p[0][j]);
+        float sr, cr;
+            sincos_f32(r, sr, cr);
+            const float diag_extra = 1.0f - 0.5f * (cr * r + sr) - uj;
         float acc = fmaf(Drow[j] * uj + diag_extra, Vx[j], lx_j);   // diagonal term first (ilqr_core.h backward_pass)
         for (int kk = 0; kk < n; ++kk) if (kk != j) acc = fmaf(Drow[kk] * uj, Vx[kk], acc);
         return acc;
@@ -592,8 +595,10 @@ template <> struct Env<TFMPC_ENV_RESERVOIR> {
             float a = D[j * ldn + i] * u[j];        // D^T diag(u)
             float b = D[j * ldn + i] * x[j];        // D^T diag(x)
             if (i == j) {
-                const float r = x[i] / cap[i];
-                a += 1.0f - 0.5f * (cosf(r) * r + sinf(r)) - u[i];
+                const float r = x[i] * (1.0f / cap[i]);      // every kernel: x times the rounded reciprocal (trig.h)
+                float sr, cr;
+                sincos_f32(r, sr, cr);
+                a += 1.0f - 0.5f * (cr * r + sr) - u[i];
                 b -= x[i];
             }
             fx[i * ldn + j] = a;

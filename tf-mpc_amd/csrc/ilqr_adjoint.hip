@@ -27,6 +27,7 @@
 
 #include "../../include/tfmpc_hip.h"
 #include "ilqr_adjoint.h"
+#include "trig.h"
 #include "wave_ops.h"
 
 namespace tfmpc {
@@ -309,7 +310,7 @@ template <bool SMALL, int GS> struct Lean<TFMPC_ENV_RESERVOIR, SMALL, GS> {
         inflow += quad_xor1(inflow);
         if (it < n && part == 0) {
             const float xi = x2[it];
-            const float vaporated = 0.5f * sinf(xi / cap_t) * xi;                          // :87
+            const float vaporated = 0.5f * sin_f32(xi * (1.0f / cap_t)) * xi;                          // :87
             const float v = xi + rain_t + inflow - vaporated - u[it] * xi;                 // :56-60
             xn2[it] = v;
             xn2[n + it] = v;
@@ -321,8 +322,10 @@ template <bool SMALL, int GS> struct Lean<TFMPC_ENV_RESERVOIR, SMALL, GS> {
         float acc = 0.0f;
         if (lane < n) {
             const float uj = uh[lane];
-            const float r = xh[lane] / cap;
-            const float diag_extra = 1.0f - 0.5f * (cosf(r) * r + sinf(r)) - uj;
+            const float r = xh[lane] * (1.0f / cap);
+            float sr, cr;
+            sincos_f32(r, sr, cr);
+            const float diag_extra = 1.0f - 0.5f * (cr * r + sr) - uj;
             // diagonal term first, then the row by ascending column with a zero in the diagonal slot
             acc = fmaf(Dii * uj + diag_extra, vx[lane], grad_x(xh[lane]));
 #pragma unroll

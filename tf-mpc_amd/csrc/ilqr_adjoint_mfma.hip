@@ -35,6 +35,7 @@
 
 #include "../../include/tfmpc_hip.h"
 #include "ilqr_adjoint.h"
+#include "trig.h"
 #include "wave_ops.h"
 
 namespace tfmpc {
@@ -47,15 +48,22 @@ constexpr int kCols = 16;                 // instances per wave
 
 __device__ __forceinline__ float sgnf_(float y) { return (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f); }
 
-// exchange with the lanes that hold the other rows of this column: lane ^ 16, lane ^ 32
-__device__ __forceinline__ float xq16(float v) { return __shfl_xor(v, 16, kWave); }
-__device__ __forceinline__ float xq32(float v) { return __shfl_xor(v, 32, kWave); }
+// Exchange across the lane quarters that hold the other rows of a column, on gfx950's row swaps:
+// v_permlane16_swap a, b swaps row 1 of a with row 0 of b and row 3 of a with row 2 of b (rows of 16 lanes);
+// v_permlane32_swap a, b swaps the upper half of a with the lower half of b.  With a == b == v going in,
+// a' (+) b' is v (+) v[lane ^ 16] resp. v (+) v[lane ^ 32] in every lane.  (The s_nop covers the VALU-write ->
+// permlane-read hazard the compiler cannot see inside the asm.)
+__device__ __forceinline__ void swap16(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap32(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 // sum over the 16 rows of one tile, balanced tree in row order (= the row tree of wave_sum / group_sum)
 __device__ __forceinline__ float tile_sum(float s4)
 {
-    s4 += xq16(s4);
-    s4 += xq32(s4);
-    return s4;
+    float a = s4, b = s4;
+    swap16(a, b);
+    a += b;
+    b = a;
+    swap32(a, b);
+    return a + b;
 }
 template <int NT>
 __device__ __forceinline__ float col_sum(const float (&v)[4 * NT])
@@ -67,13 +75,26 @@ __device__ __forceinline__ float col_sum(const float (&v)[4 * NT])
 template <int NT>
 __device__ __forceinline__ float col_max(const float (&v)[4 * NT])         // non-negative inputs
 {
-    float mx = v[0];
+    float a = v[0];
 #pragma unroll
-    for (int e = 1; e < 4 * NT; ++e) mx = fmaxf(mx, v[e]);
-    mx = fmaxf(mx, xq16(mx));
-    mx = fmaxf(mx, xq32(mx));
-    return mx;
+    for (int e = 1; e < 4 * NT; ++e) a = fmaxf(a, v[e]);
+    float b = a;
+    swap16(a, b);
+    a = fmaxf(a, b);
+    b = a;
+    swap32(a, b);
+    return fmaxf(a, b);
 }
+
+// The trajectory pointers are picked per column (output array or workspace), which hides their address space from the
+// compiler: say "global" explicitly, or every access becomes a flat_* instruction (which also waits on the LDS counter).
+#define TFMPC_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ TFMPC_GLOBAL T *as_global(T *p) { return (TFMPC_GLOBAL T *)p; }
+template <class T>
+__device__ __forceinline__ T gld(const T *p) { return *as_global(p); }
+template <class T>
+__device__ __forceinline__ void gst(T *p, T v) { *as_global(p) = v; }
 
 template <int NT>
 __device__ __forceinline__ int row_of(int e, int q) { return 16 * (e >> 2) + 4 * q + (e & 3); }
@@ -97,12 +118,12 @@ __device__ __forceinline__ void ldv(const float *p, int n, int q, float (&o)[4 *
     for (int b = 0; b < NT; ++b) {
         const int r0 = 16 * b + 4 * q;
         if (VEC) {
-            float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (r0 < n) t = *reinterpret_cast<const float4 *>(p + r0);
-            o[4 * b] = t.x; o[4 * b + 1] = t.y; o[4 * b + 2] = t.z; o[4 * b + 3] = t.w;
+            f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (r0 < n) t = gld(reinterpret_cast<const f32x4 *>(p + r0));
+            o[4 * b] = t[0]; o[4 * b + 1] = t[1]; o[4 * b + 2] = t[2]; o[4 * b + 3] = t[3];
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[4 * b + r] = (r0 + r < n) ? p[r0 + r] : 0.0f;
+            for (int r = 0; r < 4; ++r) o[4 * b + r] = (r0 + r < n) ? gld(p + r0 + r) : 0.0f;
         }
     }
 }
@@ -113,11 +134,11 @@ __device__ __forceinline__ void stv(float *p, int n, int q, bool keep, const flo
     for (int b = 0; b < NT; ++b) {
         const int r0 = 16 * b + 4 * q;
         if (VEC) {
-            if (keep && r0 < n) *reinterpret_cast<float4 *>(p + r0) = make_float4(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]);
+            if (keep && r0 < n) gst(reinterpret_cast<f32x4 *>(p + r0), f32x4{v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]});
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (keep && r0 + r < n) p[r0 + r] = v[4 * b + r];
+                if (keep && r0 + r < n) gst(p + r0 + r, v[4 * b + r]);
         }
     }
 }
@@ -142,6 +163,14 @@ __device__ __forceinline__ void mat_apply(const float (&A)[NT][NT][4], const flo
     }
 }
 
+// A copy of a lane-dependent index the optimiser cannot see through: what is computed from it inside a loop stays
+// inside (hoisted out, the 16 operand addresses of each phase would stay live across the whole solve).
+__device__ __forceinline__ int opaque(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // A operands of  Y = M Z  for a matrix given element-wise: el(R, C) = M[R][C] (0 outside n x n)
 template <int NT, class F>
 __device__ __forceinline__ void load_operand(int n, int i, int q, F el, float (&A)[NT][NT][4])
@@ -157,6 +186,22 @@ __device__ __forceinline__ void load_operand(int n, int i, int q, F el, float (&
             }
 }
 
+// Per-row parameter vectors that a step uses ONCE live in LDS ([slot][32] floats, rows >= n padded), not in registers:
+// a lane reads its rows 16 b + 4 q .. + 3 as one ds_read_b128 per tile (a broadcast within the lane quarter).  `qo` is
+// an opaque copy of q made once per step, so that the reads stay inside the time loops instead of being hoisted back
+// into registers.
+constexpr int kRowSlots = 8, kRowLd = 32;
+template <int NT>
+__device__ __forceinline__ void lds_rows(const float *lds, int slot, int qo, float (&o)[4 * NT])
+{
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const float4 t = *reinterpret_cast<const float4 *>(lds + slot * kRowLd + 16 * b + 4 * qo);
+        o[4 * b] = t.x; o[4 * b + 1] = t.y; o[4 * b + 2] = t.z; o[4 * b + 3] = t.w;
+    }
+}
+constexpr int kSlotALow = 6, kSlotAHigh = 7;          // action bounds (both envs)
+
 template <int KIND, int NT> struct EnvM;
 
 // ---------------------------------------------------------------------------------- HVAC ----
@@ -166,25 +211,39 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
     static constexpr int NV = 4 * NT;
     static constexpr float CAP_AIR = 1.006f, COST_AIR = 1.0f, TEMP_AIR = 40.0f, TIME_DELTA = 1.0f;
     static constexpr float PENALTY = 20000.0f, SET_POINT_PENALTY = 10.0f;
-    float Af[NT][NT][4], Ab[NT][NT][4];
-    float lo[NV], hi[NV], am[NV], rcap[NV], c0[NV];
+    static constexpr int kC0 = 0;                       // LDS slot
+    float lo[NV], hi[NV], am[NV], rcap[NV];
+    const float *lds;
 
-    __device__ void load(const TfmpcEnv &g, int i, int q)
+    // A[R][C] = G[R][C] - (R == C) (gsum_R + k_out_R + k_hall_R); the operands of a phase are loaded when it starts
+    // (they come from L2) so that the two sets are never live together
+    static __device__ __forceinline__ float el(const TfmpcEnv &g, int R, int C)
+    {
+        const int n = g.n;
+        const float *G = g.p[8];
+        float v = G[R * n + C];
+        if (R == C) {
+            float gs = 0.0f;
+            for (int k = 0; k < n; ++k) gs += G[R * n + k];
+            v -= gs + g.p[4][R] + g.p[5][R];
+        }
+        return v;
+    }
+    __device__ __forceinline__ void load_forward(const TfmpcEnv &g, int i, int q, float (&A)[NT][NT][4]) const
+    {
+        load_operand<NT>(g.n, i, q, [&](int R, int C) { return el(g, R, C); }, A);
+    }
+    __device__ __forceinline__ void load_backward(const TfmpcEnv &g, int i, int q, float (&A)[NT][NT][4]) const
+    {
+        load_operand<NT>(g.n, i, q, [&](int R, int C) { return el(g, C, R); }, A);
+    }
+    __device__ void load(const TfmpcEnv &g, int lane, int q, float *lds_)
     {
         const int n = g.n;
         const float *pt_out = g.p[0], *pt_hall = g.p[1], *plo = g.p[2], *phi = g.p[3], *pk_out = g.p[4], *pk_hall = g.p[5],
-                    *pcap = g.p[6], *pam = g.p[7], *G = g.p[8];
-        auto el = [&](int R, int C) {
-            float v = G[R * n + C];
-            if (R == C) {
-                float gs = 0.0f;
-                for (int k = 0; k < n; ++k) gs += G[R * n + k];
-                v -= gs + pk_out[R] + pk_hall[R];
-            }
-            return v;
-        };
-        load_operand<NT>(n, i, q, el, Af);
-        load_operand<NT>(n, i, q, [&](int R, int C) { return el(C, R); }, Ab);
+                    *pcap = g.p[6], *pam = g.p[7];
+        lds = lds_;
+        if (lane < kRowLd) lds_[kC0 * kRowLd + lane] = (lane < n) ? pk_out[lane] * pt_out[lane] + pk_hall[lane] * pt_hall[lane] : 0.0f;
         load_rows<NT>(plo, n, q, 0.0f, lo);
         load_rows<NT>(phi, n, q, 0.0f, hi);
         load_rows<NT>(pam, n, q, 0.0f, am);
@@ -192,7 +251,6 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
         for (int e = 0; e < NV; ++e) {
             const int r = row_of<NT>(e, q);
             rcap[e] = (r < n) ? TIME_DELTA / pcap[r] : 0.0f;
-            c0[e] = (r < n) ? pk_out[r] * pt_out[r] + pk_hall[r] * pt_hall[r] : 0.0f;
         }
     }
     __device__ __forceinline__ float penalties(float x, int e) const
@@ -202,19 +260,32 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
         const float sp = SET_POINT_PENALTY * fabsf(mid - x);                              // :101-105
         return oob + sp;
     }
-    __device__ __forceinline__ float stage_cost(float x, float u, int e) const { return COST_AIR * (u * am[e]) + penalties(x, e); }
-    __device__ __forceinline__ float final_cost(float x, int e) const { return penalties(x, e); }
+    __device__ __forceinline__ void stage_costs(const float (&x)[NV], const float (&u)[NV], int, float (&c)[NV]) const
+    {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) c[e] = COST_AIR * (u[e] * am[e]) + penalties(x[e], e);      // :91-110
+    }
+    __device__ __forceinline__ void final_costs(const float (&x)[NV], int, float (&c)[NV]) const
+    {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) c[e] = penalties(x[e], e);                           // :112-129
+    }
     __device__ __forceinline__ float grad_x(float x, int e) const
     {
         const float mid = (lo[e] + hi[e]) / 2;
         return PENALTY * (-(lo[e] > x ? 1.0f : 0.0f) + (x > hi[e] ? 1.0f : 0.0f)) - SET_POINT_PENALTY * sgnf_(mid - x);
     }
-    __device__ __forceinline__ void step(const float (&x)[NV], const float (&u)[NV], float (&xn)[NV]) const
+    __device__ __forceinline__ void grads(const float (&x)[NV], int, float (&gx)[NV]) const
+    {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) gx[e] = grad_x(x[e], e);
+    }
+    __device__ __forceinline__ void step(const float (&A)[NT][NT][4], const float (&x)[NV], const float (&u)[NV], int qo,
+                                         float (&xn)[NV]) const
     {
         float acc[NV];
-#pragma unroll
-        for (int e = 0; e < NV; ++e) acc[e] = c0[e];
-        mat_apply<NT>(Af, x, acc);
+        lds_rows<NT>(lds, kC0, qo, acc);
+        mat_apply<NT>(A, x, acc);
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
             const float air = u[e] * am[e];                                               // :72
@@ -222,8 +293,8 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
             xn[e] = x[e] + rcap[e] * (heating + acc[e]);                                  // :80-88
         }
     }
-    __device__ __forceinline__ void adjoint(const float (&xh)[NV], const float (&uh)[NV], const float (&vx)[NV],
-                                            float (&Qx)[NV], float (&Qu)[NV]) const
+    __device__ __forceinline__ void adjoint(const float (&A)[NT][NT][4], const float (&xh)[NV], const float (&uh)[NV],
+                                            const float (&vx)[NV], int, float (&Qx)[NV], float (&Qu)[NV]) const
     {
         float w[NV];
 #pragma unroll
@@ -231,7 +302,7 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
             w[e] = rcap[e] * vx[e];
             Qx[e] = fmaf(-(uh[e] * am[e] * CAP_AIR), w[e], grad_x(xh[e], e) + vx[e]);
         }
-        mat_apply<NT>(Ab, w, Qx);
+        mat_apply<NT>(A, w, Qx);
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
             const float d = rcap[e] * am[e] * CAP_AIR * (TEMP_AIR - xh[e]);
@@ -244,151 +315,214 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
 // element-wise expressions in the order of ilqr_adjoint.hip / envs.h (reservoir/__init__.py:47-105)
 template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
     static constexpr int NV = 4 * NT;
-    float Af[NT][NT][4], Ab[NT][NT][4];              // D^T (inflow = D^T (u x)), D without its diagonal
-    float cap[NV], lo[NV], hi[NV], LP[NV], HP[NV], SP[NV], rain[NV], Dii[NV];
+    static constexpr int kRain = 0, kDii = 1, kLP = 2, kHP = 3, kSP = 4;      // LDS slots
+    float rcap[NV], lo[NV], hi[NV];                  // 1 / max_res_cap: x / cap is x times the rounded reciprocal everywhere
+    const float *lds;
 
-    __device__ void load(const TfmpcEnv &g, int i, int q)
+    // forward: D^T (inflow = D^T (u x)); backward: D without its diagonal.  Loaded when a phase starts (from L2), so
+    // the two operand sets are never live together.
+    __device__ __forceinline__ void load_forward(const TfmpcEnv &g, int i, int q, float (&A)[NT][NT][4]) const
+    {
+        const float *D = g.p[7];
+        const int n = g.n;
+        load_operand<NT>(n, i, q, [&](int R, int C) { return D[C * n + R]; }, A);
+    }
+    __device__ __forceinline__ void load_backward(const TfmpcEnv &g, int i, int q, float (&A)[NT][NT][4]) const
+    {
+        const float *D = g.p[7];
+        const int n = g.n;
+        load_operand<NT>(n, i, q, [&](int R, int C) { return (R == C) ? 0.0f : D[R * n + C]; }, A);
+    }
+    __device__ void load(const TfmpcEnv &g, int lane, int q, float *lds_)
     {
         const int n = g.n;
         const float *pcap = g.p[0], *plo = g.p[1], *phi = g.p[2], *plp = g.p[3], *php = g.p[4], *psp = g.p[5], *prain = g.p[6],
                     *D = g.p[7];
-        load_operand<NT>(n, i, q, [&](int R, int C) { return D[C * n + R]; }, Af);
-        load_operand<NT>(n, i, q, [&](int R, int C) { return (R == C) ? 0.0f : D[R * n + C]; }, Ab);
-        load_rows<NT>(pcap, n, q, 1.0f, cap);
+        lds = lds_;
+        if (lane < kRowLd) {
+            const bool st = lane < n;
+            lds_[kRain * kRowLd + lane] = st ? prain[lane] : 0.0f;
+            lds_[kDii * kRowLd + lane] = st ? D[lane * n + lane] : 0.0f;
+            lds_[kLP * kRowLd + lane] = st ? -plp[lane] : 0.0f;
+            lds_[kHP * kRowLd + lane] = st ? -php[lane] : 0.0f;
+            lds_[kSP * kRowLd + lane] = st ? -psp[lane] : 0.0f;
+        }
+        load_rows<NT>(pcap, n, q, 1.0f, rcap);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) rcap[e] = 1.0f / rcap[e];
         load_rows<NT>(plo, n, q, 0.0f, lo);
         load_rows<NT>(phi, n, q, 0.0f, hi);
-        load_rows<NT>(prain, n, q, 0.0f, rain);
+    }
+    __device__ __forceinline__ void stage_costs(const float (&x)[NV], const float (&)[NV], int qo, float (&c)[NV]) const
+    {
+        float LP[NV], HP[NV], SP[NV];                                                     // reservoir :63-79
+        lds_rows<NT>(lds, kLP, qo, LP);
+        lds_rows<NT>(lds, kHP, qo, HP);
+        lds_rows<NT>(lds, kSP, qo, SP);
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
-            const int r = row_of<NT>(e, q);
-            const bool st = r < n;
-            LP[e] = st ? -plp[r] : 0.0f; HP[e] = st ? -php[r] : 0.0f; SP[e] = st ? -psp[r] : 0.0f;
-            Dii[e] = st ? D[r * n + r] : 0.0f;
+            const float mid = (lo[e] + hi[e]) / 2.0f;
+            const float c1 = LP[e] * fmaxf(0.0f, lo[e] - x[e]);
+            const float c2 = HP[e] * fmaxf(0.0f, x[e] - hi[e]);
+            const float c3 = SP[e] * fabsf(mid - x[e]);
+            c[e] = c1 + c2 + c3;
         }
     }
-    __device__ __forceinline__ float stage_cost(float x, float, int e) const               // reservoir :63-79
+    __device__ __forceinline__ void final_costs(const float (&x)[NV], int qo, float (&c)[NV]) const { stage_costs(x, x, qo, c); }   // :81-83
+    __device__ __forceinline__ void grads(const float (&x)[NV], int qo, float (&gx)[NV]) const
     {
-        const float mid = (lo[e] + hi[e]) / 2.0f;
-        const float c1 = LP[e] * fmaxf(0.0f, lo[e] - x);
-        const float c2 = HP[e] * fmaxf(0.0f, x - hi[e]);
-        const float c3 = SP[e] * fabsf(mid - x);
-        return c1 + c2 + c3;
+        float LP[NV], HP[NV], SP[NV];
+        lds_rows<NT>(lds, kLP, qo, LP);
+        lds_rows<NT>(lds, kHP, qo, HP);
+        lds_rows<NT>(lds, kSP, qo, SP);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const float mid = (lo[e] + hi[e]) / 2.0f;
+            gx[e] = -LP[e] * (lo[e] > x[e] ? 1.0f : 0.0f) + HP[e] * (x[e] > hi[e] ? 1.0f : 0.0f) - SP[e] * sgnf_(mid - x[e]);
+        }
     }
-    __device__ __forceinline__ float final_cost(float x, int e) const { return stage_cost(x, 0.0f, e); }     // :81-83
-    __device__ __forceinline__ float grad_x(float x, int e) const
+    __device__ __forceinline__ void step(const float (&A)[NT][NT][4], const float (&x)[NV], const float (&u)[NV], int qo,
+                                         float (&xn)[NV]) const
     {
-        const float mid = (lo[e] + hi[e]) / 2.0f;
-        return -LP[e] * (lo[e] > x ? 1.0f : 0.0f) + HP[e] * (x > hi[e] ? 1.0f : 0.0f) - SP[e] * sgnf_(mid - x);
-    }
-    __device__ __forceinline__ void step(const float (&x)[NV], const float (&u)[NV], float (&xn)[NV]) const
-    {
-        float z[NV], inflow[NV];
+        float z[NV], inflow[NV], rain[NV];
 #pragma unroll
         for (int e = 0; e < NV; ++e) { z[e] = u[e] * x[e]; inflow[e] = 0.0f; }
-        mat_apply<NT>(Af, z, inflow);
+        mat_apply<NT>(A, z, inflow);
+        lds_rows<NT>(lds, kRain, qo, rain);
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
             const float xi = x[e];
-            const float vaporated = 0.5f * sinf(xi / cap[e]) * xi;                        // :87
+            const float vaporated = 0.5f * sin_f32(xi * rcap[e]) * xi;                        // :87
             xn[e] = xi + rain[e] + inflow[e] - vaporated - u[e] * xi;                     // :56-60
         }
     }
-    __device__ __forceinline__ void adjoint(const float (&xh)[NV], const float (&uh)[NV], const float (&vx)[NV],
-                                            float (&Qx)[NV], float (&Qu)[NV]) const
+    __device__ __forceinline__ void adjoint(const float (&A)[NT][NT][4], const float (&xh)[NV], const float (&uh)[NV],
+                                            const float (&vx)[NV], int qo, float (&Qx)[NV], float (&Qu)[NV]) const
     {
-        float Y[NV];
+        float Y[NV], Dii[NV], gx[NV];
 #pragma unroll
         for (int e = 0; e < NV; ++e) Y[e] = 0.0f;
-        mat_apply<NT>(Ab, vx, Y);                                                         // sum_{k != i} D[i][k] V_x[k]
+        mat_apply<NT>(A, vx, Y);                                                          // sum_{k != i} D[i][k] V_x[k]
+        lds_rows<NT>(lds, kDii, qo, Dii);
+        grads(xh, qo, gx);
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
             const float uj = uh[e], xa = xh[e];
-            const float r = xa / cap[e];
-            const float diag_extra = 1.0f - 0.5f * (cosf(r) * r + sinf(r)) - uj;
-            Qx[e] = fmaf(uj, Y[e], fmaf(Dii[e] * uj + diag_extra, vx[e], grad_x(xa, e)));
+            const float r = xa * rcap[e];
+            float sr, cr;
+            sincos_f32(r, sr, cr);
+            const float diag_extra = 1.0f - 0.5f * (cr * r + sr) - uj;
+            Qx[e] = fmaf(uj, Y[e], fmaf(Dii[e] * uj + diag_extra, vx[e], gx[e]));
             Qu[e] = fmaf(xa, Y[e], fmaf(Dii[e] * xa - xa, vx[e], 0.0f));
         }
     }
 };
 
 template <int KIND, int NT, bool VEC>
-__global__ __launch_bounds__(kWave) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
 {
     constexpr int NV = 4 * NT;
     const int lane = lane_id(), j = lane & 15, q = lane >> 4, n = genv.n, m = n, T = a.T;
     const int b_raw = blockIdx.x * kCols + j;
     const bool live = b_raw < a.B;                       // the last wave may carry empty columns: they compute on the
     const size_t b = live ? b_raw : a.B - 1;             // last instance's data and store nothing
+    __shared__ __attribute__((aligned(16))) float rows[kRowSlots * kRowLd];
     EnvM<KIND, NT> env;
-    env.load(genv, j, q);
-    float alow[NV], ahigh[NV];
-    load_rows<NT>(genv.low, m, q, 0.0f, alow);
-    load_rows<NT>(genv.high, m, q, 0.0f, ahigh);
+    env.load(genv, lane, q, rows);
+    if (lane < kRowLd) {
+        rows[kSlotALow * kRowLd + lane] = (lane < m) ? genv.low[lane] : 0.0f;
+        rows[kSlotAHigh * kRowLd + lane] = (lane < m) ? genv.high[lane] : 0.0f;
+    }
+    wsync();
 
     // trajectories of this column: [0] the output arrays, [1] the workspace; the nominal one is [flip]
     float *const xbuf[2] = {a.states + b * (T + 1) * n, a.wsx + b * (T + 1) * n};
     float *const ubuf[2] = {a.actions + b * T * m, a.wsu + b * T * m};
     float *const cbuf[2] = {a.costs + b * (T + 1), a.wsc + b * (T + 1)};
-    float *const kg = a.wsk + b * T * m;
+    unsigned char *const ksel = reinterpret_cast<unsigned char *>(a.wsk) + b * T * 4;    // [t][lane quarter]: 4 NT selector bits
     const float *const x0p = a.x0 + b * n;
     int flip = 0;
 
     // One rollout of every column from x0.  SEARCH: u_t = clip(u_hat_t + alpha k_t) (ilqr.py:193-197), else the
-    // injected start actions (:53-82).  Inputs of step t + 1 are requested before step t is computed.
-    auto rollout = [&](auto search, float alpha, const float *uh, bool keep, float *xs, float *us, float *cs, float &J_out,
-                       float &res_out) {
-        constexpr bool SEARCH = decltype(search)::value;
-        float x[NV], ur[NV], kr[NV], rmax[NV];
+    // injected start actions (:53-82).  The bang-bang gain is k_t = bound - u_hat_t (:140-141), so the sweep leaves ONE
+    // BIT per action (which bound) and the rollout rebuilds k_t from u_hat_t with the sweep's own expression.
+    // A wave alone waits ~3 000 cycles on every HBM / L2 round trip and only two waves share a SIMD, so the inputs of
+    // step t + kAhead are requested before step t is computed (a register ring, the time loop unrolled by kAhead).
+    constexpr int kAhead = 2;
+    // STORE: the trajectory is written (rows of columns with `keep`).  The line search only needs J: its rollouts store
+    // nothing, and the one step size a column settles on is rolled out again with STORE (same arithmetic, same bits)
+    // -- every speculative rollout writing its 25 KB per instance made the solve HBM-write-bound.
+    auto rollout = [&](auto search, auto store, float alpha, const float *uh, bool keep, float *xs, float *us, float *cs,
+                       float &J_out) {
+        constexpr bool SEARCH = decltype(search)::value, STORE = decltype(store)::value;
+        float A[NT][NT][4];
+        env.load_forward(genv, opaque(j), opaque(q), A);
+        float x[NV], ur[kAhead][NV];
+        unsigned kb[kAhead];
         ldv<NT, VEC>(x0p, n, q, x);
-        stv<NT, VEC>(xs, n, q, keep, x);
+        if (STORE) stv<NT, VEC>(xs, n, q, keep, x);
+        auto request = [&](int t, float (&u_)[NV], unsigned &k_) {
+            ldv<NT, VEC>(uh + (size_t)t * m, m, q, u_);
+            if (SEARCH) k_ = gld(ksel + (size_t)t * 4 + q);
+        };
 #pragma unroll
-        for (int e = 0; e < NV; ++e) { rmax[e] = 0.0f; kr[e] = 0.0f; ur[e] = 0.0f; }
-        if (T > 0) {
-            ldv<NT, VEC>(uh, m, q, ur);
-            if (SEARCH) ldv<NT, VEC>(kg, m, q, kr);
+        for (int d = 0; d < kAhead; ++d) {
+            kb[d] = 0;
+#pragma unroll
+            for (int e = 0; e < NV; ++e) ur[d][e] = 0.0f;
+            if (d < T) request(d, ur[d], kb[d]);
         }
         float J = 0.0f;
-        for (int t = 0; t < T; ++t) {
-            float u[NV];
+        for (int t0 = 0; t0 < T; t0 += kAhead) {
 #pragma unroll
-            for (int e = 0; e < NV; ++e) {
-                if (SEARCH) {
-                    const float du = alpha * kr[e];
-                    rmax[e] = fmaxf(rmax[e], fabsf(du));
-                    u[e] = fminf(fmaxf(ur[e] + du, alow[e]), ahigh[e]);
-                } else {
-                    u[e] = ur[e];
+            for (int d = 0; d < kAhead; ++d) {
+                const int t = t0 + d;
+                __builtin_amdgcn_sched_barrier(0);          // the unrolled steps are not interleaved (registers)
+                if (t < T) {
+                    const int qo = opaque(q);
+                    float u[NV];
+                    if (SEARCH) {
+                        float alow[NV], ahigh[NV];
+                        lds_rows<NT>(rows, kSlotALow, qo, alow);
+                        lds_rows<NT>(rows, kSlotAHigh, qo, ahigh);
+#pragma unroll
+                        for (int e = 0; e < NV; ++e) {
+                            const float uh_e = ur[d][e];
+                            const float kt = ((kb[d] >> e) & 1u) ? (alow[e] - uh_e) : (ahigh[e] - uh_e);      // :140-141
+                            const float du = alpha * kt;                                                     // :193-194
+                            u[e] = __builtin_amdgcn_fmed3f(uh_e + du, alow[e], ahigh[e]);                    // :196-197 (low <= high)
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < NV; ++e) u[e] = ur[d][e];
+                    }
+                    if (t + kAhead < T) request(t + kAhead, ur[d], kb[d]);
+                    float cp[NV], xn[NV];
+                    env.stage_costs(x, u, qo, cp);
+                    const float c = col_sum<NT>(cp);
+                    env.step(A, x, u, qo, xn);
+                    J += c;
+                    if (STORE) {
+                        stv<NT, VEC>(us + (size_t)t * m, m, q, keep, u);
+                        stv<NT, VEC>(xs + (size_t)(t + 1) * n, n, q, keep, xn);
+                        if (keep && q == 0) gst(cs + t, c);
+                    }
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) x[e] = xn[e];
                 }
             }
-            if (t + 1 < T) {
-                ldv<NT, VEC>(uh + (size_t)(t + 1) * m, m, q, ur);
-                if (SEARCH) ldv<NT, VEC>(kg + (size_t)(t + 1) * m, m, q, kr);
-            }
-            float cp[NV], xn[NV];
-#pragma unroll
-            for (int e = 0; e < NV; ++e) cp[e] = env.stage_cost(x[e], u[e], e);
-            const float c = col_sum<NT>(cp);
-            env.step(x, u, xn);
-            J += c;
-            stv<NT, VEC>(us + (size_t)t * m, m, q, keep, u);
-            stv<NT, VEC>(xs + (size_t)(t + 1) * n, n, q, keep, xn);
-            if (keep && q == 0) cs[t] = c;
-#pragma unroll
-            for (int e = 0; e < NV; ++e) x[e] = xn[e];
         }
         float cp[NV];
-#pragma unroll
-        for (int e = 0; e < NV; ++e) cp[e] = env.final_cost(x[e], e);
+        env.final_costs(x, opaque(q), cp);
         const float fc = col_sum<NT>(cp);
-        if (keep && q == 0) cs[T] = fc;
+        if (STORE && keep && q == 0) gst(cs + T, fc);
         J_out = J + fc;
-        res_out = col_max<NT>(rmax);
-        wsync();                 // costs are written by lane quarter 0 and read by all four in the next sweep
+        if (STORE) wsync();                 // costs are written by lane quarter 0 and read by all four in the next sweep
     };
 
     {
-        float J, res;
-        rollout(std::false_type{}, 0.0f, a.u_init + b * T * m, live, xbuf[0], ubuf[0], cbuf[0], J, res);
+        float J;
+        rollout(std::false_type{}, std::true_type{}, 0.0f, a.u_init + b * T * m, live, xbuf[0], ubuf[0], cbuf[0], J);
     }
 
     float mu = 0.0f, delta = 1.0f;
@@ -398,42 +532,63 @@ __global__ __launch_bounds__(kWave) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv,
         float *const xhat = xbuf[flip], *const uhat = ubuf[flip], *const chat = cbuf[flip];
         float *const xc = xbuf[flip ^ 1], *const uc = ubuf[flip ^ 1], *const cc = cbuf[flip ^ 1];
         // ---- backward (ilqr.py:94-172 on the bang-bang branch): costate recursion, all columns ------------
-        float rJ, dV1, g_norm;
+        float rJ, dV1, g_norm, kmax;
         {
-            float vx[NV], xr[NV], ur[NV], xT[NV], p1[NV];
+            float A[NT][NT][4];
+            env.load_backward(genv, opaque(j), opaque(q), A);
+            float vx[NV], xT[NV], p1[NV], ka[NV], xr[kAhead][NV], ur[kAhead][NV], lr[kAhead];
             ldv<NT, VEC>(xhat + (size_t)T * n, n, q, xT);
+            env.grads(xT, opaque(q), vx);                     // V_x = l_x^f
 #pragma unroll
-            for (int e = 0; e < NV; ++e) { vx[e] = env.grad_x(xT[e], e); p1[e] = 0.0f; xr[e] = 0.0f; ur[e] = 0.0f; }    // V_x = l_x^f
-            rJ = chat[T];                                    // the stage costs of the nominal trajectory are the l_t
-            float gsum = 0.0f, l_n = 0.0f;
-            if (T > 0) {
-                ldv<NT, VEC>(xhat + (size_t)(T - 1) * n, n, q, xr);
-                ldv<NT, VEC>(uhat + (size_t)(T - 1) * m, m, q, ur);
-                l_n = chat[T - 1];
+            for (int e = 0; e < NV; ++e) { p1[e] = 0.0f; ka[e] = 0.0f; }
+            rJ = gld(chat + T);                                    // the stage costs of the nominal trajectory are the l_t
+            float gsum = 0.0f;
+            auto request = [&](int t, float (&x_)[NV], float (&u_)[NV], float &l_) {
+                ldv<NT, VEC>(xhat + (size_t)t * n, n, q, x_);
+                ldv<NT, VEC>(uhat + (size_t)t * m, m, q, u_);
+                l_ = gld(chat + t);
+            };
+#pragma unroll
+            for (int d = 0; d < kAhead; ++d) {
+                lr[d] = 0.0f;
+#pragma unroll
+                for (int e = 0; e < NV; ++e) { xr[d][e] = 0.0f; ur[d][e] = 0.0f; }
+                if (T - 1 - d >= 0) request(T - 1 - d, xr[d], ur[d], lr[d]);
             }
-            for (int t = T - 1; t >= 0; --t) {
-                float xh[NV], uh[NV];
+            for (int t0 = T - 1; t0 >= 0; t0 -= kAhead) {
 #pragma unroll
-                for (int e = 0; e < NV; ++e) { xh[e] = xr[e]; uh[e] = ur[e]; }
-                const float l = l_n;
-                if (t > 0) {
-                    ldv<NT, VEC>(xhat + (size_t)(t - 1) * n, n, q, xr);
-                    ldv<NT, VEC>(uhat + (size_t)(t - 1) * m, m, q, ur);
-                    l_n = chat[t - 1];
-                }
-                float Qx[NV], Qu[NV], kt[NV], gm[NV];
-                env.adjoint(xh, uh, vx, Qx, Qu);
+                for (int d = 0; d < kAhead; ++d) {
+                    const int t = t0 - d;
+                    __builtin_amdgcn_sched_barrier(0);      // the unrolled steps are not interleaved (registers)
+                    if (t >= 0) {
+                        const int qo = opaque(q);
+                        float xh[NV], uh[NV];
 #pragma unroll
-                for (int e = 0; e < NV; ++e) {
-                    kt[e] = (Qu[e] >= 0.0f) ? (alow[e] - uh[e]) : (ahigh[e] - uh[e]);           // :140-141
-                    p1[e] = fmaf(kt[e], Qu[e], p1[e]);
-                    gm[e] = fabsf(kt[e]) / (fabsf(uh[e]) + 1.0f);
-                    vx[e] = Qx[e];                                                              // V_x <- Q_x
+                        for (int e = 0; e < NV; ++e) { xh[e] = xr[d][e]; uh[e] = ur[d][e]; }
+                        const float l = lr[d];
+                        if (t - kAhead >= 0) request(t - kAhead, xr[d], ur[d], lr[d]);
+                        float Qx[NV], Qu[NV], gm[NV], alow[NV], ahigh[NV];
+                        env.adjoint(A, xh, uh, vx, qo, Qx, Qu);
+                        lds_rows<NT>(rows, kSlotALow, qo, alow);
+                        lds_rows<NT>(rows, kSlotAHigh, qo, ahigh);
+                        unsigned sel = 0;
+#pragma unroll
+                        for (int e = 0; e < NV; ++e) {
+                            const bool lowb = Qu[e] >= 0.0f;
+                            const float kt = lowb ? (alow[e] - uh[e]) : (ahigh[e] - uh[e]);         // :140-141
+                            sel |= lowb ? (1u << e) : 0u;
+                            p1[e] = fmaf(kt, Qu[e], p1[e]);
+                            ka[e] = fmaxf(ka[e], fabsf(kt));
+                            gm[e] = fabsf(kt) / (fabsf(uh[e]) + 1.0f);
+                            vx[e] = Qx[e];                                                          // V_x <- Q_x
+                        }
+                        if (!done) gst(ksel + (size_t)t * 4 + q, (unsigned char)sel);
+                        rJ += l;
+                        gsum += col_max<NT>(gm);
+                    }
                 }
-                stv<NT, VEC>(kg + (size_t)t * m, m, q, !done, kt);
-                rJ += l;
-                gsum += col_max<NT>(gm);
             }
+            kmax = col_max<NT>(ka);
             dV1 = col_sum<NT>(p1);
             g_norm = T > 0 ? gsum / (float)T : 0.0f;
         }
@@ -441,22 +596,30 @@ __global__ __launch_bounds__(kWave) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv,
         // ---- line search rounds (ilqr.py:317-355): every searching column tries its next step size ------
         const bool searching = !done && !converged_g;
         bool accept = false;
-        float residual = 0.0f;
+        float residual = 0.0f, alpha_last = 0.0f;          // alpha_last: the step size of this column's last rollout
         for (int ai = 0; ai < cfg.n_alphas && __any(searching && !accept); ++ai) {
             const float alpha = cfg.alphas[ai];
             const bool trying = searching && !accept;
-            float J, res;
-            rollout(std::true_type{}, alpha, uhat, trying, xc, uc, cc, J, res);
+            float J;
+            rollout(std::true_type{}, std::false_type{}, alpha, uhat, trying, xc, uc, cc, J);
+            // residual = max |alpha k_t| (:206, before clipping) = alpha max |k_t|: rounding is monotone and alpha >= 0
+            const float res = alpha * kmax;
             const float delta_J = -alpha * (dV1 + alpha * 0.0f);               // :339 (dV2 == 0 here)
             const float dcost = rJ - J;
             const float z = (delta_J > 0.0f) ? dcost / delta_J : sgnf_(dcost); // :342-346
             if (trying) {
                 residual = res;
+                alpha_last = alpha;
                 if (z >= cfg.c1) accept = true;                                // :351-353
             }
         }
         const bool small_step = searching && residual < cfg.atol;              // :253-257
-        if (searching && (small_step || accept)) flip ^= 1;                    // the candidate becomes the nominal
+        const bool take = searching && (small_step || accept);                 // (:253 takes the last rollout even if rejected)
+        if (__any(take)) {
+            float J;
+            rollout(std::true_type{}, std::true_type{}, alpha_last, uhat, take, xc, uc, cc, J);
+        }
+        if (take) flip ^= 1;                                                   // the candidate becomes the nominal
         if (converged_g || small_step) done = true;                            // converged
         else if (searching && accept) {                                        // :259-266
             delta = fminf(1.0f / cfg.delta_0, delta / cfg.delta_0);
@@ -479,12 +642,12 @@ __global__ __launch_bounds__(kWave) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv,
                 ldv<NT, VEC>(ubuf[1] + (size_t)t * m, m, q, v);
                 stv<NT, VEC>(ubuf[0] + (size_t)t * m, m, q, mv, v);
             }
-            if (q == 0) { const float c = cbuf[1][t]; if (mv) cbuf[0][t] = c; }
+            if (q == 0) { const float c = gld(cbuf[1] + t); if (mv) gst(cbuf[0] + t, c); }
         }
     }
     if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
     if (q == 0 && live) {
-        const float cT = cbuf[flip][T];
+        const float cT = gld(cbuf[flip] + T);
         if (!(cT == cT)) status |= TFMPC_ST_NAN;
         a.iterations[b] = iteration;
         a.status[b] = status;
