@@ -1,6 +1,6 @@
 """Sixteen instances per wavefront with the coupling-matrix products on the matrix cores
 (tf-mpc_amd/csrc/ilqr_adjoint_mfma.hip; HVAC / Reservoir envs shared by the batch, `TFMPC_ILQR_KERNEL=costate_mfma`,
-the default from B = 16) against the generic wave-per-instance kernel and the fp64 oracle.
+the default for large batches) against the generic wave-per-instance kernel and the fp64 oracle.
 
 Reservoir keeps the wave kernels' operation order and reduction trees, and on a 0/1 `downstream` matrix (every
 reference config) a row of the coupling product is a single exact term: there every output must be BIT-identical, which
@@ -81,13 +81,14 @@ def test_reservoir_columns_finish_at_different_times(force_kernel, n, T, B, iter
         assert torch.equal(out["costate_mfma"][key], out["wave"][key]), key
 
 
-def test_default_dispatch_takes_the_matrix_core_kernel_from_16_instances(force_kernel):
-    """B >= 16 on a shared env goes to the 16-per-wave kernel without any forcing; per-instance envs and small batches
-    stay on the register-resident kernels (both equal the wave kernel bit for bit on Reservoir)."""
-    env, x0 = _env("reservoir", 24, 40, 3)
-    solver = iLQR(env, max_iterations=5)
-    u0 = solver.random_actions(15, 40, seed=2)
-    out = _both(force_kernel, solver, x0, 15, u0, kernels=("wave", None, "costate_mfma"))
+@pytest.mark.parametrize("n,B", [(24, 6200), (10, 4100), (24, 40)])
+def test_default_dispatch(force_kernel, n, B):
+    """Large batches on a shared env go to the 16-per-wave kernel without any forcing (from 6144 instances at n > 16,
+    4096 below), small ones stay on the register-resident kernels: on Reservoir all equal the wave kernel bit for bit."""
+    env, x0 = _env("reservoir", n, B, 3)
+    solver = iLQR(env, max_iterations=4)
+    u0 = solver.random_actions(10, B, seed=2)
+    out = _both(force_kernel, solver, x0, 10, u0, kernels=("wave", None, "costate_mfma"))
     for key in ("iterations", "states", "actions", "costs"):
         assert torch.equal(out[None][key], out["wave"][key]) and torch.equal(out["costate_mfma"][key], out["wave"][key])
 

@@ -389,10 +389,14 @@ template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
         for (int e = 0; e < NV; ++e) { z[e] = u[e] * x[e]; inflow[e] = 0.0f; }
         mat_apply<NT>(A, z, inflow);
         lds_rows<NT>(lds, kRain, qo, rain);
+        float r[NV], sr[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) r[e] = x[e] * rcap[e];
+        sin_vec<NV>(r, sr);
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
             const float xi = x[e];
-            const float vaporated = 0.5f * sin_f32(xi * rcap[e]) * xi;                        // :87
+            const float vaporated = 0.5f * sr[e] * xi;                                    // :87
             xn[e] = xi + rain[e] + inflow[e] - vaporated - u[e] * xi;                     // :56-60
         }
     }
@@ -405,13 +409,14 @@ template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
         mat_apply<NT>(A, vx, Y);                                                          // sum_{k != i} D[i][k] V_x[k]
         lds_rows<NT>(lds, kDii, qo, Dii);
         grads(xh, qo, gx);
+        float r[NV], sr[NV], cr[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) r[e] = xh[e] * rcap[e];
+        sincos_vec<NV>(r, sr, cr);
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
             const float uj = uh[e], xa = xh[e];
-            const float r = xa * rcap[e];
-            float sr, cr;
-            sincos_f32(r, sr, cr);
-            const float diag_extra = 1.0f - 0.5f * (cr * r + sr) - uj;
+            const float diag_extra = 1.0f - 0.5f * (cr[e] * r[e] + sr[e]) - uj;
             Qx[e] = fmaf(uj, Y[e], fmaf(Dii[e] * uj + diag_extra, vx[e], gx[e]));
             Qu[e] = fmaf(xa, Y[e], fmaf(Dii[e] * xa - xa, vx[e], 0.0f));
         }

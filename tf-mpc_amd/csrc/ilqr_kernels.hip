@@ -127,7 +127,10 @@ __global__ __launch_bounds__(kWave) void ilqr_derivatives_kernel(TfmpcEnv env, i
     if (o.fl_xx) store_matrix(o.fl_xx + (size_t)b * n * n, s.Vxx, ldn, n, n);
 }
 
-constexpr int kCostateMfmaMinBatch = 16; // shared-env HVAC / Reservoir batches from this size: 16 instances per wave
+// shared-env HVAC / Reservoir batches from this size run 16 instances per wave (ilqr_adjoint_mfma.hip): one such wave
+// takes ~2x as long as a one-instance wave, so it pays once the register-resident kernels have filled the chip
+// (measured crossover, tools/costate_mfma_check.py --small: n = 32 between 4096 and 8192, n <= 16 near 4096)
+constexpr int kCostateMfmaMinBatchLarge = 6144, kCostateMfmaMinBatchSmall = 4096;
 constexpr int kBlockedFrom = 12;         // state dimension from which the register-blocked products pay
 
 struct BackwardArgs {
@@ -504,7 +507,7 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
             // cores (ilqr_adjoint_mfma.hip); TFMPC_ILQR_KERNEL=costate_mfma forces it, lean / lean1 the kernels above
             const bool forced_lean = force && (std::strcmp(force, "lean") == 0 || std::strcmp(force, "lean1") == 0);
             const bool forced_mfma = force && std::strcmp(force, "costate_mfma") == 0;
-            if (!forced_lean && ilqr_adjoint_mfma_supported(*env, *cfg) && (forced_mfma || B >= kCostateMfmaMinBatch))
+            if (!forced_lean && ilqr_adjoint_mfma_supported(*env, *cfg) && (forced_mfma || B >= (n > 16 ? kCostateMfmaMinBatchLarge : kCostateMfmaMinBatchSmall)))
                 return ilqr_adjoint_mfma_launch(*env, *cfg, aa, st);
             return ilqr_adjoint_launch(*env, *cfg, aa, st);
         }

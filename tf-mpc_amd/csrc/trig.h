@@ -1,19 +1,22 @@
-// trig.h -- sine / cosine of one fp32 argument, shared by every kernel that evaluates the Reservoir env
+// trig.h -- sine / cosine of fp32 arguments, shared by every kernel that evaluates the Reservoir env
 // (evaporation 0.5 sin(x / cap) x, tfmpc/envs/reservoir/__init__.py:85-89, and its derivative), so that all of them
-// round identically.
+// round identically: the value depends on the argument alone, never on which kernel or lane evaluates it.
 //
-// Branch-free: the argument is reduced in fp64 (k = rint(r 2/pi), y = r - k pi/2 with a two-part pi/2: exact to fp32
-// rounding for |r| < 2^30; beyond that -- a reservoir a billion times over capacity -- the result is some value in
-// [-1, 1]), then the Cephes single-precision minimax kernels on [-pi/4, pi/4] (peak relative error 1.2e-7) and the
-// quadrant fix-up.  libm's sinf carries a Payne-Hanek slow path whose registers and branches every caller pays for; the
-// MI355X runs fp64 FMAs at half the fp32 rate, which makes the seven fp64 instructions here the cheaper reduction.
+// |r| <= pi/2 -- every physical state, r = level / capacity -- takes the Taylor polynomials through r^13 (sine) and
+// r^14 (cosine) in Horner form: truncation < 1e-9, eight instructions.  Any other argument (and NaN) takes the general
+// path: reduction in fp64 (k = rint(r 2/pi), y = r - k pi/2 with a two-part pi/2: exact to fp32 rounding for
+// |r| < 2^30; beyond that -- a reservoir a billion times over capacity -- the result is some value in [-1, 1]), the
+// Cephes single-precision minimax kernels on [-pi/4, pi/4] and the quadrant fix-up, all branch-free.  The general path
+// sits behind ONE wave-uniform branch per call ("does any lane of the wave need it"); lanes are then selected by their
+// own argument.  libm's sinf carries a Payne-Hanek slow path whose registers and branches every caller pays for; the
+// MI355X runs fp64 FMAs at half the fp32 rate, which makes seven fp64 instructions the cheaper general reduction.
 #pragma once
 
 #include <hip/hip_runtime.h>
 
 namespace tfmpc {
 
-__device__ __forceinline__ void sincos_f32(float r, float &s, float &c)
+__device__ __forceinline__ void sincos_general(float r, float &s, float &c)
 {
     const double rd = (double)r;
     const double kd = __builtin_rint(rd * 0.63661977236758134308);
@@ -33,11 +36,74 @@ __device__ __forceinline__ void sincos_f32(float r, float &s, float &c)
     if (!(r == r)) { s = r; c = r; }                           // NaN in, NaN out
 }
 
+__device__ __forceinline__ bool trig_small(float r) { return fabsf(r) <= 1.5707963f; }       // false for NaN
+
+__device__ __forceinline__ float sin_small(float r)
+{
+    const float z = r * r;
+    float p = fmaf(z, 1.6059044e-10f, -2.5052108e-08f);        // 1/13!, -1/11!
+    p = fmaf(p, z, 2.7557319e-06f);                            // 1/9!
+    p = fmaf(p, z, -1.9841270e-04f);                           // -1/7!
+    p = fmaf(p, z, 8.3333333e-03f);                            // 1/5!
+    p = fmaf(p, z, -1.6666667e-01f);                           // -1/3!
+    return fmaf(r * z, p, r);
+}
+__device__ __forceinline__ float cos_small(float r)
+{
+    const float z = r * r;
+    float p = fmaf(z, -1.1470746e-11f, 2.0876757e-09f);        // -1/14!, 1/12!
+    p = fmaf(p, z, -2.7557319e-07f);                           // -1/10!
+    p = fmaf(p, z, 2.4801587e-05f);                            // 1/8!
+    p = fmaf(p, z, -1.3888889e-03f);                           // -1/6!
+    p = fmaf(p, z, 4.1666668e-02f);                            // 1/4!
+    return fmaf(z * z, p, fmaf(-0.5f, z, 1.0f));
+}
+
+// s[e] = sin(r[e]) (and c[e] = cos(r[e])) for the N arguments of a lane
+template <int N>
+__device__ __forceinline__ void sin_vec(const float (&r)[N], float (&s)[N])
+{
+    bool all_small = true;
+#pragma unroll
+    for (int e = 0; e < N; ++e) { s[e] = sin_small(r[e]); all_small = all_small && trig_small(r[e]); }
+    if (__any(!all_small)) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            float sg, cg;
+            sincos_general(r[e], sg, cg);
+            if (!trig_small(r[e])) s[e] = sg;
+        }
+    }
+}
+template <int N>
+__device__ __forceinline__ void sincos_vec(const float (&r)[N], float (&s)[N], float (&c)[N])
+{
+    bool all_small = true;
+#pragma unroll
+    for (int e = 0; e < N; ++e) { s[e] = sin_small(r[e]); c[e] = cos_small(r[e]); all_small = all_small && trig_small(r[e]); }
+    if (__any(!all_small)) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            float sg, cg;
+            sincos_general(r[e], sg, cg);
+            if (!trig_small(r[e])) { s[e] = sg; c[e] = cg; }
+        }
+    }
+}
+
+__device__ __forceinline__ void sincos_f32(float r, float &s, float &c)
+{
+    const float r1[1] = {r};
+    float s1[1], c1[1];
+    sincos_vec<1>(r1, s1, c1);
+    s = s1[0]; c = c1[0];
+}
 __device__ __forceinline__ float sin_f32(float r)
 {
-    float s, c;
-    sincos_f32(r, s, c);
-    return s;
+    const float r1[1] = {r};
+    float s1[1];
+    sin_vec<1>(r1, s1);
+    return s1[0];
 }
 
 }  // namespace tfmpc

@@ -117,9 +117,11 @@ def main():
         timing(kind)
     if args.small:
         for kind in ("hvac", "reservoir"):
-            timing(kind, n=32, T=100, B=16, iters=12)
-            timing(kind, n=32, T=100, B=1024, iters=12)
-            timing(kind, n=6 if kind == "hvac" else 4, T=100, B=16384, iters=12)
+            for B in (16, 1024, 2048, 4096, 8192, 16384):
+                timing(kind, n=32, T=100, B=B, iters=12)
+            for B in (4096, 16384, 65536):
+                timing(kind, n=6 if kind == "hvac" else 4, T=100, B=B, iters=12)
+                timing(kind, n=16, T=100, B=B, iters=12)
 
 
 if __name__ == "__main__":

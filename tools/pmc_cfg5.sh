@@ -25,7 +25,7 @@ for f in glob.glob(os.path.join(out, "pass*", "*", "*_counter_collection.csv")):
     per = defaultdict(float)
     for r in csv.DictReader(open(f)):
         if "ilqr_adjoint" not in r["Kernel_Name"]: continue
-        kind = "hvac" if "ILi3E" in r["Kernel_Name"] or "(3)" in r["Kernel_Name"] or "<3>" in r["Kernel_Name"] else "reservoir"
+        kind = "hvac" if "ILi3E" in r["Kernel_Name"] or "(3)" in r["Kernel_Name"] or "<3>" in r["Kernel_Name"] or "<3," in r["Kernel_Name"] else "reservoir"
         per[(kind, r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
     for (kind, _, name), v in per.items(): res[kind][name].append(v)
 summary = {k: {n: sum(v) / len(v) for n, v in d.items()} for k, d in res.items()}
