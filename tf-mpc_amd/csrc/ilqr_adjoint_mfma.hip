@@ -171,6 +171,8 @@ __device__ __forceinline__ int opaque(int v)
     return v;
 }
 
+__device__ __forceinline__ void opaque_f(float &v) { asm volatile("" : "+v"(v)); }
+
 // A operands of  Y = M Z  for a matrix given element-wise: el(R, C) = M[R][C] (0 outside n x n)
 template <int NT, class F>
 __device__ __forceinline__ void load_operand(int n, int i, int q, F el, float (&A)[NT][NT][4])
@@ -252,6 +254,14 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
             const int r = row_of<NT>(e, q);
             rcap[e] = (r < n) ? TIME_DELTA / pcap[r] : 0.0f;
         }
+    }
+    // Called when a phase (one rollout, one sweep) starts: what the optimiser derives from the parameters (midpoints,
+    // products of constants ...) is then derived per phase instead of once per kernel, where the derived values of ALL
+    // phases stayed live through every loop (~100 registers).  No instruction is emitted.
+    __device__ __forceinline__ void fence()
+    {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) { opaque_f(lo[e]); opaque_f(hi[e]); opaque_f(am[e]); opaque_f(rcap[e]); }
     }
     __device__ __forceinline__ float penalties(float x, int e) const
     {
@@ -353,6 +363,11 @@ template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
         load_rows<NT>(plo, n, q, 0.0f, lo);
         load_rows<NT>(phi, n, q, 0.0f, hi);
     }
+    __device__ __forceinline__ void fence()             // see EnvM<HVAC>::fence
+    {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) { opaque_f(lo[e]); opaque_f(hi[e]); opaque_f(rcap[e]); }
+    }
     __device__ __forceinline__ void stage_costs(const float (&x)[NV], const float (&)[NV], int qo, float (&c)[NV]) const
     {
         float LP[NV], HP[NV], SP[NV];                                                     // reservoir :63-79
@@ -453,7 +468,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     // BIT per action (which bound) and the rollout rebuilds k_t from u_hat_t with the sweep's own expression.
     // A wave alone waits ~3 000 cycles on every HBM / L2 round trip and only two waves share a SIMD, so the inputs of
     // step t + kAhead are requested before step t is computed (a register ring, the time loop unrolled by kAhead).
-    constexpr int kAhead = 2;
+    constexpr int kAheadRoll = 4, kAhead = 2;        // rollouts (few live registers) / costate sweep
     // STORE: the trajectory is written (rows of columns with `keep`).  The line search only needs J: its rollouts store
     // nothing, and the one step size a column settles on is rolled out again with STORE (same arithmetic, same bits)
     // -- every speculative rollout writing its 25 KB per instance made the solve HBM-write-bound.
@@ -461,9 +476,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                        float &J_out) {
         constexpr bool SEARCH = decltype(search)::value, STORE = decltype(store)::value;
         float A[NT][NT][4];
+        env.fence();
         env.load_forward(genv, opaque(j), opaque(q), A);
-        float x[NV], ur[kAhead][NV];
-        unsigned kb[kAhead];
+        float x[NV], ur[kAheadRoll][NV];
+        unsigned kb[kAheadRoll];
         ldv<NT, VEC>(x0p, n, q, x);
         if (STORE) stv<NT, VEC>(xs, n, q, keep, x);
         auto request = [&](int t, float (&u_)[NV], unsigned &k_) {
@@ -471,16 +487,16 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             if (SEARCH) k_ = gld(ksel + (size_t)t * 4 + q);
         };
 #pragma unroll
-        for (int d = 0; d < kAhead; ++d) {
+        for (int d = 0; d < kAheadRoll; ++d) {
             kb[d] = 0;
 #pragma unroll
             for (int e = 0; e < NV; ++e) ur[d][e] = 0.0f;
             if (d < T) request(d, ur[d], kb[d]);
         }
         float J = 0.0f;
-        for (int t0 = 0; t0 < T; t0 += kAhead) {
+        for (int t0 = 0; t0 < T; t0 += kAheadRoll) {
 #pragma unroll
-            for (int d = 0; d < kAhead; ++d) {
+            for (int d = 0; d < kAheadRoll; ++d) {
                 const int t = t0 + d;
                 __builtin_amdgcn_sched_barrier(0);          // the unrolled steps are not interleaved (registers)
                 if (t < T) {
@@ -501,7 +517,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll
                         for (int e = 0; e < NV; ++e) u[e] = ur[d][e];
                     }
-                    if (t + kAhead < T) request(t + kAhead, ur[d], kb[d]);
+                    if (t + kAheadRoll < T) request(t + kAheadRoll, ur[d], kb[d]);
                     float cp[NV], xn[NV];
                     env.stage_costs(x, u, qo, cp);
                     const float c = col_sum<NT>(cp);
@@ -540,6 +556,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         float rJ, dV1, g_norm, kmax;
         {
             float A[NT][NT][4];
+            env.fence();
             env.load_backward(genv, opaque(j), opaque(q), A);
             float vx[NV], xT[NV], p1[NV], ka[NV], xr[kAhead][NV], ur[kAhead][NV], lr[kAhead];
             ldv<NT, VEC>(xhat + (size_t)T * n, n, q, xT);
