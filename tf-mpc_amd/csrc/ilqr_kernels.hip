@@ -129,8 +129,9 @@ __global__ __launch_bounds__(kWave) void ilqr_derivatives_kernel(TfmpcEnv env, i
 
 // shared-env HVAC / Reservoir batches from this size run 16 instances per wave (ilqr_adjoint_mfma.hip): one such wave
 // takes ~2x as long as a one-instance wave, so it pays once the register-resident kernels have filled the chip
-// (measured crossover, tools/costate_mfma_check.py --small: n = 32 between 4096 and 8192, n <= 16 near 4096)
-constexpr int kCostateMfmaMinBatchLarge = 6144, kCostateMfmaMinBatchSmall = 4096;
+// (measured crossover, tools/costate_mfma_check.py --small: n = 32 between 4096 and 8192, n = 16 below 4096; for n <= 8
+// the packed register-resident kernels hold out until ~16384-32768: hvac6 7.0 vs 7.2 ms at 16384, 20.6 vs 14.6 at 65536)
+constexpr int kCostateMfmaMinBatchLarge = 6144, kCostateMfmaMinBatchSmall = 4096, kCostateMfmaMinBatchTiny = 32768;
 constexpr int kBlockedFrom = 12;         // state dimension from which the register-blocked products pay
 
 struct BackwardArgs {
@@ -507,7 +508,7 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
             // cores (ilqr_adjoint_mfma.hip); TFMPC_ILQR_KERNEL=costate_mfma forces it, lean / lean1 the kernels above
             const bool forced_lean = force && (std::strcmp(force, "lean") == 0 || std::strcmp(force, "lean1") == 0);
             const bool forced_mfma = force && std::strcmp(force, "costate_mfma") == 0;
-            if (!forced_lean && ilqr_adjoint_mfma_supported(*env, *cfg) && (forced_mfma || B >= (n > 16 ? kCostateMfmaMinBatchLarge : kCostateMfmaMinBatchSmall)))
+            if (!forced_lean && ilqr_adjoint_mfma_supported(*env, *cfg) && (forced_mfma || B >= (n > 16 ? kCostateMfmaMinBatchLarge : (n > 8 ? kCostateMfmaMinBatchSmall : kCostateMfmaMinBatchTiny))))
                 return ilqr_adjoint_mfma_launch(*env, *cfg, aa, st);
             return ilqr_adjoint_launch(*env, *cfg, aa, st);
         }
