@@ -214,6 +214,9 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
     static constexpr float CAP_AIR = 1.006f, COST_AIR = 1.0f, TEMP_AIR = 40.0f, TIME_DELTA = 1.0f;
     static constexpr float PENALTY = 20000.0f, SET_POINT_PENALTY = 10.0f;
     static constexpr int kC0 = 0;                       // LDS slot
+    // step sizes per line-search pass: the HVAC step is short and latency-bound (two chains cover each other's waits:
+    // 20.1 -> 16.6 ms on cfg5), the Reservoir step is bound by vector issue (a speculative second chain only adds work)
+    static constexpr int kSearchAlphas = 2;
     float lo[NV], hi[NV], am[NV], rcap[NV];
     const float *lds;
 
@@ -326,6 +329,7 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
 template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
     static constexpr int NV = 4 * NT;
     static constexpr int kRain = 0, kDii = 1, kLP = 2, kHP = 3, kSP = 4;      // LDS slots
+    static constexpr int kSearchAlphas = 1;             // see EnvM<HVAC>
     float rcap[NV], lo[NV], hi[NV];                  // 1 / max_res_cap: x / cap is x times the rounded reciprocal everywhere
     const float *lds;
 
@@ -472,16 +476,27 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     // STORE: the trajectory is written (rows of columns with `keep`).  The line search only needs J: its rollouts store
     // nothing, and the one step size a column settles on is rolled out again with STORE (same arithmetic, same bits)
     // -- every speculative rollout writing its 25 KB per instance made the solve HBM-write-bound.
-    auto rollout = [&](auto search, auto store, float alpha, const float *uh, bool keep, float *xs, float *us, float *cs,
-                       float &J_out) {
+    // NA = 2 (the HVAC line search): TWO step sizes in one pass -- the inputs u_hat_t and the selector byte are loaded once,
+    // and the two independent state chains give a wave something to issue while the other chain waits on its LDS
+    // reads and MFMA results (only two waves share a SIMD at BASELINE's batch).
+    auto rollout = [&](auto search, auto store, auto n_alpha, const float (&alpha)[decltype(n_alpha)::value], const float *uh,
+                       bool keep, float *xs, float *us, float *cs, float (&J_out)[decltype(n_alpha)::value]) {
         constexpr bool SEARCH = decltype(search)::value, STORE = decltype(store)::value;
+        constexpr int NA = decltype(n_alpha)::value;
+        static_assert(!STORE || NA == 1, "only a single rollout is stored");
         float A[NT][NT][4];
         env.fence();
         env.load_forward(genv, opaque(j), opaque(q), A);
-        float x[NV], ur[kAheadRoll][NV];
+        float x[NA][NV], ur[kAheadRoll][NV], J[NA];
         unsigned kb[kAheadRoll];
-        ldv<NT, VEC>(x0p, n, q, x);
-        if (STORE) stv<NT, VEC>(xs, n, q, keep, x);
+        ldv<NT, VEC>(x0p, n, q, x[0]);
+        if (STORE) stv<NT, VEC>(xs, n, q, keep, x[0]);
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            J[k] = 0.0f;
+#pragma unroll
+            for (int e = 0; e < NV; ++e) x[k][e] = x[0][e];
+        }
         auto request = [&](int t, float (&u_)[NV], unsigned &k_) {
             ldv<NT, VEC>(uh + (size_t)t * m, m, q, u_);
             if (SEARCH) k_ = gld(ksel + (size_t)t * 4 + q);
@@ -493,7 +508,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             for (int e = 0; e < NV; ++e) ur[d][e] = 0.0f;
             if (d < T) request(d, ur[d], kb[d]);
         }
-        float J = 0.0f;
         for (int t0 = 0; t0 < T; t0 += kAheadRoll) {
 #pragma unroll
             for (int d = 0; d < kAheadRoll; ++d) {
@@ -501,7 +515,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 __builtin_amdgcn_sched_barrier(0);          // the unrolled steps are not interleaved (registers)
                 if (t < T) {
                     const int qo = opaque(q);
-                    float u[NV];
+                    float u[NA][NV];
                     if (SEARCH) {
                         float alow[NV], ahigh[NV];
                         lds_rows<NT>(rows, kSlotALow, qo, alow);
@@ -510,40 +524,51 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                         for (int e = 0; e < NV; ++e) {
                             const float uh_e = ur[d][e];
                             const float kt = ((kb[d] >> e) & 1u) ? (alow[e] - uh_e) : (ahigh[e] - uh_e);      // :140-141
-                            const float du = alpha * kt;                                                     // :193-194
-                            u[e] = __builtin_amdgcn_fmed3f(uh_e + du, alow[e], ahigh[e]);                    // :196-197 (low <= high)
+#pragma unroll
+                            for (int k = 0; k < NA; ++k) {
+                                const float du = alpha[k] * kt;                                              // :193-194
+                                u[k][e] = __builtin_amdgcn_fmed3f(uh_e + du, alow[e], ahigh[e]);             // :196-197 (low <= high)
+                            }
                         }
                     } else {
 #pragma unroll
-                        for (int e = 0; e < NV; ++e) u[e] = ur[d][e];
+                        for (int e = 0; e < NV; ++e) u[0][e] = ur[d][e];
                     }
                     if (t + kAheadRoll < T) request(t + kAheadRoll, ur[d], kb[d]);
-                    float cp[NV], xn[NV];
-                    env.stage_costs(x, u, qo, cp);
-                    const float c = col_sum<NT>(cp);
-                    env.step(A, x, u, qo, xn);
-                    J += c;
-                    if (STORE) {
-                        stv<NT, VEC>(us + (size_t)t * m, m, q, keep, u);
-                        stv<NT, VEC>(xs + (size_t)(t + 1) * n, n, q, keep, xn);
-                        if (keep && q == 0) gst(cs + t, c);
-                    }
 #pragma unroll
-                    for (int e = 0; e < NV; ++e) x[e] = xn[e];
+                    for (int k = 0; k < NA; ++k) {
+                        float cp[NV], xn[NV];
+                        env.stage_costs(x[k], u[k], qo, cp);
+                        const float c = col_sum<NT>(cp);
+                        env.step(A, x[k], u[k], qo, xn);
+                        J[k] += c;
+                        if (STORE) {
+                            stv<NT, VEC>(us + (size_t)t * m, m, q, keep, u[k]);
+                            stv<NT, VEC>(xs + (size_t)(t + 1) * n, n, q, keep, xn);
+                            if (keep && q == 0) gst(cs + t, c);
+                        }
+#pragma unroll
+                        for (int e = 0; e < NV; ++e) x[k][e] = xn[e];
+                    }
                 }
             }
         }
-        float cp[NV];
-        env.final_costs(x, opaque(q), cp);
-        const float fc = col_sum<NT>(cp);
-        if (STORE && keep && q == 0) gst(cs + T, fc);
-        J_out = J + fc;
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            float cp[NV];
+            env.final_costs(x[k], opaque(q), cp);
+            const float fc = col_sum<NT>(cp);
+            if (STORE && keep && q == 0) gst(cs + T, fc);
+            J_out[k] = J[k] + fc;
+        }
         if (STORE) wsync();                 // costs are written by lane quarter 0 and read by all four in the next sweep
     };
+    using one_t = std::integral_constant<int, 1>;
 
     {
-        float J;
-        rollout(std::false_type{}, std::true_type{}, 0.0f, a.u_init + b * T * m, live, xbuf[0], ubuf[0], cbuf[0], J);
+        const float a0[1] = {0.0f};
+        float J[1];
+        rollout(std::false_type{}, std::true_type{}, one_t{}, a0, a.u_init + b * T * m, live, xbuf[0], ubuf[0], cbuf[0], J);
     }
 
     float mu = 0.0f, delta = 1.0f;
@@ -619,27 +644,34 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         const bool searching = !done && !converged_g;
         bool accept = false;
         float residual = 0.0f, alpha_last = 0.0f;          // alpha_last: the step size of this column's last rollout
-        for (int ai = 0; ai < cfg.n_alphas && __any(searching && !accept); ++ai) {
-            const float alpha = cfg.alphas[ai];
-            const bool trying = searching && !accept;
-            float J;
-            rollout(std::true_type{}, std::false_type{}, alpha, uhat, trying, xc, uc, cc, J);
-            // residual = max |alpha k_t| (:206, before clipping) = alpha max |k_t|: rounding is monotone and alpha >= 0
-            const float res = alpha * kmax;
-            const float delta_J = -alpha * (dV1 + alpha * 0.0f);               // :339 (dV2 == 0 here)
-            const float dcost = rJ - J;
-            const float z = (delta_J > 0.0f) ? dcost / delta_J : sgnf_(dcost); // :342-346
-            if (trying) {
-                residual = res;
-                alpha_last = alpha;
-                if (z >= cfg.c1) accept = true;                                // :351-353
+        constexpr int NA = EnvM<KIND, NT>::kSearchAlphas;
+        for (int ai = 0; ai < cfg.n_alphas && __any(searching && !accept); ai += NA) {
+            float al[NA], J[NA];
+#pragma unroll
+            for (int k = 0; k < NA; ++k) al[k] = cfg.alphas[ai + k < cfg.n_alphas ? ai + k : ai];
+            rollout(std::true_type{}, std::false_type{}, std::integral_constant<int, NA>{}, al, uhat, false, xc, uc, cc, J);
+#pragma unroll
+            for (int k = 0; k < NA; ++k) {                                     // in the reference's order
+                const bool trying = searching && !accept && ai + k < cfg.n_alphas;
+                const float alpha = al[k];
+                // residual = max |alpha k_t| (:206, before clipping) = alpha max |k_t|: rounding is monotone and alpha >= 0
+                const float res = alpha * kmax;
+                const float delta_J = -alpha * (dV1 + alpha * 0.0f);           // :339 (dV2 == 0 here)
+                const float dcost = rJ - J[k];
+                const float z = (delta_J > 0.0f) ? dcost / delta_J : sgnf_(dcost); // :342-346
+                if (trying) {
+                    residual = res;
+                    alpha_last = alpha;
+                    if (z >= cfg.c1) accept = true;                            // :351-353
+                }
             }
         }
         const bool small_step = searching && residual < cfg.atol;              // :253-257
         const bool take = searching && (small_step || accept);                 // (:253 takes the last rollout even if rejected)
         if (__any(take)) {
-            float J;
-            rollout(std::true_type{}, std::true_type{}, alpha_last, uhat, take, xc, uc, cc, J);
+            const float al[1] = {alpha_last};
+            float J[1];
+            rollout(std::true_type{}, std::true_type{}, one_t{}, al, uhat, take, xc, uc, cc, J);
         }
         if (take) flip ^= 1;                                                   // the candidate becomes the nominal
         if (converged_g || small_step) done = true;                            // converged
