@@ -155,6 +155,32 @@ def test_reservoir_parameters_and_closed_forms():
     assert noisy.shape == lin.f[0].shape and not torch.equal(noisy, lin.f[0])
 
 
+def test_reservoir_sine_and_cosine_over_both_paths_of_trig_h():
+    """csrc/trig.h: level / capacity <= pi/2 takes the Taylor path, anything else the fp64-reduced general path.  Drive
+    both through the env kernels (transition: sine; f_x: sine and cosine) with capacities of 1 so that the argument IS
+    the state: physical levels, arguments beyond pi/2, negative and large ones, against numpy in fp64."""
+    n = 4
+    cfg = dict(problems.reservoir_config(n, seed=2, max_res_cap=1.0))
+    env = Reservoir(**cfg)
+    D, rain = env.downstream.astype(np.float64), env.rain_shape.astype(np.float64) * env.rain_scale
+    rng = np.random.default_rng(0)
+    levels = np.concatenate([rng.uniform(0.0, 1.5707, size=64), rng.uniform(-1.5707, 0.0, size=16),        # fast path
+                             rng.uniform(1.5708, 10.0, size=64), rng.uniform(-300.0, 300.0, size=64),      # general path
+                             rng.uniform(1e3, 1e5, size=32), [0.0, 1.5707963, 1.5707964, -1.5707964, 3.1415927, 1e6, -1e6, 12345.678]])
+    levels = levels[: (len(levels) // n) * n].astype(np.float32).reshape(-1, n, 1)
+    u = rng.uniform(size=levels.shape).astype(np.float32)
+    lin = env.get_linear_transition(levels, u, batch=True)
+    nxt = env.transition(levels, u, batch=True)
+    for t in range(len(levels)):
+        xt, ut = levels[t].astype(np.float64), u[t].astype(np.float64)
+        ref = xt + rain - 0.5 * np.sin(xt) * xt - ut * xt + D.T @ (ut * xt)
+        scale = np.abs(xt).max() + 1.0
+        assert np.abs(_np(nxt[t]) - ref).max() <= 4e-7 * scale, (t, xt.ravel())           # |sin error| <= ~2 ulp of 1
+        assert np.abs(_np(lin.f[t]) - ref).max() <= 4e-7 * scale
+        fx = np.eye(n) - np.diag((0.5 * (np.cos(xt) * xt + np.sin(xt)))[:, 0]) - np.diag(ut[:, 0]) + D.T @ np.diag(ut[:, 0])
+        assert np.abs(_np(lin.f_x[t]) - fx).max() <= 4e-7 * scale, (t, xt.ravel())
+
+
 # ------------------------------------------------------------ test_env_navigation.py ---
 @pytest.mark.parametrize("zones", [1, 2])
 def test_navigation_closed_forms(zones):
