@@ -443,7 +443,7 @@ template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
 };
 
 template <int KIND, int NT, bool VEC>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 3 : 2, NT == 1 ? 3 : 2))) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
 {
     constexpr int NV = 4 * NT;
     const int lane = lane_id(), j = lane & 15, q = lane >> 4, n = genv.n, m = n, T = a.T;

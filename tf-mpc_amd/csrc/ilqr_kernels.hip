@@ -130,8 +130,9 @@ __global__ __launch_bounds__(kWave) void ilqr_derivatives_kernel(TfmpcEnv env, i
 // shared-env HVAC / Reservoir batches from this size run 16 instances per wave (ilqr_adjoint_mfma.hip): one such wave
 // takes ~2x as long as a one-instance wave, so it pays once the register-resident kernels have filled the chip
 // (measured crossover, tools/costate_mfma_check.py --small: n = 32 between 4096 and 8192, n = 16 below 4096; for n <= 8
-// the packed register-resident kernels hold out until ~16384-32768: hvac6 7.0 vs 7.2 ms at 16384, 20.6 vs 14.6 at 65536)
-constexpr int kCostateMfmaMinBatchLarge = 6144, kCostateMfmaMinBatchSmall = 4096, kCostateMfmaMinBatchTiny = 32768;
+// the packed register-resident kernels hold out until ~16384: n = 6 / 4 there 5.5 / 7.3 vs 4.7 / 5.2 ms, at 65536 20.5 / 27.1
+// vs 14.6 / 14.0 ms)
+constexpr int kCostateMfmaMinBatchLarge = 6144, kCostateMfmaMinBatchSmall = 4096, kCostateMfmaMinBatchTiny = 16384;
 constexpr int kBlockedFrom = 12;         // state dimension from which the register-blocked products pay
 
 struct BackwardArgs {
