@@ -55,32 +55,38 @@ __device__ __forceinline__ float sgnf_(float y) { return (y > 0.0f) ? 1.0f : ((y
 // permlane-read hazard the compiler cannot see inside the asm.)
 __device__ __forceinline__ void swap16(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void swap32(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-// sum over the 16 rows of one tile, balanced tree in row order (= the row tree of wave_sum / group_sum)
+// sum over the rows of one tile that belong to this lane's instance, balanced tree in row order (= the row tree of
+// wave_sum / group_sum).  PK instances share a tile (PK = 2: 8 rows = 2 lane quarters each, PK = 4: one quarter each).
+template <int PK>
 __device__ __forceinline__ float tile_sum(float s4)
 {
+    if (PK == 4) return s4;
     float a = s4, b = s4;
     swap16(a, b);
     a += b;
+    if (PK == 2) return a;
     b = a;
     swap32(a, b);
     return a + b;
 }
-template <int NT>
+template <int NT, int PK>
 __device__ __forceinline__ float col_sum(const float (&v)[4 * NT])
 {
-    float t = tile_sum((v[0] + v[1]) + (v[2] + v[3]));
-    if (NT == 2) t += tile_sum((v[4] + v[5]) + (v[6] + v[7]));
+    float t = tile_sum<PK>((v[0] + v[1]) + (v[2] + v[3]));
+    if (NT == 2) t += tile_sum<PK>((v[4] + v[5]) + (v[6] + v[7]));
     return t;
 }
-template <int NT>
+template <int NT, int PK>
 __device__ __forceinline__ float col_max(const float (&v)[4 * NT])         // non-negative inputs
 {
     float a = v[0];
 #pragma unroll
     for (int e = 1; e < 4 * NT; ++e) a = fmaxf(a, v[e]);
+    if (PK == 4) return a;
     float b = a;
     swap16(a, b);
     a = fmaxf(a, b);
+    if (PK == 2) return a;
     b = a;
     swap32(a, b);
     return fmaxf(a, b);
@@ -110,37 +116,48 @@ __device__ __forceinline__ void load_rows(const float *p, int n, int q, float df
     }
 }
 
-// one instance-time vector v[0..n) of a trajectory <-> this lane's rows; VEC: n % 4 == 0 and 16-byte aligned arrays
-template <int NT, bool VEC>
+// one instance-time vector v[0..n) of a trajectory <-> this lane's rows, in pieces of VW = 4, 2 or 1 floats: VW divides
+// n (a piece is then inside or outside the vector as a whole) and the arrays are 4 VW-byte aligned
+template <int VW> struct VecOf { using type = float; };
+template <> struct VecOf<2> { using type = __attribute__((ext_vector_type(2))) float; };
+template <> struct VecOf<4> { using type = f32x4; };
+template <int NT, int VW>
 __device__ __forceinline__ void ldv(const float *p, int n, int q, float (&o)[4 * NT])
 {
+    using V = typename VecOf<VW>::type;
 #pragma unroll
-    for (int b = 0; b < NT; ++b) {
-        const int r0 = 16 * b + 4 * q;
-        if (VEC) {
-            f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (r0 < n) t = gld(reinterpret_cast<const f32x4 *>(p + r0));
-            o[4 * b] = t[0]; o[4 * b + 1] = t[1]; o[4 * b + 2] = t[2]; o[4 * b + 3] = t[3];
-        } else {
+    for (int b = 0; b < NT; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[4 * b + r] = (r0 + r < n) ? gld(p + r0 + r) : 0.0f;
+        for (int c = 0; c < 4; c += VW) {
+            const int r0 = 16 * b + 4 * q + c;
+            if constexpr (VW == 1) {
+                o[4 * b + c] = (r0 < n) ? gld(p + r0) : 0.0f;
+            } else {
+                V t = {};
+                if (r0 < n) t = gld(reinterpret_cast<const V *>(p + r0));
+#pragma unroll
+                for (int i = 0; i < VW; ++i) o[4 * b + c + i] = t[i];
+            }
         }
-    }
 }
-template <int NT, bool VEC>
+template <int NT, int VW>
 __device__ __forceinline__ void stv(float *p, int n, int q, bool keep, const float (&v)[4 * NT])
 {
+    using V = typename VecOf<VW>::type;
 #pragma unroll
-    for (int b = 0; b < NT; ++b) {
-        const int r0 = 16 * b + 4 * q;
-        if (VEC) {
-            if (keep && r0 < n) gst(reinterpret_cast<f32x4 *>(p + r0), f32x4{v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]});
-        } else {
+    for (int b = 0; b < NT; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (keep && r0 + r < n) gst(p + r0 + r, v[4 * b + r]);
+        for (int c = 0; c < 4; c += VW) {
+            const int r0 = 16 * b + 4 * q + c;
+            if constexpr (VW == 1) {
+                if (keep && r0 < n) gst(p + r0, v[4 * b + c]);
+            } else {
+                V t;
+#pragma unroll
+                for (int i = 0; i < VW; ++i) t[i] = v[4 * b + c + i];
+                if (keep && r0 < n) gst(reinterpret_cast<V *>(p + r0), t);
+            }
         }
-    }
 }
 
 // acc (tile a, this lane's rows) += sum over rows of A[a][.] * z : NT x NT x 4 MFMAs, the NT accumulation chains
@@ -173,10 +190,12 @@ __device__ __forceinline__ int opaque(int v)
 
 __device__ __forceinline__ void opaque_f(float &v) { asm volatile("" : "+v"(v)); }
 
-// A operands of  Y = M Z  for a matrix given element-wise: el(R, C) = M[R][C] (0 outside n x n)
-template <int NT, class F>
+// A operands of  Y = M Z  for a matrix given element-wise: el(R, C) = M[R][C] (0 outside n x n).  PK > 1 (one tile,
+// n <= 16 / PK): the tile carries PK instances in its rows, the operand is diag(M, .., M).
+template <int NT, int PK, class F>
 __device__ __forceinline__ void load_operand(int n, int i, int q, F el, float (&A)[NT][NT][4])
 {
+    constexpr int kSub = 16 / PK;
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -184,7 +203,12 @@ __device__ __forceinline__ void load_operand(int n, int i, int q, F el, float (&
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int R = 16 * a + i, C = 16 * b + 4 * q + r;
-                A[a][b][r] = (R < n && C < n) ? el(R, C) : 0.0f;
+                if (PK == 1) {
+                    A[a][b][r] = (R < n && C < n) ? el(R, C) : 0.0f;
+                } else {
+                    const int Rl = R % kSub, Cl = C % kSub;
+                    A[a][b][r] = (R / kSub == C / kSub && Rl < n && Cl < n) ? el(Rl, Cl) : 0.0f;
+                }
             }
 }
 
@@ -234,13 +258,15 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
         }
         return v;
     }
+    template <int PK>
     __device__ __forceinline__ void load_forward(const TfmpcEnv &g, int i, int q, float (&A)[NT][NT][4]) const
     {
-        load_operand<NT>(g.n, i, q, [&](int R, int C) { return el(g, R, C); }, A);
+        load_operand<NT, PK>(g.n, i, q, [&](int R, int C) { return el(g, R, C); }, A);
     }
+    template <int PK>
     __device__ __forceinline__ void load_backward(const TfmpcEnv &g, int i, int q, float (&A)[NT][NT][4]) const
     {
-        load_operand<NT>(g.n, i, q, [&](int R, int C) { return el(g, C, R); }, A);
+        load_operand<NT, PK>(g.n, i, q, [&](int R, int C) { return el(g, C, R); }, A);
     }
     __device__ void load(const TfmpcEnv &g, int lane, int q, float *lds_)
     {
@@ -335,17 +361,19 @@ template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
 
     // forward: D^T (inflow = D^T (u x)); backward: D without its diagonal.  Loaded when a phase starts (from L2), so
     // the two operand sets are never live together.
+    template <int PK>
     __device__ __forceinline__ void load_forward(const TfmpcEnv &g, int i, int q, float (&A)[NT][NT][4]) const
     {
         const float *D = g.p[7];
         const int n = g.n;
-        load_operand<NT>(n, i, q, [&](int R, int C) { return D[C * n + R]; }, A);
+        load_operand<NT, PK>(n, i, q, [&](int R, int C) { return D[C * n + R]; }, A);
     }
+    template <int PK>
     __device__ __forceinline__ void load_backward(const TfmpcEnv &g, int i, int q, float (&A)[NT][NT][4]) const
     {
         const float *D = g.p[7];
         const int n = g.n;
-        load_operand<NT>(n, i, q, [&](int R, int C) { return (R == C) ? 0.0f : D[R * n + C]; }, A);
+        load_operand<NT, PK>(n, i, q, [&](int R, int C) { return (R == C) ? 0.0f : D[R * n + C]; }, A);
     }
     __device__ void load(const TfmpcEnv &g, int lane, int q, float *lds_)
     {
@@ -442,17 +470,21 @@ template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
     }
 };
 
-template <int KIND, int NT, bool VEC>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 3 : 2, NT == 1 ? 3 : 2))) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
+template <int KIND, int NT, int VW, int PK>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 && PK == 1 ? 3 : 2, NT == 1 && PK == 1 ? 3 : 2))) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
 {
     constexpr int NV = 4 * NT;
+    static_assert(PK == 1 || NT == 1, "instances are packed into ONE tile");
     const int lane = lane_id(), j = lane & 15, q = lane >> 4, n = genv.n, m = n, T = a.T;
-    const int b_raw = blockIdx.x * kCols + j;
+    // PK instances per column (n <= 16 / PK): lane quarter q belongs to sub-instance q / (4 / PK) and holds its rows
+    // 4 ql .. 4 ql + 3, ql = q mod (4 / PK).  Everything below indexes rows with ql; only the MFMA operands know q.
+    const int ql = q & (4 / PK - 1);
+    const int b_raw = (blockIdx.x * kCols + j) * PK + q / (4 / PK);
     const bool live = b_raw < a.B;                       // the last wave may carry empty columns: they compute on the
     const size_t b = live ? b_raw : a.B - 1;             // last instance's data and store nothing
     __shared__ __attribute__((aligned(16))) float rows[kRowSlots * kRowLd];
     EnvM<KIND, NT> env;
-    env.load(genv, lane, q, rows);
+    env.load(genv, lane, ql, rows);
     if (lane < kRowLd) {
         rows[kSlotALow * kRowLd + lane] = (lane < m) ? genv.low[lane] : 0.0f;
         rows[kSlotAHigh * kRowLd + lane] = (lane < m) ? genv.high[lane] : 0.0f;
@@ -486,11 +518,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 ?
         static_assert(!STORE || NA == 1, "only a single rollout is stored");
         float A[NT][NT][4];
         env.fence();
-        env.load_forward(genv, opaque(j), opaque(q), A);
+        env.template load_forward<PK>(genv, opaque(j), opaque(q), A);
         float x[NA][NV], ur[kAheadRoll][NV], J[NA];
         unsigned kb[kAheadRoll];
-        ldv<NT, VEC>(x0p, n, q, x[0]);
-        if (STORE) stv<NT, VEC>(xs, n, q, keep, x[0]);
+        ldv<NT, VW>(x0p, n, ql, x[0]);
+        if (STORE) stv<NT, VW>(xs, n, ql, keep, x[0]);
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             J[k] = 0.0f;
@@ -498,8 +530,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 ?
             for (int e = 0; e < NV; ++e) x[k][e] = x[0][e];
         }
         auto request = [&](int t, float (&u_)[NV], unsigned &k_) {
-            ldv<NT, VEC>(uh + (size_t)t * m, m, q, u_);
-            if (SEARCH) k_ = gld(ksel + (size_t)t * 4 + q);
+            ldv<NT, VW>(uh + (size_t)t * m, m, ql, u_);
+            if (SEARCH) k_ = gld(ksel + (size_t)t * 4 + ql);
         };
 #pragma unroll
         for (int d = 0; d < kAheadRoll; ++d) {
@@ -514,7 +546,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 ?
                 const int t = t0 + d;
                 __builtin_amdgcn_sched_barrier(0);          // the unrolled steps are not interleaved (registers)
                 if (t < T) {
-                    const int qo = opaque(q);
+                    const int qo = opaque(ql);
                     float u[NA][NV];
                     if (SEARCH) {
                         float alow[NV], ahigh[NV];
@@ -539,13 +571,13 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 ?
                     for (int k = 0; k < NA; ++k) {
                         float cp[NV], xn[NV];
                         env.stage_costs(x[k], u[k], qo, cp);
-                        const float c = col_sum<NT>(cp);
+                        const float c = col_sum<NT, PK>(cp);
                         env.step(A, x[k], u[k], qo, xn);
                         J[k] += c;
                         if (STORE) {
-                            stv<NT, VEC>(us + (size_t)t * m, m, q, keep, u[k]);
-                            stv<NT, VEC>(xs + (size_t)(t + 1) * n, n, q, keep, xn);
-                            if (keep && q == 0) gst(cs + t, c);
+                            stv<NT, VW>(us + (size_t)t * m, m, ql, keep, u[k]);
+                            stv<NT, VW>(xs + (size_t)(t + 1) * n, n, ql, keep, xn);
+                            if (keep && ql == 0) gst(cs + t, c);
                         }
 #pragma unroll
                         for (int e = 0; e < NV; ++e) x[k][e] = xn[e];
@@ -556,9 +588,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 ?
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             float cp[NV];
-            env.final_costs(x[k], opaque(q), cp);
-            const float fc = col_sum<NT>(cp);
-            if (STORE && keep && q == 0) gst(cs + T, fc);
+            env.final_costs(x[k], opaque(ql), cp);
+            const float fc = col_sum<NT, PK>(cp);
+            if (STORE && keep && ql == 0) gst(cs + T, fc);
             J_out[k] = J[k] + fc;
         }
         if (STORE) wsync();                 // costs are written by lane quarter 0 and read by all four in the next sweep
@@ -582,17 +614,17 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 ?
         {
             float A[NT][NT][4];
             env.fence();
-            env.load_backward(genv, opaque(j), opaque(q), A);
+            env.template load_backward<PK>(genv, opaque(j), opaque(q), A);
             float vx[NV], xT[NV], p1[NV], ka[NV], xr[kAhead][NV], ur[kAhead][NV], lr[kAhead];
-            ldv<NT, VEC>(xhat + (size_t)T * n, n, q, xT);
-            env.grads(xT, opaque(q), vx);                     // V_x = l_x^f
+            ldv<NT, VW>(xhat + (size_t)T * n, n, ql, xT);
+            env.grads(xT, opaque(ql), vx);                     // V_x = l_x^f
 #pragma unroll
             for (int e = 0; e < NV; ++e) { p1[e] = 0.0f; ka[e] = 0.0f; }
             rJ = gld(chat + T);                                    // the stage costs of the nominal trajectory are the l_t
             float gsum = 0.0f;
             auto request = [&](int t, float (&x_)[NV], float (&u_)[NV], float &l_) {
-                ldv<NT, VEC>(xhat + (size_t)t * n, n, q, x_);
-                ldv<NT, VEC>(uhat + (size_t)t * m, m, q, u_);
+                ldv<NT, VW>(xhat + (size_t)t * n, n, ql, x_);
+                ldv<NT, VW>(uhat + (size_t)t * m, m, ql, u_);
                 l_ = gld(chat + t);
             };
 #pragma unroll
@@ -608,7 +640,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 ?
                     const int t = t0 - d;
                     __builtin_amdgcn_sched_barrier(0);      // the unrolled steps are not interleaved (registers)
                     if (t >= 0) {
-                        const int qo = opaque(q);
+                        const int qo = opaque(ql);
                         float xh[NV], uh[NV];
 #pragma unroll
                         for (int e = 0; e < NV; ++e) { xh[e] = xr[d][e]; uh[e] = ur[d][e]; }
@@ -629,14 +661,14 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 ?
                             gm[e] = fabsf(kt) / (fabsf(uh[e]) + 1.0f);
                             vx[e] = Qx[e];                                                          // V_x <- Q_x
                         }
-                        if (!done) gst(ksel + (size_t)t * 4 + q, (unsigned char)sel);
+                        if (!done) gst(ksel + (size_t)t * 4 + ql, (unsigned char)sel);
                         rJ += l;
-                        gsum += col_max<NT>(gm);
+                        gsum += col_max<NT, PK>(gm);
                     }
                 }
             }
-            kmax = col_max<NT>(ka);
-            dV1 = col_sum<NT>(p1);
+            kmax = col_max<NT, PK>(ka);
+            dV1 = col_sum<NT, PK>(p1);
             g_norm = T > 0 ? gsum / (float)T : 0.0f;
         }
         const bool converged_g = !done && g_norm < cfg.atol;                   // :243-248
@@ -690,17 +722,17 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 ?
         const bool mv = live && flip;
         for (int t = 0; t <= T; ++t) {
             float v[NV];
-            ldv<NT, VEC>(xbuf[1] + (size_t)t * n, n, q, v);
-            stv<NT, VEC>(xbuf[0] + (size_t)t * n, n, q, mv, v);
+            ldv<NT, VW>(xbuf[1] + (size_t)t * n, n, ql, v);
+            stv<NT, VW>(xbuf[0] + (size_t)t * n, n, ql, mv, v);
             if (t < T) {
-                ldv<NT, VEC>(ubuf[1] + (size_t)t * m, m, q, v);
-                stv<NT, VEC>(ubuf[0] + (size_t)t * m, m, q, mv, v);
+                ldv<NT, VW>(ubuf[1] + (size_t)t * m, m, ql, v);
+                stv<NT, VW>(ubuf[0] + (size_t)t * m, m, ql, mv, v);
             }
-            if (q == 0) { const float c = gld(cbuf[1] + t); if (mv) gst(cbuf[0] + t, c); }
+            if (ql == 0) { const float c = gld(cbuf[1] + t); if (mv) gst(cbuf[0] + t, c); }
         }
     }
     if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
-    if (q == 0 && live) {
+    if (ql == 0 && live) {
         const float cT = gld(cbuf[flip] + T);
         if (!(cT == cT)) status |= TFMPC_ST_NAN;
         a.iterations[b] = iteration;
@@ -720,21 +752,33 @@ bool ilqr_adjoint_mfma_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg
 
 int ilqr_adjoint_mfma_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const AdjointSolveArgs &a, hipStream_t stream)
 {
-    const dim3 block(kWave), grid((a.B + kCols - 1) / kCols);
-    auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-    const bool vec = env.n % 4 == 0 && aligned(a.x0) && aligned(a.u_init) && aligned(a.states) && aligned(a.actions) &&
-                     aligned(a.wsk) && aligned(a.wsx) && aligned(a.wsu);
-    const bool two = env.n > 16;
+    auto aligned = [&](unsigned mask) {
+        const void *ps[] = {a.x0, a.u_init, a.states, a.actions, a.wsk, a.wsx, a.wsu};
+        for (const void *p : ps)
+            if (reinterpret_cast<uintptr_t>(p) & mask) return false;
+        return true;
+    };
+    const int vw = (env.n % 4 == 0 && aligned(15u)) ? 4 : ((env.n % 2 == 0 && aligned(7u)) ? 2 : 1);
+    // instances per column: one up to n = 32 (two tiles) or 16, two for n <= 8, four for n <= 4
+    const int pk = env.n <= 4 ? 4 : (env.n <= 8 ? 2 : 1);
+    const dim3 block(kWave), grid((a.B + kCols * pk - 1) / (kCols * pk));
+#define TFMPC_LAUNCH_AM2(KIND, NT_, PK_)                                                                                        \
+    do {                                                                                                                       \
+        if (vw == 4) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, 4, PK_>), grid, block, 0, stream, env, cfg, a);   \
+        else if (vw == 2) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, 2, PK_>), grid, block, 0, stream, env, cfg, a); \
+        else hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, 1, PK_>), grid, block, 0, stream, env, cfg, a);           \
+    } while (0)
 #define TFMPC_LAUNCH_AM(KIND)                                                                                                  \
     do {                                                                                                                       \
-        if (two && vec) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, 2, true>), grid, block, 0, stream, env, cfg, a);     \
-        else if (two) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, 2, false>), grid, block, 0, stream, env, cfg, a);      \
-        else if (vec) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, 1, true>), grid, block, 0, stream, env, cfg, a);       \
-        else hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, 1, false>), grid, block, 0, stream, env, cfg, a);               \
+        if (env.n > 16) TFMPC_LAUNCH_AM2(KIND, 2, 1);                                                                          \
+        else if (pk == 1) TFMPC_LAUNCH_AM2(KIND, 1, 1);                                                                        \
+        else if (pk == 2) TFMPC_LAUNCH_AM2(KIND, 1, 2);                                                                        \
+        else TFMPC_LAUNCH_AM2(KIND, 1, 4);                                                                                     \
     } while (0)
     if (env.kind == TFMPC_ENV_HVAC) TFMPC_LAUNCH_AM(TFMPC_ENV_HVAC);
     else TFMPC_LAUNCH_AM(TFMPC_ENV_RESERVOIR);
 #undef TFMPC_LAUNCH_AM
+#undef TFMPC_LAUNCH_AM2
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
 }
 
