@@ -17,10 +17,13 @@
 //   * everything else of a step is element-wise on the 4 NT values a lane owns (costs, clipping, the bilinear / sine
 //     terms), with per-row parameters in registers; the only cross-lane work is the column sum of the stage cost and
 //     the column max of the gradient norm (two lane exchanges each).
-// The 16 instances run the reference state machine in lockstep with masked stores (as ilqr_adjoint_group_kernel does
+//   * n <= 8 / n <= 4: a column carries two / four instances (rows 0-7 | 8-15, or one per lane quarter) against the
+//     block-diagonal operand diag(M, .., M); the column reductions then span two lane quarters / one.
+// The 16 (32, 64) instances run the reference state machine in lockstep with masked stores (as ilqr_adjoint_group_kernel does
 // for its 2 / 4 groups): one costate sweep, then line-search rounds in which every instance still searching rolls out
-// ITS next step size; the nominal and candidate trajectories ping-pong between the output arrays and the workspace per
-// instance (no copy on acceptance), the gains k_t stream through the workspace.
+// ITS next step size(s) WITHOUT storing them, then the step size each instance settled on is rolled out once more with
+// stores; the nominal and candidate trajectories ping-pong between the output arrays and the workspace per instance (no
+// copy on acceptance); of the gains only one selector bit per action goes through the workspace (k_t = bound - u_t).
 //
 // Arithmetic: Reservoir keeps the operation order of the wave kernels for every element-wise expression, the cost
 // reduction tree and the J / value bookkeeping, so on 0/1 `downstream` matrices (every reference config: a row sum is
