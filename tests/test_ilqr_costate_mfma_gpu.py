@@ -81,10 +81,10 @@ def test_reservoir_columns_finish_at_different_times(force_kernel, n, T, B, iter
         assert torch.equal(out["costate_mfma"][key], out["wave"][key]), key
 
 
-@pytest.mark.parametrize("n,B", [(24, 6200), (10, 4100), (24, 40)])
+@pytest.mark.parametrize("n,B", [(24, 4200), (10, 4100), (24, 40), (10, 40), (4, 3)])
 def test_default_dispatch(force_kernel, n, B):
-    """Large batches on a shared env go to the 16-per-wave kernel without any forcing (from 6144 instances at n > 16,
-    4096 at 8 < n <= 16, 16384 at n <= 8), small ones stay on the register-resident kernels: on Reservoir all equal the wave kernel bit for bit."""
+    """A shared env goes to the 16-per-wave kernel without any forcing at n <= 16 (any batch size) and from 4097 instances
+    at n > 16; smaller large-n batches stay on the register-resident kernels: on Reservoir all equal the wave kernel bit for bit."""
     env, x0 = _env("reservoir", n, B, 3)
     solver = iLQR(env, max_iterations=4)
     u0 = solver.random_actions(10, B, seed=2)

@@ -127,12 +127,13 @@ __global__ __launch_bounds__(kWave) void ilqr_derivatives_kernel(TfmpcEnv env, i
     if (o.fl_xx) store_matrix(o.fl_xx + (size_t)b * n * n, s.Vxx, ldn, n, n);
 }
 
-// shared-env HVAC / Reservoir batches from this size run 16 instances per wave (ilqr_adjoint_mfma.hip): one such wave
-// takes ~2x as long as a one-instance wave, so it pays once the register-resident kernels have filled the chip
-// (measured crossover, tools/costate_mfma_check.py --small: n = 32 between 4096 and 8192, n = 16 below 4096; for n <= 8
-// the packed register-resident kernels hold out until ~16384: n = 6 / 4 there 5.5 / 7.3 vs 4.7 / 5.2 ms, at 65536 20.5 / 27.1
-// vs 14.6 / 14.0 ms)
-constexpr int kCostateMfmaMinBatchLarge = 6144, kCostateMfmaMinBatchSmall = 4096, kCostateMfmaMinBatchTiny = 16384;
+// Shared-env HVAC / Reservoir batches run 16 (n <= 16: up to 64) instances per wave on the matrix cores
+// (ilqr_adjoint_mfma.hip).  For n <= 16 that kernel is the faster one at EVERY batch size, one instance included
+// (n = 16, 12, 6 / 4 at B = 1 ... 256: 3.0-5.4 ms against 3.4-5.8 for the register-resident kernels).  For n > 16 one of its waves
+// takes ~1.3x as long as a one-instance wave, so it pays once the register-resident kernels need a second round of
+// waves (4 per SIMD x 1024 SIMDs): B = 4096 6.9 / 11.3 ms against 8.2 / 12.6, B = 6144 12.3 / 19.0 against 8.6 / 12.8
+// (HVAC / Reservoir, T = 100, 12 iterations; tools/costate_mfma_check.py).
+constexpr int kCostateMfmaMinBatchLarge = 4097, kCostateMfmaMinBatchSmall = 1;
 constexpr int kBlockedFrom = 12;         // state dimension from which the register-blocked products pay
 
 struct BackwardArgs {
@@ -509,7 +510,7 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
             // cores (ilqr_adjoint_mfma.hip); TFMPC_ILQR_KERNEL=costate_mfma forces it, lean / lean1 the kernels above
             const bool forced_lean = force && (std::strcmp(force, "lean") == 0 || std::strcmp(force, "lean1") == 0);
             const bool forced_mfma = force && std::strcmp(force, "costate_mfma") == 0;
-            if (!forced_lean && ilqr_adjoint_mfma_supported(*env, *cfg) && (forced_mfma || B >= (n > 16 ? kCostateMfmaMinBatchLarge : (n > 8 ? kCostateMfmaMinBatchSmall : kCostateMfmaMinBatchTiny))))
+            if (!forced_lean && ilqr_adjoint_mfma_supported(*env, *cfg) && (forced_mfma || B >= (n > 16 ? kCostateMfmaMinBatchLarge : kCostateMfmaMinBatchSmall)))
                 return ilqr_adjoint_mfma_launch(*env, *cfg, aa, st);
             return ilqr_adjoint_launch(*env, *cfg, aa, st);
         }
