@@ -358,7 +358,7 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
 template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
     static constexpr int NV = 4 * NT;
     static constexpr int kRain = 0, kDii = 1, kLP = 2, kHP = 3, kSP = 4;      // LDS slots
-    static constexpr int kSearchAlphas = 1;             // see EnvM<HVAC>
+    static constexpr int kSearchAlphas = NT == 1 ? 2 : 1;     // see EnvM<HVAC>; the one-tile variants run few waves
     float rcap[NV], lo[NV], hi[NV];                  // 1 / max_res_cap: x / cap is x times the rounded reciprocal everywhere
     const float *lds;
 
