@@ -1,3 +1,8 @@
+#!/bin/bash
+# Round-end measurements on the GPU box, into gpurun_out/final/ (copy what is to be judged into profiles/):
+#   cfg5 PMC passes (tools/pmc_cfg5.sh), rocprofv3 --kernel-trace --stats of bench.py (headline kernel) and of
+#   tools/all_kernels_once.py (every kernel family), and the full bench.py line.
+#   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/profile_round.sh'
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/final
