@@ -100,7 +100,8 @@ def ilqr_api_rate(n, m, T, B, reps=5):
 def other_config_rates():
     """Secondary numbers (not `value`): the other BASELINE.json configs, one timed launch each after a warm-up --
     cfg2 navlin LQR (B=4096), cfg4 Navigation iLQR (B=16384), cfg5 HVAC / Reservoir iLQR (n=32, T=100, B=32768,
-    <= 12 iterations; shared env: 16 instances per wave, coupling products on the matrix cores), and a dense LQR beyond the headline tile (n=32, m=16, B=8192).  Inputs as in SURVEY.md 8(d)."""
+    <= 12 iterations; shared env: 16 instances per wave, coupling products on the matrix cores), the reference's own
+    hvac6 / res4 configs (B=16384), and a dense LQR beyond the headline tile (n=32, m=16, B=8192).  Inputs as in SURVEY.md 8(d)."""
     import problems
     from tfmpc.envs import make_lqr_linear_navigation
     from tfmpc.envs.hvac import HVAC
@@ -141,6 +142,13 @@ def other_config_rates():
             env, x0 = Reservoir.load(dict(problems.reservoir_config(n, seed=5))), rng.uniform(50, 75, size=(B, n, 1)).astype(np.float32)
         solver = iLQR(env, max_iterations=12)
         res[f"cfg5_{kind}_ilqr_n32"] = ilqr_line(solver, x0, T, solver.random_actions(T, B, seed=5), 1)
+    # the reference's own env configs (hvac6.config.json n = 6, res4.config.json n = 4) at a large batch
+    for name, env, x0r in (("hvac6", HVAC.load(dict(problems.HVAC6_CONFIG)), problems.HVAC6_X0),
+                           ("res4", Reservoir.load(dict(problems.RES4_CONFIG)), problems.RES4_X0)):
+        B, T = 16384, 100
+        x0 = (np.array(x0r, dtype=np.float32)[None] * rng.uniform(0.9, 1.1, size=(B, 1, 1))).astype(np.float32)
+        solver = iLQR(env, max_iterations=12)
+        res[f"{name}_reference_config_ilqr"] = ilqr_line(solver, x0, T, solver.random_actions(T, B, seed=1), 2)
     F, f, C, c, x0 = problems.make_lqr_batch_fast(8192, 32, 16, seed=1)
     big = LQR(0.5 * F, f, C, c)
     x0d = big._prep_x0(x0)
