@@ -11,6 +11,12 @@ Inputs are resident in HBM before the timed region.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` with N > 1 and no launcher (WORLD_SIZE unset) starts the N ranks itself: a
+`torch.distributed.run` CHILD process, created before this process touches the GPU.
+The headline batch is drawn by tests/problems.py:make_lqr_batch_spd -- the reference's
+make_lqr (tfmpc/envs/__init__.py:9-18) vectorised: F, f, c ~ N(0,1), C by make_spd_matrix's
+formula (eigenvalues ~1e-3 .. n+m).
+
 Prints ONE JSON line on rank 0 (see the task contract) with `roofline` for the
 dominant kernel and `cpu_baseline` (the oracle's C port timed on this host).
 """
@@ -169,7 +175,7 @@ def numpy_single_instance_rate(n, m, T, instances=24):
     Optimistic for the reference: no TensorFlow op-dispatch or graph-tracing overhead."""
     import problems
     from oracle import lqr_ref
-    F, f, C, c, x0 = problems.make_lqr_batch_fast(instances, n, m, seed=5)
+    F, f, C, c, x0 = problems.make_lqr_batch_spd(instances, n, m, seed=5)
     t0 = time.perf_counter()
     for b in range(instances):
         lqr_ref.solve(F[b], f[b], C[b], c[b], x0[b], T, dtype=np.float32)
@@ -187,7 +193,7 @@ def cpu_baseline(n, m, T, target_seconds=12.0):
     cores = os.cpu_count() or 1
     threads = max(1, min(cores, c_oracle.max_threads()))
     calib = 64 * threads
-    F, f, C, c, x0 = problems.make_lqr_batch_fast(calib, n, m, seed=99)
+    F, f, C, c, x0 = problems.make_lqr_batch_spd(calib, n, m, seed=99)
     c_oracle.lqr_solve(F, f, C, c, x0, T, dtype=np.float32, nthreads=threads)       # warm up threads
     t0 = time.perf_counter()
     c_oracle.lqr_solve(F, f, C, c, x0, T, dtype=np.float32, nthreads=threads)
@@ -248,9 +254,23 @@ def dry_run_cpu(args):
         dist.destroy_process_group()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a torch.distributed.run child
+    process (never a re-exec: this process has not touched the GPU and never will) and hand back its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="instances per GPU (default = BASELINE config)")
@@ -260,6 +280,11 @@ def main():
                     help="TEST ONLY: no GPU work; a fixed-sleep stand-in step drives the multi-rank control flow "
                          "(barriers, MAX over ranks, the final gather) over gloo so it can be tested without GPUs")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus is not None and args.gpus > 1:
+            raise SystemExit(self_launch(args))         # before any GPU call in this process
+    elif args.gpus is not None and args.gpus != int(os.environ["WORLD_SIZE"]):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
     if args.dry_run_cpu:
         return dry_run_cpu(args)
 
@@ -282,7 +307,7 @@ def main():
 
     n, m, T, B = N_STATE, N_ACTION, HORIZON, args.batch
     # each rank owns its own contiguous shard of the global batch (weak scaling)
-    F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=1234 + rank)
+    F, f, C, c, x0 = problems.make_lqr_batch_spd(B, n, m, seed=1234 + rank)
     lqr = LQR(F, f, C, c)
     x0_dev = lqr._prep_x0(x0)
     lib = _hip.require_gpu()
@@ -315,14 +340,31 @@ def main():
     kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if ev else float("nan")
 
     status_bad = int((out["status"] != 0).sum())
+    # the same steps with the sweep's products on the f32 matrix-core instruction (TFMPC_LQR_MFMA=f32): the strict
+    # variant of the kernel, reported beside the default (bf16x3) -- not part of `value`
+    f32_ms = None
+    if world == 1:
+        with _hip.option("TFMPC_LQR_MFMA", "f32"):
+            step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(max(1, args.steps // 2)):
+                step()
+            e1.record()
+            torch.cuda.synchronize()
+        f32_ms = e0.elapsed_time(e1) / max(1, args.steps // 2)
     # the one collective of the path: gather the result trajectories on rank 0 (outside
-    # the timed region: it happens once per job, not per step)
-    gathered, gather_error = None, None
+    # the timed region: it happens once per job, not per step).  gather_trajectories fails on ALL ranks or none.
+    gathered, gather_error, gather_ms = None, None, None
     if world > 1:
+        fence()
+        g0 = time.perf_counter()
         try:
             gathered = gather_trajectories(out["states"], out["actions"], out["costs"])
-        except Exception as exc:        # the collective is outside the timed region: report, do not lose the line
+        except RuntimeError as exc:
             gather_error = repr(exc)
+        fence()
+        gather_ms = (time.perf_counter() - g0) * 1e3
 
     if world > 1:
         tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
@@ -342,8 +384,10 @@ def main():
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "random LQR n=16 m=8 horizon=50, batch=65536 per GPU (BASELINE configs[2]); "
+            "config": {"workload": f"random LQR n=16 m=8 horizon=50, batch={B} per GPU (BASELINE configs[2]); "
                                    "one LQR solve = one iLQR iteration",
+                       "generator": "tests/problems.py:make_lqr_batch_spd = the reference's make_lqr (tfmpc/envs/__init__.py:9-18) "
+                                    "vectorised: F, f, c ~ N(0,1), C by sklearn make_spd_matrix's formula (eigenvalues ~1e-3 .. n+m)",
                        "state_dim": n, "action_dim": m, "horizon": T, "batch_per_gpu": B,
                        "global_batch": B * world, "parallelism": f"batch-sharded x{world}, one gather at the end",
                        "kernel": kernel},
@@ -359,8 +403,18 @@ def main():
                          "hbm_frac_at_algorithmic_bytes": lqr_bytes_per_solve(n, m, T) * B / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
             "status_flagged_instances": status_bad,
         }
+        if f32_ms is not None:
+            flop_s = flops / (f32_ms * 1e-3) / 1e12
+            line["strict_f32_variant"] = {"option": "TFMPC_LQR_MFMA=f32 (v_mfma_f32_16x16x4_f32 instead of bf16x3)",
+                                          "kernel_ms": f32_ms, "achieved": flop_s, "frac": flop_s / PEAK_F32_TFLOPS}
         if gathered is not None:
             line["gathered_states_shape"] = list(gathered[0].shape)
+        if gather_ms is not None:
+            from tfmpc.parallel import gather_bytes_per_rank
+            per_rank = gather_bytes_per_rank(out["states"], out["actions"], out["costs"])
+            line["gather"] = {"collective": "ONE dist.gather (RCCL) of the packed trajectories onto rank 0, after the timed steps",
+                              "ms": gather_ms, "bytes_per_rank": per_rank, "bytes_total": per_rank * world,
+                              "GB_per_s_into_rank0": per_rank * (world - 1) / (gather_ms * 1e-3) / 1e9}
         if gather_error is not None:
             line["gather_error"] = gather_error
         if world == 1 and not args.no_cpu_baseline:

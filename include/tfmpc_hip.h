@@ -43,6 +43,12 @@ extern "C" {
 
 /* Library / device information ------------------------------------------------ */
 int tfmpc_version(void);
+/* Kernel-variant overrides for A/B timing and tests.  The environment variables TFMPC_LQR_KERNEL
+ * (generic | lane | block), TFMPC_LQR_MFMA (f32 | bf16x3) and TFMPC_ILQR_KERNEL (wave | lane | lane1 |
+ * lean | lean1 | costate_mfma) are read ONCE per process, at the first use of the library; afterwards only
+ * this call changes them (value NULL or "" = back to the dispatcher's own choice).  Returns TFMPC_ERR_ARG
+ * for an unknown name.  Process-wide; not meant to be flipped while other threads launch. */
+int tfmpc_set_option(const char *name, const char *value);
 /* Name of the kernel variant the dispatcher would pick for an LQR shape
  * ("generic_wave", "mfma_16x8", ...).  Host-only; never touches the GPU. */
 const char *tfmpc_lqr_kernel_name(int n, int m, int T);
@@ -52,6 +58,16 @@ const char *tfmpc_lqr_kernel_name(int n, int m, int T);
  * 1/2 z^T C z + c^T z, final cost 1/2 x^T C_xx x + c_x^T x, with
  * F[n][n+m], f[n], C[n+m][n+m], c[n+m].
  */
+
+/* PRECONDITION of tfmpc_lqr_backward_f32 / _forward_f32 / _solve_f32: C is symmetric (every problem the
+ * reference builds is: make_lqr draws make_spd_matrix, make_lqr_linear_navigation a diagonal,
+ * tfmpc/envs/__init__.py:9-30).  The fast kernels use it: Q_xu is read as Q_ux^T, Q_uu is eliminated from its
+ * upper triangle without pivoting (so Q_uu must be positive definite: C_uu > 0, C >= 0; a non-positive pivot
+ * is reported as TFMPC_ST_NOT_PD / TFMPC_ST_SINGULAR) and V is kept exactly symmetric.  For a C that is NOT
+ * symmetric the reference's recursion (lqr.py:74-105: Q_ux and Q_xu separately, tf.linalg.inv, four-term
+ * update, no symmetrisation) gives a different answer than any symmetrised solve; call the *_general_f32
+ * twins below, which restate it term by term on the wave-per-instance kernel (same arguments, any C).
+ * The Python class checks C once at construction and picks the entry points accordingly. */
 
 /* Bytes of scratch tfmpc_lqr_solve_f32 needs when K / k are not requested as
  * outputs (the gains are kept for the forward pass). */
@@ -87,6 +103,27 @@ int tfmpc_lqr_solve_f32(int B, int n, int m, int T,
                         float *states, float *actions, float *costs,
                         float *K, float *k, float *V, float *v, float *cst,
                         int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+
+
+/* The same three calls for a C that is not symmetric (see PRECONDITION above). */
+int tfmpc_lqr_backward_general_f32(int B, int n, int m, int T,
+                                   const float *F, long strideF, const float *f, long stride_f,
+                                   const float *C, long strideC, const float *c, long stride_c,
+                                   float *K, float *k, float *V, float *v, float *cst,
+                                   int32_t *status, void *stream);
+int tfmpc_lqr_forward_general_f32(int B, int n, int m, int T,
+                                  const float *F, long strideF, const float *f, long stride_f,
+                                  const float *C, long strideC, const float *c, long stride_c,
+                                  const float *K, long strideK, const float *k, long stride_k,
+                                  const float *x0,
+                                  float *states, float *actions, float *costs, void *stream);
+int tfmpc_lqr_solve_general_f32(int B, int n, int m, int T,
+                                const float *F, long strideF, const float *f, long stride_f,
+                                const float *C, long strideC, const float *c, long stride_c,
+                                const float *x0,
+                                float *states, float *actions, float *costs,
+                                float *K, float *k, float *V, float *v, float *cst,
+                                int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
 
 
 /* --------------------------------------------------------------- iLQR --------

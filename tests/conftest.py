@@ -16,6 +16,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest` on a box without a GPU skips the `gpu`-marked tests instead of failing them (the product
+    path raises there: no CPU fallback).  `torch.cuda.device_count()` does not initialise the GPU."""
+    import torch
+    if torch.cuda.device_count() > 0:
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (no ROCm device visible)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

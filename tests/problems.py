@@ -52,6 +52,30 @@ def make_lqr_batch_fast(B, n, m, seed=0):
     return F, f, C, c, x0
 
 
+def make_lqr_batch_spd(B, n, m, seed=0, chunk=8192):
+    """``make_lqr`` (``tfmpc/envs/__init__.py:9-18``) vectorised over the batch: F, f, c ~ N(0,1) and
+    C by the very formula of sklearn's ``make_spd_matrix`` -- ``A ~ U(0,1)^{d x d}``, ``U, _, Vt =
+    svd(A^T A)``, ``C = U (1.0 + diag(r)) Vt`` with ``r ~ U(0,1)^d``, where the ``1.0`` is added to EVERY
+    entry of the middle factor, not just its diagonal.  Same distribution as ``make_lqr_instance``
+    (eigenvalues of C from ~1e-3 .. 0.04 up to ~n+m, rho(F_x) ~ 5); the draws come from ``default_rng(seed)``
+    instead of one global ``RandomState`` per instance, so the VALUES differ from the seeded instances.
+    The generator of bench.py's headline batch and of the full-size parity tests."""
+    rng = np.random.default_rng(seed)
+    d = n + m
+    F = rng.normal(size=(B, n, d))
+    f = rng.normal(size=(B, n))
+    c = rng.normal(size=(B, d))
+    x0 = rng.normal(size=(B, n))
+    C = np.empty((B, d, d))
+    for lo in range(0, B, chunk):
+        hi = min(B, lo + chunk)
+        A = rng.uniform(size=(hi - lo, d, d))
+        U, _, Vt = np.linalg.svd(np.einsum("bki,bkj->bij", A, A))
+        mid = 1.0 + rng.uniform(size=(hi - lo, d))[:, :, None] * np.eye(d)
+        C[lo:hi] = U @ mid @ Vt
+    return F, f, C, c, x0
+
+
 def make_navlin_batch(B, beta, seed=2):
     """cfg2: ``x0_i, goal_i ~ U(-10,10)^2``; instance 0 is the README pair."""
     rng = np.random.default_rng(seed)

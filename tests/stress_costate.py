@@ -4,10 +4,12 @@ seeds and iteration caps; the 16-instances-per-wave matrix-core kernel == wave k
 on HVAC (whose linear terms it folds into the matrix) within 2e-6 for the instances whose decisions did not flip.
 Run on the GPU box: python tests/stress_costate.py [cases]"""
 import os, sys
-sys.path.insert(0, '/root/repo/tf-mpc_amd'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in ('tf-mpc_amd', 'tests', ''): sys.path.insert(0, os.path.join(ROOT, _p))
 import numpy as np, torch, problems
 from tfmpc.envs.hvac import HVAC
 from tfmpc.envs.reservoir import Reservoir
+from tfmpc import _hip
 from tfmpc.solvers.ilqr import iLQR
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -25,10 +27,9 @@ for case in range(cases):
     u0 = s.random_actions(T, B, seed=seed)
     out = {}
     for kern in ("lean", "wave", "costate_mfma"):
-        if kern is None: os.environ.pop("TFMPC_ILQR_KERNEL", None)
-        else: os.environ["TFMPC_ILQR_KERNEL"] = kern
+        _hip.set_option("TFMPC_ILQR_KERNEL", kern)
         out[kern] = s.solve_device(x0, T, u_init=u0); torch.cuda.synchronize()
-    os.environ.pop("TFMPC_ILQR_KERNEL", None)
+    _hip.set_option("TFMPC_ILQR_KERNEL", None)
     keys = ("states", "actions", "costs", "iterations", "status")
     same = all(torch.equal(out["lean"][k], out["wave"][k]) for k in keys)
     finite = bool(torch.isfinite(out["lean"]["costs"]).all()) and bool(torch.isfinite(out["costate_mfma"]["costs"]).all())

@@ -4,8 +4,9 @@ kernel; `python tests/stress_lqr.py [cases] large` draws n <= 40, m <= 24 instea
 horizons 1..60, well- and ill-conditioned costs (make_spd_matrix-like spectra down to 0.02), unstable F.
 Reports, per case, the device error relative to the fp32 restatement's error.  Run on the GPU box:
 python tests/stress_lqr.py [cases]"""
-import sys, time
-sys.path.insert(0, '/root/repo/tf-mpc_amd'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in ('tf-mpc_amd', 'tests', ''): sys.path.insert(0, os.path.join(ROOT, _p))
 import numpy as np, torch
 from oracle import c_oracle
 from tfmpc.solvers.lqr import LQR

@@ -38,3 +38,22 @@ def test_two_rank_dry_run_aggregates_over_ranks():
     assert line["n_gpus"] == 2 and line["total_instances"] == 64 + 65          # whole-job aggregate
     assert line["gathered_states_shape"] == [129, 6, 4, 1] and line["gathered_rank_of_last_instance"] == 1.0
     assert line["ms_per_step"] >= 3.5                                          # the slower rank (4 ms sleeps) sets the time
+
+
+def test_gpus_flag_alone_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with NO launcher (the form the driver uses for N = 1) must not silently run one
+    rank: bench.py starts the two ranks as a torch.distributed.run child process and rank 0 prints the line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry-run-cpu", "--steps", "2", "--warmup", "1"],
+                         cwd=ROOT, env=dict(env, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["total_instances"] == 64 + 65
+
+
+def test_gpus_flag_must_match_the_launcher():
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--dry-run-cpu"], cwd=ROOT,
+                         env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr

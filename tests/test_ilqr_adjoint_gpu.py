@@ -10,6 +10,7 @@ import pytest
 import torch
 
 import problems
+from tfmpc import _hip
 from tfmpc.envs.hvac import HVAC
 from tfmpc.envs.reservoir import Reservoir
 from tfmpc.solvers.ilqr import iLQR
@@ -19,15 +20,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def force_kernel():
-    old = os.environ.get("TFMPC_ILQR_KERNEL")
-
     def set_(name):
-        if name is None:
-            os.environ.pop("TFMPC_ILQR_KERNEL", None)
-        else:
-            os.environ["TFMPC_ILQR_KERNEL"] = name
+        _hip.set_option("TFMPC_ILQR_KERNEL", name)
     yield set_
-    set_(old)
+    set_(None)
 
 
 @pytest.mark.parametrize("kind", ["hvac", "reservoir"])

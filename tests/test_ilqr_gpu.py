@@ -197,13 +197,8 @@ def test_fused_solve_matches_golden_and_host_driven_loop(golden, case):
     x0, u0 = G("x0")[:, None], G("u_init")[..., None]
     # (a) the fused WAVE kernel == the reference's loop driven over the single kernels, bit for bit
     # (the LQ env would otherwise take the matrix-core solve kernel, which rounds differently)
-    import os
-    old_force = os.environ.get("TFMPC_ILQR_KERNEL")
-    os.environ["TFMPC_ILQR_KERNEL"] = "wave"
-    try:
+    with _hip.option("TFMPC_ILQR_KERNEL", "wave"):
         traj, iteration = solver.solve(x0, T, show_progress=False, u_init=u0)
-    finally:
-        os.environ.pop("TFMPC_ILQR_KERNEL") if old_force is None else os.environ.__setitem__("TFMPC_ILQR_KERNEL", old_force)
     assert int(solver.last_status[0]) & ~_hip.ST_QP_MAXITER == 0
     xh, uh, ch, it_h = _host_driven_solve(solver, x0, T, u0)
     assert iteration == it_h

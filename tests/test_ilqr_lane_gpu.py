@@ -21,15 +21,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def force_kernel():
-    old = os.environ.get("TFMPC_ILQR_KERNEL")
-
     def set_(name):
-        if name is None:
-            os.environ.pop("TFMPC_ILQR_KERNEL", None)
-        else:
-            os.environ["TFMPC_ILQR_KERNEL"] = name
+        _hip.set_option("TFMPC_ILQR_KERNEL", name)
     yield set_
-    set_(old)
+    set_(None)
 
 
 def _solve_both(force_kernel, solver, x0, T, u0):

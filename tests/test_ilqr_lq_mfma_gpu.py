@@ -20,15 +20,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def force_kernel():
-    old = os.environ.get("TFMPC_ILQR_KERNEL")
-
     def set_(name):
-        if name is None:
-            os.environ.pop("TFMPC_ILQR_KERNEL", None)
-        else:
-            os.environ["TFMPC_ILQR_KERNEL"] = name
+        _hip.set_option("TFMPC_ILQR_KERNEL", name)
     yield set_
-    set_(old)
+    set_(None)
 
 
 def _problem(B, n, m, seed, scale=0.25):

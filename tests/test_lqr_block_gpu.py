@@ -20,15 +20,10 @@ BUDGET = 5.0
 
 @pytest.fixture
 def force_kernel():
-    old = os.environ.get("TFMPC_LQR_KERNEL")
-
     def set_(name):
-        if name is None:
-            os.environ.pop("TFMPC_LQR_KERNEL", None)
-        else:
-            os.environ["TFMPC_LQR_KERNEL"] = name
+        _hip.set_option("TFMPC_LQR_KERNEL", name)
     yield set_
-    set_(old)
+    set_(None)
 
 
 def _problem(B, n, m, seed):

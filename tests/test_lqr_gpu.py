@@ -179,21 +179,16 @@ def test_mfma_kernel_on_padded_shapes(n, m):
 def test_f32_mfma_variant_agrees_with_bf16x3_default():
     """TFMPC_LQR_MFMA=f32 keeps the sweep's big products on v_mfma_f32_16x16x4_f32; the default
     evaluates them as bf16x3.  Both are fp32-accurate, so they agree like two fp32 programs."""
-    import os
     B, n, m, T = 128, 16, 8, 50
     F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=21)
     lqr = LQR(F, f, C, c)
     ref64 = c_oracle.lqr_solve(F, f, C, c, x0, T, dtype=np.float64)
     outs = {}
-    old = os.environ.get("TFMPC_LQR_MFMA")
-    try:
-        for mode in ("bf16x3", "f32"):
-            os.environ["TFMPC_LQR_MFMA"] = mode
+    for mode in ("bf16x3", "f32"):
+        with _hip.option("TFMPC_LQR_MFMA", mode):
             outs[mode] = lqr.solve_device(x0, T)
-            torch.cuda.synchronize()
-            assert int(outs[mode]["status"].abs().sum()) == 0
-    finally:
-        os.environ.pop("TFMPC_LQR_MFMA") if old is None else os.environ.__setitem__("TFMPC_LQR_MFMA", old)
+        torch.cuda.synchronize()
+        assert int(outs[mode]["status"].abs().sum()) == 0
     errs = {}
     for mode, o in outs.items():
         got = _np(o["states"]).reshape(ref64["states"].shape)

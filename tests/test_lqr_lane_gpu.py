@@ -9,6 +9,7 @@ import torch
 
 import problems
 from oracle import c_oracle
+from tfmpc import _hip
 from tfmpc.solvers.lqr import LQR
 
 pytestmark = pytest.mark.gpu
@@ -17,15 +18,10 @@ BUDGET = 5.0
 
 @pytest.fixture
 def force_kernel():
-    old = os.environ.get("TFMPC_LQR_KERNEL")
-
     def set_(name):
-        if name is None:
-            os.environ.pop("TFMPC_LQR_KERNEL", None)
-        else:
-            os.environ["TFMPC_LQR_KERNEL"] = name
+        _hip.set_option("TFMPC_LQR_KERNEL", name)
     yield set_
-    set_(old)
+    set_(None)
 
 
 @pytest.mark.parametrize("n,m", [(1, 1), (2, 1), (2, 2), (3, 2), (3, 3), (4, 2)])

@@ -27,6 +27,7 @@
 
 #include "../../include/tfmpc_hip.h"
 #include "ilqr_adjoint.h"
+#include "options.h"
 #include "trig.h"
 #include "wave_ops.h"
 
@@ -679,8 +680,7 @@ int ilqr_adjoint_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const A
     const bool small = env.n <= kHalf;
     // lanes an instance needs: two per row of the transition, and 2 n for Q_x, Q_u
     const int lanes = 2 * env.n;
-    const char *force = std::getenv("TFMPC_ILQR_KERNEL");                  // "lean1": one instance per wave (A/B, tests)
-    const bool packed = lanes <= 32 && !(force && std::strcmp(force, "lean1") == 0);
+    const bool packed = lanes <= 32 && !option_is(kOptIlqrKernel, "lean1");     // "lean1": one instance per wave (A/B, tests)
     if (packed && lanes <= 16) {
         const dim3 grid((a.B + 3) / 4);
         if (env.kind == TFMPC_ENV_HVAC) hipLaunchKernelGGL((ilqr_adjoint_group_kernel<TFMPC_ENV_HVAC, 16>), grid, block, 0, stream, env, cfg, a);

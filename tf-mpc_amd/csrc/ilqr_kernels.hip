@@ -11,6 +11,7 @@
 #include "ilqr_core.h"
 #include "ilqr_lq_mfma.h"
 #include "lqr_kernels.h"
+#include "options.h"
 
 namespace tfmpc {
 
@@ -480,10 +481,7 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
         // tiny 2-D envs: 16 lanes per instance with a speculative parallel line search (ilqr_lane.hip) at EVERY batch
         // size -- also for one instance it has the shorter critical path (Navigation, T = 50, B = 1: 2.3 ms against
         // 7.2 ms for the wave kernel; tools/small_batch_lane_vs_wave.py).  TFMPC_ILQR_KERNEL=lane|lane1|wave forces.
-        const char *force = std::getenv("TFMPC_ILQR_KERNEL");
-        const bool forced_lane = force && (std::strcmp(force, "lane") == 0 || std::strcmp(force, "lane1") == 0);
-        const bool forced_wave = force && std::strcmp(force, "wave") == 0;
-        (void)forced_lane;
+        const bool forced_wave = option_is(kOptIlqrKernel, "wave");
         if (ilqr_lane_supported(*env) && !forced_wave && !cfg->storage_bf16)
             return ilqr_lane_solve_launch(*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status,
                                           a.wsK, a.wsk, a.wsx, a.wsu, a.wsc, st);
@@ -491,8 +489,7 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
     {
         // LQ env on the matrix cores (ilqr_lq_mfma.hip); instances it cannot finish (mu > 0 needed)
         // come back flagged and are re-solved from scratch by the wave kernel right behind it
-        const char *force = std::getenv("TFMPC_ILQR_KERNEL");
-        const bool forced_wave = force && std::strcmp(force, "wave") == 0;
+        const bool forced_wave = option_is(kOptIlqrKernel, "wave");
         if (!forced_wave && !cfg->storage_bf16 && ilqr_lq_mfma_supported(*env, T)) {
             IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk, a.wsu};
             if ((rc = ilqr_lq_mfma_launch(la, st)) != TFMPC_OK) return rc;
@@ -502,14 +499,13 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
     {
         // HVAC / Reservoir at n <= 32: register-resident costate kernel (ilqr_adjoint.hip),
         // bit-identical to the generic wave kernel below (TFMPC_ILQR_KERNEL=wave selects that one)
-        const char *force = std::getenv("TFMPC_ILQR_KERNEL");
-        const bool forced_wave = force && std::strcmp(force, "wave") == 0;
+        const bool forced_wave = option_is(kOptIlqrKernel, "wave");
         if (!forced_wave && ilqr_adjoint_supported(*env, *cfg)) {
             const AdjointSolveArgs aa{B, T, x0, u_init, states, actions, costs, iterations, status, a.wsk, a.wsx, a.wsu, a.wsc};
             // a batch that shares one env: 16 instances per wave with the coupling-matrix products on the matrix
             // cores (ilqr_adjoint_mfma.hip); TFMPC_ILQR_KERNEL=costate_mfma forces it, lean / lean1 the kernels above
-            const bool forced_lean = force && (std::strcmp(force, "lean") == 0 || std::strcmp(force, "lean1") == 0);
-            const bool forced_mfma = force && std::strcmp(force, "costate_mfma") == 0;
+            const bool forced_lean = option_is(kOptIlqrKernel, "lean") || option_is(kOptIlqrKernel, "lean1");
+            const bool forced_mfma = option_is(kOptIlqrKernel, "costate_mfma");
             if (!forced_lean && ilqr_adjoint_mfma_supported(*env, *cfg) && (forced_mfma || B >= (n > 16 ? kCostateMfmaMinBatchLarge : kCostateMfmaMinBatchSmall)))
                 return ilqr_adjoint_mfma_launch(*env, *cfg, aa, st);
             return ilqr_adjoint_launch(*env, *cfg, aa, st);

@@ -14,6 +14,7 @@
 
 #include "envs.h"
 #include "lqr_kernels.h"
+#include "options.h"
 #include "small_linalg.h"
 
 namespace tfmpc {
@@ -801,8 +802,7 @@ int ilqr_lane_solve_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, int 
 {
     SolveArgsLane a{B, T, x0, u_init, states, actions, costs, iterations, status, wsK, wsk, wsx, wsu, wsc};
     {
-        const char *force = std::getenv("TFMPC_ILQR_KERNEL");
-        const bool per_lane = force && std::strcmp(force, "lane1") == 0;
+        const bool per_lane = option_is(kOptIlqrKernel, "lane1");
         const size_t glds = GroupStore<2, 2>::bytes(T);
         if (!per_lane && glds <= 64 * 1024) {
             const dim3 ggrid((B + 3) / 4), gblock(64);

@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "lqr_kernels.h"
+#include "options.h"
 
 using namespace tfmpc;
 
@@ -13,8 +14,7 @@ namespace {
 
 bool want_mfma(int n, int m)
 {
-    const char *force = std::getenv("TFMPC_LQR_KERNEL");   // "generic" | "mfma" (testing / A-B timing)
-    if (force && std::strcmp(force, "generic") == 0) return false;
+    if (option_is(kOptLqrKernel, "generic")) return false;   // testing / A-B timing
     return lqr_mfma_supported(n, m);
 }
 
@@ -25,9 +25,8 @@ constexpr int kLaneMinBatch = 32;
 bool want_lane(int n, int m, int B)
 {
     if (!lqr_lane_supported(n, m)) return false;
-    const char *force = std::getenv("TFMPC_LQR_KERNEL");
-    if (force && std::strcmp(force, "generic") == 0) return false;
-    if (force && std::strcmp(force, "lane") == 0) return true;
+    if (option_is(kOptLqrKernel, "generic")) return false;
+    if (option_is(kOptLqrKernel, "lane")) return true;
     return B >= kLaneMinBatch;
 }
 
@@ -41,25 +40,28 @@ constexpr int kBlockMaxSmallBatch = 2048;
 bool want_block(int n, int m, int B)
 {
     if (lqr_block_smem_bytes(n, m) > kMaxLdsBytes) return false;
-    const char *force = std::getenv("TFMPC_LQR_KERNEL");
-    if (force && std::strcmp(force, "generic") == 0) return false;
-    if (force && std::strcmp(force, "block") == 0) return true;
+    if (option_is(kOptLqrKernel, "generic")) return false;
+    if (option_is(kOptLqrKernel, "block")) return true;
     if (lqr_lane_supported(n, m)) return false;           // tiny shapes: one wave (or one lane) is already the short path
     return n + m >= kBlockFrom || B <= kBlockMaxSmallBatch;
 }
 
-int check_common(int B, int n, int m, int T, const void *F, const void *f, const void *C, const void *c)
+int check_common(int B, int n, int m, int T, const void *F, const void *f, const void *C, const void *c, bool general)
 {
     if (B < 0 || n <= 0 || m <= 0 || T < 0) return TFMPC_ERR_ARG;
     if (!F || !f || !C || !c) return TFMPC_ERR_ARG;
-    if (!want_mfma(n, m) && lqr_generic_smem_bytes(n, m) > kMaxLdsBytes) return TFMPC_ERR_UNSUPPORTED;
+    if ((general || !want_mfma(n, m)) && lqr_generic_smem_bytes(n, m) > kMaxLdsBytes) return TFMPC_ERR_UNSUPPORTED;
     return TFMPC_OK;
 }
 
-int run(const LqrArgs &a, bool bw, bool fw, void *stream)
+int run(const LqrArgs &a, bool bw, bool fw, bool general, void *stream)
 {
     if (a.B == 0) return TFMPC_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // `general`: C is not symmetric.  Only the wave kernel restates lqr.py:74-105 term by term (Q_ux and Q_xu
+    // read separately, pivoted general inverse, four-term update, no symmetrisation); every other variant uses
+    // the symmetry of C and V.
+    if (general) return lqr_generic_launch(a, bw, fw, s);
     if (want_mfma(a.n, a.m)) return lqr_mfma_launch(a, bw, fw, s);
     if (want_lane(a.n, a.m, a.B)) return lqr_lane_launch(a, bw, fw, s);
     if (want_block(a.n, a.m, a.B)) return lqr_block_launch(a, bw, fw, s);
@@ -70,7 +72,7 @@ int run(const LqrArgs &a, bool bw, bool fw, void *stream)
 
 extern "C" {
 
-int tfmpc_version(void) { return 100; }
+int tfmpc_version(void) { return 200; }
 
 const char *tfmpc_lqr_kernel_name(int n, int m, int T)
 {
@@ -90,11 +92,15 @@ size_t tfmpc_lqr_workspace_bytes(int B, int n, int m, int T)
     return (size_t)B * T * m * (n + 1) * sizeof(float);
 }
 
-int tfmpc_lqr_backward_f32(int B, int n, int m, int T, const float *F, long strideF, const float *f,
-                           long stride_f, const float *C, long strideC, const float *c, long stride_c,
-                           float *K, float *k, float *V, float *v, float *cst, int32_t *status, void *stream)
+}  // extern "C"
+
+namespace {
+
+int backward_impl(bool general, int B, int n, int m, int T, const float *F, long strideF, const float *f,
+                  long stride_f, const float *C, long strideC, const float *c, long stride_c,
+                  float *K, float *k, float *V, float *v, float *cst, int32_t *status, void *stream)
 {
-    int rc = check_common(B, n, m, T, F, f, C, c);
+    int rc = check_common(B, n, m, T, F, f, C, c, general);
     if (rc != TFMPC_OK) return rc;
     if (T > 0 && B > 0 && (!K || !k)) return TFMPC_ERR_ARG;
     LqrArgs a{};
@@ -103,15 +109,15 @@ int tfmpc_lqr_backward_f32(int B, int n, int m, int T, const float *F, long stri
     a.sF = strideF; a.sf = stride_f; a.sC = strideC; a.sc = stride_c;
     a.K = K; a.k = k; a.sK = (long)T * m * n; a.sk = (long)T * m;
     a.V = V; a.v = v; a.cst = cst; a.status = status;
-    return run(a, true, false, stream);
+    return run(a, true, false, general, stream);
 }
 
-int tfmpc_lqr_forward_f32(int B, int n, int m, int T, const float *F, long strideF, const float *f,
-                          long stride_f, const float *C, long strideC, const float *c, long stride_c,
-                          const float *K, long strideK, const float *k, long stride_k, const float *x0,
-                          float *states, float *actions, float *costs, void *stream)
+int forward_impl(bool general, int B, int n, int m, int T, const float *F, long strideF, const float *f,
+                 long stride_f, const float *C, long strideC, const float *c, long stride_c,
+                 const float *K, long strideK, const float *k, long stride_k, const float *x0,
+                 float *states, float *actions, float *costs, void *stream)
 {
-    int rc = check_common(B, n, m, T, F, f, C, c);
+    int rc = check_common(B, n, m, T, F, f, C, c, general);
     if (rc != TFMPC_OK) return rc;
     if (B > 0 && (!x0 || !states || !costs)) return TFMPC_ERR_ARG;
     if (B > 0 && T > 0 && (!K || !k || !actions)) return TFMPC_ERR_ARG;
@@ -121,16 +127,16 @@ int tfmpc_lqr_forward_f32(int B, int n, int m, int T, const float *F, long strid
     a.sF = strideF; a.sf = stride_f; a.sC = strideC; a.sc = stride_c;
     a.K = const_cast<float *>(K); a.k = const_cast<float *>(k); a.sK = strideK; a.sk = stride_k;
     a.states = states; a.actions = actions; a.costs = costs;
-    return run(a, false, true, stream);
+    return run(a, false, true, general, stream);
 }
 
-int tfmpc_lqr_solve_f32(int B, int n, int m, int T, const float *F, long strideF, const float *f,
-                        long stride_f, const float *C, long strideC, const float *c, long stride_c,
-                        const float *x0, float *states, float *actions, float *costs, float *K, float *k,
-                        float *V, float *v, float *cst, int32_t *status, void *workspace,
-                        size_t workspace_bytes, void *stream)
+int solve_impl(bool general, int B, int n, int m, int T, const float *F, long strideF, const float *f,
+               long stride_f, const float *C, long strideC, const float *c, long stride_c,
+               const float *x0, float *states, float *actions, float *costs, float *K, float *k,
+               float *V, float *v, float *cst, int32_t *status, void *workspace,
+               size_t workspace_bytes, void *stream)
 {
-    int rc = check_common(B, n, m, T, F, f, C, c);
+    int rc = check_common(B, n, m, T, F, f, C, c, general);
     if (rc != TFMPC_OK) return rc;
     if (B > 0 && (!x0 || !states || !costs)) return TFMPC_ERR_ARG;
     if (B > 0 && T > 0 && !actions) return TFMPC_ERR_ARG;
@@ -148,7 +154,39 @@ int tfmpc_lqr_solve_f32(int B, int n, int m, int T, const float *F, long strideF
     a.K = K; a.k = k; a.sK = (long)T * m * n; a.sk = (long)T * m;
     a.V = V; a.v = v; a.cst = cst;
     a.states = states; a.actions = actions; a.costs = costs; a.status = status;
-    return run(a, true, true, stream);
+    return run(a, true, true, general, stream);
 }
+
+}  // namespace
+
+extern "C" {
+
+#define TFMPC_LQR_BACKWARD_PARAMS                                                                              \
+    int B, int n, int m, int T, const float *F, long strideF, const float *f, long stride_f, const float *C,   \
+        long strideC, const float *c, long stride_c, float *K, float *k, float *V, float *v, float *cst,       \
+        int32_t *status, void *stream
+#define TFMPC_LQR_BACKWARD_ARGS B, n, m, T, F, strideF, f, stride_f, C, strideC, c, stride_c, K, k, V, v, cst, status, stream
+#define TFMPC_LQR_FORWARD_PARAMS                                                                               \
+    int B, int n, int m, int T, const float *F, long strideF, const float *f, long stride_f, const float *C,   \
+        long strideC, const float *c, long stride_c, const float *K, long strideK, const float *k,             \
+        long stride_k, const float *x0, float *states, float *actions, float *costs, void *stream
+#define TFMPC_LQR_FORWARD_ARGS \
+    B, n, m, T, F, strideF, f, stride_f, C, strideC, c, stride_c, K, strideK, k, stride_k, x0, states, actions, costs, stream
+#define TFMPC_LQR_SOLVE_PARAMS                                                                                 \
+    int B, int n, int m, int T, const float *F, long strideF, const float *f, long stride_f, const float *C,   \
+        long strideC, const float *c, long stride_c, const float *x0, float *states, float *actions,           \
+        float *costs, float *K, float *k, float *V, float *v, float *cst, int32_t *status, void *workspace,    \
+        size_t workspace_bytes, void *stream
+#define TFMPC_LQR_SOLVE_ARGS                                                                                   \
+    B, n, m, T, F, strideF, f, stride_f, C, strideC, c, stride_c, x0, states, actions, costs, K, k, V, v, cst, \
+        status, workspace, workspace_bytes, stream
+
+int tfmpc_lqr_backward_f32(TFMPC_LQR_BACKWARD_PARAMS) { return backward_impl(false, TFMPC_LQR_BACKWARD_ARGS); }
+int tfmpc_lqr_forward_f32(TFMPC_LQR_FORWARD_PARAMS) { return forward_impl(false, TFMPC_LQR_FORWARD_ARGS); }
+int tfmpc_lqr_solve_f32(TFMPC_LQR_SOLVE_PARAMS) { return solve_impl(false, TFMPC_LQR_SOLVE_ARGS); }
+// C not symmetric: the reference's term-by-term recursion (see tfmpc_hip.h)
+int tfmpc_lqr_backward_general_f32(TFMPC_LQR_BACKWARD_PARAMS) { return backward_impl(true, TFMPC_LQR_BACKWARD_ARGS); }
+int tfmpc_lqr_forward_general_f32(TFMPC_LQR_FORWARD_PARAMS) { return forward_impl(true, TFMPC_LQR_FORWARD_ARGS); }
+int tfmpc_lqr_solve_general_f32(TFMPC_LQR_SOLVE_PARAMS) { return solve_impl(true, TFMPC_LQR_SOLVE_ARGS); }
 
 }  // extern "C"

@@ -6,32 +6,48 @@
 // wavefront owns one problem instance for the whole solve.
 //
 // Backward sweep (lqr.py:73-127), per timestep, all in registers:
-//   F~ = [F_x | F_u f 0] (16 x 32) and C~ = [[C, c],[.,0]] (32 x 32, padded) are loaded
-//   once in MFMA operand layout and stay resident for all T steps.
-//   1. W  = V F~            8 x v_mfma_f32_16x16x4_f32   (column 24 of W is V f; += v)
-//   2. Q~ = C~ + F~^T W    16 x mfma                      (Q_xx | Q_xu q_x ; Q_ux | Q_uu q_u)
-//      The accumulator layout of a 16x16x4 MFMA (lane (j, q) holds rows 4q..4q+3 of
-//      column j) IS the B-operand layout of the next MFMA if the contraction index is
-//      enumerated as k = 4q + r (r = k-step): W feeds step 2 and V feeds step 1 with no
-//      data movement, and one register set of F~ serves as B operand in 1 and as
-//      A operand (F~^T) in 2.
-//   3. [Q_uu | q_u | Q_ux] (8 x 25) goes through LDS into "one column per lane, eight
-//      rows in registers" and is eliminated by Gauss-Jordan with v_readlane broadcasts
-//      (general inverse of lqr.py:84-87; Q_uu is SPD, no pivoting) -> K, k.
-//   4. V' = Q_xx + Q_xu K, v' = q_x + Q_xu k   8 x mfma (the Schur-complement form of
-//      lqr.py:97-105, equal to its four-term form in exact arithmetic).
+//   F~ = [F_x | F_u f 0] (16 x 32) and the tiles of C~ = [[C, c],[.,0]] are loaded once in
+//   matrix-core operand layout and stay resident for all T steps.
+//   1. W = V F~ (two 16 x 16 tiles; column 24 of W is V f; += v).
+//   2. THREE 16 x 16 tiles of Q~ = C~ + F~^T W:  Q_xx = F_x^T W_0;  [Q_uu | q_u] = F~_1^T W_1;
+//      and W_1^T F_x, whose rows 0..7 are Q_ux and whose row 8 is q_x^T (V is kept exactly
+//      symmetric, step 4, so the F~_1^T W_0 tile is redundant).
+//      The accumulator layout of a 16x16 MFMA (lane (j, q) holds rows 4q..4q+3 of column j) IS the
+//      operand layout of the next product when the contraction index is enumerated k = 4q + r:
+//      W feeds step 2 and V feeds step 1 with no data movement, and one register set of F~ is
+//      the B operand of step 1 and the A operand (F~^T) of step 2.
+//      Default (BF3): each of these five products is evaluated as "bf16x3" on the bf16 matrix
+//      cores -- every fp32 operand split into three bf16 parts (24 mantissa bits), six partial
+//      products carried by three v_mfma_f32_16x16x32_bf16 with fp32 accumulation
+//      (mfma_bf16x3.h): 15 MFMAs per step.  TFMPC_LQR_MFMA=f32 (tfmpc_set_option) keeps them on
+//      v_mfma_f32_16x16x4_f32: 20 MFMAs per step, exact fp32 FMA chains.
+//   3. [Q_ux | Q_uu | q_u] (8 x 25) crosses LDS once into "one column per lane, eight rows in
+//      registers" and is solved by an LDL^T elimination WITHOUT pivoting that reads only the
+//      upper triangle of Q_uu (wave_ldlt8.h; one v_readlane per multiplier serves the forward and
+//      the backward sweep) -> K~ = -Q_uu^-1 [Q_ux | q_u].  The reference takes a general
+//      inverse (lqr.py:84-87); for a symmetric C with C_uu > 0 (the precondition stated in
+//      include/tfmpc_hip.h) Q_uu is SPD and the two agree to rounding.  A non-positive pivot is
+//      reported in status[b] (TFMPC_ST_NOT_PD / _SINGULAR).
+//   4. V' = Q_xx + Q_xu K, v' = q_x + Q_xu k: 4 x v_mfma_f32_16x16x4_f32 (the Schur-complement
+//      form of the four-term update lqr.py:97-105, equal to it in exact arithmetic), then
+//      V' <- (V' + V'^T) / 2 through an LDS transpose: steps 2 and 3 use the symmetry of V, so its
+//      rounding-level antisymmetric part must not survive a step (it would grow like |F_u K|^2
+//      per step; the reference does not symmetrise, quirk Q6 of SURVEY.md).
 //   K_t, k_t stream to HBM (row-major, the public K/k layout) for the rollout.
-// Forward rollout (lqr.py:141-155): wave-wide fp32 FMA mat-vecs with F and C rows
-//   resident in registers, x/u exchanged through 96 bytes of LDS, K_t prefetched.
+// Forward rollout (lqr.py:141-155): wave-wide fp32 FMA mat-vecs with F rows resident in
+//   registers, z_t = [x_t; u_t] staged in LDS, K_t prefetched one step ahead, DPP reductions;
+//   the stage costs are priced afterwards as C Z on the matrix cores, states / actions leave in
+//   bulk coalesced stores.
 //
-// fp32 MFMA is an exact fp32 fma chain (MI355X_MICROARCH.md), so numerics are those
-// of fp32 VALU code with a different summation order.
+// The f32 MFMA is an exact fp32 FMA chain (MI355X_MICROARCH.md) and bf16x3 drops only terms below
+// 2^-24 relative, so numerics are those of fp32 VALU code with a different summation order.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
 #include <cstring>
 
 #include "lqr_kernels.h"
+#include "options.h"
 #include "mfma_bf16x3.h"
 #include "wave_ldlt8.h"
 #include "wave_ops.h"
@@ -452,8 +468,7 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
 // evaluates them as bf16x3 on the bf16 matrix cores (same fp32-level accuracy, see split3).
 bool use_bf16x3()
 {
-    const char *v = std::getenv("TFMPC_LQR_MFMA");
-    return !(v && std::strcmp(v, "f32") == 0);
+    return !option_is(kOptLqrMfma, "f32");
 }
 
 template <bool BW, bool FW, bool VAL>

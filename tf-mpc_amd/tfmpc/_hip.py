@@ -10,7 +10,8 @@ import os
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libtfmpc_hip.so")
+# TFMPC_LIB: load another build of the library (A/B timing of an experimental build without touching the product file)
+_LIB_PATH = os.environ.get("TFMPC_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libtfmpc_hip.so")
 _lib = None
 
 ERRORS = {-1: "bad argument", -2: "shape not supported by any kernel variant",
@@ -22,6 +23,7 @@ _P, _I, _L, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t
 
 _SIGNATURES = {
     "tfmpc_version": (ctypes.c_int, []),
+    "tfmpc_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p]),
     "tfmpc_lqr_kernel_name": (ctypes.c_char_p, [_I, _I, _I]),
     "tfmpc_lqr_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "tfmpc_lqr_backward_f32": (_I, [_I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L,
@@ -32,6 +34,9 @@ _SIGNATURES = {
                                  _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
 }
 
+
+for _name in ("backward", "forward", "solve"):       # twins for a non-symmetric C (tfmpc_hip.h PRECONDITION)
+    _SIGNATURES[f"tfmpc_lqr_{_name}_general_f32"] = _SIGNATURES[f"tfmpc_lqr_{_name}_f32"]
 
 ENV_LQ, ENV_NAVLQR, ENV_NAVIGATION, ENV_HVAC, ENV_RESERVOIR = range(5)
 ENV_MAX_PARAMS = 10
@@ -96,6 +101,30 @@ def require_gpu():
         raise RuntimeError("tfmpc: no ROCm GPU visible; the LQR/iLQR solvers only run as HIP kernels "
                            "on gfx950 (no CPU fallback).")
     return lib
+
+
+def set_option(name, value):
+    """``tfmpc_set_option``: force a kernel variant (``value=None`` = the dispatcher's own choice).  The library
+    reads the environment variables of the same names once, at its first use; afterwards only this call counts."""
+    rc = load().tfmpc_set_option(name.encode(), None if value is None else str(value).encode())
+    if rc != 0:
+        raise ValueError(f"tfmpc: unknown option {name!r}")
+
+
+class option:
+    """``with _hip.option("TFMPC_LQR_MFMA", "f32"): ...`` -- variant override for the duration of a block
+    (restores "no override", not a previous override)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, None)
+        return False
 
 
 def default_device():

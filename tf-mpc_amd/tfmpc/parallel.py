@@ -24,12 +24,18 @@ def shard(tensor, world_size=None, rank=None):
 
 def gather_trajectories(states, actions, costs, dst=0, group=None):
     """Gather per-rank result shards ``states[b,T+1,n,1]``, ``actions[b,T,m,1]``,
-    ``costs[b,T+1,...]`` on rank ``dst`` as ONE collective over a single packed
+    ``costs[b,T+1,...]`` on GLOBAL rank ``dst`` as ONE collective over a single packed
     buffer.  Shards may differ in size by one instance.  Returns the concatenated
-    tensors on ``dst`` and ``None`` elsewhere."""
+    tensors on ``dst`` and ``None`` elsewhere.
+
+    Every rank takes the same sequence of collectives whatever happens locally: buffers are
+    allocated first, the ranks then agree (one 4-byte all_reduce) that all allocations
+    succeeded, and only then enter the gather -- an out-of-memory on the destination raises
+    ``RuntimeError`` on EVERY rank instead of leaving the others inside the collective."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return states, actions, costs
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    world = dist.get_world_size(group)
+    is_dst = dist.get_rank() == dst                          # `dst` is a global rank, as dist.gather takes it
     b = states.shape[0]
     ns, na, nc = states.shape[1:].numel(), actions.shape[1:].numel(), costs.shape[1:].numel()   # valid for an empty shard too
     per = ns + na + nc
@@ -38,13 +44,26 @@ def gather_trajectories(states, actions, costs, dst=0, group=None):
     dist.all_gather(all_sizes, sizes, group=group)          # 8 bytes per rank; sizes only
     all_b = [int(s.item()) for s in all_sizes]
     bmax = max(all_b)
-    packed = torch.zeros((bmax, per), device=states.device, dtype=states.dtype)
-    packed[:b] = torch.cat([states.reshape(b, ns), actions.reshape(b, na), costs.reshape(b, nc)], dim=1)
-    recv = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
+    packed, recv, error = None, None, None
+    try:
+        packed = torch.zeros((bmax, per), device=states.device, dtype=states.dtype)
+        packed[:b] = torch.cat([states.reshape(b, ns), actions.reshape(b, na), costs.reshape(b, nc)], dim=1)
+        recv = [torch.empty_like(packed) for _ in range(world)] if is_dst else None
+    except RuntimeError as exc:                              # e.g. out of memory for the receive buffers
+        error = exc
+    ok = torch.tensor([0 if error is not None else 1], device=states.device, dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 0:
+        raise RuntimeError(f"gather_trajectories: buffer allocation failed on at least one rank ({error!r} here)")
     dist.gather(packed, recv, dst=dst, group=group)        # the one data-path collective
-    if rank != dst:
+    if not is_dst:
         return None
     full = torch.cat([r[:nb] for r, nb in zip(recv, all_b)], dim=0)
     B = full.shape[0]
     return (full[:, :ns].reshape(B, *states.shape[1:]), full[:, ns:ns + na].reshape(B, *actions.shape[1:]),
             full[:, ns + na:].reshape(B, *costs.shape[1:]))
+
+
+def gather_bytes_per_rank(states, actions, costs):
+    """Payload one rank contributes to the gather (the packed fp32 rows)."""
+    return int(states.numel() + actions.numel() + costs.numel()) * states.element_size()

@@ -390,14 +390,26 @@ class iLQR:
             converged = torch.zeros_like(active)
             while bool(pending.any()):
                 mu_l, delta_l = mu.clone(), delta.clone()   # _backward's local retry (ilqr.py:285-315)
-                for _ in range(64):
+                gave_up = torch.zeros_like(pending)
+                for retry in range(41):                     # the fused kernels give up after retry 40 too
                     K, k, _, dV1, dV2 = self.backward(T, uh.unsqueeze(-1), tm, cm, fm, mu=mu_l)
                     failed = ((self.last_status & _hip.ST_NOT_PD) != 0) & pending
                     if not bool(failed.any()):
                         break
                     status[failed] |= _hip.ST_NOT_PD
+                    if retry == 40:
+                        gave_up = failed                    # their K, k are undefined: never rolled out
+                        break
                     delta_l = torch.where(failed, torch.clamp(delta_l * d0, min=d0), delta_l)
                     mu_l = torch.where(failed, torch.clamp(mu_l * delta_l, min=mu_min), mu_l)
+                if bool(gave_up.any()):
+                    status[gave_up] |= _hip.ST_MAX_ATTEMPTS
+                    pending = pending & ~gave_up
+                    converged |= gave_up                    # retired with their last nominal trajectory
+                    K = torch.where(gave_up.reshape(-1, 1, 1, 1), torch.zeros_like(K), K)
+                    k = torch.where(gave_up.reshape(-1, 1, 1, 1), torch.zeros_like(k), k)
+                    if not bool(pending.any()):
+                        break
                 if K.dim() == 3:
                     K, k, dV1, dV2 = K.unsqueeze(0), k.unsqueeze(0), dV1.reshape(1), dV2.reshape(1)
                 k = k[..., 0]

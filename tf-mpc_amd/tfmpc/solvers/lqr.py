@@ -11,6 +11,12 @@ Differences from the reference, all additive:
   the axis is shared by all instances);
 * ``backward`` / ``forward`` / ``solve`` execute as hand-written gfx950 kernels
   through the C ABI (``include/tfmpc_hip.h``).  No CPU fallback.
+* ``C`` is expected to be symmetric (every problem the reference builds is:
+  ``make_lqr`` draws ``make_spd_matrix``, ``tfmpc/envs/__init__.py:9-18``) with ``C_uu``
+  positive definite; the fast kernels use that.  A ``C`` that is NOT symmetric is detected
+  once at construction and solved by the ``*_general_f32`` entry points, which restate the
+  reference's recursion term by term (``lqr.py:74-105``: ``Q_ux`` and ``Q_xu`` separately,
+  general inverse, no symmetrisation) -- slower, same results as the reference.
 """
 
 import json
@@ -73,6 +79,10 @@ class LQR:
         self.F, self.f, self.C, self.c = (t.contiguous() for t in (F, f, C, c))
         self.batch_size = batches.pop() if batches else None
         self.last_status = None
+        # asymmetry beyond fp32 rounding of a symmetric matrix -> the reference's term-by-term recursion
+        asym = (self.C - self.C.transpose(-1, -2)).abs().amax()
+        self.symmetric_cost = bool(asym <= 1e-6 * self.C.abs().amax())
+        self._suffix = "_f32" if self.symmetric_cost else "_general_f32"
 
     # -- reference properties (lqr.py:24-34) -----------------------------------
     @property
@@ -147,7 +157,7 @@ class LQR:
         v = torch.empty((Bk, T, n, 1), device=dev)
         const = torch.empty((Bk, T, 1, 1), device=dev)
         status = torch.zeros((Bk,), dtype=torch.int32, device=dev)
-        rc = lib.tfmpc_lqr_backward_f32(Bk, n, m, T, *self._ptr_args(),
+        rc = getattr(lib, "tfmpc_lqr_backward" + self._suffix)(Bk, n, m, T, *self._ptr_args(),
                                         _hip.ptr(K), _hip.ptr(k), _hip.ptr(V), _hip.ptr(v), _hip.ptr(const),
                                         _hip.ptr(status), _hip.stream())
         _hip.check(rc, "tfmpc_lqr_backward_f32")
@@ -186,7 +196,7 @@ class LQR:
         costs = torch.empty((Bk, T + 1, 1, 1), device=dev)
         sK = K[0].numel() if pol_batched else 0
         sk = k[0].numel() if pol_batched else 0
-        rc = lib.tfmpc_lqr_forward_f32(Bk, n, m, T, *self._ptr_args(),
+        rc = getattr(lib, "tfmpc_lqr_forward" + self._suffix)(Bk, n, m, T, *self._ptr_args(),
                                        _hip.ptr(K), sK, _hip.ptr(k), sk, _hip.ptr(x0),
                                        _hip.ptr(states), _hip.ptr(actions), _hip.ptr(costs), _hip.stream())
         _hip.check(rc, "tfmpc_lqr_forward_f32")
@@ -223,7 +233,7 @@ class LQR:
             if workspace is None or workspace.numel() * workspace.element_size() < ws_bytes:
                 workspace = torch.empty((max(ws_bytes, 4) + 3) // 4, dtype=torch.float32, device=dev)
             ws_bytes = workspace.numel() * workspace.element_size()
-        rc = lib.tfmpc_lqr_solve_f32(Bk, n, m, T, *self._ptr_args(), _hip.ptr(x0),
+        rc = getattr(lib, "tfmpc_lqr_solve" + self._suffix)(Bk, n, m, T, *self._ptr_args(), _hip.ptr(x0),
                                      _hip.ptr(out["states"]), _hip.ptr(out["actions"]), _hip.ptr(out["costs"]),
                                      _hip.ptr(out.get("K")), _hip.ptr(out.get("k")), _hip.ptr(out.get("V")),
                                      _hip.ptr(out.get("v")), _hip.ptr(out.get("const")), _hip.ptr(out["status"]),

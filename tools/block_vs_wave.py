@@ -1,20 +1,22 @@
 """Workgroup-per-instance (lqr_block.hip) vs wave-per-instance (lqr_generic.hip) LQR kernels over shapes and batch
 sizes: where the dispatcher's threshold (kBlockFrom in lqr_dispatch.hip) should sit.  Run on the GPU box."""
 import os, sys, time
-sys.path.insert(0, '/root/repo/tf-mpc_amd'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in ('tf-mpc_amd', 'tests', ''): sys.path.insert(0, os.path.join(ROOT, _p))
 import numpy as np, torch, problems
+from tfmpc import _hip
 from tfmpc.solvers.lqr import LQR
 
 
 def t_lqr(n, m, B, T, force):
-    os.environ["TFMPC_LQR_KERNEL"] = force
+    _hip.set_option("TFMPC_LQR_KERNEL", force)
     F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=1); F *= 1.0 / np.sqrt(n)
     lqr = LQR(F, f, C, c); x0d = lqr._prep_x0(x0)
     out = lqr.solve_device(x0d, T); torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(5): out = lqr.solve_device(x0d, T, workspace=out["workspace"])
     torch.cuda.synchronize()
-    os.environ.pop("TFMPC_LQR_KERNEL", None)
+    _hip.set_option("TFMPC_LQR_KERNEL", None)
     return (time.perf_counter() - t) / 5 * 1e3
 
 

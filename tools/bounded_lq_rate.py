@@ -1,8 +1,9 @@
 """Control-limited iLQR (Tassa et al. 2014, the reference's algorithm) on the headline shape: LQ env n=16, m=8, T=50
 with a box on the actions, so the backward pass runs the projected-Newton box-QP at every step.  Goes through the
 generic wave kernel.  Run on the GPU box: python tools/bounded_lq_rate.py"""
-import sys, time
-sys.path.insert(0, '/root/repo/tf-mpc_amd'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in ('tf-mpc_amd', 'tests', ''): sys.path.insert(0, os.path.join(ROOT, _p))
 import numpy as np, torch, problems
 from tfmpc.envs.lq import LQEnv
 from tfmpc.solvers.ilqr import iLQR

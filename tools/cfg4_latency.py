@@ -1,7 +1,8 @@
 """Per-iteration latency of one Navigation iLQR instance (cfg4 tail): B small, atol = 0 so every instance runs
 max_iterations.  Bounded (box-QP in the backward pass) vs unbounded actions.  Run on the GPU box."""
-import sys, time
-sys.path.insert(0, '/root/repo/tf-mpc_amd'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in ('tf-mpc_amd', 'tests', ''): sys.path.insert(0, os.path.join(ROOT, _p))
 import numpy as np, torch, problems
 from tfmpc.envs.navigation import Navigation
 from tfmpc.solvers.ilqr import iLQR

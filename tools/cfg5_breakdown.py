@@ -1,8 +1,9 @@
 """cfg5 (HVAC / Reservoir n = m = 32, T = 100): where an iLQR iteration's time goes.  Solves with the
 full 11-point line search and with a 1-point one (every iteration = one backward + one rollout), at
 several iteration caps.  Run on the GPU box: python tools/cfg5_breakdown.py"""
-import sys, time
-sys.path.insert(0, '/root/repo/tf-mpc_amd'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in ('tf-mpc_amd', 'tests', ''): sys.path.insert(0, os.path.join(ROOT, _p))
 import numpy as np, torch, problems
 from tfmpc.envs.hvac import HVAC
 from tfmpc.envs.reservoir import Reservoir

@@ -1,7 +1,8 @@
 """One HVAC and one Reservoir cfg5 solve (n = m = 32, T = 100, B = 32768, 12 iterations) for profiling:
 rocprofv3 --kernel-trace --pmc ... -- python3 tools/cfg5_once.py"""
-import sys
-sys.path.insert(0, '/root/repo/tf-mpc_amd'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in ('tf-mpc_amd', 'tests', ''): sys.path.insert(0, os.path.join(ROOT, _p))
 import numpy as np, torch, problems
 from tfmpc.envs.hvac import HVAC
 from tfmpc.envs.reservoir import Reservoir

@@ -20,14 +20,12 @@ import torch
 import problems
 from tfmpc.envs.hvac import HVAC
 from tfmpc.envs.reservoir import Reservoir
+from tfmpc import _hip
 from tfmpc.solvers.ilqr import iLQR
 
 
 def force(name):
-    if name is None:
-        os.environ.pop("TFMPC_ILQR_KERNEL", None)
-    else:
-        os.environ["TFMPC_ILQR_KERNEL"] = name
+    _hip.set_option("TFMPC_ILQR_KERNEL", name)
 
 
 def make(kind, n, B, seed, dense=False):

@@ -1,7 +1,8 @@
 """Shape-generic LQR kernel (lqr_generic.hip) at n=32, m=16, T=50, B=8192: fused solve vs the Riccati sweep alone vs
 the rollout alone.  Run on the GPU box: python tools/generic_phase_split.py [n m B]"""
-import sys, time
-sys.path.insert(0, '/root/repo/tf-mpc_amd'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in ('tf-mpc_amd', 'tests', ''): sys.path.insert(0, os.path.join(ROOT, _p))
 import numpy as np, torch, problems
 from tfmpc import _hip
 from tfmpc.solvers.lqr import LQR, Policy

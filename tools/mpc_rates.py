@@ -1,7 +1,8 @@
 """Receding-horizon MPC episodes batched over episodes: wall time per control step, split
 into the iLQR re-solve and the rest (env step, noise, Python).  Run on the GPU box."""
-import sys, time
-sys.path.insert(0, '/root/repo/tf-mpc_amd'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in ('tf-mpc_amd', 'tests', ''): sys.path.insert(0, os.path.join(ROOT, _p))
 import numpy as np, torch, problems
 from tfmpc import agents, runners
 from tfmpc.envs.navigation import Navigation

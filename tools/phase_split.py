@@ -3,7 +3,8 @@ Riccati sweep and the rollout.  Times the fused solve, the sweep alone (tfmpc_lq
 value outputs), the rollout alone (tfmpc_lqr_forward_f32 on the stored policy), and the two launched
 concurrently on two streams.  Run on the GPU box: python tools/phase_split.py"""
 import ctypes, sys, time
-sys.path.insert(0, '/root/repo/tf-mpc_amd'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in ('tf-mpc_amd', 'tests', ''): sys.path.insert(0, os.path.join(ROOT, _p))
 import numpy as np, torch, problems
 from tfmpc import _hip
 from tfmpc.solvers.lqr import LQR, Policy

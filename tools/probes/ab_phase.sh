@@ -1,5 +1,5 @@
 #!/bin/bash
 for L in "$@"; do
-  cp tools/probes/ab/$L tf-mpc_amd/tfmpc/_lib/libtfmpc_hip.so
+  export TFMPC_LIB=$PWD/tools/probes/ab/$L      # tfmpc/_hip.py loads this build; the product library is never touched
   echo "== $L"; python tools/phase_split.py 2>&1 | grep -v amdgpu.ids | head -3
 done

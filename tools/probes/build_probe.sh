@@ -1,7 +1,7 @@
 #!/bin/bash
 # Probe build of the library: lqr_block.hip with -DTFMPC_PHASE_PROBE, everything else from tf-mpc_amd/csrc/build.
 set -e
-ROOT=/root/repo
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 mkdir -p $ROOT/tools/probes/ab
 make -C $ROOT/tf-mpc_amd/csrc > /dev/null
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -DTFMPC_PHASE_PROBE \

@@ -1,7 +1,8 @@
 """Throughput of the BASELINE configs that are NOT bench lines (cfg2, cfg4, cfg5) and of the
 headline shape through the iLQR API.  Run on the GPU box: python tools/secondary_rates.py"""
-import sys, time
-sys.path.insert(0, '/root/repo/tf-mpc_amd'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in ('tf-mpc_amd', 'tests', ''): sys.path.insert(0, os.path.join(ROOT, _p))
 import numpy as np, torch, problems
 from tfmpc.envs.navigation import Navigation
 from tfmpc.envs.hvac import HVAC

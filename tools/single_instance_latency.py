@@ -1,7 +1,8 @@
 """What a drop-in user sees first: ONE problem instance (no batch axis) through the reference's API, wall time of
 solver.solve(...) including Python, launch and the copy back.  Run on the GPU box."""
-import sys, time
-sys.path.insert(0, '/root/repo/tf-mpc_amd'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in ('tf-mpc_amd', 'tests', ''): sys.path.insert(0, os.path.join(ROOT, _p))
 import numpy as np, torch, problems
 from tfmpc.envs import make_lqr, make_lqr_linear_navigation
 from tfmpc.envs.hvac import HVAC

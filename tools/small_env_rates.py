@@ -1,7 +1,8 @@
 """iLQR on the reference's own small env configs (hvac6.config.json, res4.config.json: n = 6 / 4) at large batch.
 Run on the GPU box."""
-import sys, time
-sys.path.insert(0, '/root/repo/tf-mpc_amd'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in ('tf-mpc_amd', 'tests', ''): sys.path.insert(0, os.path.join(ROOT, _p))
 import numpy as np, torch, problems
 from tfmpc.envs.hvac import HVAC
 from tfmpc.envs.reservoir import Reservoir
