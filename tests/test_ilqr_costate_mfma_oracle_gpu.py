@@ -71,13 +71,14 @@ def _oracle_sweep(o, xs, us):
     K, k, J, dV1, dV2 = o.backward(T, us, tm, cm, fm, mu=0.0)
     assert not K.any() and dV2 == 0.0                       # V_xx == 0, bang-bang branch every step
     V_x = fm.l_x
-    margin = np.empty_like(us)
+    margin, Q_u_all = np.empty_like(us), np.empty_like(us)
     for t in range(T - 1, -1, -1):
         Q_u = cm.l_u[t] + tm.f_u[t].T @ V_x
         mag = np.abs(cm.l_u[t]) + np.abs(tm.f_u[t]).T @ np.abs(V_x) + 1e-300
-        margin[t] = np.abs(Q_u) / mag
+        margin[t], Q_u_all[t] = np.abs(Q_u) / mag, Q_u
         V_x = cm.l_x[t] + tm.f_x[t].T @ V_x
-    return k, J, dV1, margin
+    assert np.isclose(dV1, (k * Q_u_all).sum(), rtol=1e-9)     # ilqr.py:166 with this recursion's Q_u
+    return k, J, dV1, margin, Q_u_all
 
 
 def _oracle_line_search(o, xs, us, J_hat, k, dV1):
@@ -99,7 +100,7 @@ def _check_iteration(o64, o32, xs_dev, us_dev, out_next, tag):
     the nominal (xs_dev, us_dev) to out_next = (states, actions, costs)."""
     T, m = us_dev.shape[0], us_dev.shape[1]
     xs, us = xs_dev.astype(np.float64), us_dev.astype(np.float64)
-    k64, J64, dV1, margin = _oracle_sweep(o64, xs, us)
+    k64, J64, dV1, margin, Q_u = _oracle_sweep(o64, xs, us)
     x1, u1, c1 = (a.astype(np.float64) for a in out_next)
     du = u1 - us
     moved = np.abs(du) > 0
@@ -117,9 +118,12 @@ def _check_iteration(o64, o32, xs_dev, us_dev, out_next, tag):
     a_dev = ALPHAS[np.argmin(np.abs(np.log(ALPHAS) - np.log(np.median(ratio))))]
     # du is the fp32 difference of two numbers of size <= 1: absolute rounding ~1e-7 against alpha * |k| >= alpha / 20
     assert np.abs(ratio / a_dev - 1.0).max() < 1e-4 + 4e-6 / a_dev, (tag, "alpha", a_dev, ratio.min(), ratio.max())
-    a64, ls_margin = _oracle_line_search(o64, xs, us, J64, k64, dV1)
+    # the line search of ilqr.py:322-353 in fp64 on the candidate direction the device built (its selector; equal to
+    # the oracle's own except on near-tie entries): the first accepted step size must be the device's whenever the
+    # oracle's accept / reject comparisons on the way were not themselves within rounding
     same_selector = np.array_equal(sel_dev_high[moved & (np.abs(k64) > 0)], sel_64_high[moved & (np.abs(k64) > 0)])
-    if same_selector and ls_margin > 1e-5:                   # the oracle's own accept/reject decisions were clear-cut
+    a64, ls_margin = _oracle_line_search(o64, xs, us, J64, k_dev, (k_dev * Q_u).sum())
+    if ls_margin > 1e-5:
         assert a64 is not None and np.isclose(a_dev, a64), (tag, "accepted alpha", a_dev, a64, ls_margin)
     # arithmetic, decision by decision: the oracle's forward pass with the device's selector and step size
     K0 = np.zeros((T, m, xs.shape[1]))
