@@ -88,3 +88,117 @@ def test_generic_env_solve_tracks_builtin_on_nonlinear_navigation():
     assert np.median(rel) <= 1e-4 and np.quantile(rel, 0.9) <= 2e-2       # a few flipped line searches
     assert np.mean(ib == ig) >= 0.7
     assert np.abs(tg.actions).max() <= 1.0
+
+
+# ---- HVAC and Reservoir written as plain torch functions, against the ORACLE (oracle/envs_ref.py = the reference's
+# ---- env equations differentiated by autodiff, oracle/ilqr_ref.py = ilqr.py), not against the built-in kernels --------
+def _hvac_torch(cfg):
+    """tfmpc/envs/hvac/__init__.py:69-149 for one instance: x[n], u[n]."""
+    t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32), device="cuda")
+    vec = lambda key: t(cfg[key]).reshape(-1)
+    adj = np.asarray(cfg["adj"], dtype=bool)
+    G = t(np.logical_or(adj, adj.T).astype(np.float32)) / t(cfg["R_wall"])
+    k_out = t(np.asarray(cfg["adj_outside"], dtype=np.float32)).reshape(-1) / vec("R_outside")
+    k_hall = t(np.asarray(cfg["adj_hall"], dtype=np.float32)).reshape(-1) / vec("R_hall")
+    t_out, t_hall, cap, air_max = vec("temp_outside"), vec("temp_hall"), vec("capacity"), vec("air_max")
+    lo, hi = vec("temp_lower_bound"), vec("temp_upper_bound")
+    n = lo.numel()
+
+    def transition(x, u):
+        heating = u * air_max * 1.006 * (40.0 - x)
+        between = -(G * (x[:, None] - x[None, :])).sum(dim=-1)
+        return x + 1.0 / cap * (heating + between + k_out * (t_out - x) + k_hall * (t_hall - x))
+
+    def penalties(x):
+        return (20000.0 * (torch.relu(lo - x) + torch.relu(x - hi)) + 10.0 * torch.abs((lo + hi) / 2 - x)).sum()
+
+    return TorchEnv(transition, lambda x, u: (u * air_max).sum() + penalties(x), penalties, n, n, 0.0, 1.0)
+
+
+def _reservoir_torch(cfg):
+    """tfmpc/envs/reservoir/__init__.py:47-105 (cec=True) for one instance."""
+    t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32), device="cuda")
+    vec = lambda key: t(cfg[key]).reshape(-1)
+    cap, lo, hi = vec("max_res_cap"), vec("lower_bound"), vec("upper_bound")
+    lp, hp, sp = vec("low_penalty"), vec("high_penalty"), vec("set_point_penalty")
+    rain, D = vec("rain_shape") * vec("rain_scale"), t(cfg["downstream"])
+    n = lo.numel()
+
+    def transition(x, u):
+        out = u * x
+        return x + rain + D.T @ out - 0.5 * torch.sin(x / cap) * x - out
+
+    def cost(x, u=None):
+        return (-lp * torch.relu(lo - x) - hp * torch.relu(x - hi) - sp * torch.abs((lo + hi) / 2.0 - x)).sum()
+
+    return TorchEnv(transition, cost, cost, n, n, 0.0, 1.0)
+
+
+def _oracle_pair(kind):
+    from oracle import envs_ref
+    if kind == "hvac":
+        cfg = dict(problems.HVAC6_CONFIG)
+        return cfg, _hvac_torch(cfg), envs_ref.HVAC(**cfg), np.asarray(problems.HVAC6_X0, dtype=np.float32)
+    cfg = dict(problems.RES4_CONFIG)
+    return cfg, _reservoir_torch(cfg), envs_ref.Reservoir(**cfg), np.asarray(problems.RES4_X0, dtype=np.float32)
+
+
+@pytest.mark.parametrize("kind", ["hvac", "reservoir"])
+def test_generic_env_pieces_match_the_oracle(kind):
+    """start / derivatives / backward / forward of the reference's API (tests/test_ilqr.py:48-109) on an env given as
+    torch functions, each piece against the fp64 oracle on the oracle's own inputs (so a flipped bang-bang decision
+    cannot leak from one piece into the next)."""
+    from oracle import ilqr_ref
+    cfg, genv, oenv, x0 = _oracle_pair(kind)
+    n, T = genv.state_size, 12
+    sg, o = iLQR(genv), ilqr_ref.ILQRRef(oenv)
+    u0 = problems.scalar_uniform_actions(T, o.low, o.high, np.random.default_rng(9)).astype(np.float32)
+    xs, us, cs = o.start(x0, T, u_init=u0)
+    gx, gu, gc = sg.start(x0, T, u_init=u0)
+    assert np.abs(gx.cpu().numpy() - xs).max() <= 2e-5 * np.abs(xs).max()
+    assert np.abs(gc.cpu().numpy() - cs).max() <= 2e-5 * np.abs(cs).max()
+    # derivatives: torch.func on the user's functions vs autodiff of the oracle's env restatement (diffenv.py:13-101)
+    tm, cm, fm = o.derivatives(xs, us)
+    gtm, gcm, gfm = sg.derivatives(xs.astype(np.float32), us.astype(np.float32))
+    for got, ref, name in [(gtm.f, tm.f, "f"), (gtm.f_x, tm.f_x, "f_x"), (gtm.f_u, tm.f_u, "f_u"), (gcm.l, cm.l, "l"),
+                           (gcm.l_x, cm.l_x, "l_x"), (gcm.l_u, cm.l_u, "l_u"), (gcm.l_xx, cm.l_xx, "l_xx"),
+                           (gcm.l_uu, cm.l_uu, "l_uu"), (gcm.l_ux, cm.l_ux, "l_ux"), (gcm.l_xu, cm.l_xu, "l_xu"),
+                           (gfm.l, fm.l, "fl"), (gfm.l_x, fm.l_x, "fl_x"), (gfm.l_xx, fm.l_xx, "fl_xx")]:
+        g = got.cpu().numpy().reshape(np.shape(ref))
+        assert np.abs(g - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1.0), name
+    # backward on the oracle's models (HIP Riccati kernel, bang-bang branch: V_xx == 0 on these envs)
+    K, k, J, dV1, dV2 = o.backward(T, us, tm, cm, fm, mu=0.0)
+    gK, gk, gJ, g1, g2 = sg.backward(T, us.astype(np.float32), gtm, gcm, gfm, mu=0.0)
+    assert not K.any() and not bool(gK.any())
+    assert np.array_equal(np.sign(gk.cpu().numpy()), np.sign(k))                   # same bound for every action
+    assert abs(float(gJ) - J) <= 2e-5 * abs(J) and abs(float(g1) - dV1) <= 1e-4 * abs(dV1) and float(g2) == dV2 == 0.0
+    # forward with the oracle's gains at two step sizes (ilqr.py:174-212)
+    for alpha in (1.0, 0.0631):
+        x1, u1, c1, J1, r1 = o.forward(xs, us, K, k, alpha)
+        fx, fu, fc, fJ, fr = sg.forward(xs.astype(np.float32), us.astype(np.float32), K.astype(np.float32), k.astype(np.float32), alpha)
+        assert np.abs(fx.cpu().numpy() - x1).max() <= 5e-5 * np.abs(x1).max(), alpha
+        assert np.abs(fu.cpu().numpy() - u1).max() <= 1e-6 and abs(float(fr) - r1) <= 1e-6
+        assert abs(float(fJ) - J1) <= 5e-5 * abs(J1)
+
+
+def test_generic_hvac_two_iterations_match_the_oracle():
+    """Two whole iterations of the host-driven loop (ilqr.py:214-283) on HVAC-as-torch-functions against the fp64
+    restatement; the fp32 restatement sets the budget (its decisions are clear-cut on this env)."""
+    from oracle import envs_ref, ilqr_ref
+    cfg, genv, oenv, _ = _oracle_pair("hvac")
+    T, B = 12, 5
+    rng = np.random.default_rng(4)
+    x0 = rng.uniform(5.0, 30.0, size=(B, 6, 1)).astype(np.float32)
+    sg = iLQR(genv, max_iterations=2)
+    u0 = sg.random_actions(T, B, seed=2)
+    tg, ig = sg.solve(x0, T, u_init=u0)
+    o64 = ilqr_ref.ILQRRef(oenv, max_iterations=2)
+    o32 = ilqr_ref.ILQRRef(envs_ref.HVAC(**cfg, dtype=np.float32), dtype=np.float32, max_iterations=2)
+    for b in range(B):
+        ub = u0[b].cpu().numpy()
+        x64, u64, c64, it64 = o64.solve(x0[b], T, u_init=ub)
+        x32, u32, c32, it32 = o32.solve(x0[b], T, u_init=ub)
+        assert int(ig[b]) == it64
+        for got, r64, r32, what in ((tg.states[b], x64, x32, "states"), (tg.actions[b], u64, u32, "actions"), (tg.costs[b], c64, c32, "costs")):
+            allowed = 5 * max(np.abs(r32.astype(np.float64) - r64).max(), 1e-6 * np.abs(r64).max())
+            assert np.abs(got - r64).max() <= allowed, (b, what, np.abs(got - r64).max(), allowed)

@@ -20,6 +20,16 @@ class GymEnv:
         self._state = None
         self._info = {}
         self._generator = None
+        self._injected = None
+
+    def inject_noise(self, samples):
+        """Replace the env's random draws by a fixed sequence: ``samples[t]`` is the raw draw of the env's noise
+        model for the step that ends at time t + 1 (Navigation: the truncated-normal displacement,
+        ``navigation/__init__.py:45``; Reservoir: the Gamma rainfall, ``reservoir/__init__.py:101-104``), shaped
+        like the state.  ``None`` returns to drawing.  This is how episodes are compared with the oracle's
+        restatement of the loop: TensorFlow's RNG stream cannot be reproduced, an injected sequence can."""
+        self._injected = None if samples is None else [
+            torch.as_tensor(s, dtype=torch.float32).to(self._device()) for s in samples]
 
     def setup(self, initial_state, horizon):
         self.initial_state = initial_state
@@ -41,8 +51,12 @@ class GymEnv:
         return self._state
 
     def _noise(self, state):
-        """Additive difference between a stochastic and the certainty-equivalent step."""
+        """Additive difference between a stochastic and the certainty-equivalent step (drawn)."""
         return torch.zeros_like(state)
+
+    def _noise_from_sample(self, sample, state):
+        """The same difference for an injected raw draw of the env's noise model."""
+        return sample.expand_as(state)
 
     def step(self, action):
         self._t += 1
@@ -51,7 +65,10 @@ class GymEnv:
         if self.stochastic:
             if getattr(self, "_generator", None) is None:
                 self.seed(None)
-            next_state = next_state + self._noise(next_state)
+            if self._injected is not None:
+                next_state = next_state + self._noise_from_sample(self._injected[self._t - 1], next_state)
+            else:
+                next_state = next_state + self._noise(next_state)
         cost = self.cost(self._state, action, batch=batched)
         done = self._t == self.horizon
         self._state = next_state

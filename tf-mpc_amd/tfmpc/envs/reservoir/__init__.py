@@ -60,6 +60,11 @@ class Reservoir(DiffEnv, GymEnv):
             sample = torch._standard_gamma(shape) * scale
         return sample - shape * scale
 
+    def _noise_from_sample(self, sample, state):
+        import torch
+        mean = torch.as_tensor(self.rain_shape * self.rain_scale, device=state.device)
+        return (sample - mean).expand_as(state)         # an injected rainfall draw replaces the mean rainfall
+
     @classmethod
     def load(cls, config):
         return cls(**{k: np.asarray(v, dtype=np.float32) for k, v in config.items()})
