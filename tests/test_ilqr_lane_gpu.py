@@ -113,3 +113,25 @@ def test_group_kernel_equals_per_lane_kernel(force_kernel, kind, B, T):
     assert torch.equal(g["status"], l["status"])
     for key in ("states", "actions", "costs"):
         assert torch.equal(g[key], l[key]), key
+
+
+@pytest.mark.parametrize("kind,T", [("navigation", 50), ("navlqr", 12)])
+def test_four_groups_per_wave_equal_the_per_lane_kernel(force_kernel, kind, T):
+    """Batches beyond 2048 instances run four instances per wavefront (smaller ones a wavefront per instance, covered
+    above): bit-identical to the one-lane-per-instance kernel, iterations and status included."""
+    rng = np.random.default_rng(33)
+    B = 2300                                   # > 2048, and not a multiple of 4
+    if kind == "navlqr":
+        solver = iLQR(NavigationLQR(rng.uniform(-10, 10, size=(B, 2, 1)).astype(np.float32), 5.0, -1.0, 1.0))
+        x0 = rng.normal(size=(B, 2, 1)).astype(np.float32)
+    else:
+        solver = iLQR(Navigation.load(problems.NAV_CONFIG))
+        x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
+    u0 = solver.random_actions(T, B, seed=8)
+    out = {}
+    for kern in ("lane1", None):
+        force_kernel(kern)
+        out[kern] = solver.solve_device(x0, T, u_init=u0)
+        torch.cuda.synchronize()
+    for key in ("iterations", "status", "states", "actions", "costs"):
+        assert torch.equal(out[None][key], out["lane1"][key]), key

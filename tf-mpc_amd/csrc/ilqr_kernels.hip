@@ -19,8 +19,9 @@ namespace tfmpc {
 bool ilqr_lane_supported(const TfmpcEnv &env);
 int ilqr_lane_solve_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, int B, int T, const float *x0,
                            const float *u_init, float *states, float *actions, float *costs, int32_t *iterations,
-                           int32_t *status, float *wsK, float *wsk, float *wsx, float *wsu, float *wsc,
+                           int32_t *status, float *wsK, float *wsk, float *wsx, float *wsu, float *wsc, void *extra,
                            hipStream_t stream);
+size_t ilqr_lane_extra_workspace_bytes(int B, int n, int m, int T);
 
 // ---- model providers for backward_pass ------------------------------------------
 template <int KIND>
@@ -452,7 +453,8 @@ size_t tfmpc_ilqr_workspace_bytes(int B, int n, int m, int T)
 {
     if (B <= 0 || n <= 0 || m <= 0 || T < 0) return 0;
     const size_t per = (size_t)T * m * n + (size_t)T * m + (size_t)(T + 1) * n + (size_t)T * m + (size_t)(T + 1);
-    return (size_t)B * per * sizeof(float);
+    const size_t slabs = ((size_t)B * per * sizeof(float) + 255) & ~(size_t)255;
+    return slabs + ilqr_lane_extra_workspace_bytes(B, n, m, T);      // 2-D envs: parked list + line-search scratch
 }
 
 int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B, int T, const float *x0,
@@ -484,7 +486,9 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
         const bool forced_wave = option_is(kOptIlqrKernel, "wave");
         if (ilqr_lane_supported(*env) && !forced_wave && !cfg->storage_bf16)
             return ilqr_lane_solve_launch(*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status,
-                                          a.wsK, a.wsk, a.wsx, a.wsu, a.wsc, st);
+                                          a.wsK, a.wsk, a.wsx, a.wsu, a.wsc,
+                                          static_cast<char *>(workspace) + (((size_t)B * ((size_t)T * m * n + (size_t)T * m + (size_t)(T + 1) * n + (size_t)T * m + (size_t)(T + 1)) * sizeof(float) + 255) & ~(size_t)255),
+                                          st);
     }
     {
         // LQ env on the matrix cores (ilqr_lq_mfma.hip); instances it cannot finish (mu > 0 needed)

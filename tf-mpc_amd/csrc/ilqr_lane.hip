@@ -63,6 +63,10 @@ struct LaneEnv<TFMPC_ENV_NAVLQR, N, N> {                 // envs/lqr/navigation/
         for (int i = 0; i < N; ++i) c2 += u[i] * u[i];
         return final_cost(x) + beta * c2;
     }
+    // nothing of the linearisation is worth precomputing here (see LaneEnv<NAVIGATION>)
+    static constexpr int kPre = 0;
+    __device__ void prelinearize(const float *, float *) const {}
+    __device__ void linearize_pre(const float *, const float *x, const float *u, LaneModel<N, N> &md) const { linearize(x, u, md); }
     __device__ void linearize(const float *x, const float *u, LaneModel<N, N> &md) const
     {
 #pragma unroll
@@ -145,10 +149,28 @@ struct LaneEnv<TFMPC_ENV_NAVIGATION, N, N> {             // envs/navigation/__in
         return c1;
     }
     __device__ float cost(const float *x, const float *) const { return final_cost(x); }
-    __device__ void linearize(const float *x, const float *u, LaneModel<N, N> &md) const
+    // The deceleration factor and its gradient depend on x alone and are most of an iteration's backward sweep
+    // (sqrt, exp and divisions per zone): pre = {lambda, grad lambda}.  linearize == prelinearize + linearize_pre,
+    // the same expressions in the same order, so a kernel that evaluates the first part elsewhere (the group kernel:
+    // all timesteps at once, one per lane) gets the same bits.
+    static constexpr int kPre = N + 1;
+    __device__ void prelinearize(const float *x, float *pre) const
     {
         float grad[N];
-        const float lam = deceleration(x, grad);
+        pre[0] = deceleration(x, grad);
+#pragma unroll
+        for (int i = 0; i < N; ++i) pre[1 + i] = grad[i];
+    }
+    __device__ void linearize(const float *x, const float *u, LaneModel<N, N> &md) const
+    {
+        float pre[kPre];
+        prelinearize(x, pre);
+        linearize_pre(pre, x, u, md);
+    }
+    __device__ void linearize_pre(const float *pre, const float *x, const float *u, LaneModel<N, N> &md) const
+    {
+        const float lam = pre[0];
+        const float *grad = pre + 1;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             md.lx[i] = 2.0f * (x[i] - goal[i]);
@@ -305,6 +327,22 @@ struct LdsStore {
     static size_t bytes(int T) { return (size_t)(T + 1) * kPerStep * 64 * sizeof(float); }
 };
 
+// -DTFMPC_PHASE_PROBE (tools/probes/lane_probe.py): every lane accumulates s_memtime deltas per phase of an iteration;
+// the group kernel leaves those of instance 0 in costs[0..7] (as floats) instead of the stage costs.
+#ifdef TFMPC_PHASE_PROBE
+struct LaneProbe { long long acc[8]; long long last; };
+__device__ LaneProbe g_probe_dummy;
+#define TFMPC_PROBE_ARG , LaneProbe &pr
+#define TFMPC_PROBE_PASS , pr
+#define TFMPC_PROBE_START() (pr.last = __builtin_amdgcn_s_memtime())
+#define TFMPC_PROBE(i) do { const long long now_ = __builtin_amdgcn_s_memtime(); pr.acc[i] += now_ - pr.last; pr.last = now_; } while (0)
+#else
+#define TFMPC_PROBE_ARG
+#define TFMPC_PROBE_PASS
+#define TFMPC_PROBE_START() ((void)0)
+#define TFMPC_PROBE(i) ((void)0)
+#endif
+
 // ---- the solve ------------------------------------------------------------------------
 struct LaneBackward { float J, dV1, dV2, g_norm; int failed, flags; };
 
@@ -314,11 +352,12 @@ struct SolveArgsLane {
     float *states, *actions, *costs;
     int32_t *iterations, *status;
     float *wsK, *wsk, *wsx, *wsu, *wsc;
+    float *scratch;          // group kernel only: one block of candidate trajectories per wavefront
 };
 
-template <int KIND, int N, int M, class Store>
+template <int KIND, int N, int M, class Store, bool PRE = false>
 __device__ inline LaneBackward backward_lane(const LaneEnv<KIND, N, M> &env, int T, float mu, bool bounded,
-                                             const float *low, const float *high, Store &st)
+                                             const float *low, const float *high, Store &st TFMPC_PROBE_ARG)
 {
     LaneBackward r{0.0f, 0.0f, 0.0f, 0.0f, 0, 0};
     float Vx[N];
@@ -337,7 +376,16 @@ __device__ inline LaneBackward backward_lane(const LaneEnv<KIND, N, M> &env, int
 #pragma unroll
         for (int a = 0; a < M; ++a) u[a] = st.u(t, a);
         LaneModel<N, M> md;
-        env.linearize(x, u, md);
+        TFMPC_PROBE_START();
+        if constexpr (PRE && LaneEnv<KIND, N, M>::kPre > 0) {
+            float pre[LaneEnv<KIND, N, M>::kPre];
+#pragma unroll
+            for (int j = 0; j < LaneEnv<KIND, N, M>::kPre; ++j) pre[j] = st.pre(t, j);
+            env.linearize_pre(pre, x, u, md);
+        } else {
+            env.linearize(x, u, md);
+        }
+        TFMPC_PROBE(0);
         float Qx[N], Qu[M];
 #pragma unroll
         for (int i = 0; i < N; ++i) {                                       // :122
@@ -395,6 +443,7 @@ __device__ inline LaneBackward backward_lane(const LaneEnv<KIND, N, M> &env, int
         }
         Mat<M, N> K;
         float kk[M];
+        TFMPC_PROBE(1);
         if (!bounded) {                                                     // :357-362
             Mat<M, M + 1 + N> aug;
 #pragma unroll
@@ -421,6 +470,7 @@ __device__ inline LaneBackward backward_lane(const LaneEnv<KIND, N, M> &env, int
                 kk[a] = (lo[a] + hi[a]) / 2;
             }
             const int rc = boxqp_lane<M>(Quur, Qu, lo, hi, kk, fre);
+            TFMPC_PROBE(2);
             if (rc == TFMPC_ST_NOT_PD) { r.failed = 1; return r; }
             r.flags |= rc;
             Mat<M, N> sol;
@@ -437,6 +487,7 @@ __device__ inline LaneBackward backward_lane(const LaneEnv<KIND, N, M> &env, int
                 for (int j = 0; j < N; ++j) K(a, j) = 0.0f;
             }
         }
+        TFMPC_PROBE(3);
         Mat<N, M> KtQ;                                                      // :147
 #pragma unroll
         for (int i = 0; i < N; ++i)
@@ -491,6 +542,7 @@ __device__ inline LaneBackward backward_lane(const LaneEnv<KIND, N, M> &env, int
         r.dV1 += p1;
         r.dV2 += 0.5f * p2;
         gsum += gmax;
+        TFMPC_PROBE(4);
     }
     r.g_norm = T > 0 ? gsum / (float)T : 0.0f;
     return r;
@@ -584,12 +636,15 @@ __global__ __launch_bounds__(64) void ilqr_lane_solve_kernel(TfmpcEnv genv, Tfmp
     float mu = 0.0f, delta = 1.0f;
     int status = 0, attempts = 0, iteration = 0;
     bool converged = false, give_up = false;
+#ifdef TFMPC_PHASE_PROBE
+    LaneProbe pr{};
+#endif
     for (iteration = 0; iteration < cfg.max_iterations; ++iteration) {
         for (;;) {
             float mu_l = mu, delta_l = delta;
             LaneBackward r;
             for (int retry = 0;; ++retry) {                                  // :285-315
-                r = backward_lane<KIND, N, M>(env, T, mu_l, bounded, low, high, st);
+                r = backward_lane<KIND, N, M>(env, T, mu_l, bounded, low, high, st TFMPC_PROBE_PASS);
                 status |= r.flags;
                 if (!r.failed) break;
                 status |= TFMPC_ST_NOT_PD;
@@ -652,138 +707,196 @@ __global__ __launch_bounds__(64) void ilqr_lane_solve_kernel(TfmpcEnv genv, Tfmp
     a.status[b] = status;
 }
 
+// Batches up to this size run one group per wavefront in a single launch (B waves fit the chip at <= 2 per SIMD).
+constexpr int kOneGroupMaxBatch = 2048;
 // ---- group-per-instance variant: speculative PARALLEL line search ---------------------------
-// 16 lanes own one instance (4 instances per wave).  Everything that is sequential in the
-// reference runs redundantly on all 16 lanes (same data, same control flow, so no broadcast is
-// needed), but the 11 line-search rollouts of ilqr.py:322 run AT ONCE, one step size per lane;
-// the first accepted one is picked with a ballot -- exactly the reference's "first alpha that
-// passes" -- and that rollout is replayed once into the other nominal buffer.  An iteration costs
-// backward + 2 rollouts of latency instead of backward + up to 11.
-template <int N, int M>
+// 16 lanes own one instance.  What is sequential in the reference (the backward sweep with its box-QPs) runs
+// redundantly on all 16 lanes -- same data, same control flow, so no broadcast is needed -- and everything that is
+// NOT sequential is spread over the lanes:
+//   * the x-only part of the linearisation (LaneEnv::prelinearize: the deceleration factor and its gradient, a third of
+//     an iteration when it sat inside the sweep) is evaluated for all timesteps at once, one timestep per lane, into LDS;
+//   * the 11 line-search rollouts of ilqr.py:322 run AT ONCE, one step size per lane, each lane leaving its candidate
+//     trajectory in its own column of a per-wave HBM scratch (coalesced fire-and-forget stores); a ballot picks the
+//     first accepted step size -- exactly the reference's "first alpha that passes" -- and the group copies that column
+//     into its nominal buffer (no second rollout).
+// Arithmetic per instance is that of ilqr_lane_solve_kernel, bit for bit (tested).
+//
+// GROUPS instances share a wavefront: 4 for large batches (the chip is full and latency-bound; the groups of a wave
+// pay for each other's divergent box-QP trip counts), 1 while the chip has room for a wavefront per instance (0.55x the
+// latency per iteration).  The launch lasts as long as its slowest instance (cfg4: median 8 iterations, p99 20, max 87).
+// Tried and measured worse (round 2, tools/cfg4_sustained.py): stopping the main launch after 8 .. 32 iterations and
+// resuming the parked stragglers in a tail launch with a wavefront each -- a straggler that stays in the main launch
+// already runs alone in its wave once its neighbours have converged, so the cut only adds a launch and a reload
+// (single batch 13.1 -> 15.1 .. 16.5 ms; 8 batches in flight 4.2 -> 5.1 ms per batch).
+template <int N, int M, int GROUPS, int PRE>
 struct GroupStore {
-    static constexpr int kGroups = 4;
-    float *base;                 // wave's LDS + group index; slot stride = kGroups
-    int T, cur;                  // cur: which nominal buffer is live
-    __device__ int xoff(int buf) const { return buf * ((T + 1) * N + T * M); }
-    __device__ int koff() const { return 2 * ((T + 1) * N + T * M); }
-    __device__ float &at(int slot) const { return base[slot * kGroups]; }
-    __device__ float x(int t, int i) const { return at(xoff(cur) + t * N + i); }
-    __device__ float u(int t, int a) const { return at(xoff(cur) + (T + 1) * N + t * M + a); }
-    __device__ float K(int t, int a, int j) const { return at(koff() + t * M * N + a * N + j); }
-    __device__ float k(int t, int a) const { return at(koff() + T * M * N + t * M + a); }
-    __device__ void set_x(int t, int i, float v) { at(xoff(cur) + t * N + i) = v; }
-    __device__ void set_u(int t, int a, float v) { at(xoff(cur) + (T + 1) * N + t * M + a) = v; }
-    __device__ void set_K(int t, int a, int j, float v) { at(koff() + t * M * N + a * N + j) = v; }
-    __device__ void set_k(int t, int a, float v) { at(koff() + T * M * N + t * M + a) = v; }
-    static size_t bytes(int T) { return (size_t)(2 * ((T + 1) * N + T * M) + T * M * N + T * M) * kGroups * sizeof(float); }
+    float *base;                 // wave's LDS + group index; slot stride = GROUPS
+    int T;
+
+    __device__ int uoff() const { return (T + 1) * N; }
+    __device__ int Koff() const { return (T + 1) * N + T * M; }
+    __device__ int koff() const { return Koff() + T * M * N; }
+    __device__ int poff() const { return koff() + T * M; }
+    __device__ float &at(int slot) const { return base[slot * GROUPS]; }
+    __device__ float x(int t, int i) const { return at(t * N + i); }
+    __device__ float u(int t, int a) const { return at(uoff() + t * M + a); }
+    __device__ float K(int t, int a, int j) const { return at(Koff() + t * M * N + a * N + j); }
+    __device__ float k(int t, int a) const { return at(koff() + t * M + a); }
+    __device__ float pre(int t, int j) const { return at(poff() + t * PRE + j); }
+    __device__ void set_x(int t, int i, float v) { at(t * N + i) = v; }
+    __device__ void set_u(int t, int a, float v) { at(uoff() + t * M + a) = v; }
+    __device__ void set_K(int t, int a, int j, float v) { at(Koff() + t * M * N + a * N + j) = v; }
+    __device__ void set_k(int t, int a, float v) { at(koff() + t * M + a) = v; }
+    __device__ void set_pre(int t, int j, float v) { at(poff() + t * PRE + j) = v; }
+    static size_t bytes(int T) { return (size_t)((T + 1) * N + T * M + T * M * N + T * M + T * PRE) * GROUPS * sizeof(float); }
 };
 
+// Candidate trajectory of one lane's speculative rollout: rows [x_1 .. x_T | u_0 .. u_{T-1} | c_0 .. c_T] of the
+// wave's scratch, one column per lane (x_0 never changes).
 template <int N, int M>
-struct GroupReplaySink {        // replay of the chosen rollout: other nominal buffer + costs to HBM
-    GroupStore<N, M> st;
-    float *chat;
-    bool leader;
-    __device__ void x(int t, int i, float v) const { st.at(st.xoff(st.cur ^ 1) + t * N + i) = v; }
-    __device__ void u(int t, int a, float v) const { st.at(st.xoff(st.cur ^ 1) + (st.T + 1) * N + t * M + a) = v; }
-    __device__ void c(int t, float v) const { if (leader) chat[t] = v; }
+struct ScratchSink {
+    float *col;                  // wave's scratch + lane
+    int T;
+    bool live;                   // lanes beyond the number of step sizes repeat the last one: nothing to keep
+    __host__ __device__ static int rows(int T) { return T * N + T * M + T + 1; }
+    __device__ void x(int t, int i, float v) const { if (live && t > 0) col[((t - 1) * N + i) * 64] = v; }
+    __device__ void u(int t, int a, float v) const { if (live) col[(T * N + t * M + a) * 64] = v; }
+    __device__ void c(int t, float v) const { if (live) col[(T * N + T * M + t) * 64] = v; }
 };
 
-template <int KIND, int N, int M>
-__global__ __launch_bounds__(64) void ilqr_group_solve_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, SolveArgsLane a)
+template <int KIND, int N, int M, int GROUPS>
+__global__ __launch_bounds__(64, 4) void ilqr_group_solve_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, SolveArgsLane a)
 {
     extern __shared__ float lane_lds[];
     constexpr int G = 16;
+    constexpr int PRE = LaneEnv<KIND, N, M>::kPre;
+    using Store = GroupStore<N, M, GROUPS, PRE>;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
-    const int b = blockIdx.x * GroupStore<N, M>::kGroups + grp;
-    if (b >= a.B) return;                           // whole group leaves together
+    if (grp >= GROUPS) return;                      // one group per wave: lanes 16..63 idle
     const int T = a.T;
-    LaneEnv<KIND, N, M> env;
-    env.load(genv, b);
     float low[M], high[M];
 #pragma unroll
     for (int i = 0; i < M; ++i) { low[i] = genv.low[i]; high[i] = genv.high[i]; }
     const bool bounded = genv.bounded != 0;
     const bool leader = gl == 0;
-    float *xout = a.states + (size_t)b * (T + 1) * N, *uout = a.actions + (size_t)b * T * M,
-          *chat = a.costs + (size_t)b * (T + 1);
-    GroupStore<N, M> st{lane_lds + grp, T, 0};
-
-    {   // start (ilqr.py:218), redundantly on every lane of the group
-        float x[N], xn[N], u[M];
-#pragma unroll
-        for (int i = 0; i < N; ++i) { x[i] = a.x0[(size_t)b * N + i]; st.set_x(0, i, x[i]); }
-        for (int t = 0; t < T; ++t) {
-#pragma unroll
-            for (int i = 0; i < M; ++i) { u[i] = a.u_init[((size_t)b * T + t) * M + i]; st.set_u(t, i, u[i]); }
-            const float c = env.cost(x, u);
-            if (leader) chat[t] = c;
-            env.transition(x, u, xn);
-#pragma unroll
-            for (int i = 0; i < N; ++i) { x[i] = xn[i]; st.set_x(t + 1, i, xn[i]); }
-        }
-        const float fc = env.final_cost(x);
-        if (leader) chat[T] = fc;
-    }
-
     const int my_alpha_idx = (gl < cfg.n_alphas) ? gl : cfg.n_alphas - 1;
     const float my_alpha = cfg.alphas[my_alpha_idx];
-    float mu = 0.0f, delta = 1.0f;
-    int status = 0, attempts = 0, iteration = 0;
-    bool converged = false, give_up = false;
-    for (iteration = 0; iteration < cfg.max_iterations; ++iteration) {
-        for (;;) {
-            float mu_l = mu, delta_l = delta;
-            LaneBackward r;
-            for (int retry = 0;; ++retry) {                                  // :285-315
-                r = backward_lane<KIND, N, M>(env, T, mu_l, bounded, low, high, st);
-                status |= r.flags;
-                if (!r.failed) break;
-                status |= TFMPC_ST_NOT_PD;
-                delta_l = fmaxf(cfg.delta_0, delta_l * cfg.delta_0);
-                mu_l = fmaxf(cfg.mu_min, mu_l * delta_l);
-                if (retry >= 40) { give_up = true; break; }
+    float *scratch = a.scratch + (size_t)blockIdx.x * ScratchSink<N, M>::rows(T) * 64;
+    const ScratchSink<N, M> sink{scratch + threadIdx.x, T, gl < cfg.n_alphas};
+    Store st{lane_lds + grp, T};
+
+    const int b = blockIdx.x * GROUPS + grp;
+    if (b < a.B) {                                  // whole group leaves together
+        LaneEnv<KIND, N, M> env;
+        env.load(genv, b);
+        float *xout = a.states + (size_t)b * (T + 1) * N, *uout = a.actions + (size_t)b * T * M,
+              *chat = a.costs + (size_t)b * (T + 1);
+        float mu = 0.0f, delta = 1.0f;
+        int status = 0, attempts = 0, iteration = 0;
+        {   // start (ilqr.py:218), redundantly on every lane of the group
+            float x[N], xn[N], u[M];
+#pragma unroll
+            for (int i = 0; i < N; ++i) { x[i] = a.x0[(size_t)b * N + i]; st.set_x(0, i, x[i]); }
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int i = 0; i < M; ++i) { u[i] = a.u_init[((size_t)b * T + t) * M + i]; st.set_u(t, i, u[i]); }
+                const float c = env.cost(x, u);
+                if (leader) chat[t] = c;
+                env.transition(x, u, xn);
+#pragma unroll
+                for (int i = 0; i < N; ++i) { x[i] = xn[i]; st.set_x(t + 1, i, xn[i]); }
             }
-            if (give_up) break;
-            if (r.g_norm < cfg.atol) { converged = true; break; }            // :243-248
-            // all step sizes at once, one per lane (ilqr.py:322-353)
-            float J, residual;
-            forward_lane<KIND, N, M>(env, T, my_alpha, low, high, st, NullSink{}, J, residual);
-            const float delta_J = -my_alpha * (r.dV1 + my_alpha * r.dV2);
-            const float dcost = r.J - J;
-            const float z = (delta_J > 0.0f) ? dcost / delta_J : sgnf(dcost);
-            const bool ok = gl < cfg.n_alphas && z >= cfg.c1;
-            const unsigned mask = (unsigned)((__ballot(ok) >> (grp * G)) & 0xFFFFu);
-            const bool accept = mask != 0;
-            const int chosen = accept ? (__ffs(mask) - 1) : cfg.n_alphas - 1;     // first accepted, else the last tried
-            const float res_chosen = __shfl(residual, grp * G + chosen, 64);
-            const bool small_step = res_chosen < cfg.atol;                   // :253-257
-            if (small_step || accept) {
-                float J2, r2;
-                forward_lane<KIND, N, M>(env, T, cfg.alphas[chosen], low, high, st,
-                                         GroupReplaySink<N, M>{st, chat, leader}, J2, r2);
-                st.cur ^= 1;
-            }
-            if (small_step) { converged = true; break; }
-            if (accept) {                                                    // :259-266
-                delta = fminf(1.0f / cfg.delta_0, delta / cfg.delta_0);
-                mu = (mu * delta > cfg.mu_min) ? mu * delta : 0.0f;
-                break;
-            }
-            delta = fmaxf(cfg.delta_0, delta * cfg.delta_0);                 // :267-270
-            mu = fmaxf(cfg.mu_min, mu * delta);
-            if (++attempts >= cfg.max_attempts || !(mu < 1e30f)) { give_up = true; break; }
+            const float fc = env.final_cost(x);
+            if (leader) chat[T] = fc;
         }
-        if (converged || give_up) break;
-    }
-    if (give_up) status |= TFMPC_ST_MAX_ATTEMPTS;
-    if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
-    for (int idx = gl; idx < (T + 1) * N; idx += G) xout[idx] = st.at(st.xoff(st.cur) + idx);
-    for (int idx = gl; idx < T * M; idx += G) uout[idx] = st.at(st.xoff(st.cur) + (T + 1) * N + idx);
-    if (leader) {
-        const float cT = chat[T];
-        if (!(cT == cT)) status |= TFMPC_ST_NAN;
-        a.iterations[b] = iteration;
-        a.status[b] = status;
+#ifdef TFMPC_PHASE_PROBE
+        LaneProbe pr{};
+#endif
+        bool converged = false, give_up = false;
+        for (; iteration < cfg.max_iterations; ++iteration) {
+            if constexpr (PRE > 0) {
+                // x-only part of the linearisation of every timestep, one timestep per lane (the nominal trajectory is
+                // fixed until a candidate is adopted, also across the regularisation retries below)
+                TFMPC_PROBE_START();
+                for (int t = gl; t < T; t += G) {
+                    float x[N], pre[PRE];
+#pragma unroll
+                    for (int i = 0; i < N; ++i) x[i] = st.x(t, i);
+                    env.prelinearize(x, pre);
+#pragma unroll
+                    for (int j = 0; j < PRE; ++j) st.set_pre(t, j, pre[j]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                TFMPC_PROBE(7);
+            }
+            for (;;) {
+                float mu_l = mu, delta_l = delta;
+                LaneBackward r;
+                for (int retry = 0;; ++retry) {                                  // :285-315
+                    r = backward_lane<KIND, N, M, Store, true>(env, T, mu_l, bounded, low, high, st TFMPC_PROBE_PASS);
+                    status |= r.flags;
+                    if (!r.failed) break;
+                    status |= TFMPC_ST_NOT_PD;
+                    delta_l = fmaxf(cfg.delta_0, delta_l * cfg.delta_0);
+                    mu_l = fmaxf(cfg.mu_min, mu_l * delta_l);
+                    if (retry >= 40) { give_up = true; break; }
+                }
+                if (give_up) break;
+                if (r.g_norm < cfg.atol) { converged = true; break; }            // :243-248
+                // all step sizes at once, one per lane (ilqr.py:322-353), candidates into the scratch columns
+                float J, residual;
+                TFMPC_PROBE_START();
+                forward_lane<KIND, N, M>(env, T, my_alpha, low, high, st, sink, J, residual);
+                TFMPC_PROBE(5);
+                const float delta_J = -my_alpha * (r.dV1 + my_alpha * r.dV2);
+                const float dcost = r.J - J;
+                const float z = (delta_J > 0.0f) ? dcost / delta_J : sgnf(dcost);
+                const bool ok = gl < cfg.n_alphas && z >= cfg.c1;
+                const unsigned mask = (unsigned)((__ballot(ok) >> (grp * G)) & 0xFFFFu);
+                const bool accept = mask != 0;
+                const int chosen = accept ? (__ffs(mask) - 1) : cfg.n_alphas - 1;     // first accepted, else the last tried
+                const float res_chosen = __shfl(residual, grp * G + chosen, 64);
+                const bool small_step = res_chosen < cfg.atol;                   // :253-257
+                if (small_step || accept) {
+                    // adopt the chosen lane's candidate: its scratch column becomes the nominal trajectory
+                    TFMPC_PROBE_START();
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const float *col = scratch + grp * G + chosen;
+                    const int rx = T * N, ru = T * M;
+                    for (int rr = gl; rr < rx; rr += G) st.at(N + rr) = col[rr * 64];
+                    for (int rr = gl; rr < ru; rr += G) st.at(st.uoff() + rr) = col[(rx + rr) * 64];
+                    for (int rr = gl; rr <= T; rr += G) chat[rr] = col[(rx + ru + rr) * 64];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    TFMPC_PROBE(6);
+                }
+                if (small_step) { converged = true; break; }
+                if (accept) {                                                    // :259-266
+                    delta = fminf(1.0f / cfg.delta_0, delta / cfg.delta_0);
+                    mu = (mu * delta > cfg.mu_min) ? mu * delta : 0.0f;
+                    break;
+                }
+                delta = fmaxf(cfg.delta_0, delta * cfg.delta_0);                 // :267-270
+                mu = fmaxf(cfg.mu_min, mu * delta);
+                if (++attempts >= cfg.max_attempts || !(mu < 1e30f)) { give_up = true; break; }
+            }
+            if (converged || give_up) break;
+        }
+        if (give_up) status |= TFMPC_ST_MAX_ATTEMPTS;
+        if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
+        for (int idx = gl; idx < (T + 1) * N; idx += G) xout[idx] = st.at(idx);
+        for (int idx = gl; idx < T * M; idx += G) uout[idx] = st.at(st.uoff() + idx);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // chat[T] may have been written by another lane
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (leader) {
+            const float cT = chat[T];
+            if (!(cT == cT)) status |= TFMPC_ST_NAN;
+            a.iterations[b] = iteration;
+            a.status[b] = status;
+#ifdef TFMPC_PHASE_PROBE
+            for (int i = 0; i < 8; ++i) chat[i] = (float)pr.acc[i];
+#endif
+        }
     }
 }
 
@@ -795,24 +908,43 @@ bool ilqr_lane_supported(const TfmpcEnv &env)
     return false;
 }
 
+// Workspace of the group kernel beyond the five slabs every solve kernel gets: one scratch block per wavefront
+// (candidate trajectories of the line search, ScratchSink).
+size_t ilqr_lane_extra_workspace_bytes(int B, int n, int m, int T)
+{
+    if (n != 2 || m != 2 || B <= 0) return 0;
+    const size_t blocks = B <= kOneGroupMaxBatch ? (size_t)B : ((size_t)B + 3) / 4;
+    return blocks * (size_t)ScratchSink<2, 2>::rows(T) * 64 * sizeof(float) + 256;
+}
+
+template <int KIND>
+static int group_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const SolveArgsLane &a, hipStream_t stream)
+{
+    constexpr int PRE = LaneEnv<KIND, 2, 2>::kPre;
+    const int B = a.B, T = a.T;
+    const dim3 block(64);
+    const size_t lds1 = GroupStore<2, 2, 1, PRE>::bytes(T), lds4 = GroupStore<2, 2, 4, PRE>::bytes(T);
+    if (B <= kOneGroupMaxBatch)      // the chip has room for a wavefront per instance: no divergence between groups
+        hipLaunchKernelGGL((ilqr_group_solve_kernel<KIND, 2, 2, 1>), dim3(B), block, lds1, stream, env, cfg, a);
+    else
+        hipLaunchKernelGGL((ilqr_group_solve_kernel<KIND, 2, 2, 4>), dim3((B + 3) / 4), block, lds4, stream, env, cfg, a);
+    return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
+}
+
 int ilqr_lane_solve_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, int B, int T, const float *x0,
                            const float *u_init, float *states, float *actions, float *costs, int32_t *iterations,
-                           int32_t *status, float *wsK, float *wsk, float *wsx, float *wsu, float *wsc,
+                           int32_t *status, float *wsK, float *wsk, float *wsx, float *wsu, float *wsc, void *extra,
                            hipStream_t stream)
 {
     SolveArgsLane a{B, T, x0, u_init, states, actions, costs, iterations, status, wsK, wsk, wsx, wsu, wsc};
     {
         const bool per_lane = option_is(kOptIlqrKernel, "lane1");
-        const size_t glds = GroupStore<2, 2>::bytes(T);
+        const size_t glds = GroupStore<2, 2, 4, 3>::bytes(T);
         if (!per_lane && glds <= 64 * 1024) {
-            const dim3 ggrid((B + 3) / 4), gblock(64);
-            if (env.kind == TFMPC_ENV_NAVLQR)
-                hipLaunchKernelGGL((ilqr_group_solve_kernel<TFMPC_ENV_NAVLQR, 2, 2>), ggrid, gblock, glds, stream, env, cfg, a);
-            else if (env.kind == TFMPC_ENV_NAVIGATION)
-                hipLaunchKernelGGL((ilqr_group_solve_kernel<TFMPC_ENV_NAVIGATION, 2, 2>), ggrid, gblock, glds, stream, env, cfg, a);
-            else
-                return TFMPC_ERR_UNSUPPORTED;
-            return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
+            a.scratch = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(extra) + 255) & ~(uintptr_t)255);
+            if (env.kind == TFMPC_ENV_NAVLQR) return group_launch<TFMPC_ENV_NAVLQR>(env, cfg, a, stream);
+            if (env.kind == TFMPC_ENV_NAVIGATION) return group_launch<TFMPC_ENV_NAVIGATION>(env, cfg, a, stream);
+            return TFMPC_ERR_UNSUPPORTED;
         }
     }
     const dim3 grid((B + 63) / 64), block(64);

@@ -1,4 +1,4 @@
-// options.h -- kernel-variant overrides for A/B timing and tests.  The three environment variables
+// options.h -- kernel-variant overrides for A/B timing and tests.  The environment variables
 // TFMPC_LQR_KERNEL, TFMPC_LQR_MFMA, TFMPC_ILQR_KERNEL are read ONCE per process (first launch);
 // afterwards only tfmpc_set_option (include/tfmpc_hip.h) changes them.  Launchers compare by value:
 //     if (option_is(kOptIlqrKernel, "wave")) ...
@@ -10,5 +10,7 @@ enum Option { kOptLqrKernel = 0, kOptLqrMfma = 1, kOptIlqrKernel = 2, kOptCount 
 
 // true when the option is set and equals `value`
 bool option_is(Option which, const char *value);
+// the option as an integer, `fallback` when unset or not a number
+int option_int(Option which, int fallback);
 
 }  // namespace tfmpc

@@ -41,6 +41,16 @@ bool option_is(Option which, const char *value)
     return t.value[which][0] != 0 && std::strcmp(t.value[which], value) == 0;
 }
 
+int option_int(Option which, int fallback)
+{
+    Table &t = table();
+    std::lock_guard<std::mutex> g(t.lock);
+    if (t.value[which][0] == 0) return fallback;
+    char *end = nullptr;
+    const long v = std::strtol(t.value[which], &end, 10);
+    return (end && *end == 0) ? (int)v : fallback;
+}
+
 }  // namespace tfmpc
 
 extern "C" int tfmpc_set_option(const char *name, const char *value)

@@ -1,10 +1,9 @@
 """Per-phase cycle counts of lqr_block_kernel's Riccati step.  Needs a probe build of the library:
   hipcc ... -DTFMPC_PHASE_PROBE -c tf-mpc_amd/csrc/lqr_block.hip -o tools/probes/ab/lqr_block_probe.o, linked with the other
-  objects into tools/probes/ab/lib_probe.so (tools/probes/build_probe.sh).  Run on the GPU box; the box is ephemeral, so the
-  product library is simply overwritten by the probe build."""
-import shutil, sys
-root = '/root/repo'
-shutil.copy(f'{root}/tools/probes/ab/lib_probe.so', f'{root}/tf-mpc_amd/tfmpc/_lib/libtfmpc_hip.so')
+  objects into tools/probes/ab/lib_probe.so (tools/probes/build_probe.sh).  Run on the GPU box."""
+import os, sys
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["TFMPC_LIB"] = f'{root}/tools/probes/ab/lib_probe.so'        # tfmpc/_hip.py loads the probe build instead of the product library
 sys.path.insert(0, f'{root}/tf-mpc_amd'); sys.path.insert(0, f'{root}/tests')
 import numpy as np, torch, problems
 from tfmpc.solvers.lqr import LQR
