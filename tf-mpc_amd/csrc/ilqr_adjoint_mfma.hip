@@ -295,6 +295,14 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
 #pragma unroll
         for (int e = 0; e < NV; ++e) { opaque_f(lo[e]); opaque_f(hi[e]); opaque_f(am[e]); opaque_f(rcap[e]); }
     }
+    // every stage / final cost is >= 0 for actions in [0, 1] (then partial cost sums never decrease)
+    __device__ __forceinline__ bool costs_nonnegative() const
+    {
+        bool ok = true;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) ok = ok && am[e] >= 0.0f;
+        return __all(ok);
+    }
     __device__ __forceinline__ float penalties(float x, int e) const
     {
         const float mid = (lo[e] + hi[e]) / 2;
@@ -403,6 +411,20 @@ template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
 #pragma unroll
         for (int e = 0; e < NV; ++e) { opaque_f(lo[e]); opaque_f(hi[e]); opaque_f(rcap[e]); }
     }
+    __device__ __forceinline__ bool costs_nonnegative() const          // see EnvM<HVAC>
+    {
+        float LP[NV], HP[NV], SP[NV];
+        bool ok = true;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {                 // all rows, whatever this lane's quarter
+            lds_rows<NT>(lds, kLP, q4, LP);
+            lds_rows<NT>(lds, kHP, q4, HP);
+            lds_rows<NT>(lds, kSP, q4, SP);
+#pragma unroll
+            for (int e = 0; e < NV; ++e) ok = ok && LP[e] >= 0.0f && HP[e] >= 0.0f && SP[e] >= 0.0f;
+        }
+        return __all(ok);
+    }
     __device__ __forceinline__ void stage_costs(const float (&x)[NV], const float (&)[NV], int qo, float (&c)[NV]) const
     {
         float LP[NV], HP[NV], SP[NV];                                                     // reservoir :63-79
@@ -493,6 +515,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
         rows[kSlotAHigh * kRowLd + lane] = (lane < m) ? genv.high[lane] : 0.0f;
     }
     wsync();
+    const bool early_exit = cfg.c1 == 0.0f && env.costs_nonnegative();     // see `rollout`
 
     // trajectories of this column: [0] the output arrays, [1] the workspace; the nominal one is [flip]
     float *const xbuf[2] = {a.states + b * (T + 1) * n, a.wsx + b * (T + 1) * n};
@@ -507,15 +530,21 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
     // BIT per action (which bound) and the rollout rebuilds k_t from u_hat_t with the sweep's own expression.
     // A wave alone waits ~3 000 cycles on every HBM / L2 round trip and only two waves share a SIMD, so the inputs of
     // step t + kAhead are requested before step t is computed (a register ring, the time loop unrolled by kAhead).
-    constexpr int kAheadRoll = 4, kAhead = 2;        // rollouts (few live registers) / costate sweep
+    constexpr int kAheadRoll = NT == 2 ? 2 : 4, kAhead = 2;        // rollouts / costate sweep (two tiles: the ring is 8 registers per step ahead)
     // STORE: the trajectory is written (rows of columns with `keep`).  The line search only needs J: its rollouts store
     // nothing, and the one step size a column settles on is rolled out again with STORE (same arithmetic, same bits)
     // -- every speculative rollout writing its 25 KB per instance made the solve HBM-write-bound.
     // NA = 2 (the HVAC line search): TWO step sizes in one pass -- the inputs u_hat_t and the selector byte are loaded once,
     // and the two independent state chains give a wave something to issue while the other chain waits on its LDS
     // reads and MFMA results (only two waves share a SIMD at BASELINE's batch).
+    // A line-search rollout that stores nothing exists to answer "is J(alpha) <= J_hat?" (ilqr.py:339-353 with c1 = 0:
+    // z >= 0 <=> J_hat - J >= 0 on either branch of :342-346).  Stage costs are >= 0 on both envs, so the partial sum only
+    // grows: once it is above `reject_above` (= J_hat) in every column that is still trying (`trying`), the answer is
+    // "no" whatever follows, and the pass stops -- the first, too long step sizes of a Reservoir search blow the cost
+    // up within 5 .. 40 of the 100 steps.  Same decisions, so same results, bit for bit.
     auto rollout = [&](auto search, auto store, auto n_alpha, const float (&alpha)[decltype(n_alpha)::value], const float *uh,
-                       bool keep, float *xs, float *us, float *cs, float (&J_out)[decltype(n_alpha)::value]) {
+                       bool keep, float *xs, float *us, float *cs, float (&J_out)[decltype(n_alpha)::value],
+                       bool trying = false, float reject_above = 0.0f, bool may_stop = false, bool *stopped_out = nullptr) {
         constexpr bool SEARCH = decltype(search)::value, STORE = decltype(store)::value;
         constexpr int NA = decltype(n_alpha)::value;
         static_assert(!STORE || NA == 1, "only a single rollout is stored");
@@ -543,7 +572,14 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
             for (int e = 0; e < NV; ++e) ur[d][e] = 0.0f;
             if (d < T) request(d, ur[d], kb[d]);
         }
+        bool stopped = false;
         for (int t0 = 0; t0 < T; t0 += kAheadRoll) {
+            if (SEARCH && early_exit && may_stop) {
+                bool open = false;                       // a trying column whose partial cost may still end at or below J_hat
+#pragma unroll
+                for (int k = 0; k < NA; ++k) open = open || (trying && !(J[k] > reject_above));
+                if (!__any(open)) { stopped = true; break; }
+            }
 #pragma unroll
             for (int d = 0; d < kAheadRoll; ++d) {
                 const int t = t0 + d;
@@ -594,8 +630,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
             env.final_costs(x[k], opaque(ql), cp);
             const float fc = col_sum<NT, PK>(cp);
             if (STORE && keep && ql == 0) gst(cs + T, fc);
-            J_out[k] = J[k] + fc;
+            J_out[k] = stopped ? J[k] : J[k] + fc;       // stopped: already above J_hat in every column that asked
         }
+        if (stopped_out) *stopped_out = stopped;
         if (STORE) wsync();                 // costs are written by lane quarter 0 and read by all four in the next sweep
     };
     using one_t = std::integral_constant<int, 1>;
@@ -680,11 +717,21 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
         bool accept = false;
         float residual = 0.0f, alpha_last = 0.0f;          // alpha_last: the step size of this column's last rollout
         constexpr int NA = EnvM<KIND, NT>::kSearchAlphas;
+        // One step size per pass: the pass WRITES the candidate of every column that is trying it (a column's buffer is
+        // then final the moment the column accepts: no second rollout), and the early stop keeps the passes that are
+        // rejected anyway -- most of a Reservoir search -- from writing much.  `complete`: this column's last try ran to
+        // the end of the horizon.  (Two step sizes per pass, HVAC: nothing is written, the accepted one is rolled out again.)
+        constexpr bool kStoreWhileSearching = NA == 1;
+        bool complete = false;
         for (int ai = 0; ai < cfg.n_alphas && __any(searching && !accept); ai += NA) {
             float al[NA], J[NA];
 #pragma unroll
             for (int k = 0; k < NA; ++k) al[k] = cfg.alphas[ai + k < cfg.n_alphas ? ai + k : ai];
-            rollout(std::true_type{}, std::false_type{}, std::integral_constant<int, NA>{}, al, uhat, false, xc, uc, cc, J);
+            const bool trying_now = searching && !accept;
+            bool stopped = false;
+            rollout(std::true_type{}, std::integral_constant<bool, kStoreWhileSearching>{}, std::integral_constant<int, NA>{}, al,
+                    uhat, kStoreWhileSearching && trying_now, xc, uc, cc, J, trying_now, rJ, true, &stopped);
+            if (trying_now) complete = kStoreWhileSearching && !stopped;
 #pragma unroll
             for (int k = 0; k < NA; ++k) {                                     // in the reference's order
                 const bool trying = searching && !accept && ai + k < cfg.n_alphas;
@@ -703,10 +750,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
         }
         const bool small_step = searching && residual < cfg.atol;              // :253-257
         const bool take = searching && (small_step || accept);                 // (:253 takes the last rollout even if rejected)
-        if (__any(take)) {
+        if (__any(take && !complete)) {     // (also: the last step size tried was cut short and :253 takes it all the same)
             const float al[1] = {alpha_last};
             float J[1];
-            rollout(std::true_type{}, std::true_type{}, one_t{}, al, uhat, take, xc, uc, cc, J);
+            rollout(std::true_type{}, std::true_type{}, one_t{}, al, uhat, take && !complete, xc, uc, cc, J);
         }
         if (take) flip ^= 1;                                                   // the candidate becomes the nominal
         if (converged_g || small_step) done = true;                            // converged
