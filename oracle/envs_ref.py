@@ -254,9 +254,9 @@ class LQEnv(OracleEnv):
     """Time-invariant LQ problem ``(F, f, C, c)`` of ``tfmpc/solvers/lqr.py:36-57``
     presented through the DiffEnv protocol, so that iLQR can be driven on the
     BASELINE.json headline shape (n=16, m=8) -- the reference's own envs all
-    have ``action_size == state_size``.  Unbounded actions."""
+    have ``action_size == state_size``.  Actions unbounded unless ``low`` / ``high`` are given."""
 
-    def __init__(self, F, f, C, c, dtype=np.float64):
+    def __init__(self, F, f, C, c, low=None, high=None, dtype=np.float64):
         super().__init__(dtype)
         self.F = np.asarray(F, dtype=self.dtype)
         self.f = np.asarray(f, dtype=self.dtype).reshape(-1, 1)
@@ -264,7 +264,7 @@ class LQEnv(OracleEnv):
         self.c = np.asarray(c, dtype=self.dtype).reshape(-1, 1)
         self.state_size = self.F.shape[0]
         self.action_size = self.F.shape[1] - self.state_size
-        self.action_space = Box(-np.inf, np.inf, (self.action_size, 1))
+        self.action_space = Box(-np.inf if low is None else low, np.inf if high is None else high, (self.action_size, 1))
 
     def _transition(self, x, u):
         return self._t(self.F) @ torch.cat([x, u], dim=0) + self._t(self.f)

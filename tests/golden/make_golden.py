@@ -193,6 +193,20 @@ def ilqr_cases():
     rec = ilqr_record(env, x0, 12, u0)
     save("ilqr_lq16x8", source="oracle-fp64 ilqr_ref.ILQRRef on LQEnv(make_lqr seed 1000, F*0.25) (PARITY UNPINNED)",
          lq_F=F, lq_f=f, lq_C=C, lq_c=c, **rec)
+    ilqr_lq_bounded_case()
+
+
+def ilqr_lq_bounded_case():
+    """The headline shape with CONTROL LIMITS (ilqr.py:136-138,364-387 + optimization.py:6-101): the same LQ problem,
+    actions boxed to [-1.5, 1.5]."""
+    F, f, C, c = problems.make_lqr_instance(1000, 16, 8)
+    F = 0.25 * F
+    env = envs_ref.LQEnv(F, f, C, c, low=-1.5, high=1.5)
+    x0 = np.random.default_rng(1000).normal(size=(16, 1))
+    u0 = np.random.default_rng(500).normal(size=(12, 8, 1)) * 0.1
+    rec = ilqr_record(env, x0, 12, u0)
+    save("ilqr_lq16x8_bounded", source="oracle-fp64 ilqr_ref.ILQRRef on LQEnv(make_lqr seed 1000, F*0.25), actions in "
+         "[-1.5, 1.5] (PARITY UNPINNED)", lq_F=F, lq_f=f, lq_C=C, lq_c=c, low=-1.5, high=1.5, **rec)
 
 
 if __name__ == "__main__":

@@ -95,7 +95,8 @@ def test_second_chance_launch_handles_non_pd_instances(force_kernel):
     assert float((mixed["states"][good] - wave["states"][good]).abs().max()) <= 5e-4 * float(wave["states"][good].abs().max())
 
 
-def test_bounded_lq_env_stays_on_the_wave_kernel():
+def test_bounded_lq_env_is_clipped():
+    """(bounded LQ envs run on the control-limited matrix-core kernel: tests/test_ilqr_lq_box_mfma_gpu.py)"""
     lib = _hip.require_gpu()
     F, f, C, c, x0 = _problem(4, 16, 8, seed=3)
     solver = iLQR(LQEnv(F, f, C, c, low=-0.5, high=0.5))

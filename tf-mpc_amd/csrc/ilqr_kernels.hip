@@ -494,6 +494,11 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
         // LQ env on the matrix cores (ilqr_lq_mfma.hip); instances it cannot finish (mu > 0 needed)
         // come back flagged and are re-solved from scratch by the wave kernel right behind it
         const bool forced_wave = option_is(kOptIlqrKernel, "wave");
+        if (!forced_wave && !cfg->storage_bf16 && ilqr_lq_box_mfma_supported(*env, T)) {
+            // control-limited LQ problems: box-QP in registers, the complete solve loop in one kernel
+            IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk, a.wsu};
+            return ilqr_lq_box_mfma_launch(la, st);
+        }
         if (!forced_wave && !cfg->storage_bf16 && ilqr_lq_mfma_supported(*env, T)) {
             IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk, a.wsu};
             if ((rc = ilqr_lq_mfma_launch(la, st)) != TFMPC_OK) return rc;

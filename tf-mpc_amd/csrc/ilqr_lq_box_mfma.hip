@@ -1,0 +1,616 @@
+// ilqr_lq_box_mfma.hip -- CONTROL-LIMITED iLQR.solve (tfmpc/solvers/ilqr.py:214-387 with the projected-Newton
+// box-QP of tfmpc/utils/optimization.py:6-101) on the matrix cores for the time-invariant LQ env (ENV_LQ),
+// n <= 16, m <= 8: the BASELINE.json headline shape with bounded actions -- the reference's defining feature.
+//
+// One wavefront = one instance for its whole solve, the complete state machine in the kernel: regularisation
+// mu / delta schedule (:259-270), the local retry of a failed factorisation (:285-315), 11-point line search
+// (:317-355) with clipped rollouts (:196-197), both convergence tests (:243-257).  No second launch, no host
+// round trip.  (The unbounded sibling ilqr_lq_mfma.hip keeps its leaner mu = 0 sweep and hands the rare
+// instance that needs mu > 0 to the wave kernel.)
+//
+// Backward step (ilqr.py:119-170), per timestep:
+//   1. the three 16 x 16 tiles Q_xx, [Q_ux; Q_x^T], [Q_uu | Q_u] on the bf16 matrix cores as bf16x3
+//      (mfma_bf16x3.h), exactly as in lqr_mfma16x8.hip / ilqr_lq_mfma.hip; V_xx is kept exactly symmetric.
+//   2. the regularised twins are  Q~_uu = Q_uu + mu F_u^T F_u,  Q~_ux = Q_ux + mu F_u^T F_x  (:127,133-134;
+//      F is constant on this env, so the two Gram matrices are formed once per solve).
+//   3. controller (:136-143):
+//      bounded, V_xx != 0 -- box-QP IN REGISTERS: lane r (mod 8) owns row r of H = Q~_uu and x_r; the iterate x
+//        is wave-uniform (8 v_readlane per update), so gradient, clamp test (:121-127) and objective are 8 FMAs
+//        per lane plus one DPP reduction over 8 lanes; the Newton system of the free set is the 8 x 25 LDL^T
+//        elimination of wave_ldlt8.h on [Q~_ux | H | g~] with the clamped rows / columns replaced by identity
+//        rows -- which yields the step AND the feedback gain K_free = -H_ff^-1 Q~_ux,f (:375-385) of that free set
+//        in the same 36 readlanes; Armijo backtracking (:82-95) and all five exits are wave-uniform branches.
+//        ~250 instructions per QP iteration against ~10 000 cycles for the LDS Gauss-Jordan of the wave kernel.
+//      bounded, V_xx == 0 -- K = 0, bang-bang k (:140-141);   unbounded -- [K | k] = -Q~_uu^-1 [Q~_ux | Q_u].
+//   4. four-term value update with the UNREGULARISED Q_uu, Q_ux (:149-161), on the f32 matrix cores:
+//        P = Q_uu K, p = Q_uu k;  V_xx' = Q_xx + Q_xu K + K^T (Q_ux + P);  V_x' = Q_x + Q_xu k + K^T (Q_u + p);
+//      then V_xx <- (V_xx + V_xx^T) / 2 (:162).  dV1 += k^T Q_u, dV2 += 1/2 k^T p (:164-167).
+// Forward (:174-212): as ilqr_lq_mfma.hip plus the clip; stage costs as one C Z product per rollout.
+#include <hip/hip_runtime.h>
+
+#include "ilqr_lq_mfma.h"
+#include "mfma_bf16x3.h"
+#include "wave_ldlt8.h"
+#include "wave_ops.h"
+
+namespace tfmpc {
+
+namespace {
+
+constexpr int N = 16, M = 8, D = 24;
+using f32x4 = bf3::f32x4;
+using namespace bf3;
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float readlane(float v, int lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141;
+// sum / max over each group of 8 adjacent lanes (every lane of the group gets the result)
+__device__ __forceinline__ float sum8(float v)
+{
+    v += dpp<kDppXor1>(v);
+    v += dpp<kDppXor2>(v);
+    v += dpp<kDppHalfMirror>(v);
+    return v;
+}
+__device__ __forceinline__ float max8(float v)           // non-negative values
+{
+    v = fmaxf(v, dpp<kDppXor1>(v));
+    v = fmaxf(v, dpp<kDppXor2>(v));
+    v = fmaxf(v, dpp<kDppHalfMirror>(v));
+    return v;
+}
+
+// fixed part of the LDS slice ([col][8 rows] blocks are column-major like the elimination input):
+//   kMs  [32][8]  Q_ux (cols 0..15) | Q_uu (16..23) | Q_u (24); pad columns 25.. always zero, 28-29 stage Q_x
+//   kKs  [32][8]  K (cols 0..15), k (col 24)
+//   kPs  [32][8]  S = Q_ux + Q_uu K (cols 0..15), sp = Q_u + Q_uu k (col 24)
+//   kVt  [16][20] V_xx transpose staging
+constexpr int kMs = 0, kKs = 256, kPs = 512, kVt = 768, kVtLd = 20, kDyn = kVt + 16 * kVtLd;
+constexpr int kZero = kMs + 25 * 8, kQx = kMs + 28 * 8;
+constexpr int kZld = 26;
+
+__device__ __forceinline__ float sgn(float y) { return (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f); }
+
+struct StepResult { float J, dV1, dV2, g_norm; bool failed; int flags; };
+
+__global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int i = lane & 15, q = lane >> 4;
+    const int r8 = lane & 7;                       // QP: the row this lane owns
+    const int c32 = lane & 31;                     // elimination: the column this lane owns
+    const int T = a.T, Tp = T + 1;
+    const int n = a.env.n, m = a.env.m, d = n + m;
+    const TfmpcIlqrConfig &cfg = a.cfg;
+    const bool bounded = a.env.bounded != 0;
+
+    float *bufA = lds + kDyn;                    // [(T+1)][26]
+    float *bufB = bufA + Tp * kZld;
+    float *costA = bufB + Tp * kZld;             // [T+1]
+    float *costB = costA + ((Tp + 3) & ~3);
+
+    const float *Fg = a.env.p[0] + (size_t)b * a.env.stride[0];
+    const float *fg = a.env.p[1] + (size_t)b * a.env.stride[1];
+    const float *Cg = a.env.p[2] + (size_t)b * a.env.stride[2];
+    const float *cg = a.env.p[3] + (size_t)b * a.env.stride[3];
+    float *Kg = a.wsK + (size_t)b * T * m * n;
+    float *kg = a.wsk + (size_t)b * T * m;
+
+    auto Fxx = [&](int row, int xi) { return (row < n && xi < n) ? Fg[row * d + xi] : 0.0f; };
+    auto Fxu = [&](int row, int ui) { return (row < n && ui < m) ? Fg[row * d + n + ui] : 0.0f; };
+    auto zmap = [&](int zi) { return zi < N ? (zi < n ? zi : -1) : (zi - N < m ? n + zi - N : -1); };
+    auto Cs = [&](int zr, int zc) {            // symmetric part of C (gradient / Hessian of the cost)
+        const int r = zmap(zr), c_ = zmap(zc);
+        return (r >= 0 && c_ >= 0) ? 0.5f * (Cg[r * d + c_] + Cg[c_ * d + r]) : 0.0f;
+    };
+    auto cz = [&](int zr) { const int r = zmap(zr); return r >= 0 ? cg[r] : 0.0f; };
+
+    // ---- operands resident in registers for the whole solve ------------------------------
+    float Fb0[4], Fb1[4];
+    f32x4 Cd00, Cd01t, Cd11;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = 4 * q + r, ku = N + k;
+        Fb0[r] = Fxx(k, i);
+        Fb1[r] = (i < M) ? Fxu(k, i) : 0.0f;
+        Cd00[r] = Cs(k, i);
+        Cd01t[r] = (k < M) ? Cs(N + k, i) : 0.0f;
+        float c11 = 0.0f;
+        if (ku < D && i < M) c11 = (k >= m && i == k) ? 1.0f : Cs(ku, N + i);     // unit diagonal on padded actions
+        Cd11[r] = c11;
+    }
+    const int fi = lane >> 2, fc = lane & 3;       // F rows for x' = F z + f
+    const int ka = lane >> 3, jc = lane & 7;       // K rows for du = K dx
+    float Fr[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int zc = 6 * fc + j;
+        Fr[j] = zc < N ? Fxx(fi, zc) : Fxu(fi, zc - N);
+    }
+    const float f_i = fi < n ? fg[fi] : 0.0f;
+    float Ca0[6], Ca1[6];                          // A operand of C Z (k = 4s + q)
+    f32x4 cq0, cq1;
+#pragma unroll
+    for (int s2 = 0; s2 < 6; ++s2) {
+        Ca0[s2] = Cs(i, 4 * s2 + q);
+        Ca1[s2] = (i < M) ? Cs(N + i, 4 * s2 + q) : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        cq0[r] = cz(4 * q + r);
+        cq1[r] = (q < 2) ? cz(N + 4 * q + r) : 0.0f;
+    }
+    const ConstFrag Fc0 = const_frag(f32x4{Fb0[0], Fb0[1], Fb0[2], Fb0[3]});
+    const ConstFrag Fc1 = const_frag(f32x4{Fb1[0], Fb1[1], Fb1[2], Fb1[3]});
+    // Gram matrices of the regularisation, constant on this env (ilqr.py:127,133-134 with f_x, f_u fixed):
+    //   column layout (lane c32): Gcol[e] = (F_u^T [F_x | . | F_u])[e][c]  -> added to the elimination input
+    //   row layout (lane r8):     Grow[j] = (F_u^T F_u)[r8][j]             -> added to the QP's H
+    // The same ascending-k FMA chain in both, so G_uu[a][b] == G_uu[b][a] bit for bit.
+    float Gcol[8], Grow[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float gc = 0.0f, gr = 0.0f;
+        for (int k = 0; k < n; ++k) {
+            const float fue = Fxu(k, e);
+            const float other = c32 < N ? Fxx(k, c32) : (c32 < N + M ? Fxu(k, c32 - N) : 0.0f);
+            gc = fmaf(fue, other, gc);
+            gr = fmaf(Fxu(k, r8), fue, gr);
+        }
+        Gcol[e] = gc;
+        Grow[e] = gr;
+    }
+    // action bounds of row r8 (padded actions: any box around 0; their Q_u is 0 and their H row the unit vector)
+    const float low_r = r8 < m ? a.env.low[r8] : -1.0f, high_r = r8 < m ? a.env.high[r8] : 1.0f;
+    const float low_k = ka < m ? a.env.low[ka] : 0.0f, high_k = ka < m ? a.env.high[ka] : 0.0f;   // rollout: action row ka
+    // row r8 of the symmetric H read from the upper triangle of the staged Q_uu (what the LDL^T reads)
+    int hoff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hoff[j] = kMs + (N + (r8 > j ? r8 : j)) * 8 + (r8 > j ? j : r8);
+
+    for (int idx = lane; idx < kDyn; idx += kWave) lds[idx] = 0.0f;
+    const int t01_src = (i == M) ? kQx + 4 * q : kZero;
+    const int g1_src = (i == M) ? kKs + (N + M) * 8 + q : kZero + q;
+    const int s1_src = (i == M) ? kPs + (N + M) * 8 + q : kZero + q;
+
+    auto cz_pass = [&](const float *Z, int rows, float *out, bool grad) {
+        for (int nt = 0; nt * 16 < rows; ++nt) {
+            const int t = 16 * nt + i;
+            const float *zrow = Z + ((t < rows) ? t : rows - 1) * kZld;
+            f32x4 D0 = {0.f, 0.f, 0.f, 0.f}, D1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 6; ++s2) {
+                const float bz = zrow[4 * s2 + q];
+                D0 = mfma(Ca0[s2], bz, D0);
+                D1 = mfma(Ca1[s2], bz, D1);
+            }
+            if (grad) {
+                if (t < rows) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        out[t * kZld + 4 * q + r] = D0[r] + cq0[r];
+                        if (q < 2) out[t * kZld + N + 4 * q + r] = D1[r] + cq1[r];
+                    }
+                }
+            } else {
+                float part = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    part = fmaf(zrow[4 * q + r], fmaf(0.5f, D0[r], cq0[r]), part);
+                    if (q < 2) part = fmaf(zrow[N + 4 * q + r], fmaf(0.5f, D1[r], cq1[r]), part);
+                }
+                part += __shfl_xor(part, 16, kWave);
+                part += __shfl_xor(part, 32, kWave);
+                if (q == 0 && t < rows) out[t] = part;
+            }
+        }
+    };
+    auto sum_costs = [&](const float *cbuf) {
+        float p = 0.0f;
+        for (int idx = lane; idx < Tp; idx += kWave) p += cbuf[idx];
+        return wave_sum(p);
+    };
+    // x' = F z + f for the row of F this lane shares (4 lanes per row), z_t in LDS
+    auto next_state = [&](const float *zt) {
+        float xn = 0.0f;
+        const float2 *zp = reinterpret_cast<const float2 *>(&zt[6 * fc]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float2 z2 = zp[j];
+            xn = fmaf(Fr[2 * j], z2.x, xn);
+            xn = fmaf(Fr[2 * j + 1], z2.y, xn);
+        }
+        xn += dpp<kDppXor1>(xn);
+        xn += dpp<kDppXor2>(xn);
+        return xn + f_i;
+    };
+
+    // ---- start (ilqr.py:218): roll the env under the injected actions --------------------
+    float *nom = bufA, *cand = bufB, *cnom = costA, *ccand = costB;
+    if (lane < N) nom[lane] = (lane < n) ? a.x0[(size_t)b * n + lane] : 0.0f;
+    for (int idx = lane; idx < T * M; idx += kWave) {
+        const int t = idx >> 3, ua = idx & 7;
+        nom[t * kZld + N + ua] = (ua < m) ? a.u_init[((size_t)b * T + t) * m + ua] : 0.0f;
+    }
+    if (lane < M) nom[T * kZld + N + lane] = 0.0f;
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const float xn = next_state(nom + t * kZld);
+        if (fc == 0) nom[(t + 1) * kZld + fi] = xn;
+        __syncthreads();
+    }
+    cz_pass(nom, Tp, cnom, false);
+    __syncthreads();
+
+    // ---- projected-Newton box-QP (optimization.py:6-101) of one timestep, in registers -----------------
+    // In: Hrow (row r8 of the regularised H), Mreg (column c32 of the regularised [Q~_ux | H | .]), q_r, lo_r, hi_r.
+    // Out: x_r (the solution k), Kcol (column c32 of K for the last factorised free set).  Returns 0 ok,
+    // TFMPC_ST_QP_MAXITER, or -1: a factorisation failed (ilqr.py:305 raises mu).
+    auto boxqp8 = [&](const float (&Hrow)[8], const float (&Mreg)[8], float q_r, float lo_r, float hi_r, float &x_r,
+                      float (&Kcol)[8]) -> int {
+        const float rtol = 1e-8f, step_dec = 0.6f, min_step = 1e-22f, armijo = 0.1f, eps = 1e-6f;       // :13-17
+        float xs[8];
+        auto bcast = [&](float v) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xs[j] = readlane(v, j);
+        };
+        auto objective = [&](float xv) {            // 1/2 x^T H x + q^T x (:8-11) with xs = the whole x
+            float hx = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hx = fmaf(Hrow[j], xs[j], hx);
+            return sum8(xv * fmaf(0.5f, hx, q_r));
+        };
+        x_r = (lo_r + hi_r) / 2;                                                                        // ilqr.py:369
+        bcast(x_r);
+        float value = objective(x_r), old_value = value;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Kcol[e] = 0.0f;
+        for (int it = 0; it < 100; ++it) {                                                               // :24
+            if (it > 0 && (old_value - value) < rtol * fabsf(old_value)) return 0;                      // :27-29
+            old_value = value;
+            float g = q_r;                                                                               // :34
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g = fmaf(Hrow[j], xs[j], g);
+            const bool clamped = (fabsf(x_r - lo_r) < eps && g > 0.0f) || (fabsf(hi_r - x_r) < eps && g < 0.0f);   // :121-127
+            const unsigned fmask = (unsigned)(__ballot(!clamped) & 0xFFull);                             // free rows, wave-uniform
+            const float gn = sum8(clamped ? 0.0f : g * g);
+            float gc = q_r;                                                                              // :65 grad_clamped
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gc = fmaf(Hrow[j], ((fmask >> j) & 1u) ? 0.0f : xs[j], gc);
+            float gcs[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gcs[j] = readlane(gc, j);
+            // [Q~_ux,f | H_ff | g~_f] with identity rows / columns on the clamped set -> LDL^T (:40-51, :66-72, ilqr.py:375-385)
+            f32x2 M2[4];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool fe = (fmask >> e) & 1u;
+                float v;
+                if (c32 < N) v = fe ? Mreg[e] : 0.0f;
+                else if (c32 < N + M) v = (fe && ((fmask >> (c32 - N)) & 1u)) ? Mreg[e] : ((e == c32 - N) ? 1.0f : 0.0f);
+                else if (c32 == N + M) v = fe ? gcs[e] : 0.0f;
+                else v = 0.0f;
+                M2[e >> 1][e & 1] = v;
+            }
+            float X[8];
+            int mpb = 0x3f800000;
+            ldlt8_solve_neg(M2, X, mpb);
+            if (mpb <= 0) return -1;                            // H_ff not positive definite
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Kcol[e] = X[e];         // lanes < 16: K[.][c32] of this free set
+            if (fmask == 0u) return 0;                                                                   // :53-55
+            if (sqrtf(gn) < eps) return 0;                                                               // :58-62
+            // search direction -H_ff^-1 g~_f - x_f (:66-72): lane 24 holds -H_ff^-1 g~
+            float sr = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float ye = readlane(X[e], N + M);
+                if (r8 == e) sr = ye;
+            }
+            sr = clamped ? 0.0f : sr - x_r;
+            const float sdotg = sum8(sr * g);                                                            // :75
+            if (sdotg >= 0.0f) return 0;                                                                 // :77-79
+            float step = 1.0f, xc, vc;                                                                   // :82-95
+            for (;;) {
+                xc = fminf(fmaxf(fmaf(step, sr, x_r), lo_r), hi_r);
+                bcast(xc);
+                vc = objective(xc);
+                if (!((vc - old_value) / (step * sdotg) < armijo)) break;
+                step *= step_dec;
+                if (step < min_step) {
+                    xc = fminf(fmaxf(fmaf(step, sr, x_r), lo_r), hi_r);
+                    bcast(xc);
+                    vc = objective(xc);
+                    break;
+                }
+            }
+            x_r = xc;                                                                                    // :98-99 (xs == x already)
+            value = vc;
+        }
+        return TFMPC_ST_QP_MAXITER;
+    };
+
+    // ---- regularised backward pass (ilqr.py:94-172) over the nominal trajectory `nom` with gradients Lz -------------
+    auto backward = [&](const float *Lz, float mu) -> StepResult {
+        StepResult res{0.0f, 0.0f, 0.0f, 0.0f, false, 0};
+        f32x4 Vd = Cd00, vd = {0.f, 0.f, 0.f, 0.f};
+        if (i == M) vd = *reinterpret_cast<const f32x4 *>(&Lz[T * kZld + 4 * q]);     // V_x = l_x^f
+        float gsum = 0.0f;
+        for (int t = T - 1; t >= 0; --t) {
+            const bool vxx_nonzero = __any(Vd[0] != 0.0f || Vd[1] != 0.0f || Vd[2] != 0.0f || Vd[3] != 0.0f);   // :137
+            f32x4 W0 = {0.f, 0.f, 0.f, 0.f}, W1 = {0.f, 0.f, 0.f, 0.f};
+            {
+                const VarFrag Vf = var_frag(Vd);
+                W0 = mm_var_const(Vf, Fc0, W0);
+                W1 = mm_var_const(Vf, Fc1, W1);
+            }
+            W1 += vd;
+            f32x4 T00 = Cd00, T01t = Cd01t, T11 = Cd11;
+            if (q == 2) T01t[0] = Lz[t * kZld + i];                                     // l_x(t)
+            if (i == M && q < 2) T11 = *reinterpret_cast<const f32x4 *>(&Lz[t * kZld + N + 4 * q]);   // l_u(t)
+            {
+                const VarFrag W0f = var_frag(W0), W1f = var_frag(W1);
+                T00 = mm_const_var(Fc0, W0f, T00);                 // Q_xx                 :129
+                T01t = mm_var_const(W1f, Fc0, T01t);               // Q_ux | Q_x           :131,122
+                T11 = mm_const_var(Fc1, W1f, T11);                 // Q_uu | Q_u           :130,123
+            }
+            if (q < 2) {
+                *reinterpret_cast<f32x4 *>(&lds[kMs + i * 8 + 4 * q]) = T01t;
+                if (i <= M) *reinterpret_cast<f32x4 *>(&lds[kMs + (N + i) * 8 + 4 * q]) = T11;
+            } else if (q == 2) {
+                lds[kQx + i] = T01t[0];                            // Q_x[i]               :122
+            }
+            __syncthreads();
+            // this lane's column of [Q_ux | Q_uu | Q_u] and its regularised twin; its row of H and of Q_uu; Q_u[r8], u_hat[r8]
+            float Mcol[8], Mreg[8], Hrow0[8], Hrow[8];
+            {
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(&lds[kMs + c32 * 8]);
+                const f32x4 hi = *reinterpret_cast<const f32x4 *>(&lds[kMs + c32 * 8 + 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { Mcol[e] = lo[e]; Mcol[4 + e] = hi[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                Mreg[e] = (c32 < N + M) ? fmaf(mu, Gcol[e], Mcol[e]) : Mcol[e];          // Q_u (column 24) is not regularised
+                Hrow0[e] = lds[hoff[e]];
+                Hrow[e] = fmaf(mu, Grow[e], Hrow0[e]);
+            }
+            const float Qu_r = lds[kMs + (N + M) * 8 + r8];
+            const float uh_r = nom[t * kZld + N + r8];
+            float k_r;                 // k[r8]
+            float Kcol[8];             // K[.][c32] in lanes c32 < 16
+            if (!bounded) {
+                // [K | k] = -Q~_uu^-1 [Q~_ux | Q_u]                                       :357-362
+                f32x2 M2[4];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) M2[e >> 1][e & 1] = Mreg[e];
+                int mpb = 0x3f800000;
+                ldlt8_solve_neg(M2, Kcol, mpb);
+                if (mpb <= 0) { res.failed = true; return res; }
+                k_r = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float ke = readlane(Kcol[e], N + M);
+                    if (r8 == e) k_r = ke;
+                }
+            } else if (vxx_nonzero) {
+                const int rc = boxqp8(Hrow, Mreg, Qu_r, low_r - uh_r, high_r - uh_r, k_r, Kcol);       // :364-371
+                if (rc < 0) { res.failed = true; return res; }
+                res.flags |= rc;
+            } else {
+                k_r = (Qu_r >= 0.0f) ? (low_r - uh_r) : (high_r - uh_r);                               // :140-141
+#pragma unroll
+                for (int e = 0; e < 8; ++e) Kcol[e] = 0.0f;
+            }
+            // K~ to LDS: columns 0..15 = K, column 24 = k
+            if (lane < N) {
+                *reinterpret_cast<f32x4 *>(&lds[kKs + lane * 8]) = f32x4{Kcol[0], Kcol[1], Kcol[2], Kcol[3]};
+                *reinterpret_cast<f32x4 *>(&lds[kKs + lane * 8 + 4]) = f32x4{Kcol[4], Kcol[5], Kcol[6], Kcol[7]};
+            }
+            if (lane < M) lds[kKs + (N + M) * 8 + lane] = k_r;
+            __syncthreads();
+            // dV1 += k^T Q_u, dV2 += 1/2 k^T Q_uu k (:164-167), g_norm term (:243)
+            {
+                const f32x4 k03 = *reinterpret_cast<const f32x4 *>(&lds[kKs + (N + M) * 8]);
+                const f32x4 k47 = *reinterpret_cast<const f32x4 *>(&lds[kKs + (N + M) * 8 + 4]);
+                float quk = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) quk = fmaf(Hrow0[j], k03[j], quk);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) quk = fmaf(Hrow0[4 + j], k47[j], quk);
+                res.dV1 += sum8(k_r * Qu_r);
+                res.dV2 += 0.5f * sum8(k_r * quk);
+                gsum += max8(r8 < m ? fabsf(k_r) / (fabsf(uh_r) + 1.0f) : 0.0f);
+            }
+            // P = Q_uu K, p = Q_uu k on the matrix cores (contraction over the 8 actions: 2 k-steps)
+            f32x4 Pt = {0.f, 0.f, 0.f, 0.f}, pt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const float au = (i < M) ? lds[kMs + (N + 4 * s2 + q) * 8 + i] : 0.0f;   // Q_uu[i][4s+q] (column 4s+q, row i)
+                const float g0 = lds[kKs + i * 8 + 4 * s2 + q];                          // K[4s+q][i]
+                const float g1 = lds[g1_src + 4 * s2];                                   // k[4s+q] in lanes i == 8
+                Pt = mfma(au, g0, Pt);
+                pt = mfma(au, g1, pt);
+            }
+            // S = Q_ux + P (rows 4q+r, q < 2), sp = Q_u + p (column 24)
+            if (q < 2) {
+                *reinterpret_cast<f32x4 *>(&lds[kPs + i * 8 + 4 * q]) = Pt + T01t;
+                if (i == M) *reinterpret_cast<f32x4 *>(&lds[kPs + (N + M) * 8 + 4 * q]) = pt + T11;
+            }
+            __syncthreads();
+            // V_xx' = Q_xx + Q_xu K + K^T S ; V_x' = Q_x + Q_xu k + K^T sp                :149-161
+            f32x4 vacc = *reinterpret_cast<const f32x4 *>(&lds[t01_src]);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const float ax = lds[kMs + i * 8 + 4 * s2 + q];            // Q_xu[i][4s+q] = Q_ux[4s+q][i]
+                const float g0 = lds[kKs + i * 8 + 4 * s2 + q];            // K[4s+q][i]: B operand of Q_xu K, A operand of K^T S
+                const float g1 = lds[g1_src + 4 * s2];
+                const float sb = lds[kPs + i * 8 + 4 * s2 + q];            // S[4s+q][i]
+                const float s1 = lds[s1_src + 4 * s2];                     // sp[4s+q] in lanes i == 8
+                T00 = mfma(ax, g0, T00);
+                T00 = mfma(g0, sb, T00);
+                vacc = mfma(ax, g1, vacc);
+                vacc = mfma(g0, s1, vacc);
+            }
+            *reinterpret_cast<f32x4 *>(&lds[kVt + i * kVtLd + 4 * q]) = T00;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Vd[r] = 0.5f * (T00[r] + lds[kVt + (4 * q + r) * kVtLd + i]);      // :162
+            vd = vacc;
+            {   // gains to HBM, row-major K[t][a][j] (guarded for padded shapes)
+                const float kx = lds[kKs + (2 * jc) * 8 + ka], ky = lds[kKs + (2 * jc + 1) * 8 + ka];
+                if (ka < m && 2 * jc < n) Kg[(size_t)t * m * n + ka * n + 2 * jc] = kx;
+                if (ka < m && 2 * jc + 1 < n) Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] = ky;
+                if (lane < m) kg[(size_t)t * m + lane] = lds[kKs + (N + M) * 8 + lane];
+            }
+            __syncthreads();
+        }
+        res.g_norm = T > 0 ? gsum / (float)T : 0.0f;
+        return res;
+    };
+
+    // ---- closed-loop rollout with step alpha into `cand` (ilqr.py:174-212) ---------------------------------------
+    auto forward = [&](float alpha, float &J, float &residual) {
+        if (lane < N) cand[lane] = nom[lane];
+        if (lane < M) cand[T * kZld + N + lane] = 0.0f;
+        float rmax = 0.0f;
+        const bool row = ka < m;
+        auto load_gain = [&](int t, float &gx, float &gy, float &gk) {
+            gx = (row && 2 * jc < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc] : 0.0f;
+            gy = (row && 2 * jc + 1 < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] : 0.0f;
+            gk = row ? kg[(size_t)t * m + ka] : 0.0f;
+        };
+        float Kxn = 0.0f, Kyn = 0.0f, kkn = 0.0f;
+        load_gain(0, Kxn, Kyn, kkn);
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const float *zh = nom + t * kZld;
+            float *zt = cand + t * kZld;
+            const float Kx = Kxn, Ky = Kyn, kk = kkn;
+            if (t + 1 < T) load_gain(t + 1, Kxn, Kyn, kkn);
+            const float2 xv = *reinterpret_cast<const float2 *>(&zt[2 * jc]);
+            const float2 xh = *reinterpret_cast<const float2 *>(&zh[2 * jc]);
+            float du = fmaf(Kx, xv.x - xh.x, Ky * (xv.y - xh.y));              // K (x - x_hat)  :193-194
+            du += dpp<kDppXor1>(du);
+            du += dpp<kDppXor2>(du);
+            du += dpp<kDppHalfMirror>(du);
+            du = fmaf(alpha, kk, du);
+            rmax = fmaxf(rmax, fabsf(du));                                     // :206 (before the clip)
+            if (jc == 0) zt[N + ka] = fminf(fmaxf(zh[N + ka] + du, low_k), high_k);      // :196-197
+            __syncthreads();
+            const float xn = next_state(zt);
+            if (fc == 0) zt[kZld + fi] = xn;
+            __syncthreads();
+        }
+        residual = wave_max(rmax);
+        cz_pass(cand, Tp, ccand, false);
+        __syncthreads();
+        J = sum_costs(ccand);
+    };
+
+    // ---- iLQR.solve (ilqr.py:214-283) ------------------------------------------------------------------------------
+    float mu = 0.0f, delta = 1.0f;                                         // :215-216
+    int status = 0, attempts = 0, iteration = 0;
+    bool converged = false, give_up = false;
+    for (iteration = 0; iteration < cfg.max_iterations; ++iteration) {      // :227
+        // derivatives (:234): l_z(t) of the nominal trajectory, kept in HBM-free LDS? No room beside the candidate
+        // buffer, which the line search overwrites: the gradients live in `cand` during a backward pass and are
+        // recomputed for every pass (one C Z product: 6 % of a pass).
+        for (;;) {                                                          // :238
+            float mu_l = mu, delta_l = delta;
+            StepResult r;
+            for (int retry = 0;; ++retry) {                                 // _backward :285-315
+                cz_pass(nom, Tp, cand, true);
+                __syncthreads();
+                r = backward(cand, mu_l);
+                status |= r.flags;
+                if (!r.failed) break;
+                status |= TFMPC_ST_NOT_PD;
+                delta_l = fmaxf(cfg.delta_0, delta_l * cfg.delta_0);        // :308-309
+                mu_l = fmaxf(cfg.mu_min, mu_l * delta_l);
+                if (retry >= 40) { give_up = true; break; }
+                __syncthreads();
+            }
+            if (give_up) break;
+            if (r.g_norm < cfg.atol) { converged = true; break; }           // :243-248
+            const float J_hat = sum_costs(cnom);                            // :104,164
+            bool accept = false;
+            float residual = 0.0f;
+            for (int ai = 0; ai < cfg.n_alphas; ++ai) {                     // _forward :317-355
+                const float alpha = cfg.alphas[ai];
+                float J;
+                forward(alpha, J, residual);
+                const float delta_J = -alpha * (r.dV1 + alpha * r.dV2);     // :339
+                const float dcost = J_hat - J;
+                const float z = (delta_J > 0.0f) ? dcost / delta_J : sgn(dcost);   // :342-346
+                if (z >= cfg.c1) { accept = true; break; }                  // :351-353
+            }
+            const bool small_step = residual < cfg.atol;                   // :253-257 (taken even if rejected)
+            if (small_step || accept) {
+                float *tz = nom; nom = cand; cand = tz;
+                float *tcst = cnom; cnom = ccand; ccand = tcst;
+            }
+            if (small_step) { converged = true; break; }
+            if (accept) {                                                   // :259-266
+                delta = fminf(1.0f / cfg.delta_0, delta / cfg.delta_0);
+                mu = (mu * delta > cfg.mu_min) ? mu * delta : 0.0f;
+                break;
+            }
+            delta = fmaxf(cfg.delta_0, delta * cfg.delta_0);                // :267-270
+            mu = fmaxf(cfg.mu_min, mu * delta);
+            if (++attempts >= cfg.max_attempts || !(mu < 1e30f)) { give_up = true; break; }
+        }
+        if (converged || give_up) break;                                    // :276-277
+    }
+    if (give_up) status |= TFMPC_ST_MAX_ATTEMPTS;
+    if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
+
+    // ---- results: the nominal trajectory leaves LDS once ----------------------------------------
+    __syncthreads();
+    float *xs = a.states + (size_t)b * Tp * n, *us = a.actions + (size_t)b * T * m, *cs = a.costs + (size_t)b * Tp;
+    for (int idx = lane; idx < Tp * n; idx += kWave) xs[idx] = nom[(idx / n) * kZld + idx % n];
+    for (int idx = lane; idx < T * m; idx += kWave) us[idx] = nom[(idx / m) * kZld + N + idx % m];
+    for (int idx = lane; idx < Tp; idx += kWave) cs[idx] = cnom[idx];
+    if (lane == 0) {
+        const float cT = cnom[T];
+        if (!(cT == cT)) status |= TFMPC_ST_NAN;
+        a.iterations[b] = iteration;
+        a.status[b] = status;
+    }
+}
+
+size_t box_lds_bytes(int T)
+{
+    const size_t Tp = T + 1;
+    return (kDyn + 2 * Tp * kZld + 2 * ((Tp + 3) & ~(size_t)3) + 8) * sizeof(float);
+}
+
+}  // namespace
+
+// Bounded actions (gym's Box.is_bounded(), ilqr.py:136) or any finite bound (the rollout clips against it, :197).
+bool ilqr_lq_box_mfma_supported(const TfmpcEnv &env, int T)
+{
+    return env.kind == TFMPC_ENV_LQ && (env.bounded || env.any_finite_bound) && env.n <= N && env.m <= M && env.n + env.m > 6 &&
+           T >= 1 && box_lds_bytes(T) <= 48 * 1024;
+}
+
+int ilqr_lq_box_mfma_launch(const IlqrLqArgs &a, hipStream_t stream)
+{
+    const size_t lds = box_lds_bytes(a.T);
+    hipLaunchKernelGGL(ilqr_lq_box_mfma_kernel, dim3(a.B), dim3(kWave), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
+}
+
+}  // namespace tfmpc

@@ -24,6 +24,11 @@ struct IlqrLqArgs {
     float *wsK, *wsk, *wsq;      // gains K[T][m][n], k[T][m] and Q_u[T][m] scratch (HBM)
 };
 
+// Control-limited twin (ilqr_lq_box_mfma.hip): bounded actions or any finite bound; the whole state machine
+// (mu > 0, retries, rejections) in the kernel, so no second-chance launch.  Uses wsK, wsk only.
+bool ilqr_lq_box_mfma_supported(const TfmpcEnv &env, int T);
+int ilqr_lq_box_mfma_launch(const IlqrLqArgs &a, hipStream_t stream);
+
 size_t ilqr_lq_mfma_lds_bytes(int T);
 bool ilqr_lq_mfma_supported(const TfmpcEnv &env, int T);
 int ilqr_lq_mfma_launch(const IlqrLqArgs &a, hipStream_t stream);
