@@ -78,39 +78,87 @@ def measured_traffic(kernel, batch):
     return per_instance * batch
 
 
+def pmc_traffic(kernel_substring, per_launch_units, units):
+    """HBM bytes of one launch of a secondary kernel, from the committed PMC summaries of this round
+    (profiles/r02_*_pmc.json, written by tools/pmc_kernel.sh: separate --pmc passes, FETCH_SIZE x2 + WRITE_SIZE as
+    MI355X_MICROARCH.md prescribes), scaled to `units` work units (the summary was taken at `per_launch_units`)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_*_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        for name, c in d.get("counters_per_launch", {}).items():
+            if kernel_substring in name and "hbm_bytes_per_launch" in c:
+                return c["hbm_bytes_per_launch"]["total_corrected"] * units / float(per_launch_units)
+    return None
+
+
+def roofline_hbm(alg_bytes, seconds, traffic):
+    gbs = alg_bytes / seconds / 1e9
+    return {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+            "algorithmic_bytes": alg_bytes, "traffic": traffic}
+
+
 def ilqr_api_rate(n, m, T, B, reps=5):
     """Secondary number (not `value`): the same shape driven through tfmpc.solvers.ilqr.iLQR.solve
     on the LQ env (whole iteration loops in one launch, matrix-core kernel).  F is scaled to
     spectral radius ~1: iLQR's OPEN-LOOP start rollout of a rho ~ 5 system overflows fp32 long
-    before T = 50, in any implementation.  Iterations counted = reference loop index + 1."""
+    before T = 50, in any implementation.  Iterations counted = reference loop index + 1.
+    Roofline: algorithmic flop = backward passes x T x 45.0 kflop + rollouts x T x 2.2 kflop with
+    backward passes = iterations and rollouts >= iterations - 1 (a converged instance ends on a backward pass)."""
     import problems
     from tfmpc.envs.lq import LQEnv
     from tfmpc.solvers.ilqr import iLQR
     F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=4321)
-    solver = iLQR(LQEnv(0.25 * F, f, C, c))
     x0 = torch.as_tensor(x0[..., None].astype(np.float32), device="cuda")
     u0 = torch.zeros(B, T, m, 1, device="cuda")
-    out = solver.solve_device(x0, T, u_init=u0)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        out = solver.solve_device(x0, T, u_init=u0, workspace=out["workspace"])
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+
+    def run(solver):
+        out = solver.solve_device(x0, T, u_init=u0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = solver.solve_device(x0, T, u_init=u0, workspace=out["workspace"])
+        torch.cuda.synchronize()
+        return out, (time.perf_counter() - t0) / reps
+
+    out, dt = run(iLQR(LQEnv(0.25 * F, f, C, c)))
     its = float((out["iterations"].double() + 1).sum())
-    return {"iterations_per_s": its / dt, "ms_per_batch": dt * 1e3, "mean_iterations": its / B,
-            "flagged_instances": int((out["status"] != 0).sum()),
-            "workload": f"iLQR.solve on LQEnv(0.25 F, f, C, c), n={n} m={m} T={T} B={B}, zero initial actions"}
+    flop = its * T * 45.0e3 + max(its - B, 0.0) * T * 2.2e3
+    tf = flop / dt / 1e12
+    res = {"iterations_per_s": its / dt, "ms_per_batch": dt * 1e3, "mean_iterations": its / B,
+           "flagged_instances": int((out["status"] != 0).sum()),
+           "workload": f"iLQR.solve on LQEnv(0.25 F, f, C, c), n={n} m={m} T={T} B={B}, zero initial actions",
+           "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
+                        "algorithmic_flop": flop, "traffic": pmc_traffic("ilqr_lq_mfma_kernel", 65536, B),
+                        "kernel": "ilqr_lq_mfma_kernel (profiles/r02_ilqr_api_kernel_stats.csv)"}}
+    # the same problems with CONTROL LIMITS: box-QP at every backward step, regularisation loop in the kernel
+    reps = 1
+    out, dt = run(iLQR(LQEnv(0.25 * F, f, C, c, low=-0.5, high=0.5)))
+    its = float((out["iterations"].double() + 1).sum())
+    st = out["status"]
+    res["control_limited"] = {"workload": f"same problems, actions in [-0.5, 0.5] (ilqr.py:136-138,364-387: box-QP at every step), B={B}",
+                              "ms_per_batch": dt * 1e3, "solves_per_s": B / dt, "iterations_per_s": its / dt, "mean_iterations": its / B,
+                              "max_iterations": int(out["iterations"].max()) + 1,
+                              "instances_with_cholesky_retries": int(((st & 2) != 0).sum()),
+                              "instances_at_attempt_cap": int(((st & 16) != 0).sum()),
+                              "kernel": "ilqr_lq_box_mfma_kernel (profiles/r02_box_kernel_stats.csv); round 1: wave kernel, 2.3 k solves/s at B=8192"}
+    return res
 
 
 def other_config_rates():
-    """Secondary numbers (not `value`): the other BASELINE.json configs, one timed launch each after a warm-up --
-    cfg2 navlin LQR (B=4096), cfg4 Navigation iLQR (B=16384), cfg5 HVAC / Reservoir iLQR (n=32, T=100, B=32768,
-    <= 12 iterations; shared env: 16 instances per wave, coupling products on the matrix cores), the reference's own
-    hvac6 / res4 configs (B=16384), and a dense LQR beyond the headline tile (n=32, m=16, B=8192).  Inputs as in SURVEY.md 8(d)."""
+    """Secondary numbers (not `value`): the other BASELINE.json configs, timed launches after a warm-up --
+    cfg2 navlin LQR (B=4096), cfg4 Navigation iLQR (B=16384: single batch AND 8 batches in flight), cfg5 HVAC / Reservoir
+    iLQR (n=32, T=100, B=32768, <= 12 iterations; shared env: 16 instances per wave, coupling products on the matrix
+    cores), the reference's own hvac6 / res4 configs (B=16384), configs[4]'s literal dims (n=32, m=16) as iLQR on the
+    LQ env, and a dense LQR beyond the headline tile (n=32, m=16, B=8192).  Inputs as in SURVEY.md 8(d).  HBM-bound
+    configs carry a `roofline` block: algorithmic bytes per iteration x iterations / time against 8 TB/s,
+    `traffic` = PMC-measured HBM bytes of the same launch (profiles/r02_*_pmc.json)."""
     import problems
     from tfmpc.envs import make_lqr_linear_navigation
     from tfmpc.envs.hvac import HVAC
+    from tfmpc.envs.lq import LQEnv
     from tfmpc.envs.navigation import Navigation
     from tfmpc.envs.reservoir import Reservoir
     from tfmpc.solvers.ilqr import iLQR
@@ -125,11 +173,15 @@ def other_config_rates():
         torch.cuda.synchronize()
         return out, (time.perf_counter() - t0) / reps
 
-    def ilqr_line(solver, x0, T, u0, reps):
+    def ilqr_line(solver, x0, T, u0, reps, alg_bytes=None, pmc=None):
         out, dt = timed(lambda ws: solver.solve_device(x0, T, u_init=u0, workspace=ws), reps)
         its = float((out["iterations"].double() + 1).sum())
-        return {"ms_per_batch": dt * 1e3, "iterations_per_s": its / dt, "mean_iterations": its / x0.shape[0],
+        line = {"ms_per_batch": dt * 1e3, "iterations_per_s": its / dt, "mean_iterations": its / x0.shape[0],
                 "flagged_instances": int((out["status"] != 0).sum()), "batch": int(x0.shape[0]), "horizon": T}
+        if alg_bytes is not None:
+            line["roofline"] = roofline_hbm(alg_bytes * its, dt, pmc_traffic(pmc[0], pmc[1], its) if pmc else None)
+            line["roofline"]["algorithmic_bytes_per_iteration"] = alg_bytes
+        return line
 
     res = {}
     rng = np.random.default_rng(4)
@@ -137,24 +189,59 @@ def other_config_rates():
     lqr = make_lqr_linear_navigation(goal[..., None], 5.0)
     _, dt = timed(lambda ws: lqr.solve_device(x0n[..., None], 50, workspace=ws), 20)
     res["cfg2_navlin_lqr"] = {"ms_per_batch": dt * 1e3, "solves_per_s": 4096 / dt, "batch": 4096, "horizon": 50}
+    # cfg4: n = m = 2, T = 50 -> read x, u 808 B + write x, u, c 1 012 B per iteration
     solver = iLQR(Navigation.load(problems.NAV_CONFIG))
-    x0 = rng.uniform(0, 10, size=(16384, 2, 1)).astype(np.float32)
-    res["cfg4_navigation_ilqr"] = ilqr_line(solver, x0, 50, solver.random_actions(50, 16384, seed=4), 2)
-    for kind in ("hvac", "reservoir"):
+    Bn = 16384
+    x0 = rng.uniform(0, 10, size=(Bn, 2, 1)).astype(np.float32)
+    u0 = solver.random_actions(50, Bn, seed=4)
+    res["cfg4_navigation_ilqr"] = ilqr_line(solver, x0, 50, u0, 2, alg_bytes=1820, pmc=("ilqr_group_solve", 142719))
+    res["cfg4_navigation_ilqr"]["note"] = ("one launch lasts as long as its slowest instance (median 8 iterations, p99 20, max 87: "
+                                           "profiles/r02_cfg4_iteration_histogram.json); several batches in flight fill the chip")
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    data = [(torch.as_tensor(np.random.default_rng(100 + i).uniform(0, 10, size=(Bn, 2, 1)).astype(np.float32), device="cuda"),
+             solver.random_actions(50, Bn, seed=100 + i)) for i in range(8)]
+    ws, outs = [None] * 8, [None] * 8
+    for rep in range(3):
+        if rep == 1:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs[i] = solver.solve_device(data[i][0], 50, u_init=data[i][1], workspace=ws[i])
+                ws[i] = outs[i]["workspace"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    its = sum(float((o["iterations"].double() + 1).sum()) for o in outs) * 2
+    res["cfg4_navigation_ilqr"]["sustained_8_batches_in_flight"] = {
+        "ms_per_batch": dt / 16 * 1e3, "iterations_per_s": its / dt, "roofline": roofline_hbm(1820 * its, dt, None)}
+    del ws, outs, data
+    # cfg5: n = m = 32, T = 100 -> read x, u 25.7 KB + write x, u, c 26.1 KB = 51.8 KB per iteration
+    for kind, kernel_tag in (("hvac", "ilqr_adjoint_mfma_kernel<3"), ("reservoir", "ilqr_adjoint_mfma_kernel<4")):
         n, T, B = 32, 100, 32768
         if kind == "hvac":
             env, x0 = HVAC.load(dict(problems.hvac_config(n, seed=5))), np.full((B, n, 1), 10.0, dtype=np.float32)
         else:
             env, x0 = Reservoir.load(dict(problems.reservoir_config(n, seed=5))), rng.uniform(50, 75, size=(B, n, 1)).astype(np.float32)
         solver = iLQR(env, max_iterations=12)
-        res[f"cfg5_{kind}_ilqr_n32"] = ilqr_line(solver, x0, T, solver.random_actions(T, B, seed=5), 1)
+        res[f"cfg5_{kind}_ilqr_n32"] = ilqr_line(solver, x0, T, solver.random_actions(T, B, seed=5), 1,
+                                                 alg_bytes=4 * (2 * (T + 1) * n + 2 * T * n + (T + 1)), pmc=(kernel_tag, 32768 * 12))
     # the reference's own env configs (hvac6.config.json n = 6, res4.config.json n = 4) at a large batch
     for name, env, x0r in (("hvac6", HVAC.load(dict(problems.HVAC6_CONFIG)), problems.HVAC6_X0),
                            ("res4", Reservoir.load(dict(problems.RES4_CONFIG)), problems.RES4_X0)):
         B, T = 16384, 100
+        n = len(x0r)
         x0 = (np.array(x0r, dtype=np.float32)[None] * rng.uniform(0.9, 1.1, size=(B, 1, 1))).astype(np.float32)
         solver = iLQR(env, max_iterations=12)
-        res[f"{name}_reference_config_ilqr"] = ilqr_line(solver, x0, T, solver.random_actions(T, B, seed=1), 2)
+        res[f"{name}_reference_config_ilqr"] = ilqr_line(solver, x0, T, solver.random_actions(T, B, seed=1), 2,
+                                                         alg_bytes=4 * (2 * (T + 1) * n + 2 * T * n + (T + 1)))
+    # configs[4] at its literal dims (n = 32, m = 16, T = 100, B = 32 768) as iLQR on the generalised LQ env
+    n, m, T, B = 32, 16, 100, 32768
+    F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=6)
+    solver = iLQR(LQEnv(F * (0.9 / np.sqrt(n)), f, C, c))
+    x0d = torch.as_tensor(x0[..., None].astype(np.float32), device="cuda")
+    res["cfg5_literal_dims_ilqr_lq_n32_m16"] = ilqr_line(solver, x0d, T, torch.zeros(B, T, m, 1, device="cuda"), 1)
+    res["cfg5_literal_dims_ilqr_lq_n32_m16"]["kernel"] = "ilqr_solve_kernel<LQ, f32-MFMA products> (wave per instance, LDS resident)"
+    del solver, x0d
     F, f, C, c, x0 = problems.make_lqr_batch_fast(8192, 32, 16, seed=1)
     big = LQR(0.5 * F, f, C, c)
     x0d = big._prep_x0(x0)

@@ -104,3 +104,47 @@ def test_bf16_storage_mode_is_a_bounded_perturbation_on_hvac():
     # stored values really are bf16-representable
     bits = b.contiguous().view(torch.int32)
     assert int((bits & 0xFFFF).abs().sum()) == 0
+
+
+def test_cfg5_literal_dims_as_ilqr_on_the_lq_env():
+    """BASELINE configs[4] names n = 32, m = 16, horizon 100, batch 32 768 -- dims no reference env has (all of them have
+    action_size == state_size).  The survey allows a generalised env: the LQ env (lqr.py:36-57 through the
+    DiffEnv protocol) admits n != m, and iLQR on it runs the dense regularised backward pass (ilqr.py:94-172, Cholesky
+    controller) at that shape.  Oracle parity on a sample, size-independent properties on the whole batch."""
+    from tfmpc.envs.lq import LQEnv
+    from tfmpc.solvers.lqr import LQR
+    n, m, T, B = 32, 16, 100, 32768
+    F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=6)
+    F = F * (0.9 / np.sqrt(n))                       # spectral radius ~0.9: the open-loop start rollout stays in fp32 range over 100 steps
+    solver = iLQR(LQEnv(F, f, C, c))
+    x0d = torch.as_tensor(x0[..., None].astype(np.float32), device="cuda")
+    u0 = torch.zeros(B, T, m, 1, device="cuda")
+    out = solver.solve_device(x0d, T, u_init=u0)
+    torch.cuda.synchronize()
+    assert int(out["status"].abs().sum()) == 0
+    its = out["iterations"].cpu().numpy()
+    assert its.mean() <= 1.2 and its.max() <= 4       # a convex LQ problem: one Newton step and its confirmation (a few need a shorter step first)
+    states, actions, costs = out["states"][..., 0], out["actions"][..., 0], out["costs"]
+    assert torch.isfinite(states).all() and torch.isfinite(costs).all()
+    z = torch.cat([states[:, :-1], actions], dim=-1).double()
+    Fd = torch.as_tensor(F, device="cuda", dtype=torch.float64)
+    fd = torch.as_tensor(f, device="cuda", dtype=torch.float64)
+    pred = torch.einsum("bij,btj->bti", Fd, z) + fd[:, None, :]
+    rel = (pred - states[:, 1:].double()).abs().amax(dim=(1, 2)) / states.abs().amax(dim=(1, 2)).double().clamp_min(1.0)
+    assert float(rel.max()) < 2e-5
+    # iLQR lands on the LQR optimum of the same problem (sample)
+    idx = np.linspace(0, B - 1, 64).astype(int)
+    lq = LQR(F[idx], f[idx], C[idx], c[idx]).solve_device(x0[idx], T)
+    tot_i, tot_l = costs[torch.as_tensor(idx, device="cuda")].sum(dim=1), lq["costs"][:, :, 0, 0].sum(dim=1)
+    assert float(((tot_i - tot_l).abs() / lq["costs"].abs().sum(dim=(1, 2, 3))).max()) <= 2e-3
+    # fp64 oracle (and the fp32 restatement for the budget) on two instances
+    for b in (0, B - 1):
+        o = ilqr_ref.ILQRRef(envs_ref.LQEnv(F[b], f[b], C[b], c[b]))
+        x, u, cs, it = o.solve(x0[b], T, u_init=np.zeros((T, m, 1)))
+        o32 = ilqr_ref.ILQRRef(envs_ref.LQEnv(F[b], f[b], C[b], c[b], dtype=np.float32), dtype=np.float32)
+        x32, u32, c32, _ = o32.solve(x0[b].astype(np.float32), T, u_init=np.zeros((T, m, 1), dtype=np.float32))
+        assert it == int(its[b])
+        for got, r64, r32, what in ((states[b], x, x32, "states"), (actions[b], u, u32, "actions"), (costs[b], cs, c32, "costs")):
+            allowed = 5 * max(np.abs(r32.astype(np.float64) - r64).max(), 1e-5 * np.abs(r64).max())
+            err = np.abs(got.cpu().numpy().astype(np.float64) - r64).max()
+            assert err <= allowed, (b, what, err, allowed)
