@@ -174,9 +174,11 @@ typedef struct TfmpcIlqrConfig {
     float alphas[TFMPC_MAX_ALPHAS];
     int32_t max_attempts;   /* cap on rejected backward/line-search attempts per solve (the
                                reference loops without bound, ilqr.py:238-270) */
-    int32_t storage_bf16;   /* 1: trajectories and gains kept in HBM are rounded to bf16 on every store
-                               (arithmetic stays fp32) -- the storage-precision sweep of BASELINE
-                               configs[4]; honoured by the wave-per-instance solve kernel */
+    int32_t storage_bf16;   /* 1: trajectories (and gains) kept in HBM between passes are rounded to bf16 when
+                               stored, arithmetic stays fp32 -- BASELINE configs[4] "fp32 vs bf16".  HVAC /
+                               Reservoir envs shared by the batch: REAL 16-bit containers in the workspace (half
+                               the bytes); other envs: the wave kernel emulates the format in fp32 containers.
+                               Outputs are fp32 arrays holding bf16-representable values either way. */
 } TfmpcIlqrConfig;
 
 /* iLQR.start (ilqr.py:53-82) with the random actions injected: roll the env from

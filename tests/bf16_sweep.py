@@ -25,7 +25,7 @@ from tfmpc.envs.reservoir import Reservoir
 from tfmpc.solvers.ilqr import iLQR
 
 n, T, B = 32, 100, 1024
-out = {"config": f"n=m={n}, T={T}, B={B}, wave-per-instance solve kernel (adjoint backward)", "envs": {}}
+out = {"config": f"n=m={n}, T={T}, B={B}, default dispatch: 16-instances-per-wave costate kernel, real bf16 trajectory containers", "envs": {}}
 rng = np.random.default_rng(5)
 for kind in ("hvac", "reservoir"):
     if kind == "hvac":

@@ -152,3 +152,43 @@ def test_dense_couplings_solve_as_well_as_the_wave_kernel(force_kernel, kind):
     tw, tf_ = full["wave"]["costs"].sum(dim=1), full["costate_mfma"]["costs"].sum(dim=1)
     assert bool(torch.isfinite(tf_).all())
     assert float(tf_.median()) <= float(tw.median()) * 1.05 + 1e-3                # costs are positive on both envs
+
+
+@pytest.mark.parametrize("kind,n,B", [("hvac", 32, 300), ("reservoir", 32, 300), ("hvac", 6, 100), ("reservoir", 4, 100), ("hvac", 7, 33)])
+def test_sixteen_bit_trajectory_containers(force_kernel, kind, n, B):
+    """iLQR(env, storage_bf16=True) on a shared env: the 16-per-wave kernel keeps BOTH trajectory buffers of a column as
+    real bf16 arrays in the workspace (half the bytes of every pass) and widens the final nominal trajectory into the
+    fp32 outputs.  Definition of the mode (TfmpcIlqrConfig::storage_bf16): values are rounded to nearest even when stored,
+    arithmetic stays fp32 -- what the wave kernel emulates in fp32 containers.  Checked: outputs are bf16-representable;
+    the start rollout equals the fp32 one rounded; after one iteration the two implementations of the format agree to a
+    few bf16 ulps on most instances (they round different intermediate quantities: the wave kernel stores the gain k,
+    this kernel one selector bit and rebuilds k from the rounded u)."""
+    T = 25
+    env, x0 = _env(kind, n, B, 3)
+    u0 = iLQR(env).random_actions(T, B, seed=4)
+
+    def run(kern, **kw):
+        force_kernel(kern)
+        out = iLQR(env, **kw).solve_device(x0, T, u_init=u0)
+        torch.cuda.synchronize()
+        return out
+
+    start16 = run("costate_mfma", max_iterations=1, atol=1e9, storage_bf16=True)
+    start32 = run("costate_mfma", max_iterations=1, atol=1e9)
+    for key in ("states", "costs"):
+        bits = start16[key].contiguous().view(torch.int32)
+        assert int((bits & 0xFFFF).abs().sum()) == 0, key                      # bf16-representable
+        rounded = (start32[key].contiguous().view(torch.int32) + 0x7FFF + ((start32[key].contiguous().view(torch.int32) >> 16) & 1)) & ~0xFFFF
+        assert torch.equal(bits, rounded), key                                 # == the fp32 rollout, rounded to nearest even
+    one16 = run("costate_mfma", max_iterations=1, storage_bf16=True)
+    emu = run("wave", max_iterations=1, storage_bf16=True)
+    assert int((one16["actions"].contiguous().view(torch.int32) & 0xFFFF).abs().sum()) == 0
+    rel = ((one16["states"] - emu["states"]).abs().flatten(1).amax(dim=1) / emu["states"].abs().flatten(1).amax(dim=1)).cpu().numpy()
+    assert np.median(rel) <= 2e-2 and np.quantile(rel, 0.9) <= 0.1, (np.median(rel), np.quantile(rel, 0.9))
+    full = run(None, max_iterations=6, storage_bf16=True)
+    ref = run(None, max_iterations=6)
+    tf_, tr = full["costs"].sum(dim=1), ref["costs"].sum(dim=1)
+    assert bool(torch.isfinite(tf_).all())
+    # a perturbation of the solve, not a different one (Reservoir is bang-bang: its line-search decisions flip under a
+    # perturbation of any size, so individual solves move by tens of per cent at equal quality, DESIGN.md 3.3)
+    assert float(((tf_ - tr).abs() / tr.abs()).median()) <= (0.05 if kind == "hvac" else 0.3)

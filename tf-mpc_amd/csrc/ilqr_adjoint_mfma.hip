@@ -163,6 +163,71 @@ __device__ __forceinline__ void stv(float *p, int n, int q, bool keep, const flo
         }
 }
 
+// ---- 16-bit trajectory containers (cfg.storage_bf16): the same accessors on bf16 storage.  A value is rounded to nearest
+// even when it is STORED and widened exactly when it is read; arithmetic stays fp32 (the definition of the storage mode,
+// TfmpcIlqrConfig::storage_bf16: what the wave kernel emulates in fp32 containers is a real format here, half the bytes).
+using bf16_t = unsigned short;
+__device__ __forceinline__ float widen(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ bf16_t narrow(float v)
+{
+    unsigned u = __float_as_uint(v);
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;          // round to nearest even on the fp32 bits (ilqr_core.h stq)
+    return (bf16_t)u;
+}
+template <int VW> struct PackOf { using type = bf16_t; };
+template <> struct PackOf<2> { using type = unsigned; };
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+template <> struct PackOf<4> { using type = u32x2; };
+template <int NT, int VW>
+__device__ __forceinline__ void ldv(const bf16_t *p, int n, int q, float (&o)[4 * NT])
+{
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; c += VW) {
+            const int r0 = 16 * b + 4 * q + c;
+            if constexpr (VW == 1) {
+                o[4 * b + c] = (r0 < n) ? widen(gld(p + r0)) : 0.0f;
+            } else if constexpr (VW == 2) {
+                const unsigned t = (r0 < n) ? gld(reinterpret_cast<const unsigned *>(p + r0)) : 0u;
+                o[4 * b + c] = __uint_as_float(t << 16);
+                o[4 * b + c + 1] = __uint_as_float(t & 0xFFFF0000u);
+            } else {
+                u32x2 t = {0u, 0u};
+                if (r0 < n) t = gld(reinterpret_cast<const u32x2 *>(p + r0));
+                o[4 * b + c] = __uint_as_float(t.x << 16);
+                o[4 * b + c + 1] = __uint_as_float(t.x & 0xFFFF0000u);
+                o[4 * b + c + 2] = __uint_as_float(t.y << 16);
+                o[4 * b + c + 3] = __uint_as_float(t.y & 0xFFFF0000u);
+            }
+        }
+}
+template <int NT, int VW>
+__device__ __forceinline__ void stv(bf16_t *p, int n, int q, bool keep, const float (&v)[4 * NT])
+{
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; c += VW) {
+            const int r0 = 16 * b + 4 * q + c;
+            if constexpr (VW == 1) {
+                if (keep && r0 < n) gst(p + r0, narrow(v[4 * b + c]));
+            } else if constexpr (VW == 2) {
+                const unsigned t = (unsigned)narrow(v[4 * b + c]) | ((unsigned)narrow(v[4 * b + c + 1]) << 16);
+                if (keep && r0 < n) gst(reinterpret_cast<unsigned *>(p + r0), t);
+            } else {
+                u32x2 t;
+                t.x = (unsigned)narrow(v[4 * b + c]) | ((unsigned)narrow(v[4 * b + c + 1]) << 16);
+                t.y = (unsigned)narrow(v[4 * b + c + 2]) | ((unsigned)narrow(v[4 * b + c + 3]) << 16);
+                if (keep && r0 < n) gst(reinterpret_cast<u32x2 *>(p + r0), t);
+            }
+        }
+}
+__device__ __forceinline__ float ldc(const float *p) { return gld(p); }
+__device__ __forceinline__ float ldc(const bf16_t *p) { return widen(gld(p)); }
+__device__ __forceinline__ void stc(float *p, float v) { gst(p, v); }
+__device__ __forceinline__ void stc(bf16_t *p, float v) { gst(p, narrow(v)); }
+
 // acc (tile a, this lane's rows) += sum over rows of A[a][.] * z : NT x NT x 4 MFMAs, the NT accumulation chains
 // interleaved (a dependent v_mfma_f32_16x16x4_f32 waits 40 cycles, an independent one issues after 32)
 template <int NT>
@@ -495,10 +560,11 @@ template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
     }
 };
 
-template <int KIND, int NT, int VW, int PK>
+template <int KIND, int NT, int VW, int PK, bool BF16 = false>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 && PK == 1 ? 3 : 2, NT == 1 && PK == 1 ? 3 : 2))) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
 {
     constexpr int NV = 4 * NT;
+    using TT = typename std::conditional<BF16, bf16_t, float>::type;      // element type of the trajectories in HBM
     static_assert(PK == 1 || NT == 1, "instances are packed into ONE tile");
     const int lane = lane_id(), j = lane & 15, q = lane >> 4, n = genv.n, m = n, T = a.T;
     // PK instances per column (n <= 16 / PK): lane quarter q belongs to sub-instance q / (4 / PK) and holds its rows
@@ -517,10 +583,21 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
     wsync();
     const bool early_exit = cfg.c1 == 0.0f && env.costs_nonnegative();     // see `rollout`
 
-    // trajectories of this column: [0] the output arrays, [1] the workspace; the nominal one is [flip]
-    float *const xbuf[2] = {a.states + b * (T + 1) * n, a.wsx + b * (T + 1) * n};
-    float *const ubuf[2] = {a.actions + b * T * m, a.wsu + b * T * m};
-    float *const cbuf[2] = {a.costs + b * (T + 1), a.wsc + b * (T + 1)};
+    // trajectories of this column: [0] the output arrays, [1] the workspace; the nominal one is [flip].  16-bit
+    // containers: BOTH live in the workspace (two half-size buffers in each fp32-sized slab) and the final nominal
+    // trajectory is widened into the fp32 output arrays at the end.
+    TT *xbuf[2], *ubuf[2], *cbuf[2];
+    if constexpr (BF16) {
+        bf16_t *wx = reinterpret_cast<bf16_t *>(a.wsx + b * (T + 1) * n), *wu = reinterpret_cast<bf16_t *>(a.wsu + b * T * m),
+               *wc = reinterpret_cast<bf16_t *>(a.wsc + b * (T + 1));
+        xbuf[0] = wx; xbuf[1] = wx + (size_t)(T + 1) * n;
+        ubuf[0] = wu; ubuf[1] = wu + (size_t)T * m;
+        cbuf[0] = wc; cbuf[1] = wc + (T + 1);
+    } else {
+        xbuf[0] = a.states + b * (T + 1) * n; xbuf[1] = a.wsx + b * (T + 1) * n;
+        ubuf[0] = a.actions + b * T * m; ubuf[1] = a.wsu + b * T * m;
+        cbuf[0] = a.costs + b * (T + 1); cbuf[1] = a.wsc + b * (T + 1);
+    }
     unsigned char *const ksel = reinterpret_cast<unsigned char *>(a.wsk) + b * T * 4;    // [t][lane quarter]: 4 NT selector bits
     const float *const x0p = a.x0 + b * n;
     int flip = 0;
@@ -542,8 +619,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
     // grows: once it is above `reject_above` (= J_hat) in every column that is still trying (`trying`), the answer is
     // "no" whatever follows, and the pass stops -- the first, too long step sizes of a Reservoir search blow the cost
     // up within 5 .. 40 of the 100 steps.  Same decisions, so same results, bit for bit.
-    auto rollout = [&](auto search, auto store, auto n_alpha, const float (&alpha)[decltype(n_alpha)::value], const float *uh,
-                       bool keep, float *xs, float *us, float *cs, float (&J_out)[decltype(n_alpha)::value],
+    auto rollout = [&](auto search, auto store, auto n_alpha, const float (&alpha)[decltype(n_alpha)::value], auto uh,
+                       bool keep, TT *xs, TT *us, TT *cs, float (&J_out)[decltype(n_alpha)::value],
                        bool trying = false, float reject_above = 0.0f, bool may_stop = false, bool *stopped_out = nullptr) {
         constexpr bool SEARCH = decltype(search)::value, STORE = decltype(store)::value;
         constexpr int NA = decltype(n_alpha)::value;
@@ -616,7 +693,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
                         if (STORE) {
                             stv<NT, VW>(us + (size_t)t * m, m, ql, keep, u[k]);
                             stv<NT, VW>(xs + (size_t)(t + 1) * n, n, ql, keep, xn);
-                            if (keep && ql == 0) gst(cs + t, c);
+                            if (keep && ql == 0) stc(cs + t, c);
                         }
 #pragma unroll
                         for (int e = 0; e < NV; ++e) x[k][e] = xn[e];
@@ -629,7 +706,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
             float cp[NV];
             env.final_costs(x[k], opaque(ql), cp);
             const float fc = col_sum<NT, PK>(cp);
-            if (STORE && keep && ql == 0) gst(cs + T, fc);
+            if (STORE && keep && ql == 0) stc(cs + T, fc);
             J_out[k] = stopped ? J[k] : J[k] + fc;       // stopped: already above J_hat in every column that asked
         }
         if (stopped_out) *stopped_out = stopped;
@@ -647,8 +724,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
     int status = 0, attempts = 0, iteration = 0;
     bool done = !live || cfg.max_iterations <= 0;
     while (__any(!done)) {
-        float *const xhat = xbuf[flip], *const uhat = ubuf[flip], *const chat = cbuf[flip];
-        float *const xc = xbuf[flip ^ 1], *const uc = ubuf[flip ^ 1], *const cc = cbuf[flip ^ 1];
+        TT *const xhat = xbuf[flip], *const uhat = ubuf[flip], *const chat = cbuf[flip];
+        TT *const xc = xbuf[flip ^ 1], *const uc = ubuf[flip ^ 1], *const cc = cbuf[flip ^ 1];
         // ---- backward (ilqr.py:94-172 on the bang-bang branch): costate recursion, all columns ------------
         float rJ, dV1, g_norm, kmax;
         {
@@ -660,12 +737,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
             env.grads(xT, opaque(ql), vx);                     // V_x = l_x^f
 #pragma unroll
             for (int e = 0; e < NV; ++e) { p1[e] = 0.0f; ka[e] = 0.0f; }
-            rJ = gld(chat + T);                                    // the stage costs of the nominal trajectory are the l_t
+            rJ = ldc(chat + T);                                    // the stage costs of the nominal trajectory are the l_t
             float gsum = 0.0f;
             auto request = [&](int t, float (&x_)[NV], float (&u_)[NV], float &l_) {
                 ldv<NT, VW>(xhat + (size_t)t * n, n, ql, x_);
                 ldv<NT, VW>(uhat + (size_t)t * m, m, ql, u_);
-                l_ = gld(chat + t);
+                l_ = ldc(chat + t);
             };
 #pragma unroll
             for (int d = 0; d < kAhead; ++d) {
@@ -767,23 +844,26 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
             if (++attempts >= cfg.max_attempts || !(mu < 1e30f)) { status |= TFMPC_ST_MAX_ATTEMPTS; done = true; }
         }
     }
-    // columns whose final nominal trajectory sits in the workspace: copy it out (rows of this lane)
+    // columns whose final nominal trajectory sits in the workspace: copy it out (rows of this lane); 16-bit
+    // containers: every column's, widened into the fp32 output arrays
     {
-        const bool mv = live && flip;
+        const bool mv = live && (BF16 || flip);
+        const TT *xsrc = xbuf[BF16 ? flip : 1], *usrc = ubuf[BF16 ? flip : 1], *csrc = cbuf[BF16 ? flip : 1];
+        float *xdst = a.states + b * (T + 1) * n, *udst = a.actions + b * T * m, *cdst = a.costs + b * (T + 1);
         for (int t = 0; t <= T; ++t) {
             float v[NV];
-            ldv<NT, VW>(xbuf[1] + (size_t)t * n, n, ql, v);
-            stv<NT, VW>(xbuf[0] + (size_t)t * n, n, ql, mv, v);
+            ldv<NT, VW>(xsrc + (size_t)t * n, n, ql, v);
+            stv<NT, VW>(xdst + (size_t)t * n, n, ql, mv, v);
             if (t < T) {
-                ldv<NT, VW>(ubuf[1] + (size_t)t * m, m, ql, v);
-                stv<NT, VW>(ubuf[0] + (size_t)t * m, m, ql, mv, v);
+                ldv<NT, VW>(usrc + (size_t)t * m, m, ql, v);
+                stv<NT, VW>(udst + (size_t)t * m, m, ql, mv, v);
             }
-            if (ql == 0) { const float c = gld(cbuf[1] + t); if (mv) gst(cbuf[0] + t, c); }
+            if (ql == 0) { const float c = ldc(csrc + t); if (mv) gst(cdst + t, c); }
         }
     }
     if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
     if (ql == 0 && live) {
-        const float cT = gld(cbuf[flip] + T);
+        const float cT = ldc(cbuf[flip] + T);
         if (!(cT == cT)) status |= TFMPC_ST_NAN;
         a.iterations[b] = iteration;
         a.status[b] = status;
@@ -794,7 +874,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
 
 bool ilqr_adjoint_mfma_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg)
 {
-    if (!ilqr_adjoint_supported(env, cfg)) return false;
+    TfmpcIlqrConfig fp32 = cfg;
+    fp32.storage_bf16 = 0;                     // the shape test of the register-resident kernels; 16-bit containers are built in here
+    if (!ilqr_adjoint_supported(env, fp32)) return false;
     for (int i = 0; i < TFMPC_ENV_MAX_PARAMS; ++i)
         if (env.p[i] && env.stride[i] != 0) return false;          // the coupling matrix must be the batch's, not the instance's
     return true;
@@ -812,11 +894,16 @@ int ilqr_adjoint_mfma_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, co
     // instances per column: one up to n = 32 (two tiles) or 16, two for n <= 8, four for n <= 4
     const int pk = env.n <= 4 ? 4 : (env.n <= 8 ? 2 : 1);
     const dim3 block(kWave), grid((a.B + kCols * pk - 1) / (kCols * pk));
+#define TFMPC_LAUNCH_AM3(KIND, NT_, PK_, VW_)                                                                                  \
+    do {                                                                                                                       \
+        if (cfg.storage_bf16) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, VW_, PK_, true>), grid, block, 0, stream, env, cfg, a); \
+        else hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, VW_, PK_, false>), grid, block, 0, stream, env, cfg, a);  \
+    } while (0)
 #define TFMPC_LAUNCH_AM2(KIND, NT_, PK_)                                                                                        \
     do {                                                                                                                       \
-        if (vw == 4) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, 4, PK_>), grid, block, 0, stream, env, cfg, a);   \
-        else if (vw == 2) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, 2, PK_>), grid, block, 0, stream, env, cfg, a); \
-        else hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, 1, PK_>), grid, block, 0, stream, env, cfg, a);           \
+        if (vw == 4) TFMPC_LAUNCH_AM3(KIND, NT_, PK_, 4);                                                                      \
+        else if (vw == 2) TFMPC_LAUNCH_AM3(KIND, NT_, PK_, 2);                                                                 \
+        else TFMPC_LAUNCH_AM3(KIND, NT_, PK_, 1);                                                                              \
     } while (0)
 #define TFMPC_LAUNCH_AM(KIND)                                                                                                  \
     do {                                                                                                                       \
@@ -829,6 +916,7 @@ int ilqr_adjoint_mfma_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, co
     else TFMPC_LAUNCH_AM(TFMPC_ENV_RESERVOIR);
 #undef TFMPC_LAUNCH_AM
 #undef TFMPC_LAUNCH_AM2
+#undef TFMPC_LAUNCH_AM3
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
 }
 

@@ -509,16 +509,17 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
         // HVAC / Reservoir at n <= 32: register-resident costate kernel (ilqr_adjoint.hip),
         // bit-identical to the generic wave kernel below (TFMPC_ILQR_KERNEL=wave selects that one)
         const bool forced_wave = option_is(kOptIlqrKernel, "wave");
-        if (!forced_wave && ilqr_adjoint_supported(*env, *cfg)) {
-            const AdjointSolveArgs aa{B, T, x0, u_init, states, actions, costs, iterations, status, a.wsk, a.wsx, a.wsu, a.wsc};
-            // a batch that shares one env: 16 instances per wave with the coupling-matrix products on the matrix
-            // cores (ilqr_adjoint_mfma.hip); TFMPC_ILQR_KERNEL=costate_mfma forces it, lean / lean1 the kernels above
-            const bool forced_lean = option_is(kOptIlqrKernel, "lean") || option_is(kOptIlqrKernel, "lean1");
-            const bool forced_mfma = option_is(kOptIlqrKernel, "costate_mfma");
-            if (!forced_lean && ilqr_adjoint_mfma_supported(*env, *cfg) && (forced_mfma || B >= (n > 16 ? kCostateMfmaMinBatchLarge : kCostateMfmaMinBatchSmall)))
-                return ilqr_adjoint_mfma_launch(*env, *cfg, aa, st);
-            return ilqr_adjoint_launch(*env, *cfg, aa, st);
-        }
+        const AdjointSolveArgs aa{B, T, x0, u_init, states, actions, costs, iterations, status, a.wsk, a.wsx, a.wsu, a.wsc};
+        // a batch that shares one env: 16 instances per wave with the coupling-matrix products on the matrix
+        // cores (ilqr_adjoint_mfma.hip); TFMPC_ILQR_KERNEL=costate_mfma forces it, lean / lean1 the kernels above.
+        // storage_bf16: that kernel keeps its trajectories in REAL 16-bit containers (the wave kernel below emulates
+        // the format in fp32 containers and serves every env the 16-per-wave kernel does not)
+        const bool forced_lean = option_is(kOptIlqrKernel, "lean") || option_is(kOptIlqrKernel, "lean1");
+        const bool forced_mfma = option_is(kOptIlqrKernel, "costate_mfma");
+        if (!forced_wave && !forced_lean && ilqr_adjoint_mfma_supported(*env, *cfg) &&
+            (forced_mfma || cfg->storage_bf16 || B >= (n > 16 ? kCostateMfmaMinBatchLarge : kCostateMfmaMinBatchSmall)))
+            return ilqr_adjoint_mfma_launch(*env, *cfg, aa, st);
+        if (!forced_wave && ilqr_adjoint_supported(*env, *cfg)) return ilqr_adjoint_launch(*env, *cfg, aa, st);
     }
     const size_t smem = ilqr_solve_smem_bytes(env->kind, n, m, env->n_zones);
     if (env->kind == TFMPC_ENV_LQ && n >= kBlockedFrom) {      // the only dense env that comes in large shapes

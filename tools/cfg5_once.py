@@ -8,12 +8,16 @@ from tfmpc.envs.hvac import HVAC
 from tfmpc.envs.reservoir import Reservoir
 from tfmpc.solvers.ilqr import iLQR
 n, T, B = 32, 100, 32768
+bf16 = len(sys.argv) > 1 and sys.argv[1] == "bf16"          # 16-bit trajectory containers (storage_bf16)
 rng = np.random.default_rng(4)
 for kind in ("hvac", "reservoir"):
     if kind == "hvac":
         env = HVAC.load(dict(problems.hvac_config(n, seed=5))); x0 = np.full((B, n, 1), 10.0, dtype=np.float32)
     else:
         env = Reservoir.load(dict(problems.reservoir_config(n, seed=5))); x0 = rng.uniform(50, 75, size=(B, n, 1)).astype(np.float32)
-    s = iLQR(env, max_iterations=12); u0 = s.random_actions(T, B, seed=5)
+    s = iLQR(env, max_iterations=12, storage_bf16=bf16); u0 = s.random_actions(T, B, seed=5)
     out = s.solve_device(x0, T, u_init=u0); torch.cuda.synchronize()
-    print(kind, float((out["iterations"].float() + 1).mean()))
+    import time
+    t0 = time.perf_counter(); out = s.solve_device(x0, T, u_init=u0, workspace=out["workspace"]); torch.cuda.synchronize()
+    print(f"{kind} {'bf16' if bf16 else 'fp32'} containers: {(time.perf_counter() - t0) * 1e3:.2f} ms")
+    print(kind, "mean iterations", float((out["iterations"].float() + 1).mean()), "mean total cost", float(out["costs"].sum(dim=1).mean()))
