@@ -62,10 +62,12 @@ def test_block_kernel_matches_oracle_and_wave_kernel(force_kernel, n, m, T):
 def test_block_kernel_is_the_default_for_large_shapes_and_split_equals_fused(force_kernel):
     force_kernel(None)
     lib = _hip.require_gpu()
-    assert lib.tfmpc_lqr_kernel_name(32, 16, 10) == b"block_mfma_f32"
+    assert lib.tfmpc_lqr_kernel_name(40, 16, 10) == b"block_mfma_f32"
+    assert lib.tfmpc_lqr_kernel_name(32, 16, 10) == b"mfma_32x16"            # round 2: 2 x 2 tiles on the bf16 matrix cores
     assert lib.tfmpc_lqr_kernel_name(16, 8, 10).startswith(b"mfma_16x8")
-    assert lib.tfmpc_lqr_kernel_name(17, 2, 10) == b"block_mfma_f32 (batch <= 2048) / generic_wave"
-    B, n, m, T = 21, 28, 12, 9
+    assert lib.tfmpc_lqr_kernel_name(5, 19, 10) == b"block_mfma_f32 (batch <= 2048) / generic_wave"
+    assert lib.tfmpc_lqr_kernel_name(17, 2, 10) == b"mfma_32x16 (zero-padded)"
+    B, n, m, T = 21, 36, 12, 9
     F, f, C, c, x0 = _problem(B, n, m, seed=5)
     lqr = LQR(F, f, C, c)
     fused = lqr.solve_device(x0, T, want_policy=True, want_value=True)

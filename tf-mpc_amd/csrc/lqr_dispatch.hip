@@ -18,6 +18,14 @@ bool want_mfma(int n, int m)
     return lqr_mfma_supported(n, m);
 }
 
+// n <= 32, m <= 16 beyond the 16 x 8 tile: one wave per instance, 2 x 2 tiles on the bf16 matrix cores
+// (TFMPC_LQR_KERNEL=generic|block select the older kernels)
+bool want_mfma32(int n, int m)
+{
+    if (option_is(kOptLqrKernel, "generic") || option_is(kOptLqrKernel, "block")) return false;
+    return lqr_mfma32_supported(n, m);
+}
+
 // lane-per-instance pays once there are enough instances to fill lanes; below that the
 // wave-per-instance kernel has the shorter critical path.  TFMPC_LQR_KERNEL=lane|generic forces.
 constexpr int kLaneMinBatch = 32;
@@ -63,6 +71,7 @@ int run(const LqrArgs &a, bool bw, bool fw, bool general, void *stream)
     // the symmetry of C and V.
     if (general) return lqr_generic_launch(a, bw, fw, s);
     if (want_mfma(a.n, a.m)) return lqr_mfma_launch(a, bw, fw, s);
+    if (want_mfma32(a.n, a.m)) return lqr_mfma32_launch(a, bw, fw, s);
     if (want_lane(a.n, a.m, a.B)) return lqr_lane_launch(a, bw, fw, s);
     if (want_block(a.n, a.m, a.B)) return lqr_block_launch(a, bw, fw, s);
     return lqr_generic_launch(a, bw, fw, s);
@@ -79,6 +88,7 @@ const char *tfmpc_lqr_kernel_name(int n, int m, int T)
     (void)T;
     if (n <= 0 || m <= 0) return "invalid";
     if (want_mfma(n, m)) return (n == 16 && m == 8) ? "mfma_16x8" : "mfma_16x8 (zero-padded)";
+    if (want_mfma32(n, m)) return (n == 32 && m == 16) ? "mfma_32x16" : "mfma_32x16 (zero-padded)";
     if (lqr_lane_supported(n, m)) return "lane (batch >= 32) / generic_wave";
     if (lqr_generic_smem_bytes(n, m) > kMaxLdsBytes) return "unsupported";
     if (want_block(n, m, 1 << 30)) return "block_mfma_f32";

@@ -36,6 +36,10 @@ int lqr_block_launch(const LqrArgs &a, bool backward, bool forward, hipStream_t 
 bool lqr_lane_supported(int n, int m);
 int lqr_lane_launch(const LqrArgs &a, bool backward, bool forward, hipStream_t stream);
 
+// MFMA variant for shapes up to n = 32, m = 16 beyond the 16 x 8 tile (lqr_mfma32x16.hip): 2 x 2 tiles of bf16x3.
+bool lqr_mfma32_supported(int n, int m);
+int lqr_mfma32_launch(const LqrArgs &a, bool backward, bool forward, hipStream_t stream);
+
 // MFMA variant for the BASELINE.json headline shape (lqr_mfma16x8.hip).
 bool lqr_mfma_supported(int n, int m);
 int lqr_mfma_launch(const LqrArgs &a, bool backward, bool forward, hipStream_t stream);
