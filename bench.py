@@ -239,15 +239,28 @@ def other_config_rates():
     F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=6)
     solver = iLQR(LQEnv(F * (0.9 / np.sqrt(n)), f, C, c))
     x0d = torch.as_tensor(x0[..., None].astype(np.float32), device="cuda")
-    res["cfg5_literal_dims_ilqr_lq_n32_m16"] = ilqr_line(solver, x0d, T, torch.zeros(B, T, m, 1, device="cuda"), 1)
-    res["cfg5_literal_dims_ilqr_lq_n32_m16"]["kernel"] = "ilqr_solve_kernel<LQ, f32-MFMA products> (wave per instance, LDS resident)"
+    line = ilqr_line(solver, x0d, T, torch.zeros(B, T, m, 1, device="cuda"), 2)
+    # algorithmic flop (SURVEY.md 8d formulas at n = 32, m = 16): backward 352.6 kflop per step, rollout 8.8 kflop per step
+    its = line["iterations_per_s"] * line["ms_per_batch"] * 1e-3
+    bw_step = 4 * n ** 3 + 4 * m * n * n + 2 * m * m * n + 2 * n * n + 2 * m * n + m ** 3 / 3.0 + 2 * m * m * (n + 1) \
+        + 6 * n * n * m + 2 * n * m * m + 6 * n * m + 2 * m * m + 2 * m
+    fw_step = 2 * m * n + 2 * n * (n + m) + 2 * (n + m) ** 2 + 2 * (n + m)
+    flop = its * T * bw_step + max(its - B, 0.0) * T * fw_step
+    tf = flop / (line["ms_per_batch"] * 1e-3) / 1e12
+    line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
+                        "algorithmic_flop": flop, "traffic": None}
+    line["kernel"] = "ilqr_lq_mfma32_kernel (2 x 2 tiles of bf16x3, trajectories in HBM); round-2 start: wave kernel, 1 123 ms"
+    res["cfg5_literal_dims_ilqr_lq_n32_m16"] = line
     del solver, x0d
     F, f, C, c, x0 = problems.make_lqr_batch_fast(8192, 32, 16, seed=1)
     big = LQR(0.5 * F, f, C, c)
     x0d = big._prep_x0(x0)
     _, dt = timed(lambda ws: big.solve_device(x0d, 50, workspace=ws), 3)
+    tf = lqr_flops_per_solve(32, 16, 50) * 8192 / dt / 1e12
     res["lqr_n32_m16"] = {"ms_per_batch": dt * 1e3, "solves_per_s": 8192 / dt, "batch": 8192, "horizon": 50,
-                          "kernel": _hip_kernel_name(32, 16, 50)}
+                          "kernel": _hip_kernel_name(32, 16, 50),
+                          "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": tf / PEAK_F32_TFLOPS, "algorithmic_flop_per_solve": lqr_flops_per_solve(32, 16, 50)}}
     return res
 
 

@@ -103,3 +103,41 @@ def test_bounded_lq_env_is_clipped():
     out = solver.solve_device(x0[..., None], 8, u_init=np.zeros((4, 8, 8, 1), dtype=np.float32))
     torch.cuda.synchronize()
     assert float(out["actions"].abs().max()) <= 0.5 + 1e-6           # clipped => box-QP path ran
+
+
+@pytest.mark.parametrize("n,m,T", [(32, 16, 100), (32, 16, 7), (24, 12, 20), (17, 9, 30), (32, 3, 16), (20, 16, 55), (9, 16, 12)])
+def test_large_tile_solve_matches_wave_kernel_oracle_and_lqr(force_kernel, n, m, T):
+    """Unbounded LQ env beyond the 16 x 8 tile, up to n = 32, m = 16 (BASELINE configs[4]'s literal dims): the 2 x 2-tile
+    matrix-core solve (ilqr_lq_mfma32.hip, trajectories in HBM) against the wave kernel, the LQR optimum and the fp64 /
+    fp32 restatement of ilqr.py."""
+    B = 48
+    F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=100 * n + m)
+    F = F * (0.9 / np.sqrt(n))
+    x0 = x0.astype(np.float32)
+    solver = iLQR(LQEnv(F, f, C, c))
+    u0 = (0.1 * np.random.default_rng(1).normal(size=(B, T, m, 1))).astype(np.float32)
+    out = {}
+    for kern in (None, "wave"):
+        force_kernel(kern)
+        out[kern] = solver.solve_device(x0[..., None], T, u_init=u0)
+        torch.cuda.synchronize()
+        assert int(out[kern]["status"].abs().sum()) == 0, kern
+    mf, wv = out[None], out["wave"]
+    assert float((mf["iterations"] == wv["iterations"]).float().mean()) >= 0.9
+    for key in ("states", "actions", "costs"):
+        diff = (mf[key] - wv[key]).abs().reshape(B, -1).amax(dim=1)
+        scale = wv[key].abs().reshape(B, -1).amax(dim=1).clamp_min(1e-6)
+        rel = (diff / scale).cpu().numpy()
+        assert np.median(rel) <= 1e-4 and np.quantile(rel, 0.9) <= 5e-3 and rel.max() <= 5e-2, (key, np.median(rel), rel.max())
+    lq = LQR(F, f, C, c).solve_device(x0, T)
+    tot_i, tot_l = mf["costs"].sum(dim=1), lq["costs"][:, :, 0, 0].sum(dim=1)
+    assert float(((tot_i - tot_l).abs() / lq["costs"].abs().sum(dim=(1, 2, 3))).max()) <= 2e-3
+    for b in (0, B - 1):
+        o = ilqr_ref.ILQRRef(envs_ref.LQEnv(F[b], f[b], C[b], c[b]))
+        x, u, cs, it = o.solve(x0[b], T, u_init=u0[b])
+        assert it == int(mf["iterations"][b])
+        o32 = ilqr_ref.ILQRRef(envs_ref.LQEnv(F[b], f[b], C[b], c[b], dtype=np.float32), dtype=np.float32)
+        x32, _, _, _ = o32.solve(x0[b], T, u_init=u0[b])
+        budget = 5 * max(np.abs(x32 - x).max(), 1e-5 * np.abs(x).max())
+        assert np.abs(mf["states"][b, ..., 0].cpu().numpy() - x).max() <= budget
+        assert abs(float(tot_i[b]) - cs.sum()) <= 2e-3 * np.abs(cs).sum()

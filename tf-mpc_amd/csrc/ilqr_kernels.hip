@@ -499,6 +499,13 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
             IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk, a.wsu};
             return ilqr_lq_box_mfma_launch(la, st);
         }
+        if (!forced_wave && !cfg->storage_bf16 && ilqr_lq_mfma32_supported(*env, T)) {
+            // BASELINE configs[4]'s literal dims (n <= 32, m <= 16): 2 x 2 tiles, trajectories in HBM; second chance as below
+            IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk, a.wsu,
+                          a.wsx, a.wsu, a.wsc};
+            if ((rc = ilqr_lq_mfma32_launch(la, st)) != TFMPC_OK) return rc;
+            a.only_flagged = 1;
+        }
         if (!forced_wave && !cfg->storage_bf16 && ilqr_lq_mfma_supported(*env, T)) {
             IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk, a.wsu};
             if ((rc = ilqr_lq_mfma_launch(la, st)) != TFMPC_OK) return rc;

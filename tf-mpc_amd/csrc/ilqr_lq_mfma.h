@@ -22,12 +22,17 @@ struct IlqrLqArgs {
     float *states, *actions, *costs;
     int32_t *iterations, *status;
     float *wsK, *wsk, *wsq;      // gains K[T][m][n], k[T][m] and Q_u[T][m] scratch (HBM)
+    float *wsx, *wsu, *wsc;      // candidate trajectory x[T+1][n], u[T][m], costs[T+1] (ilqr_lq_mfma32.hip only)
 };
 
 // Control-limited twin (ilqr_lq_box_mfma.hip): bounded actions or any finite bound; the whole state machine
 // (mu > 0, retries, rejections) in the kernel, so no second-chance launch.  Uses wsK, wsk only.
 bool ilqr_lq_box_mfma_supported(const TfmpcEnv &env, int T);
 int ilqr_lq_box_mfma_launch(const IlqrLqArgs &a, hipStream_t stream);
+
+// Large-tile twin (ilqr_lq_mfma32.hip): unbounded LQ env beyond the 16 x 8 tile up to n = 32, m = 16; trajectories in HBM.
+bool ilqr_lq_mfma32_supported(const TfmpcEnv &env, int T);
+int ilqr_lq_mfma32_launch(const IlqrLqArgs &a, hipStream_t stream);
 
 size_t ilqr_lq_mfma_lds_bytes(int T);
 bool ilqr_lq_mfma_supported(const TfmpcEnv &env, int T);
