@@ -330,9 +330,13 @@ __global__ __launch_bounds__(kWave, 2) void lqr_mfma32x16_kernel(LqrArgs a)
     }
 
     if (FORWARD) {
-        // ---- resident operands of the rollout ------------------------------------------
-        const int fi = lane >> 1, fc = lane & 1;       // F: row fi, z columns 24 fc .. 24 fc + 23
-        const int ka = lane >> 2, jc = lane & 3;       // K: row ka, columns 8 jc .. 8 jc + 7
+        // ---- resident operands of the rollout (indices derived from an opaque copy of the lane id: loaded HERE, after the
+        // sweep, not hoisted above it where 72 more live registers would spill the sweep) -----------------------------
+        int lo_ = lane;
+        asm volatile("" : "+v"(lo_));
+        const int fi = lo_ >> 1, fc = lo_ & 1;         // F: row fi, z columns 24 fc .. 24 fc + 23
+        const int ka = lo_ >> 2, jc = lo_ & 3;         // K: row ka, columns 8 jc .. 8 jc + 7
+        const int io = lo_ & 15, qo = lo_ >> 4;
         float Fr[24];
 #pragma unroll
         for (int j = 0; j < 24; ++j) Fr[j] = Fz(fi, 24 * fc + j);
@@ -344,12 +348,12 @@ __global__ __launch_bounds__(kWave, 2) void lqr_mfma32x16_kernel(LqrArgs a)
         for (int rt = 0; rt < 3; ++rt) {
 #pragma unroll
             for (int s2 = 0; s2 < 12; ++s2) {
-                const int zr = 16 * rt + i, zc = 4 * s2 + q;
+                const int zr = 16 * rt + io, zc = 4 * s2 + qo;
                 const int r = zmap(zr), c_ = zmap(zc);
                 Ca[rt][s2] = (r >= 0 && c_ >= 0) ? Cg[r * d + c_] : 0.0f;     // (no unit diagonal here: padded z entries are 0 anyway)
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) cq[rt][r] = cz(16 * rt + 4 * q + r);
+            for (int r = 0; r < 4; ++r) cq[rt][r] = cz(16 * rt + 4 * qo + r);
         }
         float *xs = a.states + (size_t)b * (T + 1) * n;
         float *us = a.actions + (size_t)b * T * m;
