@@ -72,7 +72,12 @@ def test_ilqr_entry_points_reject_bad_arguments(lib):
     assert lib.tfmpc_ilqr_solve_f32(byref(good), NULL, 4, 5, d, d, d, d, d, d, d, d, 1 << 20, NULL) == ERR_ARG
     assert lib.tfmpc_ilqr_solve_f32(byref(good), byref(cfg), 4, 5, d, d, d, d, d, d, d, d, 16, NULL) == ERR_WORKSPACE
     assert lib.tfmpc_ilqr_solve_f32(byref(good), byref(cfg), 4, 5, d, d, d, d, d, NULL, d, d, 1 << 20, NULL) == ERR_ARG   # iterations
-    assert lib.tfmpc_ilqr_workspace_bytes(4, 2, 2, 5) == 4 * (5 * 4 + 5 * 2 + 6 * 2 + 5 * 2 + 6) * 4
+    # five slabs per instance (K, k, candidate x, u, costs), rounded up to 256 bytes ...
+    slabs = lambda B, n, m, T: -(-B * (T * m * n + T * m + (T + 1) * n + T * m + (T + 1)) * 4 // 256) * 256
+    assert lib.tfmpc_ilqr_workspace_bytes(4, 3, 3, 5) == slabs(4, 3, 3, 5)
+    # ... plus, for the 2-D envs, one scratch block of line-search candidates per wavefront (5 T + 1 rows of 64 lanes)
+    assert lib.tfmpc_ilqr_workspace_bytes(4, 2, 2, 5) >= slabs(4, 2, 2, 5) + 4 * (5 * 5 + 1) * 64 * 4
+    assert lib.tfmpc_ilqr_workspace_bytes(0, 2, 2, 5) == 0
     assert lib.tfmpc_boxqp_f32(4, 0, d, d, d, d, d, d, d, d, NULL) == ERR_ARG
     assert lib.tfmpc_boxqp_f32(4, 3, NULL, d, d, d, d, d, d, d, NULL) == ERR_ARG
     assert lib.tfmpc_boxqp_f32(0, 3, d, d, d, d, d, d, d, d, NULL) == 0

@@ -44,7 +44,9 @@ def test_kernel_choice_and_workspace_queries():
     assert lib.tfmpc_lqr_kernel_name(16, 8, 50) == b"mfma_16x8"        # BASELINE headline shape
     assert lib.tfmpc_lqr_kernel_name(12, 6, 50).startswith(b"mfma_16x8")   # zero-padded into the same tiles
     assert lib.tfmpc_lqr_kernel_name(32, 32, 10) == b"block_mfma_f32"     # large: a workgroup per instance
-    assert lib.tfmpc_lqr_kernel_name(17, 2, 10).endswith(b"generic_wave")  # in between: by batch size
+    assert lib.tfmpc_lqr_kernel_name(32, 16, 10) == b"mfma_32x16"          # configs[4]'s literal dims: 2 x 2 tiles of bf16x3
+    assert lib.tfmpc_lqr_kernel_name(17, 2, 10).startswith(b"mfma_32x16")  # ... zero-padded
+    assert lib.tfmpc_lqr_kernel_name(5, 19, 10).endswith(b"generic_wave")  # in between: by batch size
     assert lib.tfmpc_lqr_kernel_name(200, 200, 10) == b"unsupported"
     assert lib.tfmpc_lqr_workspace_bytes(4, 16, 8, 50) == 4 * 50 * 8 * 17 * 4
 
