@@ -1,0 +1,192 @@
+"""Iteration-by-iteration parity of the fused whole-solve iLQR kernels with the oracle (``-m gpu``).
+
+A whole solve chains tens of iterations whose 11-point line search takes DISCRETE decisions, so comparing converged
+trajectories between fp32 and fp64 is a quality check, not parity.  Here every iteration is checked on its own: the
+device is run with ``max_iterations = k`` for k = 1, 2, ... (the fused kernels are deterministic, so run k extends run
+k-1 bit for bit); the fp64 oracle (oracle/ilqr_ref.py restating /root/reference/tfmpc/solvers/ilqr.py:214-283) then
+performs ONE iteration from the DEVICE's own nominal trajectory after k-1 iterations -- derivatives, regularised
+backward pass (incl. the box-QP), line search, mu / delta update -- and its accepted trajectory is compared with the
+device's after k iterations.  Wherever the oracle's decision (convergence test, accepted alpha) has a clear margin the
+device must have taken the SAME decision and the trajectory must agree with the fp64 one to a small multiple of the
+error of the fp32 restatement of the same iteration (budget spelled out in `_stepwise`); instances whose decision is a near-tie are not
+compared further and must be few.
+
+Covers each fused kernel: wave (NavigationLQR, unbounded and bounded), lane (Navigation, bounded, nonlinear), the
+matrix-core LQ kernels 16x8 (unbounded), 16x8 control-limited and 32x16.
+PARITY UNPINNED for numeric iLQR outputs: the reference holds no numeric iLQR answer."""
+
+import numpy as np
+import pytest
+import torch
+
+import problems
+from oracle import envs_ref, ilqr_ref
+from tfmpc.envs.lq import LQEnv
+from tfmpc.envs.lqr.navigation import NavigationLQR
+from tfmpc.envs.navigation import Navigation
+from tfmpc.solvers.ilqr import iLQR
+
+MARGIN = 1e-3          # relative margin under which an atol comparison counts as a near-tie
+COST_MARGIN = 3e-5     # ... and a cost comparison: |J_hat - J| / |J_hat| (an fp32 cost sum carries ~1e-6)
+
+
+def _one_iteration(o, x_hat, u_hat, mu, delta):
+    """The body of the reference's outer loop (ilqr.py:234-277) for one iteration, with decision margins.
+
+    Returns dict(x, u, mu, delta, converged, alpha (index into the 11 step sizes), margin) -- margin = the smallest relative distance of any
+    comparison taken on the way (g_norm / residual vs atol, cost change vs 0) from flipping."""
+    dt = o.dtype
+    T = u_hat.shape[0]
+    models = o.derivatives(x_hat, u_hat)
+    margin = np.inf
+    for _ in range(60):
+        K, k, J_hat, dV1, dV2 = o._backward(T, u_hat, *models, mu, delta)
+        g_norm = np.mean(np.max(np.abs(k) / (np.abs(u_hat) + dt(1.0)), axis=1), axis=0)[0]
+        margin = min(margin, abs(float(g_norm) - o.atol) / o.atol)
+        if g_norm < o.atol:
+            return dict(x=x_hat, u=u_hat, mu=mu, delta=delta, converged=True, alpha=None, margin=margin)
+        accept = False
+        for step, alpha in enumerate(np.geomspace(1.0, o.alpha_min, 11)):
+            a = dt(alpha)
+            x, u, c, J, residual = o.forward(x_hat, u_hat, K, k, a)
+            delta_J = -a * (dV1 + a * dV2)
+            dcost = J_hat - J
+            z = dcost / delta_J if delta_J > 0 else np.sign(dcost)
+            # z >= c1 (= 0) flips with the sign of dcost (delta_J > 0) -- relative to the cost's size
+            margin = min(margin, abs(float(dcost)) / max(abs(float(J_hat)), 1e-12) * (MARGIN / COST_MARGIN))
+            if z >= o.c1:
+                accept = True
+                break
+        margin = min(margin, abs(float(residual) - o.atol) / o.atol)
+        if residual < o.atol:
+            return dict(x=x, u=u, mu=mu, delta=delta, converged=True, alpha=step, margin=margin)
+        if accept:
+            delta = min(1 / o.delta_0, delta / o.delta_0)
+            mu = mu * delta * (mu * delta > o.mu_min)
+            return dict(x=x, u=u, mu=mu, delta=delta, converged=False, alpha=step, margin=margin)
+        delta = max(o.delta_0, delta * o.delta_0)
+        mu = max(o.mu_min, mu * delta)
+    raise AssertionError("regularisation did not recover")
+
+
+def _stepwise(make_solver, oenv64, oenv32, x0, u0, T, iterations, ambiguous_allowed):
+    """x0[B,n,1], u0[B,T,m,1] -> asserts; returns (checked, ambiguous)."""
+    B = x0.shape[0]
+    dev = []
+    for k in range(iterations + 1):
+        if k == 0:
+            dev.append(None)
+            continue
+        out = make_solver(k).solve_device(x0, T, u_init=u0)
+        torch.cuda.synchronize()
+        dev.append((out["states"].cpu().numpy().astype(np.float64), out["actions"].cpu().numpy().astype(np.float64),
+                    out["iterations"].cpu().numpy()))
+    checked = ambiguous = 0
+    records = []                                     # (b, k, what, err, err32, scale, note)
+    for b in range(B):
+        o64 = ilqr_ref.ILQRRef(oenv64(b))
+        o32 = ilqr_ref.ILQRRef(oenv32(b), dtype=np.float32)
+        x_hat, u_hat, _ = o64.start(x0[b], T, u_init=u0[b])
+        mu, delta = 0.0, 1.0
+        for k in range(1, iterations + 1):
+            r64 = _one_iteration(o64, x_hat, u_hat, mu, delta)
+            r32 = _one_iteration(o32, x_hat.astype(np.float32), u_hat.astype(np.float32), mu, delta)
+            xd, ud, itd = dev[k][0][b].reshape(x_hat.shape), dev[k][1][b].reshape(u_hat.shape), dev[k][2][b]
+            if r64["margin"] < MARGIN or r32["alpha"] != r64["alpha"] or r32["converged"] != r64["converged"]:
+                ambiguous += 1                       # a near-tie: the device may land on either side
+                break
+            for got, ref, ref32, what in ((xd, r64["x"], r32["x"], "states"), (ud, r64["u"], r32["u"], "actions")):
+                records.append((b, k, what, np.abs(got - ref).max(), np.abs(ref32.astype(np.float64) - ref).max(),
+                                max(np.abs(ref).max(), 1.0), f"alpha {r64['alpha']}, mu {mu}, margin {r64['margin']:.2e}"))
+            checked += 1
+            if r64["converged"]:
+                # the device stops in the same iteration: more allowed iterations change nothing
+                assert itd == k - 1, (b, k, itd)
+                for kk in range(k + 1, iterations + 1):
+                    assert np.array_equal(dev[kk][0][b], dev[k][0][b]) and dev[kk][2][b] == k - 1
+                break
+            # teacher forcing: the next oracle iteration starts from the DEVICE's trajectory
+            x_hat, u_hat, mu, delta = xd, ud, r64["mu"], r64["delta"]
+    # Budget.  Measured (MI355X, round 2): most iterations land within 1-2 ulp-scale errors of the fp32 restatement
+    # (ratio device error / fp32-restatement error ~ 1.0); on the few ill-conditioned iterations where fp32 itself is
+    # 1e-5 off, two different fp32 evaluation orders differ by up to ~7x.  So: every record within 10x the largest
+    # error of the fp32 restatement over the batch (same tensor and iteration index; floor 2e-5 of the tensor's
+    # scale), and the BULK (>= 85 %) within the 5x-of-its-own-fp32-error rule (floor 2e-6).
+    worst, within5 = 0.0, 0
+    for b, k, what, err, err32, scale, note in records:
+        pool = max(r[4] / r[5] for r in records if r[1] == k and r[2] == what)
+        allowed = max(10 * pool, 2e-5) * scale
+        worst = max(worst, err / allowed)
+        assert err <= allowed, f"instance {b} iteration {k} {what}: err {err:.3e} > {allowed:.3e} ({note})"
+        within5 += int(err <= max(5 * err32, 2e-6 * scale))
+    assert within5 >= 0.85 * len(records), (within5, len(records))
+    assert ambiguous <= ambiguous_allowed, (ambiguous, checked)
+    assert checked >= 2 * B, (checked, ambiguous)
+    return checked, ambiguous, worst
+
+
+def test_the_stepwise_helper_chains_into_the_oracle_solve():
+    """CPU: _one_iteration repeated from its own output IS ILQRRef.solve (same trajectory, same iteration count)."""
+    cfg = problems.NAV_CONFIG
+    oenv = envs_ref.Navigation(cfg["goal"], cfg["deceleration"]["center"], cfg["deceleration"]["decay"], cfg["low"],
+                               cfg["high"])
+    rng = np.random.default_rng(3)
+    T = 15
+    x0 = rng.uniform(0, 10, size=(2, 1))
+    u0 = problems.scalar_uniform_actions(T, [-1, -1], [1, 1], rng)
+    o = ilqr_ref.ILQRRef(oenv)
+    xs, us, cs, its = o.solve(x0, T, u_init=u0)
+    x_hat, u_hat, _ = o.start(x0, T, u_init=u0)
+    mu, delta = 0.0, 1.0
+    for k in range(100):
+        r = _one_iteration(o, x_hat, u_hat, mu, delta)
+        x_hat, u_hat, mu, delta = r["x"], r["u"], r["mu"], r["delta"]
+        if r["converged"]:
+            break
+    assert k == its and np.array_equal(x_hat[..., 0], xs) and np.array_equal(u_hat[..., 0], us)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("beta,bound", [(0.0, None), (5.0, None), (5.0, 1.0), (0.0, 0.4)])
+def test_navigation_lqr_every_iteration(beta, bound):
+    """Wave-per-instance kernel (ilqr_kernels.hip): unbounded Cholesky controller and the box-QP controller."""
+    low, high = (None, None) if bound is None else (-bound, bound)
+    goal = [[5.5], [-9.0]]
+    env = NavigationLQR(goal, beta, low, high)
+    oenv = lambda dtype: (lambda b: envs_ref.NavigationLQR(goal, beta, low, high, dtype=dtype))
+    rng = np.random.default_rng(5)
+    B, T = 8, 12
+    x0 = rng.normal(scale=3.0, size=(B, 2, 1)).astype(np.float32)
+    hi = 1.0 if bound is None else bound
+    u0 = rng.uniform(-hi, hi, size=(B, T, 2, 1)).astype(np.float32)
+    _stepwise(lambda k: iLQR(env, max_iterations=k), oenv(np.float64), oenv(np.float32), x0, u0, T, 4, 2)
+
+
+@pytest.mark.gpu
+def test_navigation_every_iteration():
+    """Lane-per-instance kernel (ilqr_lane.hip) on the nonlinear, control-limited Navigation env (configs[3])."""
+    cfg = problems.NAV_CONFIG
+    env = Navigation.load(cfg)
+    oenv = lambda dtype: (lambda b: envs_ref.Navigation(cfg["goal"], cfg["deceleration"]["center"],
+                                                         cfg["deceleration"]["decay"], cfg["low"], cfg["high"], dtype=dtype))
+    rng = np.random.default_rng(77)
+    B, T = 12, 20
+    x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
+    u0 = np.stack([problems.scalar_uniform_actions(T, [-1, -1], [1, 1], rng) for _ in range(B)]).astype(np.float32)
+    _stepwise(lambda k: iLQR(env, max_iterations=k), oenv(np.float64), oenv(np.float32), x0, u0, T, 6, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,T,bound", [(16, 8, 20, None), (16, 8, 20, 0.5), (12, 6, 16, 1.0), (32, 16, 12, None), (24, 12, 10, None)])
+def test_lq_env_every_iteration(n, m, T, bound):
+    """Matrix-core LQ kernels: ilqr_lq_mfma (16x8), ilqr_lq_box_mfma (control limits), ilqr_lq_mfma32 (32x16)."""
+    B = 6
+    F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=3 * n + m)
+    F = F * 0.25 * np.sqrt(16.0 / n)
+    low, high = (None, None) if bound is None else (-bound, bound)
+    env = LQEnv(F, f, C, c, low=low, high=high)
+    oenv = lambda dtype: (lambda b: envs_ref.LQEnv(F[b], f[b][:, None], C[b], c[b][:, None], low=low, high=high, dtype=dtype))
+    hi = 1.0 if bound is None else bound
+    u0 = np.clip(0.1 * np.random.default_rng(1).normal(size=(B, T, m, 1)), -hi, hi).astype(np.float32)
+    _stepwise(lambda k: iLQR(env, max_iterations=k), oenv(np.float64), oenv(np.float32),
+              x0.astype(np.float32)[..., None], u0, T, 3, 1)
