@@ -15,6 +15,7 @@ struct AdjointSolveArgs {
     float *states, *actions, *costs;
     int32_t *iterations, *status;
     float *wsk, *wsx, *wsu, *wsc;        // gains k[T][m], candidate x[T+1][n], u[T][m], costs[T+1]
+    void *wave_ws;                       // 16-per-wave kernel: its wave-major trajectory buffers (ilqr_adjoint_mfma_workspace_bytes)
 };
 
 bool ilqr_adjoint_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg);
@@ -24,5 +25,7 @@ int ilqr_adjoint_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const A
 // parameters are shared by the whole batch
 bool ilqr_adjoint_mfma_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg);
 int ilqr_adjoint_mfma_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const AdjointSolveArgs &a, hipStream_t stream);
+// bytes of AdjointSolveArgs::wave_ws for a batch of B instances with n states (0 for shapes the kernel does not serve)
+size_t ilqr_adjoint_mfma_workspace_bytes(int B, int n, int m, int T);
 
 }  // namespace tfmpc

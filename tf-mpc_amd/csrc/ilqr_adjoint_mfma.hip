@@ -46,8 +46,22 @@ namespace tfmpc {
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 constexpr int kCols = 16;                 // instances per wave
+
+// The element-wise work of a step is written on PAIRS of adjacent rows (registers e, e + 1 of a lane: consecutive
+// registers of a 16-byte trajectory load, an LDS parameter read and an MFMA accumulator alike), so that adds, multiplies
+// and fused multiply-adds become v_pk_{add,mul,fma}_f32 -- two rows per instruction, each rounded exactly like the
+// scalar instruction -- without the register shuffles the auto-vectoriser's own pairings needed (it paired the two
+// step-size chains of the HVAC search: 67 v_mov per 373 vector instructions of a step).  max / abs / compare / select
+// have no packed fp32 form and stay per row.
+__device__ __forceinline__ f32x2 pr(const float *a, int e) { return f32x2{a[e], a[e + 1]}; }
+__device__ __forceinline__ void unpr(float *a, int e, f32x2 v) { a[e] = v.x; a[e + 1] = v.y; }
+__device__ __forceinline__ f32x2 splat(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 max2(f32x2 a, f32x2 b) { return f32x2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+__device__ __forceinline__ f32x2 abs2(f32x2 a) { return f32x2{fabsf(a.x), fabsf(a.y)}; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 __device__ __forceinline__ float sgnf_(float y) { return (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f); }
 
@@ -223,6 +237,55 @@ __device__ __forceinline__ void stv(bf16_t *p, int n, int q, bool keep, const fl
             }
         }
 }
+// ---- the solver's OWN trajectory buffers are WAVE-major: [time step][tile][lane] pieces of this lane's four rows, so a
+// load / store instruction of the wave moves one contiguous KB (half a KB in 16-bit containers) instead of sixteen
+// 64-byte segments 12.8 KB apart.  Instance-major arrays (the ABI's inputs and outputs) are touched once each: the start
+// rollout reads u_init, the end of the kernel copies the nominal trajectory out.  Measured (tools/probes/traj_layout_probe.hip,
+// same access sequence without the arithmetic): scattered 64-byte stores sustain 3.5 TB/s, contiguous ones 6.1 TB/s --
+// a storing pass of the instance-major layout took 0.37 ms, longer than its arithmetic (0.15 ms).
+constexpr int kTileElems = 4 * kWave;            // one tile of one time step: 64 lanes x 4 rows
+template <int NT>
+__device__ __forceinline__ void ldw(const float *p, int t, int lane, float (&o)[4 * NT])
+{
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const f32x4 v = gld(reinterpret_cast<const f32x4 *>(p + ((size_t)t * NT + b) * kTileElems + 4 * lane));
+        o[4 * b] = v[0]; o[4 * b + 1] = v[1]; o[4 * b + 2] = v[2]; o[4 * b + 3] = v[3];
+    }
+}
+template <int NT>
+__device__ __forceinline__ void stw(float *p, int t, int lane, bool keep, const float (&v)[4 * NT])
+{
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const f32x4 w = {v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]};
+        if (keep) gst(reinterpret_cast<f32x4 *>(p + ((size_t)t * NT + b) * kTileElems + 4 * lane), w);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void ldw(const bf16_t *p, int t, int lane, float (&o)[4 * NT])
+{
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const u32x2 w = gld(reinterpret_cast<const u32x2 *>(p + ((size_t)t * NT + b) * kTileElems + 4 * lane));
+        o[4 * b] = __uint_as_float(w.x << 16);
+        o[4 * b + 1] = __uint_as_float(w.x & 0xFFFF0000u);
+        o[4 * b + 2] = __uint_as_float(w.y << 16);
+        o[4 * b + 3] = __uint_as_float(w.y & 0xFFFF0000u);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void stw(bf16_t *p, int t, int lane, bool keep, const float (&v)[4 * NT])
+{
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        u32x2 w;
+        w.x = (unsigned)narrow(v[4 * b]) | ((unsigned)narrow(v[4 * b + 1]) << 16);
+        w.y = (unsigned)narrow(v[4 * b + 2]) | ((unsigned)narrow(v[4 * b + 3]) << 16);
+        if (keep) gst(reinterpret_cast<u32x2 *>(p + ((size_t)t * NT + b) * kTileElems + 4 * lane), w);
+    }
+}
+constexpr int kCostLd = 64;                      // stage costs: [time step][instance of the wave] (up to 16 columns x 4)
 __device__ __forceinline__ float ldc(const float *p) { return gld(p); }
 __device__ __forceinline__ float ldc(const bf16_t *p) { return widen(gld(p)); }
 __device__ __forceinline__ void stc(float *p, float v) { gst(p, v); }
@@ -368,32 +431,35 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
         for (int e = 0; e < NV; ++e) ok = ok && am[e] >= 0.0f;
         return __all(ok);
     }
-    __device__ __forceinline__ float penalties(float x, int e) const
+    __device__ __forceinline__ f32x2 penalties(f32x2 x, int e) const
     {
-        const float mid = (lo[e] + hi[e]) / 2;
-        const float oob = PENALTY * (fmaxf(0.0f, lo[e] - x) + fmaxf(0.0f, x - hi[e]));      // hvac :97-100
-        const float sp = SET_POINT_PENALTY * fabsf(mid - x);                              // :101-105
+        const f32x2 LO = pr(lo, e), HI = pr(hi, e);
+        const f32x2 mid = (LO + HI) / 2;
+        const f32x2 oob = PENALTY * (max2(splat(0.0f), LO - x) + max2(splat(0.0f), x - HI));  // hvac :97-100
+        const f32x2 sp = SET_POINT_PENALTY * abs2(mid - x);                                   // :101-105
         return oob + sp;
     }
     __device__ __forceinline__ void stage_costs(const float (&x)[NV], const float (&u)[NV], int, float (&c)[NV]) const
     {
 #pragma unroll
-        for (int e = 0; e < NV; ++e) c[e] = COST_AIR * (u[e] * am[e]) + penalties(x[e], e);      // :91-110
+        for (int e = 0; e < NV; e += 2) unpr(c, e, COST_AIR * (pr(u, e) * pr(am, e)) + penalties(pr(x, e), e));    // :91-110
     }
     __device__ __forceinline__ void final_costs(const float (&x)[NV], int, float (&c)[NV]) const
     {
 #pragma unroll
-        for (int e = 0; e < NV; ++e) c[e] = penalties(x[e], e);                           // :112-129
+        for (int e = 0; e < NV; e += 2) unpr(c, e, penalties(pr(x, e), e));               // :112-129
     }
-    __device__ __forceinline__ float grad_x(float x, int e) const
+    __device__ __forceinline__ f32x2 grad_x(f32x2 x, int e) const
     {
-        const float mid = (lo[e] + hi[e]) / 2;
-        return PENALTY * (-(lo[e] > x ? 1.0f : 0.0f) + (x > hi[e] ? 1.0f : 0.0f)) - SET_POINT_PENALTY * sgnf_(mid - x);
+        const f32x2 LO = pr(lo, e), HI = pr(hi, e);
+        const f32x2 mid = (LO + HI) / 2, d = mid - x;
+        const f32x2 below = {LO.x > x.x ? 1.0f : 0.0f, LO.y > x.y ? 1.0f : 0.0f}, above = {x.x > HI.x ? 1.0f : 0.0f, x.y > HI.y ? 1.0f : 0.0f};
+        return PENALTY * (-below + above) - SET_POINT_PENALTY * f32x2{sgnf_(d.x), sgnf_(d.y)};
     }
     __device__ __forceinline__ void grads(const float (&x)[NV], int, float (&gx)[NV]) const
     {
 #pragma unroll
-        for (int e = 0; e < NV; ++e) gx[e] = grad_x(x[e], e);
+        for (int e = 0; e < NV; e += 2) unpr(gx, e, grad_x(pr(x, e), e));
     }
     __device__ __forceinline__ void step(const float (&A)[NT][NT][4], const float (&x)[NV], const float (&u)[NV], int qo,
                                          float (&xn)[NV]) const
@@ -402,10 +468,11 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
         lds_rows<NT>(lds, kC0, qo, acc);
         mat_apply<NT>(A, x, acc);
 #pragma unroll
-        for (int e = 0; e < NV; ++e) {
-            const float air = u[e] * am[e];                                               // :72
-            const float heating = air * CAP_AIR * (TEMP_AIR - x[e]);                      // :74
-            xn[e] = x[e] + rcap[e] * (heating + acc[e]);                                  // :80-88
+        for (int e = 0; e < NV; e += 2) {
+            const f32x2 X = pr(x, e);
+            const f32x2 air = pr(u, e) * pr(am, e);                                       // :72
+            const f32x2 heating = air * CAP_AIR * (TEMP_AIR - X);                         // :74
+            unpr(xn, e, X + pr(rcap, e) * (heating + pr(acc, e)));                        // :80-88
         }
     }
     __device__ __forceinline__ void adjoint(const float (&A)[NT][NT][4], const float (&xh)[NV], const float (&uh)[NV],
@@ -413,15 +480,16 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
     {
         float w[NV];
 #pragma unroll
-        for (int e = 0; e < NV; ++e) {
-            w[e] = rcap[e] * vx[e];
-            Qx[e] = fmaf(-(uh[e] * am[e] * CAP_AIR), w[e], grad_x(xh[e], e) + vx[e]);
+        for (int e = 0; e < NV; e += 2) {
+            const f32x2 W = pr(rcap, e) * pr(vx, e);
+            unpr(w, e, W);
+            unpr(Qx, e, fma2(-(pr(uh, e) * pr(am, e) * CAP_AIR), W, grad_x(pr(xh, e), e) + pr(vx, e)));
         }
         mat_apply<NT>(A, w, Qx);
 #pragma unroll
-        for (int e = 0; e < NV; ++e) {
-            const float d = rcap[e] * am[e] * CAP_AIR * (TEMP_AIR - xh[e]);
-            Qu[e] = fmaf(d, vx[e], COST_AIR * am[e]);
+        for (int e = 0; e < NV; e += 2) {
+            const f32x2 d = pr(rcap, e) * pr(am, e) * CAP_AIR * (TEMP_AIR - pr(xh, e));
+            unpr(Qu, e, fma2(d, pr(vx, e), COST_AIR * pr(am, e)));
         }
     }
 };
@@ -497,12 +565,13 @@ template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
         lds_rows<NT>(lds, kHP, qo, HP);
         lds_rows<NT>(lds, kSP, qo, SP);
 #pragma unroll
-        for (int e = 0; e < NV; ++e) {
-            const float mid = (lo[e] + hi[e]) / 2.0f;
-            const float c1 = LP[e] * fmaxf(0.0f, lo[e] - x[e]);
-            const float c2 = HP[e] * fmaxf(0.0f, x[e] - hi[e]);
-            const float c3 = SP[e] * fabsf(mid - x[e]);
-            c[e] = c1 + c2 + c3;
+        for (int e = 0; e < NV; e += 2) {
+            const f32x2 X = pr(x, e), LO = pr(lo, e), HI = pr(hi, e);
+            const f32x2 mid = (LO + HI) / 2.0f;
+            const f32x2 c1 = pr(LP, e) * max2(splat(0.0f), LO - X);
+            const f32x2 c2 = pr(HP, e) * max2(splat(0.0f), X - HI);
+            const f32x2 c3 = pr(SP, e) * abs2(mid - X);
+            unpr(c, e, c1 + c2 + c3);
         }
     }
     __device__ __forceinline__ void final_costs(const float (&x)[NV], int qo, float (&c)[NV]) const { stage_costs(x, x, qo, c); }   // :81-83
@@ -513,9 +582,11 @@ template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
         lds_rows<NT>(lds, kHP, qo, HP);
         lds_rows<NT>(lds, kSP, qo, SP);
 #pragma unroll
-        for (int e = 0; e < NV; ++e) {
-            const float mid = (lo[e] + hi[e]) / 2.0f;
-            gx[e] = -LP[e] * (lo[e] > x[e] ? 1.0f : 0.0f) + HP[e] * (x[e] > hi[e] ? 1.0f : 0.0f) - SP[e] * sgnf_(mid - x[e]);
+        for (int e = 0; e < NV; e += 2) {
+            const f32x2 X = pr(x, e), LO = pr(lo, e), HI = pr(hi, e);
+            const f32x2 mid = (LO + HI) / 2.0f, d = mid - X;
+            const f32x2 below = {LO.x > X.x ? 1.0f : 0.0f, LO.y > X.y ? 1.0f : 0.0f}, above = {X.x > HI.x ? 1.0f : 0.0f, X.y > HI.y ? 1.0f : 0.0f};
+            unpr(gx, e, -pr(LP, e) * below + pr(HP, e) * above - pr(SP, e) * f32x2{sgnf_(d.x), sgnf_(d.y)});
         }
     }
     __device__ __forceinline__ void step(const float (&A)[NT][NT][4], const float (&x)[NV], const float (&u)[NV], int qo,
@@ -523,18 +594,18 @@ template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
     {
         float z[NV], inflow[NV], rain[NV];
 #pragma unroll
-        for (int e = 0; e < NV; ++e) { z[e] = u[e] * x[e]; inflow[e] = 0.0f; }
+        for (int e = 0; e < NV; e += 2) { unpr(z, e, pr(u, e) * pr(x, e)); inflow[e] = 0.0f; inflow[e + 1] = 0.0f; }
         mat_apply<NT>(A, z, inflow);
         lds_rows<NT>(lds, kRain, qo, rain);
         float r[NV], sr[NV];
 #pragma unroll
-        for (int e = 0; e < NV; ++e) r[e] = x[e] * rcap[e];
+        for (int e = 0; e < NV; e += 2) unpr(r, e, pr(x, e) * pr(rcap, e));
         sin_vec<NV>(r, sr);
 #pragma unroll
-        for (int e = 0; e < NV; ++e) {
-            const float xi = x[e];
-            const float vaporated = 0.5f * sr[e] * xi;                                    // :87
-            xn[e] = xi + rain[e] + inflow[e] - vaporated - u[e] * xi;                     // :56-60
+        for (int e = 0; e < NV; e += 2) {
+            const f32x2 xi = pr(x, e);
+            const f32x2 vaporated = 0.5f * pr(sr, e) * xi;                                // :87
+            unpr(xn, e, xi + pr(rain, e) + pr(inflow, e) - vaporated - pr(u, e) * xi);    // :56-60
         }
     }
     __device__ __forceinline__ void adjoint(const float (&A)[NT][NT][4], const float (&xh)[NV], const float (&uh)[NV],
@@ -548,17 +619,30 @@ template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
         grads(xh, qo, gx);
         float r[NV], sr[NV], cr[NV];
 #pragma unroll
-        for (int e = 0; e < NV; ++e) r[e] = xh[e] * rcap[e];
+        for (int e = 0; e < NV; e += 2) unpr(r, e, pr(xh, e) * pr(rcap, e));
         sincos_vec<NV>(r, sr, cr);
 #pragma unroll
-        for (int e = 0; e < NV; ++e) {
-            const float uj = uh[e], xa = xh[e];
-            const float diag_extra = 1.0f - 0.5f * (cr[e] * r[e] + sr[e]) - uj;
-            Qx[e] = fmaf(uj, Y[e], fmaf(Dii[e] * uj + diag_extra, vx[e], gx[e]));
-            Qu[e] = fmaf(xa, Y[e], fmaf(Dii[e] * xa - xa, vx[e], 0.0f));
+        for (int e = 0; e < NV; e += 2) {
+            const f32x2 uj = pr(uh, e), xa = pr(xh, e), V = pr(vx, e), Yp = pr(Y, e), D = pr(Dii, e);
+            const f32x2 diag_extra = 1.0f - 0.5f * (pr(cr, e) * pr(r, e) + pr(sr, e)) - uj;
+            unpr(Qx, e, fma2(uj, Yp, fma2(D * uj + diag_extra, V, pr(gx, e))));
+            unpr(Qu, e, fma2(xa, Yp, fma2(D * xa - xa, V, splat(0.0f))));
         }
     }
 };
+
+#ifdef TFMPC_CFG5_TRACE
+// probe builds only (tools/probes/cfg5_trace.py): per instance and sweep, the accepted step-size index and, for every
+// step size tried, the first time step at which the partial cost was above J_hat.  [B][16][12] ints.
+__device__ int *g_cfg5_trace = nullptr;
+#endif
+
+// bytes of one wave's slice of the wave-major workspace (sized for fp32 containers; the 16-bit ones use half of each buffer)
+__host__ __device__ constexpr size_t adjoint_mfma_wave_bytes(int NT, int T)
+{
+    return (2 * ((size_t)(T + 1) * NT * kTileElems + (size_t)T * NT * kTileElems + (size_t)(T + 1) * kCostLd) * sizeof(float) +
+            (size_t)T * kWave + 255) & ~(size_t)255;
+}
 
 template <int KIND, int NT, int VW, int PK, bool BF16 = false>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 && PK == 1 ? 3 : 2, NT == 1 && PK == 1 ? 3 : 2))) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
@@ -583,22 +667,20 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
     wsync();
     const bool early_exit = cfg.c1 == 0.0f && env.costs_nonnegative();     // see `rollout`
 
-    // trajectories of this column: [0] the output arrays, [1] the workspace; the nominal one is [flip].  16-bit
-    // containers: BOTH live in the workspace (two half-size buffers in each fp32-sized slab) and the final nominal
-    // trajectory is widened into the fp32 output arrays at the end.
+    // trajectories of this wave, wave-major (see ldw): two buffers of states / actions / stage costs in the wave's slice
+    // of the workspace, the nominal one is [flip]; at the end the nominal trajectory is copied (16-bit containers:
+    // widened) into the instance-major output arrays.  Then the selector bytes [t][lane]: 4 NT bits each.
+    const size_t kXs = (size_t)(T + 1) * NT * kTileElems, kUs = (size_t)T * NT * kTileElems, kCs = (size_t)(T + 1) * kCostLd;
+    unsigned char *const wave_ws = static_cast<unsigned char *>(a.wave_ws) + (size_t)blockIdx.x * adjoint_mfma_wave_bytes(NT, T);
     TT *xbuf[2], *ubuf[2], *cbuf[2];
-    if constexpr (BF16) {
-        bf16_t *wx = reinterpret_cast<bf16_t *>(a.wsx + b * (T + 1) * n), *wu = reinterpret_cast<bf16_t *>(a.wsu + b * T * m),
-               *wc = reinterpret_cast<bf16_t *>(a.wsc + b * (T + 1));
-        xbuf[0] = wx; xbuf[1] = wx + (size_t)(T + 1) * n;
-        ubuf[0] = wu; ubuf[1] = wu + (size_t)T * m;
-        cbuf[0] = wc; cbuf[1] = wc + (T + 1);
-    } else {
-        xbuf[0] = a.states + b * (T + 1) * n; xbuf[1] = a.wsx + b * (T + 1) * n;
-        ubuf[0] = a.actions + b * T * m; ubuf[1] = a.wsu + b * T * m;
-        cbuf[0] = a.costs + b * (T + 1); cbuf[1] = a.wsc + b * (T + 1);
+    const int ccol = j * PK + q / (4 / PK);             // this lane's instance within the wave
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        xbuf[i] = reinterpret_cast<TT *>(wave_ws + (size_t)i * (kXs + kUs + kCs) * sizeof(float));
+        ubuf[i] = xbuf[i] + kXs;
+        cbuf[i] = ubuf[i] + kUs + ccol;
     }
-    unsigned char *const ksel = reinterpret_cast<unsigned char *>(a.wsk) + b * T * 4;    // [t][lane quarter]: 4 NT selector bits
+    unsigned char *const ksel = wave_ws + 2 * (kXs + kUs + kCs) * sizeof(float) + lane;
     const float *const x0p = a.x0 + b * n;
     int flip = 0;
 
@@ -619,6 +701,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
     // grows: once it is above `reject_above` (= J_hat) in every column that is still trying (`trying`), the answer is
     // "no" whatever follows, and the pass stops -- the first, too long step sizes of a Reservoir search blow the cost
     // up within 5 .. 40 of the 100 steps.  Same decisions, so same results, bit for bit.
+#ifdef TFMPC_CFG5_TRACE
+    int trace_fa[2] = {-1, -1};
+#endif
     auto rollout = [&](auto search, auto store, auto n_alpha, const float (&alpha)[decltype(n_alpha)::value], auto uh,
                        bool keep, TT *xs, TT *us, TT *cs, float (&J_out)[decltype(n_alpha)::value],
                        bool trying = false, float reject_above = 0.0f, bool may_stop = false, bool *stopped_out = nullptr) {
@@ -631,7 +716,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
         float x[NA][NV], ur[kAheadRoll][NV], J[NA];
         unsigned kb[kAheadRoll];
         ldv<NT, VW>(x0p, n, ql, x[0]);
-        if (STORE) stv<NT, VW>(xs, n, ql, keep, x[0]);
+        if (STORE) stw<NT>(xs, 0, lane, keep, x[0]);
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             J[k] = 0.0f;
@@ -639,8 +724,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
             for (int e = 0; e < NV; ++e) x[k][e] = x[0][e];
         }
         auto request = [&](int t, float (&u_)[NV], unsigned &k_) {
-            ldv<NT, VW>(uh + (size_t)t * m, m, ql, u_);
-            if (SEARCH) k_ = gld(ksel + (size_t)t * 4 + ql);
+            if constexpr (SEARCH) {
+                ldw<NT>(uh, t, lane, u_);
+                k_ = gld(ksel + (size_t)t * kWave);
+            } else {
+                ldv<NT, VW>(uh + (size_t)t * m, m, ql, u_);                 // the injected start actions: instance-major
+            }
         };
 #pragma unroll
         for (int d = 0; d < kAheadRoll; ++d) {
@@ -650,6 +739,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
             if (d < T) request(d, ur[d], kb[d]);
         }
         bool stopped = false;
+#ifdef TFMPC_CFG5_TRACE
+        trace_fa[0] = trace_fa[1] = -1;
+#endif
         for (int t0 = 0; t0 < T; t0 += kAheadRoll) {
             if (SEARCH && early_exit && may_stop) {
                 bool open = false;                       // a trying column whose partial cost may still end at or below J_hat
@@ -669,13 +761,15 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
                         lds_rows<NT>(rows, kSlotALow, qo, alow);
                         lds_rows<NT>(rows, kSlotAHigh, qo, ahigh);
 #pragma unroll
-                        for (int e = 0; e < NV; ++e) {
-                            const float uh_e = ur[d][e];
-                            const float kt = ((kb[d] >> e) & 1u) ? (alow[e] - uh_e) : (ahigh[e] - uh_e);      // :140-141
+                        for (int e = 0; e < NV; e += 2) {
+                            const f32x2 uh_e = pr(ur[d], e);
+                            const f32x2 bound = {((kb[d] >> e) & 1u) ? alow[e] : ahigh[e], ((kb[d] >> (e + 1)) & 1u) ? alow[e + 1] : ahigh[e + 1]};
+                            const f32x2 kt = bound - uh_e;                                                   // :140-141
 #pragma unroll
                             for (int k = 0; k < NA; ++k) {
-                                const float du = alpha[k] * kt;                                              // :193-194
-                                u[k][e] = __builtin_amdgcn_fmed3f(uh_e + du, alow[e], ahigh[e]);             // :196-197 (low <= high)
+                                const f32x2 un = uh_e + alpha[k] * kt;                                       // :193-194
+                                u[k][e] = __builtin_amdgcn_fmed3f(un.x, alow[e], ahigh[e]);                  // :196-197 (low <= high)
+                                u[k][e + 1] = __builtin_amdgcn_fmed3f(un.y, alow[e + 1], ahigh[e + 1]);
                             }
                         }
                     } else {
@@ -690,10 +784,13 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
                         const float c = col_sum<NT, PK>(cp);
                         env.step(A, x[k], u[k], qo, xn);
                         J[k] += c;
+#ifdef TFMPC_CFG5_TRACE
+                        if (SEARCH && trace_fa[k] < 0 && J[k] > reject_above) trace_fa[k] = t;
+#endif
                         if (STORE) {
-                            stv<NT, VW>(us + (size_t)t * m, m, ql, keep, u[k]);
-                            stv<NT, VW>(xs + (size_t)(t + 1) * n, n, ql, keep, xn);
-                            if (keep && ql == 0) stc(cs + t, c);
+                            stw<NT>(us, t, lane, keep, u[k]);
+                            stw<NT>(xs, t + 1, lane, keep, xn);
+                            if (keep && ql == 0) stc(cs + (size_t)t * kCostLd, c);
                         }
 #pragma unroll
                         for (int e = 0; e < NV; ++e) x[k][e] = xn[e];
@@ -706,7 +803,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
             float cp[NV];
             env.final_costs(x[k], opaque(ql), cp);
             const float fc = col_sum<NT, PK>(cp);
-            if (STORE && keep && ql == 0) stc(cs + T, fc);
+            if (STORE && keep && ql == 0) stc(cs + (size_t)T * kCostLd, fc);
             J_out[k] = stopped ? J[k] : J[k] + fc;       // stopped: already above J_hat in every column that asked
         }
         if (stopped_out) *stopped_out = stopped;
@@ -733,16 +830,16 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
             env.fence();
             env.template load_backward<PK>(genv, opaque(j), opaque(q), A);
             float vx[NV], xT[NV], p1[NV], ka[NV], xr[kAhead][NV], ur[kAhead][NV], lr[kAhead];
-            ldv<NT, VW>(xhat + (size_t)T * n, n, ql, xT);
+            ldw<NT>(xhat, T, lane, xT);
             env.grads(xT, opaque(ql), vx);                     // V_x = l_x^f
 #pragma unroll
             for (int e = 0; e < NV; ++e) { p1[e] = 0.0f; ka[e] = 0.0f; }
-            rJ = ldc(chat + T);                                    // the stage costs of the nominal trajectory are the l_t
+            rJ = ldc(chat + (size_t)T * kCostLd);                                    // the stage costs of the nominal trajectory are the l_t
             float gsum = 0.0f;
             auto request = [&](int t, float (&x_)[NV], float (&u_)[NV], float &l_) {
-                ldv<NT, VW>(xhat + (size_t)t * n, n, ql, x_);
-                ldv<NT, VW>(uhat + (size_t)t * m, m, ql, u_);
-                l_ = ldc(chat + t);
+                ldw<NT>(xhat, t, lane, x_);
+                ldw<NT>(uhat, t, lane, u_);
+                l_ = ldc(chat + (size_t)t * kCostLd);
             };
 #pragma unroll
             for (int d = 0; d < kAhead; ++d) {
@@ -769,16 +866,20 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
                         lds_rows<NT>(rows, kSlotAHigh, qo, ahigh);
                         unsigned sel = 0;
 #pragma unroll
-                        for (int e = 0; e < NV; ++e) {
-                            const bool lowb = Qu[e] >= 0.0f;
-                            const float kt = lowb ? (alow[e] - uh[e]) : (ahigh[e] - uh[e]);         // :140-141
-                            sel |= lowb ? (1u << e) : 0u;
-                            p1[e] = fmaf(kt, Qu[e], p1[e]);
-                            ka[e] = fmaxf(ka[e], fabsf(kt));
-                            gm[e] = fabsf(kt) / (fabsf(uh[e]) + 1.0f);
+                        for (int e = 0; e < NV; e += 2) {
+                            const bool lowb0 = Qu[e] >= 0.0f, lowb1 = Qu[e + 1] >= 0.0f;
+                            const f32x2 kt = f32x2{lowb0 ? alow[e] : ahigh[e], lowb1 ? alow[e + 1] : ahigh[e + 1]} - pr(uh, e);   // :140-141
+                            sel |= (lowb0 ? (1u << e) : 0u) | (lowb1 ? (2u << e) : 0u);
+                            unpr(p1, e, fma2(kt, pr(Qu, e), pr(p1, e)));
+                            const f32x2 akt = abs2(kt);
+                            unpr(ka, e, max2(pr(ka, e), akt));
+                            const f32x2 den = abs2(pr(uh, e)) + 1.0f;
+                            gm[e] = akt.x / den.x;
+                            gm[e + 1] = akt.y / den.y;
                             vx[e] = Qx[e];                                                          // V_x <- Q_x
+                            vx[e + 1] = Qx[e + 1];
                         }
-                        if (!done) gst(ksel + (size_t)t * 4 + ql, (unsigned char)sel);
+                        if (!done) gst(ksel + (size_t)t * kWave, (unsigned char)sel);
                         rJ += l;
                         gsum += col_max<NT, PK>(gm);
                     }
@@ -822,6 +923,13 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
                     residual = res;
                     alpha_last = alpha;
                     if (z >= cfg.c1) accept = true;                            // :351-353
+#ifdef TFMPC_CFG5_TRACE
+                    if (g_cfg5_trace && q == 0 && live && iteration + attempts < 16 && ai + k < 11) {
+                        int *tr = g_cfg5_trace + ((size_t)b * 16 + iteration + attempts) * 12;
+                        tr[1 + ai + k] = trace_fa[k] < 0 ? T + 1 : trace_fa[k];
+                        if (accept) tr[0] = ai + k;
+                    }
+#endif
                 }
             }
         }
@@ -844,26 +952,24 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
             if (++attempts >= cfg.max_attempts || !(mu < 1e30f)) { status |= TFMPC_ST_MAX_ATTEMPTS; done = true; }
         }
     }
-    // columns whose final nominal trajectory sits in the workspace: copy it out (rows of this lane); 16-bit
-    // containers: every column's, widened into the fp32 output arrays
+    // the nominal trajectory of every column goes out to the instance-major output arrays (16-bit containers: widened)
     {
-        const bool mv = live && (BF16 || flip);
-        const TT *xsrc = xbuf[BF16 ? flip : 1], *usrc = ubuf[BF16 ? flip : 1], *csrc = cbuf[BF16 ? flip : 1];
+        const TT *xsrc = xbuf[flip], *usrc = ubuf[flip], *csrc = cbuf[flip];
         float *xdst = a.states + b * (T + 1) * n, *udst = a.actions + b * T * m, *cdst = a.costs + b * (T + 1);
         for (int t = 0; t <= T; ++t) {
             float v[NV];
-            ldv<NT, VW>(xsrc + (size_t)t * n, n, ql, v);
-            stv<NT, VW>(xdst + (size_t)t * n, n, ql, mv, v);
+            ldw<NT>(xsrc, t, lane, v);
+            stv<NT, VW>(xdst + (size_t)t * n, n, ql, live, v);
             if (t < T) {
-                ldv<NT, VW>(usrc + (size_t)t * m, m, ql, v);
-                stv<NT, VW>(udst + (size_t)t * m, m, ql, mv, v);
+                ldw<NT>(usrc, t, lane, v);
+                stv<NT, VW>(udst + (size_t)t * m, m, ql, live, v);
             }
-            if (ql == 0) { const float c = ldc(csrc + t); if (mv) gst(cdst + t, c); }
+            if (ql == 0) { const float c = ldc(csrc + (size_t)t * kCostLd); if (live) gst(cdst + t, c); }
         }
     }
     if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
     if (ql == 0 && live) {
-        const float cT = ldc(cbuf[flip] + T);
+        const float cT = ldc(cbuf[flip] + (size_t)T * kCostLd);
         if (!(cT == cT)) status |= TFMPC_ST_NAN;
         a.iterations[b] = iteration;
         a.status[b] = status;
@@ -871,6 +977,21 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
 }
 
 }  // namespace
+
+#ifdef TFMPC_CFG5_TRACE
+extern "C" int tfmpc_debug_cfg5_trace(int *device_buffer)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cfg5_trace), &device_buffer, sizeof(device_buffer));
+}
+#endif
+
+size_t ilqr_adjoint_mfma_workspace_bytes(int B, int n, int m, int T)
+{
+    if (B <= 0 || n != m || n < 1 || n > 32 || T < 0) return 0;
+    const int pk = n <= 4 ? 4 : (n <= 8 ? 2 : 1);                   // as in ilqr_adjoint_mfma_launch
+    const size_t waves = ((size_t)B + kCols * pk - 1) / (kCols * pk);
+    return waves * adjoint_mfma_wave_bytes(n > 16 ? 2 : 1, T);
+}
 
 bool ilqr_adjoint_mfma_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg)
 {
@@ -885,11 +1006,12 @@ bool ilqr_adjoint_mfma_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg
 int ilqr_adjoint_mfma_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const AdjointSolveArgs &a, hipStream_t stream)
 {
     auto aligned = [&](unsigned mask) {
-        const void *ps[] = {a.x0, a.u_init, a.states, a.actions, a.wsk, a.wsx, a.wsu};
+        const void *ps[] = {a.x0, a.u_init, a.states, a.actions};
         for (const void *p : ps)
             if (reinterpret_cast<uintptr_t>(p) & mask) return false;
         return true;
     };
+    if (!a.wave_ws || (reinterpret_cast<uintptr_t>(a.wave_ws) & 15u)) return TFMPC_ERR_WORKSPACE;
     const int vw = (env.n % 4 == 0 && aligned(15u)) ? 4 : ((env.n % 2 == 0 && aligned(7u)) ? 2 : 1);
     // instances per column: one up to n = 32 (two tiles) or 16, two for n <= 8, four for n <= 4
     const int pk = env.n <= 4 ? 4 : (env.n <= 8 ? 2 : 1);

@@ -454,7 +454,8 @@ size_t tfmpc_ilqr_workspace_bytes(int B, int n, int m, int T)
     if (B <= 0 || n <= 0 || m <= 0 || T < 0) return 0;
     const size_t per = (size_t)T * m * n + (size_t)T * m + (size_t)(T + 1) * n + (size_t)T * m + (size_t)(T + 1);
     const size_t slabs = ((size_t)B * per * sizeof(float) + 255) & ~(size_t)255;
-    return slabs + ilqr_lane_extra_workspace_bytes(B, n, m, T);      // 2-D envs: parked list + line-search scratch
+    const size_t lane = (ilqr_lane_extra_workspace_bytes(B, n, m, T) + 255) & ~(size_t)255;   // 2-D envs: line-search scratch
+    return slabs + lane + ilqr_adjoint_mfma_workspace_bytes(B, n, m, T);   // n == m <= 32: wave-major trajectories (16 per wave)
 }
 
 int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B, int T, const float *x0,
@@ -478,6 +479,8 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
     a.wsx = w; w += (size_t)B * (T + 1) * n;
     a.wsu = w; w += (size_t)B * T * m;
     a.wsc = w;
+    char *const after_slabs = static_cast<char *>(workspace) + (((size_t)B * ((size_t)T * m * n + (size_t)T * m + (size_t)(T + 1) * n + (size_t)T * m + (size_t)(T + 1)) * sizeof(float) + 255) & ~(size_t)255);
+    char *const after_lane = after_slabs + ((ilqr_lane_extra_workspace_bytes(B, n, m, T) + 255) & ~(size_t)255);
     hipStream_t st = static_cast<hipStream_t>(stream);
     {
         // tiny 2-D envs: 16 lanes per instance with a speculative parallel line search (ilqr_lane.hip) at EVERY batch
@@ -487,8 +490,7 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
         if (ilqr_lane_supported(*env) && !forced_wave && !cfg->storage_bf16)
             return ilqr_lane_solve_launch(*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status,
                                           a.wsK, a.wsk, a.wsx, a.wsu, a.wsc,
-                                          static_cast<char *>(workspace) + (((size_t)B * ((size_t)T * m * n + (size_t)T * m + (size_t)(T + 1) * n + (size_t)T * m + (size_t)(T + 1)) * sizeof(float) + 255) & ~(size_t)255),
-                                          st);
+                                          after_slabs, st);
     }
     {
         // LQ env on the matrix cores (ilqr_lq_mfma.hip); instances it cannot finish (mu > 0 needed)
@@ -516,7 +518,7 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
         // HVAC / Reservoir at n <= 32: register-resident costate kernel (ilqr_adjoint.hip),
         // bit-identical to the generic wave kernel below (TFMPC_ILQR_KERNEL=wave selects that one)
         const bool forced_wave = option_is(kOptIlqrKernel, "wave");
-        const AdjointSolveArgs aa{B, T, x0, u_init, states, actions, costs, iterations, status, a.wsk, a.wsx, a.wsu, a.wsc};
+        const AdjointSolveArgs aa{B, T, x0, u_init, states, actions, costs, iterations, status, a.wsk, a.wsx, a.wsu, a.wsc, after_lane};
         // a batch that shares one env: 16 instances per wave with the coupling-matrix products on the matrix
         // cores (ilqr_adjoint_mfma.hip); TFMPC_ILQR_KERNEL=costate_mfma forces it, lean / lean1 the kernels above.
         // storage_bf16: that kernel keeps its trajectories in REAL 16-bit containers (the wave kernel below emulates
