@@ -38,6 +38,7 @@
 
 #include "../../include/tfmpc_hip.h"
 #include "ilqr_adjoint.h"
+#include "mfma_bf16x3.h"
 #include "trig.h"
 #include "wave_ops.h"
 
@@ -291,24 +292,86 @@ __device__ __forceinline__ float ldc(const bf16_t *p) { return widen(gld(p)); }
 __device__ __forceinline__ void stc(float *p, float v) { gst(p, v); }
 __device__ __forceinline__ void stc(bf16_t *p, float v) { gst(p, narrow(v)); }
 
-// acc (tile a, this lane's rows) += sum over rows of A[a][.] * z : NT x NT x 4 MFMAs, the NT accumulation chains
-// interleaved (a dependent v_mfma_f32_16x16x4_f32 waits 40 cycles, an independent one issues after 32)
-template <int NT>
-__device__ __forceinline__ void mat_apply(const float (&A)[NT][NT][4], const float (&z)[4 * NT], float (&acc)[4 * NT])
+// ---- the matrix operand of  Y = M Z ---------------------------------------------------------------------------------
+// One tile (n <= 16): M in 4 registers per lane, 4 v_mfma_f32_16x16x4_f32 (exact fp32 multiply-adds), as before.
+// Two tiles (n <= 32), round 2: the f32 MFMA costs 32 cycles, runs on the vector FMA lanes and overlaps with nothing
+// (tools/probes/coexec_probe.hip): 16 of them were 512 of a step's ~1 300 issue cycles.  Now M and Z are split into bf16
+// parts, x = h + m + l EXACTLY (8 + 8 + 8 mantissa bits, mfma_bf16x3.h), and the product is evaluated on the bf16 matrix
+// cores, K = 32 = all rows of Z in ONE v_mfma_f32_16x16x32_bf16 (16 cycles) per pair of parts: k-slot s of lane quarter
+// q is row 4 q + s (s < 4) or 16 + 4 q + s - 4, which is the order a lane holds its eight rows in -- Z needs no data
+// movement, only the split (22 vector instructions per four rows).
+//   * M exactly representable in bf16 (Reservoir's 0/1 `downstream`): M Z = M Zh + M Zm + M Zl, three MFMAs per output
+//     tile, and with a single nonzero per row (every reference config) the sum (Zh + Zm) + Zl is Z bit for bit -- the
+//     results stay BIT-identical to the wave kernels'.  6 MFMAs x 16 cycles + the split instead of 16 x 32.
+//   * general M (HVAC's conduction matrix; dense Reservoir couplings): Mh Zh + Mh Zm + Mm Zh + Mm Zm + Mh Zl + Ml Zh, the
+//     dropped terms are below 2^-24 relative (the same bound as one fp32 rounding of the product): 12 MFMAs x 16 cycles.
+using bf3::u32x4;
+template <int NT, bool SPARE_REGISTERS> struct MatOp;
+template <bool S> struct MatOp<1, S> { float a[1][1][4]; };
+// all three parts of M resident (HVAC: 24 registers)
+template <> struct MatOp<2, false> { u32x4 h[2], m[2], l[2]; };
+// only the leading part resident; the other two parts live in LDS and are read when M is not bf16-exact (Reservoir: 8 registers)
+template <> struct MatOp<2, true> { u32x4 h[2]; const u32x4 *rest; bool exact; };
+
+struct ZParts { u32x4 h, m, l; };
+__device__ __forceinline__ ZParts split_rows(const float (&z)[8])
 {
-    f32x4 c[NT];
+    const bf3::Split3 s0 = bf3::split3(f32x4{z[0], z[1], z[2], z[3]}), s1 = bf3::split3(f32x4{z[4], z[5], z[6], z[7]});
+    return ZParts{u32x4{s0.h01, s0.h23, s1.h01, s1.h23}, u32x4{s0.m01, s0.m23, s1.m01, s1.m23}, u32x4{s0.l01, s0.l23, s1.l01, s1.l23}};
+}
+template <bool S>
+__device__ __forceinline__ void mat_apply(const MatOp<1, S> &A, const float (&z)[4], float (&acc)[4])
+{
+    f32x4 c = {acc[0], acc[1], acc[2], acc[3]};
 #pragma unroll
-    for (int a = 0; a < NT; ++a) c[a] = f32x4{acc[4 * a], acc[4 * a + 1], acc[4 * a + 2], acc[4 * a + 3]};
+    for (int r = 0; r < 4; ++r) c = __builtin_amdgcn_mfma_f32_16x16x4f32(A.a[0][0][r], z[r], c, 0, 0, 0);
+    acc[0] = c[0]; acc[1] = c[1]; acc[2] = c[2]; acc[3] = c[3];
+}
+__device__ __forceinline__ void mat_apply(const MatOp<2, false> &A, const float (&z)[8], float (&acc)[8])
+{
+    const ZParts Z = split_rows(z);
+    f32x4 c[2];
 #pragma unroll
-    for (int b = 0; b < NT; ++b)
+    for (int a = 0; a < 2; ++a) c[a] = f32x4{acc[4 * a], acc[4 * a + 1], acc[4 * a + 2], acc[4 * a + 3]};
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+    for (int a = 0; a < 2; ++a) c[a] = bf3::mfma_bf(A.h[a], Z.h, c[a]);      // the two tiles' chains interleaved
 #pragma unroll
-            for (int a = 0; a < NT; ++a) c[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[a][b][r], z[4 * b + r], c[a], 0, 0, 0);
+    for (int a = 0; a < 2; ++a) c[a] = bf3::mfma_bf(A.h[a], Z.m, c[a]);
 #pragma unroll
-    for (int a = 0; a < NT; ++a) {
-        acc[4 * a] = c[a][0]; acc[4 * a + 1] = c[a][1]; acc[4 * a + 2] = c[a][2]; acc[4 * a + 3] = c[a][3];
+    for (int a = 0; a < 2; ++a) c[a] = bf3::mfma_bf(A.m[a], Z.h, c[a]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) c[a] = bf3::mfma_bf(A.m[a], Z.m, c[a]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) c[a] = bf3::mfma_bf(A.h[a], Z.l, c[a]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) c[a] = bf3::mfma_bf(A.l[a], Z.h, c[a]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) { acc[4 * a] = c[a][0]; acc[4 * a + 1] = c[a][1]; acc[4 * a + 2] = c[a][2]; acc[4 * a + 3] = c[a][3]; }
+}
+__device__ __forceinline__ void mat_apply(const MatOp<2, true> &A, const float (&z)[8], float (&acc)[8])
+{
+    const ZParts Z = split_rows(z);
+    f32x4 c[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) c[a] = f32x4{acc[4 * a], acc[4 * a + 1], acc[4 * a + 2], acc[4 * a + 3]};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) c[a] = bf3::mfma_bf(A.h[a], Z.h, c[a]);      // (0 + Zh) + Zm + Zl: exact for a single term
+#pragma unroll
+    for (int a = 0; a < 2; ++a) c[a] = bf3::mfma_bf(A.h[a], Z.m, c[a]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) c[a] = bf3::mfma_bf(A.h[a], Z.l, c[a]);
+    if (!A.exact) {                                                            // wave-uniform
+        const int lane = lane_id();
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const u32x4 Am = A.rest[(2 * a) * kWave + lane], Al = A.rest[(2 * a + 1) * kWave + lane];
+            c[a] = bf3::mfma_bf(Am, Z.h, c[a]);
+            c[a] = bf3::mfma_bf(Am, Z.m, c[a]);
+            c[a] = bf3::mfma_bf(Al, Z.h, c[a]);
+        }
     }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) { acc[4 * a] = c[a][0]; acc[4 * a + 1] = c[a][1]; acc[4 * a + 2] = c[a][2]; acc[4 * a + 3] = c[a][3]; }
 }
 
 // A copy of a lane-dependent index the optimiser cannot see through: what is computed from it inside a loop stays
@@ -323,24 +386,63 @@ __device__ __forceinline__ void opaque_f(float &v) { asm volatile("" : "+v"(v));
 
 // A operands of  Y = M Z  for a matrix given element-wise: el(R, C) = M[R][C] (0 outside n x n).  PK > 1 (one tile,
 // n <= 16 / PK): the tile carries PK instances in its rows, the operand is diag(M, .., M).
-template <int NT, int PK, class F>
-__device__ __forceinline__ void load_operand(int n, int i, int q, F el, float (&A)[NT][NT][4])
+template <int PK, bool S, class F>
+__device__ __forceinline__ void load_operand(int n, int i, int q, F el, MatOp<1, S> &A, u32x4 *)
 {
     constexpr int kSub = 16 / PK;
 #pragma unroll
-    for (int a = 0; a < NT; ++a)
+    for (int r = 0; r < 4; ++r) {
+        const int R = i, C = 4 * q + r;
+        if (PK == 1) {
+            A.a[0][0][r] = (R < n && C < n) ? el(R, C) : 0.0f;
+        } else {
+            const int Rl = R % kSub, Cl = C % kSub;
+            A.a[0][0][r] = (R / kSub == C / kSub && Rl < n && Cl < n) ? el(Rl, Cl) : 0.0f;
+        }
+    }
+}
+// two tiles: lane (i, q) holds, for output tile a, M[16 a + i][k-slots of quarter q] split into its three bf16 parts
+template <class F>
+__device__ __forceinline__ void operand_parts(int n, int i, int q, int a, F el, u32x4 &h, u32x4 &m, u32x4 &l)
+{
+    f32x4 v[2];
 #pragma unroll
-        for (int b = 0; b < NT; ++b)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int R = 16 * a + i, C = 16 * b + 4 * q + r;
-                if (PK == 1) {
-                    A[a][b][r] = (R < n && C < n) ? el(R, C) : 0.0f;
-                } else {
-                    const int Rl = R % kSub, Cl = C % kSub;
-                    A[a][b][r] = (R / kSub == C / kSub && Rl < n && Cl < n) ? el(Rl, Cl) : 0.0f;
-                }
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int R = 16 * a + i, C = 16 * b + 4 * q + r;
+            v[b][r] = (R < n && C < n) ? el(R, C) : 0.0f;
+        }
+    const bf3::Split3 s0 = bf3::split3(v[0]), s1 = bf3::split3(v[1]);
+    h = u32x4{s0.h01, s0.h23, s1.h01, s1.h23};
+    m = u32x4{s0.m01, s0.m23, s1.m01, s1.m23};
+    l = u32x4{s0.l01, s0.l23, s1.l01, s1.l23};
+}
+template <int PK, class F>
+__device__ __forceinline__ void load_operand(int n, int i, int q, F el, MatOp<2, false> &A, u32x4 *)
+{
+    static_assert(PK == 1, "instances are packed into ONE tile");
+#pragma unroll
+    for (int a = 0; a < 2; ++a) operand_parts(n, i, q, a, el, A.h[a], A.m[a], A.l[a]);
+}
+template <int PK, class F>
+__device__ __forceinline__ void load_operand(int n, int i, int q, F el, MatOp<2, true> &A, u32x4 *rest)
+{
+    static_assert(PK == 1, "instances are packed into ONE tile");
+    const int lane = lane_id();
+    bool exact = true;
+    wsync();                                     // the previous phase's reads of `rest` are done
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        u32x4 m, l;
+        operand_parts(n, i, q, a, el, A.h[a], m, l);
+        rest[(2 * a) * kWave + lane] = m;
+        rest[(2 * a + 1) * kWave + lane] = l;
+        exact = exact && ((m[0] | m[1] | m[2] | m[3] | l[0] | l[1] | l[2] | l[3]) & 0x7FFF7FFFu) == 0u;     // +-0 parts only
+    }
+    wsync();
+    A.rest = rest;
+    A.exact = __all(exact);
 }
 
 // Per-row parameter vectors that a step uses ONCE live in LDS ([slot][32] floats, rows >= n padded), not in registers:
@@ -389,15 +491,16 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
         }
         return v;
     }
+    using Operand = MatOp<NT, false>;
     template <int PK>
-    __device__ __forceinline__ void load_forward(const TfmpcEnv &g, int i, int q, float (&A)[NT][NT][4]) const
+    __device__ __forceinline__ void load_forward(const TfmpcEnv &g, int i, int q, Operand &A, u32x4 *rest) const
     {
-        load_operand<NT, PK>(g.n, i, q, [&](int R, int C) { return el(g, R, C); }, A);
+        load_operand<PK>(g.n, i, q, [&](int R, int C) { return el(g, R, C); }, A, rest);
     }
     template <int PK>
-    __device__ __forceinline__ void load_backward(const TfmpcEnv &g, int i, int q, float (&A)[NT][NT][4]) const
+    __device__ __forceinline__ void load_backward(const TfmpcEnv &g, int i, int q, Operand &A, u32x4 *rest) const
     {
-        load_operand<NT, PK>(g.n, i, q, [&](int R, int C) { return el(g, C, R); }, A);
+        load_operand<PK>(g.n, i, q, [&](int R, int C) { return el(g, C, R); }, A, rest);
     }
     __device__ void load(const TfmpcEnv &g, int lane, int q, float *lds_)
     {
@@ -461,12 +564,12 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
 #pragma unroll
         for (int e = 0; e < NV; e += 2) unpr(gx, e, grad_x(pr(x, e), e));
     }
-    __device__ __forceinline__ void step(const float (&A)[NT][NT][4], const float (&x)[NV], const float (&u)[NV], int qo,
+    __device__ __forceinline__ void step(const Operand &A, const float (&x)[NV], const float (&u)[NV], int qo,
                                          float (&xn)[NV]) const
     {
         float acc[NV];
         lds_rows<NT>(lds, kC0, qo, acc);
-        mat_apply<NT>(A, x, acc);
+        mat_apply(A, x, acc);
 #pragma unroll
         for (int e = 0; e < NV; e += 2) {
             const f32x2 X = pr(x, e);
@@ -475,7 +578,7 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
             unpr(xn, e, X + pr(rcap, e) * (heating + pr(acc, e)));                        // :80-88
         }
     }
-    __device__ __forceinline__ void adjoint(const float (&A)[NT][NT][4], const float (&xh)[NV], const float (&uh)[NV],
+    __device__ __forceinline__ void adjoint(const Operand &A, const float (&xh)[NV], const float (&uh)[NV],
                                             const float (&vx)[NV], int, float (&Qx)[NV], float (&Qu)[NV]) const
     {
         float w[NV];
@@ -485,7 +588,7 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
             unpr(w, e, W);
             unpr(Qx, e, fma2(-(pr(uh, e) * pr(am, e) * CAP_AIR), W, grad_x(pr(xh, e), e) + pr(vx, e)));
         }
-        mat_apply<NT>(A, w, Qx);
+        mat_apply(A, w, Qx);
 #pragma unroll
         for (int e = 0; e < NV; e += 2) {
             const f32x2 d = pr(rcap, e) * pr(am, e) * CAP_AIR * (TEMP_AIR - pr(xh, e));
@@ -505,19 +608,20 @@ template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
 
     // forward: D^T (inflow = D^T (u x)); backward: D without its diagonal.  Loaded when a phase starts (from L2), so
     // the two operand sets are never live together.
+    using Operand = MatOp<NT, true>;
     template <int PK>
-    __device__ __forceinline__ void load_forward(const TfmpcEnv &g, int i, int q, float (&A)[NT][NT][4]) const
+    __device__ __forceinline__ void load_forward(const TfmpcEnv &g, int i, int q, Operand &A, u32x4 *rest) const
     {
         const float *D = g.p[7];
         const int n = g.n;
-        load_operand<NT, PK>(n, i, q, [&](int R, int C) { return D[C * n + R]; }, A);
+        load_operand<PK>(n, i, q, [&](int R, int C) { return D[C * n + R]; }, A, rest);
     }
     template <int PK>
-    __device__ __forceinline__ void load_backward(const TfmpcEnv &g, int i, int q, float (&A)[NT][NT][4]) const
+    __device__ __forceinline__ void load_backward(const TfmpcEnv &g, int i, int q, Operand &A, u32x4 *rest) const
     {
         const float *D = g.p[7];
         const int n = g.n;
-        load_operand<NT, PK>(n, i, q, [&](int R, int C) { return (R == C) ? 0.0f : D[R * n + C]; }, A);
+        load_operand<PK>(n, i, q, [&](int R, int C) { return (R == C) ? 0.0f : D[R * n + C]; }, A, rest);
     }
     __device__ void load(const TfmpcEnv &g, int lane, int q, float *lds_)
     {
@@ -589,13 +693,13 @@ template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
             unpr(gx, e, -pr(LP, e) * below + pr(HP, e) * above - pr(SP, e) * f32x2{sgnf_(d.x), sgnf_(d.y)});
         }
     }
-    __device__ __forceinline__ void step(const float (&A)[NT][NT][4], const float (&x)[NV], const float (&u)[NV], int qo,
+    __device__ __forceinline__ void step(const Operand &A, const float (&x)[NV], const float (&u)[NV], int qo,
                                          float (&xn)[NV]) const
     {
         float z[NV], inflow[NV], rain[NV];
 #pragma unroll
         for (int e = 0; e < NV; e += 2) { unpr(z, e, pr(u, e) * pr(x, e)); inflow[e] = 0.0f; inflow[e + 1] = 0.0f; }
-        mat_apply<NT>(A, z, inflow);
+        mat_apply(A, z, inflow);
         lds_rows<NT>(lds, kRain, qo, rain);
         float r[NV], sr[NV];
 #pragma unroll
@@ -608,13 +712,13 @@ template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
             unpr(xn, e, xi + pr(rain, e) + pr(inflow, e) - vaporated - pr(u, e) * xi);    // :56-60
         }
     }
-    __device__ __forceinline__ void adjoint(const float (&A)[NT][NT][4], const float (&xh)[NV], const float (&uh)[NV],
+    __device__ __forceinline__ void adjoint(const Operand &A, const float (&xh)[NV], const float (&uh)[NV],
                                             const float (&vx)[NV], int qo, float (&Qx)[NV], float (&Qu)[NV]) const
     {
         float Y[NV], Dii[NV], gx[NV];
 #pragma unroll
         for (int e = 0; e < NV; ++e) Y[e] = 0.0f;
-        mat_apply<NT>(A, vx, Y);                                                          // sum_{k != i} D[i][k] V_x[k]
+        mat_apply(A, vx, Y);                                                          // sum_{k != i} D[i][k] V_x[k]
         lds_rows<NT>(lds, kDii, qo, Dii);
         grads(xh, qo, gx);
         float r[NV], sr[NV], cr[NV];
@@ -658,6 +762,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
     const bool live = b_raw < a.B;                       // the last wave may carry empty columns: they compute on the
     const size_t b = live ? b_raw : a.B - 1;             // last instance's data and store nothing
     __shared__ __attribute__((aligned(16))) float rows[kRowSlots * kRowLd];
+    __shared__ u32x4 op_rest[NT == 2 ? 4 * kWave : 1];         // MatOp<2, true>: the non-leading parts of the operand
     EnvM<KIND, NT> env;
     env.load(genv, lane, ql, rows);
     if (lane < kRowLd) {
@@ -710,9 +815,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
         constexpr bool SEARCH = decltype(search)::value, STORE = decltype(store)::value;
         constexpr int NA = decltype(n_alpha)::value;
         static_assert(!STORE || NA == 1, "only a single rollout is stored");
-        float A[NT][NT][4];
+        typename EnvM<KIND, NT>::Operand A;
         env.fence();
-        env.template load_forward<PK>(genv, opaque(j), opaque(q), A);
+        env.template load_forward<PK>(genv, opaque(j), opaque(q), A, op_rest);
         float x[NA][NV], ur[kAheadRoll][NV], J[NA];
         unsigned kb[kAheadRoll];
         ldv<NT, VW>(x0p, n, ql, x[0]);
@@ -818,7 +923,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
     }
 
     float mu = 0.0f, delta = 1.0f;
-    int status = 0, attempts = 0, iteration = 0;
+    int status = 0, attempts = 0, iteration = 0, last_index = 0;     // last_index: position of the step size accepted last
     bool done = !live || cfg.max_iterations <= 0;
     while (__any(!done)) {
         TT *const xhat = xbuf[flip], *const uhat = ubuf[flip], *const chat = cbuf[flip];
@@ -826,9 +931,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
         // ---- backward (ilqr.py:94-172 on the bang-bang branch): costate recursion, all columns ------------
         float rJ, dV1, g_norm, kmax;
         {
-            float A[NT][NT][4];
+            typename EnvM<KIND, NT>::Operand A;
             env.fence();
-            env.template load_backward<PK>(genv, opaque(j), opaque(q), A);
+            env.template load_backward<PK>(genv, opaque(j), opaque(q), A, op_rest);
             float vx[NV], xT[NV], p1[NV], ka[NV], xr[kAhead][NV], ur[kAhead][NV], lr[kAhead];
             ldw<NT>(xhat, T, lane, xT);
             env.grads(xT, opaque(ql), vx);                     // V_x = l_x^f
@@ -900,6 +1005,18 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
         // rejected anyway -- most of a Reservoir search -- from writing much.  `complete`: this column's last try ran to
         // the end of the horizon.  (Two step sizes per pass, HVAC: nothing is written, the accepted one is rolled out again.)
         constexpr bool kStoreWhileSearching = NA == 1;
+        // ... but not the passes that are all but certain to be rejected: the step size a column accepts moves by at
+        // most a position or two from one iteration to the next (Reservoir, cfg5: never below index 3 of 11, measured with
+        // tools/probes/cfg5_trace.py), so the passes more than one position before the SMALLEST index any column of the
+        // wave accepted last time only answer "J(alpha) <= J_hat?" and write nothing -- 40 % of the kernel's stores went
+        // into candidates that were thrown away.  A column that accepts in such a pass after all is rolled out again
+        // below (`complete` stays false), so the results do not depend on the guess.
+        int store_from = 0;
+        if (kStoreWhileSearching) {
+            store_from = cfg.n_alphas;
+            for (int v = 0; v < cfg.n_alphas; ++v)
+                if (__any(searching && last_index == v)) { store_from = v - 1; break; }
+        }
         bool complete = false;
         for (int ai = 0; ai < cfg.n_alphas && __any(searching && !accept); ai += NA) {
             float al[NA], J[NA];
@@ -907,9 +1024,14 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
             for (int k = 0; k < NA; ++k) al[k] = cfg.alphas[ai + k < cfg.n_alphas ? ai + k : ai];
             const bool trying_now = searching && !accept;
             bool stopped = false;
-            rollout(std::true_type{}, std::integral_constant<bool, kStoreWhileSearching>{}, std::integral_constant<int, NA>{}, al,
-                    uhat, kStoreWhileSearching && trying_now, xc, uc, cc, J, trying_now, rJ, true, &stopped);
-            if (trying_now) complete = kStoreWhileSearching && !stopped;
+            const bool storing = kStoreWhileSearching && ai >= store_from;         // wave-uniform
+            if (storing)
+                rollout(std::true_type{}, std::integral_constant<bool, kStoreWhileSearching>{}, std::integral_constant<int, NA>{}, al,
+                        uhat, trying_now, xc, uc, cc, J, trying_now, rJ, true, &stopped);
+            else
+                rollout(std::true_type{}, std::false_type{}, std::integral_constant<int, NA>{}, al,
+                        uhat, false, xc, uc, cc, J, trying_now, rJ, true, &stopped);
+            if (trying_now) complete = storing && !stopped;
 #pragma unroll
             for (int k = 0; k < NA; ++k) {                                     // in the reference's order
                 const bool trying = searching && !accept && ai + k < cfg.n_alphas;
@@ -922,7 +1044,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
                 if (trying) {
                     residual = res;
                     alpha_last = alpha;
-                    if (z >= cfg.c1) accept = true;                            // :351-353
+                    if (z >= cfg.c1) { accept = true; last_index = ai + k; }   // :351-353
 #ifdef TFMPC_CFG5_TRACE
                     if (g_cfg5_trace && q == 0 && live && iteration + attempts < 16 && ai + k < 11) {
                         int *tr = g_cfg5_trace + ((size_t)b * 16 + iteration + attempts) * 12;
