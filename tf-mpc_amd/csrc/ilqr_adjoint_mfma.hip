@@ -1005,17 +1005,17 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
         // rejected anyway -- most of a Reservoir search -- from writing much.  `complete`: this column's last try ran to
         // the end of the horizon.  (Two step sizes per pass, HVAC: nothing is written, the accepted one is rolled out again.)
         constexpr bool kStoreWhileSearching = NA == 1;
-        // ... but not the passes that are all but certain to be rejected: the step size a column accepts moves by at
-        // most a position or two from one iteration to the next (Reservoir, cfg5: never below index 3 of 11, measured with
-        // tools/probes/cfg5_trace.py), so the passes more than one position before the SMALLEST index any column of the
-        // wave accepted last time only answer "J(alpha) <= J_hat?" and write nothing -- 40 % of the kernel's stores went
-        // into candidates that were thrown away.  A column that accepts in such a pass after all is rolled out again
-        // below (`complete` stays false), so the results do not depend on the guess.
+        // ... but not the passes that are all but certain to be rejected: the step size a column accepts rarely moves to
+        // an EARLIER position from one iteration to the next (Reservoir, cfg5: never below index 3 of 11; tools/probes/
+        // cfg5_trace.py), so the passes before the SMALLEST index any column of the wave accepted last time only answer
+        // "J(alpha) <= J_hat?" and write nothing -- a third of the kernel's stores went into candidates that were thrown
+        // away (cfg5 Reservoir 19.1 -> 17.9 ms; with a margin of one position: 19.4 -> 19.1).  A column that accepts in
+        // such a pass after all is rolled out again below (`complete` stays false): the results do not depend on the guess.
         int store_from = 0;
         if (kStoreWhileSearching) {
             store_from = cfg.n_alphas;
             for (int v = 0; v < cfg.n_alphas; ++v)
-                if (__any(searching && last_index == v)) { store_from = v - 1; break; }
+                if (__any(searching && last_index == v)) { store_from = v; break; }
         }
         bool complete = false;
         for (int ai = 0; ai < cfg.n_alphas && __any(searching && !accept); ai += NA) {

@@ -7,7 +7,7 @@ import numpy as np, torch, problems
 from tfmpc.envs.hvac import HVAC
 from tfmpc.envs.reservoir import Reservoir
 from tfmpc.solvers.ilqr import iLQR
-n, T = 32, 100
+n, T = int(os.environ.get("CFG5_N", "32")), 100
 Bs = [int(a) for a in sys.argv[1:]] or [4096, 8192, 16384, 24576, 32768, 49152, 65536]
 rng = np.random.default_rng(4)
 for kind in ("hvac", "reservoir"):
@@ -23,5 +23,5 @@ for kind in ("hvac", "reservoir"):
             for _ in range(3):
                 t0 = time.perf_counter(); out = s.solve_device(x0, T, u_init=u0, workspace=out["workspace"]); torch.cuda.synchronize()
                 best = min(best, time.perf_counter() - t0)
-        print(f"{kind:9s} B = {B:6d} ({B / 16 / 1024:.2f} waves per SIMD): {best * 1e3:7.2f} ms, {B * 12 / best / 1e6:6.2f} M iterations/s", flush=True)
+        print(f"{kind:9s} B = {B:6d} ({B / 16 / 1024:.2f} waves per SIMD, n = {n}): {best * 1e3:7.2f} ms, {B * 12 / best / 1e6:6.2f} M iterations/s", flush=True)
         del out
