@@ -218,6 +218,9 @@ int tfmpc_ilqr_forward_f32(const TfmpcEnv *env, int B, int T, const float *x, co
                            float *states, float *actions, float *costs, float *J, float *residual,
                            void *stream);
 
+/* Scratch of tfmpc_ilqr_solve_f32, a function of the shape alone (the env kind is not known here): per instance the
+ * gains K, k and one candidate trajectory; for n = m = 2 a line-search block per wavefront; for n = m <= 32 the two
+ * wave-major trajectory buffers of the 16-instances-per-wave HVAC / Reservoir kernel.  256-byte aligned base. */
 size_t tfmpc_ilqr_workspace_bytes(int B, int n, int m, int T);
 
 /* iLQR.solve (ilqr.py:214-283) in ONE launch: each wave runs its instance's whole
