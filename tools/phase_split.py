@@ -2,7 +2,7 @@
 Riccati sweep and the rollout.  Times the fused solve, the sweep alone (tfmpc_lqr_backward_f32 without
 value outputs), the rollout alone (tfmpc_lqr_forward_f32 on the stored policy), and the two launched
 concurrently on two streams.  Run on the GPU box: python tools/phase_split.py"""
-import ctypes, sys, time
+import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for _p in ('tf-mpc_amd', 'tests', ''): sys.path.insert(0, os.path.join(ROOT, _p))
 import numpy as np, torch, problems
