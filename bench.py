@@ -24,6 +24,7 @@ dominant kernel and `cpu_baseline` (the oracle's C port timed on this host).
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -358,7 +359,6 @@ def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a torch.distributed.run child
     process (never a re-exec: this process has not touched the GPU and never will) and hand back its exit code."""
     import socket
-    import subprocess
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
@@ -366,6 +366,47 @@ def self_launch(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.run(cmd, env=env).returncode
+
+
+def spawn_extras(args):
+    """Start the child that measures `extra`; it blocks on stdin until collect_extras() releases it."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--extras-only", "--batch", str(args.batch)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    return subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def collect_extras(child, timeout=900):
+    """Release the child, wait for its JSON object; any failure becomes an `error` entry, never an exception."""
+    try:
+        out, err = child.communicate("go\n", timeout=timeout)
+        if child.returncode != 0:
+            return {"error": f"the extras process exited with {child.returncode}", "stderr_tail": err[-600:]}
+        return json.loads(out.strip().splitlines()[-1])
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.communicate()
+        return {"error": f"the extras process did not finish within {timeout} s"}
+    except Exception as exc:                                  # noqa: BLE001 -- secondary numbers must never cost the headline line
+        return {"error": repr(exc)}
+
+
+def extras_only(args):
+    """Child side: secondary numbers of a single-GPU run (the iLQR-API line, the other BASELINE configs, the numpy rate)."""
+    import torch                                              # (imported while waiting: importing does not touch the GPU)
+    if not sys.stdin.readline():
+        return 1                                              # the parent went away before the headline was measured
+    n, m, T, B = N_STATE, N_ACTION, HORIZON, args.batch
+    extra = {}
+    try:
+        extra["ilqr_api"] = ilqr_api_rate(n, m, T, B)
+        extra["other_configs"] = other_config_rates()
+    except Exception as exc:                                  # noqa: BLE001
+        extra["other_configs_error"] = repr(exc)
+    if not args.no_cpu_baseline:
+        extra["cpu_numpy_single_instance"] = numpy_single_instance_rate(n, m, T)
+    print(json.dumps(extra), flush=True)
+    return 0
 
 
 def main():
@@ -376,6 +417,9 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="instances per GPU (default = BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary iLQR-API measurement (profiling runs)")
+    ap.add_argument("--extras-only", action="store_true",
+                    help="internal: the child process of a single-GPU run that measures the secondary numbers (`extra`); "
+                         "it waits for a line on stdin before it touches the GPU and prints one JSON object")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="TEST ONLY: no GPU work; a fixed-sleep stand-in step drives the multi-rank control flow "
                          "(barriers, MAX over ranks, the final gather) over gloo so it can be tested without GPUs")
@@ -387,6 +431,8 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
     if args.dry_run_cpu:
         return dry_run_cpu(args)
+    if args.extras_only:
+        return extras_only(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -394,6 +440,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # The secondary numbers (`extra`) run in a CHILD process, started here -- before this process touches the GPU (no
+    # exec after GPU initialisation) -- and idle until the headline measurement is over: whatever happens in one of the
+    # secondary kernels, the headline line is printed.
+    extras_child = spawn_extras(args) if (world == 1 and not args.no_extra) else None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -519,15 +569,8 @@ def main():
             line["gather_error"] = gather_error
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, m, T)
-        if world == 1 and not args.no_extra:
-            line["extra"] = {}
-            try:                                    # secondary numbers must never cost the headline line
-                line["extra"]["ilqr_api"] = ilqr_api_rate(n, m, T, B)
-                line["extra"]["other_configs"] = other_config_rates()
-            except Exception as exc:
-                line["extra"]["other_configs_error"] = repr(exc)
-            if not args.no_cpu_baseline:
-                line["extra"]["cpu_numpy_single_instance"] = numpy_single_instance_rate(n, m, T)
+        if extras_child is not None:
+            line["extra"] = collect_extras(extras_child)
         print(json.dumps(line), flush=True)
 
     if world > 1:
@@ -536,4 +579,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

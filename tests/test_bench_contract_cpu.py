@@ -57,3 +57,27 @@ def test_gpus_flag_must_match_the_launcher():
     out = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--dry-run-cpu"], cwd=ROOT,
                          env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
+
+
+def test_secondary_numbers_come_from_a_child_that_cannot_cost_the_headline_line():
+    """bench.py measures `extra` in a child process started BEFORE the parent touches the GPU and released over stdin
+    after the headline measurement; a child that dies, prints junk or hangs becomes an `error` entry."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    def child(code):
+        return subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, text=True)
+
+    good = bench.collect_extras(child("import sys, json; assert sys.stdin.readline() == 'go\\n'; print('noise'); print(json.dumps({'a': 1}))"))
+    assert good == {"a": 1}
+    died = bench.collect_extras(child("import sys; sys.stdin.readline(); sys.stderr.write('boom'); sys.exit(3)"))
+    assert "exited with 3" in died["error"] and "boom" in died["stderr_tail"]
+    junk = bench.collect_extras(child("import sys; sys.stdin.readline(); print('not json')"))
+    assert "error" in junk
+    hung = bench.collect_extras(child("import sys, time; sys.stdin.readline(); time.sleep(60)"), timeout=2)
+    assert "did not finish" in hung["error"]
+    # the child side leaves quietly when the parent goes away before releasing it
+    out = subprocess.run([sys.executable, "bench.py", "--extras-only"], cwd=ROOT, stdin=subprocess.DEVNULL,
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 1 and out.stdout.strip() == ""
