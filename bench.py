@@ -202,7 +202,8 @@ def other_config_rates():
     data = [(torch.as_tensor(np.random.default_rng(100 + i).uniform(0, 10, size=(Bn, 2, 1)).astype(np.float32), device="cuda"),
              solver.random_actions(50, Bn, seed=100 + i)) for i in range(8)]
     ws, outs = [None] * 8, [None] * 8
-    for rep in range(3):
+    timed_reps = 6                                  # 48 batches: the slowest instance's tail (13 ms) is paid once at the end
+    for rep in range(1 + timed_reps):
         if rep == 1:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -212,9 +213,10 @@ def other_config_rates():
                 ws[i] = outs[i]["workspace"]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    its = sum(float((o["iterations"].double() + 1).sum()) for o in outs) * 2
+    its = sum(float((o["iterations"].double() + 1).sum()) for o in outs) * timed_reps
     res["cfg4_navigation_ilqr"]["sustained_8_batches_in_flight"] = {
-        "ms_per_batch": dt / 16 * 1e3, "iterations_per_s": its / dt, "roofline": roofline_hbm(1820 * its, dt, None)}
+        "ms_per_batch": dt / (8 * timed_reps) * 1e3, "iterations_per_s": its / dt, "batches_timed": 8 * timed_reps,
+        "roofline": roofline_hbm(1820 * its, dt, None)}
     del ws, outs, data
     # cfg5: n = m = 32, T = 100 -> read x, u 25.7 KB + write x, u, c 26.1 KB = 51.8 KB per iteration
     for kind, kernel_tag in (("hvac", "ilqr_adjoint_mfma_kernel<3"), ("reservoir", "ilqr_adjoint_mfma_kernel<4")):
