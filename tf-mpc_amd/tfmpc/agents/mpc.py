@@ -19,10 +19,21 @@ class MPC:
         self.seed = seed
         self._plan = None           # actions of the previous solve, [B|-, steps, m, 1]
         self.iterations = []        # per step: iterations the solve took (int or array[B])
+        # on_device: nothing is read back to the host inside __call__ (iteration counts stay device tensors, the start
+        # actions of cold solves come from `start_actions`, prepared up front) -- what a captured episode needs
+        # (runners.Runner.capture): no synchronisation and no host-to-device copy between the launches
+        self.on_device = False
+        self.start_actions = None   # on_device: per step the [B|-, steps, m, 1] start actions of a cold solve
 
     def reset(self):
         self._plan = None
         self.iterations = []
+
+    def prepare_start_actions(self, batch):
+        """The start actions of every (cold) re-solve of an episode, generated once: step t gets
+        ``solver.random_actions(horizon - t, batch, seed + t)`` -- what ``__call__`` would draw."""
+        self.start_actions = [self.solver.random_actions(self.horizon - t, batch, None if self.seed is None else self.seed + t)
+                              for t in range(self.horizon if not self.warm_start else 1)]
 
     def __call__(self, state, timestep):
         steps_to_go = self.horizon - int(timestep)
@@ -30,9 +41,14 @@ class MPC:
         if self.warm_start and self._plan is not None and self._plan.shape[-3] - 1 == steps_to_go:
             u_init = self._plan[..., 1:, :, :]
         seed = None if self.seed is None else self.seed + int(timestep)
+        if u_init is None and self.on_device:
+            u_init = self.start_actions[int(timestep)]
         out = self.solver.solve_device(state, steps_to_go, u_init=u_init, seed=seed)
         actions = out["actions"] if out["batched"] else out["actions"][0]
         self._plan = actions
         its = out["iterations"]
-        self.iterations.append(its.cpu().numpy() if out["batched"] else int(its[0]))
+        if self.on_device:
+            self.iterations.append(its if out["batched"] else its[0])
+        else:
+            self.iterations.append(its.cpu().numpy() if out["batched"] else int(its[0]))
         return actions[..., 0, :, :]            # first action, column vector(s) [.., m, 1]

@@ -62,7 +62,9 @@ class Reservoir(DiffEnv, GymEnv):
 
     def _noise_from_sample(self, sample, state):
         import torch
-        mean = torch.as_tensor(self.rain_shape * self.rain_scale, device=state.device)
+        mean = getattr(self, "_rain_mean_dev", None)     # kept on the device: no host-to-device copy per step (graph capture)
+        if mean is None or mean.device != state.device:
+            mean = self._rain_mean_dev = torch.as_tensor(self.rain_shape * self.rain_scale, device=state.device)
         return (sample - mean).expand_as(state)         # an injected rainfall draw replaces the mean rainfall
 
     @classmethod
