@@ -10,6 +10,7 @@ from tfmpc.envs.navigation import Navigation
 from tfmpc.solvers.ilqr import iLQR
 
 B, T = 16384, 50
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 3          # timed repetitions per stream
 solver = iLQR(Navigation.load(problems.NAV_CONFIG))
 res = {"single_batch": {}, "sustained": {}}
 
@@ -32,7 +33,7 @@ for n_streams in (1, 2, 4, 8):
     data = [batch(100 + i) for i in range(n_streams)]
     ws = [None] * n_streams
     outs = [None] * n_streams
-    for rep in range(4):                      # rep 0 = warm-up (allocates the workspaces)
+    for rep in range(1 + REPS):               # rep 0 = warm-up (allocates the workspaces)
         if rep == 1:
             torch.cuda.synchronize(); t = time.perf_counter()
         for i, s in enumerate(streams):
@@ -40,6 +41,6 @@ for n_streams in (1, 2, 4, 8):
                 outs[i] = solver.solve_device(data[i][0], T, u_init=data[i][1], workspace=ws[i])
                 ws[i] = outs[i]["workspace"]
     torch.cuda.synchronize(); dt = time.perf_counter() - t
-    its = sum(float((o["iterations"].double() + 1).sum()) for o in outs) * 3
-    res["sustained"][f"{n_streams}_batches_in_flight"] = {"ms_per_batch": dt / (3 * n_streams) * 1e3, "it_per_s": its / dt}
+    its = sum(float((o["iterations"].double() + 1).sum()) for o in outs) * REPS
+    res["sustained"][f"{n_streams}_batches_in_flight"] = {"ms_per_batch": dt / (REPS * n_streams) * 1e3, "it_per_s": its / dt}
 print(json.dumps(res, indent=1))
