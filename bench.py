@@ -166,8 +166,9 @@ def other_config_rates():
     from tfmpc.solvers.lqr import LQR
 
     def timed(fn, reps):
-        out = fn(None)
-        torch.cuda.synchronize()
+        out = fn(None)                               # allocates the workspace
+        out = fn(out["workspace"])                   # one more untimed launch: the first launches after host-side problem
+        torch.cuda.synchronize()                     # generation find the GPU idle (lower clocks)
         t0 = time.perf_counter()
         for _ in range(reps):
             out = fn(out["workspace"])
@@ -239,7 +240,7 @@ def other_config_rates():
         else:
             env, x0 = Reservoir.load(dict(problems.reservoir_config(n, seed=5))), rng.uniform(50, 75, size=(B, n, 1)).astype(np.float32)
         solver = iLQR(env, max_iterations=12)
-        res[f"cfg5_{kind}_ilqr_n32"] = ilqr_line(solver, x0, T, solver.random_actions(T, B, seed=5), 1,
+        res[f"cfg5_{kind}_ilqr_n32"] = ilqr_line(solver, x0, T, solver.random_actions(T, B, seed=5), 3,
                                                  alg_bytes=4 * (2 * (T + 1) * n + 2 * T * n + (T + 1)), pmc=(kernel_tag, 32768 * 12))
     # the reference's own env configs (hvac6.config.json n = 6, res4.config.json n = 4) at a large batch
     for name, env, x0r in (("hvac6", HVAC.load(dict(problems.HVAC6_CONFIG)), problems.HVAC6_X0),
