@@ -177,11 +177,15 @@ def test_navigation_every_iteration():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("spectrum", ["narrow", "reference"])
 @pytest.mark.parametrize("n,m,T,bound", [(16, 8, 20, None), (16, 8, 20, 0.5), (12, 6, 16, 1.0), (32, 16, 12, None), (24, 12, 10, None)])
-def test_lq_env_every_iteration(n, m, T, bound):
-    """Matrix-core LQ kernels: ilqr_lq_mfma (16x8), ilqr_lq_box_mfma (control limits), ilqr_lq_mfma32 (32x16)."""
+def test_lq_env_every_iteration(n, m, T, bound, spectrum):
+    """Matrix-core LQ kernels: ilqr_lq_mfma (16x8), ilqr_lq_box_mfma (control limits), ilqr_lq_mfma32 (32x16).
+    spectrum "reference": C drawn as the reference's make_lqr does (sklearn make_spd_matrix, eigenvalues ~1e-3 .. n + m,
+    cond ~ 550; tests/problems.py:make_lqr_batch_spd) instead of eigenvalues in [1, 2]."""
     B = 6
-    F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=3 * n + m)
+    gen = problems.make_lqr_batch_spd if spectrum == "reference" else problems.make_lqr_batch_fast
+    F, f, C, c, x0 = gen(B, n, m, seed=3 * n + m)
     F = F * 0.25 * np.sqrt(16.0 / n)
     low, high = (None, None) if bound is None else (-bound, bound)
     env = LQEnv(F, f, C, c, low=low, high=high)
@@ -189,4 +193,4 @@ def test_lq_env_every_iteration(n, m, T, bound):
     hi = 1.0 if bound is None else bound
     u0 = np.clip(0.1 * np.random.default_rng(1).normal(size=(B, T, m, 1)), -hi, hi).astype(np.float32)
     _stepwise(lambda k: iLQR(env, max_iterations=k), oenv(np.float64), oenv(np.float32),
-              x0.astype(np.float32)[..., None], u0, T, 3, 1)
+              x0.astype(np.float32)[..., None], u0, T, 3, 2 if spectrum == "reference" else 1)
