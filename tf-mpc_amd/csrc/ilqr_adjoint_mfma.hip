@@ -238,7 +238,7 @@ __device__ __forceinline__ void stv(bf16_t *p, int n, int q, bool keep, const fl
             }
         }
 }
-// ---- the solver's OWN trajectory buffers are WAVE-major: [time step][tile][lane] pieces of this lane's four rows, so a
+// ---- the solver's OWN trajectory buffers are WAVE-major: [time step][column][tile][lane quarter] pieces of a lane's four rows, so a
 // load / store instruction of the wave moves one contiguous KB (half a KB in 16-bit containers) instead of sixteen
 // 64-byte segments 12.8 KB apart.  Instance-major arrays (the ABI's inputs and outputs) are touched once each: the start
 // rollout reads u_init, the end of the kernel copies the nominal trajectory out.  Measured (tools/probes/traj_layout_probe.hip,
@@ -250,7 +250,7 @@ __device__ __forceinline__ void ldw(const float *p, int t, int lane, float (&o)[
 {
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
-        const f32x4 v = gld(reinterpret_cast<const f32x4 *>(p + ((size_t)t * NT + b) * kTileElems + 4 * lane));
+        const f32x4 v = gld(reinterpret_cast<const f32x4 *>(p + ((size_t)t * NT * kTileElems) + 4 * (lane + 4 * b)));
         o[4 * b] = v[0]; o[4 * b + 1] = v[1]; o[4 * b + 2] = v[2]; o[4 * b + 3] = v[3];
     }
 }
@@ -260,7 +260,7 @@ __device__ __forceinline__ void stw(float *p, int t, int lane, bool keep, const 
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
         const f32x4 w = {v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]};
-        if (keep) gst(reinterpret_cast<f32x4 *>(p + ((size_t)t * NT + b) * kTileElems + 4 * lane), w);
+        if (keep) gst(reinterpret_cast<f32x4 *>(p + ((size_t)t * NT * kTileElems) + 4 * (lane + 4 * b)), w);
     }
 }
 template <int NT>
@@ -268,7 +268,7 @@ __device__ __forceinline__ void ldw(const bf16_t *p, int t, int lane, float (&o)
 {
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
-        const u32x2 w = gld(reinterpret_cast<const u32x2 *>(p + ((size_t)t * NT + b) * kTileElems + 4 * lane));
+        const u32x2 w = gld(reinterpret_cast<const u32x2 *>(p + ((size_t)t * NT * kTileElems) + 4 * (lane + 4 * b)));
         o[4 * b] = __uint_as_float(w.x << 16);
         o[4 * b + 1] = __uint_as_float(w.x & 0xFFFF0000u);
         o[4 * b + 2] = __uint_as_float(w.y << 16);
@@ -283,7 +283,7 @@ __device__ __forceinline__ void stw(bf16_t *p, int t, int lane, bool keep, const
         u32x2 w;
         w.x = (unsigned)narrow(v[4 * b]) | ((unsigned)narrow(v[4 * b + 1]) << 16);
         w.y = (unsigned)narrow(v[4 * b + 2]) | ((unsigned)narrow(v[4 * b + 3]) << 16);
-        if (keep) gst(reinterpret_cast<u32x2 *>(p + ((size_t)t * NT + b) * kTileElems + 4 * lane), w);
+        if (keep) gst(reinterpret_cast<u32x2 *>(p + ((size_t)t * NT * kTileElems) + 4 * (lane + 4 * b)), w);
     }
 }
 constexpr int kCostLd = 64;                      // stage costs: [time step][instance of the wave] (up to 16 columns x 4)
@@ -758,6 +758,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
     // PK instances per column (n <= 16 / PK): lane quarter q belongs to sub-instance q / (4 / PK) and holds its rows
     // 4 ql .. 4 ql + 3, ql = q mod (4 / PK).  Everything below indexes rows with ql; only the MFMA operands know q.
     const int ql = q & (4 / PK - 1);
+    // position of this lane's 16-byte piece inside a wave-major tile: COLUMN-major, so that the 64 bytes of one column
+    // (instance; 128 with two tiles) are contiguous -- a store masked by column (a line-search pass that only some columns still try) then
+    // writes whole 64-byte sectors instead of 16-byte pieces 256 bytes apart
+    const int wl = j * NT * 4 + q;                      // [column][tile][lane quarter]: + 4 per tile (ldw / stw)
     const int b_raw = (blockIdx.x * kCols + j) * PK + q / (4 / PK);
     const bool live = b_raw < a.B;                       // the last wave may carry empty columns: they compute on the
     const size_t b = live ? b_raw : a.B - 1;             // last instance's data and store nothing
@@ -785,7 +789,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
         ubuf[i] = xbuf[i] + kXs;
         cbuf[i] = ubuf[i] + kUs + ccol;
     }
-    unsigned char *const ksel = wave_ws + 2 * (kXs + kUs + kCs) * sizeof(float) + lane;
+    unsigned char *const ksel = wave_ws + 2 * (kXs + kUs + kCs) * sizeof(float) + (j * 4 + q);     // [t][column][lane quarter]
     const float *const x0p = a.x0 + b * n;
     int flip = 0;
 
@@ -821,7 +825,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
         float x[NA][NV], ur[kAheadRoll][NV], J[NA];
         unsigned kb[kAheadRoll];
         ldv<NT, VW>(x0p, n, ql, x[0]);
-        if (STORE) stw<NT>(xs, 0, lane, keep, x[0]);
+        if (STORE) stw<NT>(xs, 0, wl, keep, x[0]);
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             J[k] = 0.0f;
@@ -830,7 +834,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
         }
         auto request = [&](int t, float (&u_)[NV], unsigned &k_) {
             if constexpr (SEARCH) {
-                ldw<NT>(uh, t, lane, u_);
+                ldw<NT>(uh, t, wl, u_);
                 k_ = gld(ksel + (size_t)t * kWave);
             } else {
                 ldv<NT, VW>(uh + (size_t)t * m, m, ql, u_);                 // the injected start actions: instance-major
@@ -893,8 +897,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
                         if (SEARCH && trace_fa[k] < 0 && J[k] > reject_above) trace_fa[k] = t;
 #endif
                         if (STORE) {
-                            stw<NT>(us, t, lane, keep, u[k]);
-                            stw<NT>(xs, t + 1, lane, keep, xn);
+                            stw<NT>(us, t, wl, keep, u[k]);
+                            stw<NT>(xs, t + 1, wl, keep, xn);
                             if (keep && ql == 0) stc(cs + (size_t)t * kCostLd, c);
                         }
 #pragma unroll
@@ -935,15 +939,15 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
             env.fence();
             env.template load_backward<PK>(genv, opaque(j), opaque(q), A, op_rest);
             float vx[NV], xT[NV], p1[NV], ka[NV], xr[kAhead][NV], ur[kAhead][NV], lr[kAhead];
-            ldw<NT>(xhat, T, lane, xT);
+            ldw<NT>(xhat, T, wl, xT);
             env.grads(xT, opaque(ql), vx);                     // V_x = l_x^f
 #pragma unroll
             for (int e = 0; e < NV; ++e) { p1[e] = 0.0f; ka[e] = 0.0f; }
             rJ = ldc(chat + (size_t)T * kCostLd);                                    // the stage costs of the nominal trajectory are the l_t
             float gsum = 0.0f;
             auto request = [&](int t, float (&x_)[NV], float (&u_)[NV], float &l_) {
-                ldw<NT>(xhat, t, lane, x_);
-                ldw<NT>(uhat, t, lane, u_);
+                ldw<NT>(xhat, t, wl, x_);
+                ldw<NT>(uhat, t, wl, u_);
                 l_ = ldc(chat + (size_t)t * kCostLd);
             };
 #pragma unroll
@@ -1080,10 +1084,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
         float *xdst = a.states + b * (T + 1) * n, *udst = a.actions + b * T * m, *cdst = a.costs + b * (T + 1);
         for (int t = 0; t <= T; ++t) {
             float v[NV];
-            ldw<NT>(xsrc, t, lane, v);
+            ldw<NT>(xsrc, t, wl, v);
             stv<NT, VW>(xdst + (size_t)t * n, n, ql, live, v);
             if (t < T) {
-                ldw<NT>(usrc, t, lane, v);
+                ldw<NT>(usrc, t, wl, v);
                 stv<NT, VW>(udst + (size_t)t * m, m, ql, live, v);
             }
             if (ql == 0) { const float c = ldc(csrc + (size_t)t * kCostLd); if (live) gst(cdst + t, c); }
