@@ -471,8 +471,8 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
     static constexpr float CAP_AIR = 1.006f, COST_AIR = 1.0f, TEMP_AIR = 40.0f, TIME_DELTA = 1.0f;
     static constexpr float PENALTY = 20000.0f, SET_POINT_PENALTY = 10.0f;
     static constexpr int kC0 = 0;                       // LDS slot
-    // step sizes per line-search pass: the HVAC step is short and latency-bound (two chains cover each other's waits:
-    // 20.1 -> 16.6 ms on cfg5), the Reservoir step is bound by vector issue (a speculative second chain only adds work)
+    // step sizes per line-search pass: two independent chains give a wave something to issue while the other chain waits
+    // (cfg5 HVAC: 20.1 -> 16.6 ms in round 1; one step size per pass with stored candidates, re-tried in round 2: 18.0 vs 14.1 ms)
     static constexpr int kSearchAlphas = 2;
     float lo[NV], hi[NV], am[NV], rcap[NV];
     const float *lds;
@@ -602,7 +602,12 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
 template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
     static constexpr int NV = 4 * NT;
     static constexpr int kRain = 0, kDii = 1, kLP = 2, kHP = 3, kSP = 4;      // LDS slots
-    static constexpr int kSearchAlphas = NT == 1 ? 2 : 1;     // see EnvM<HVAC>; the one-tile variants run few waves
+    // see EnvM<HVAC>.  Two tiles, round 2: with a column's rows contiguous in the buffers the single-step-size search that
+    // writes its candidates (53 GB of HBM traffic per cfg5 launch, 3.75 G vector instructions) and the two-step-size
+    // search that writes nothing and rolls the accepted size out again (41 GB, 4.66 G instructions, 23 spilled registers)
+    // take the same time on a box with fast memory (13.8 vs 13.4 ms); the one that moves fewer bytes is kept -- cfg5
+    // Reservoir varied by 20 % between boxes while it was the heavier on HBM.
+    static constexpr int kSearchAlphas = 2;
     float rcap[NV], lo[NV], hi[NV];                  // 1 / max_res_cap: x / cap is x times the rounded reciprocal everywhere
     const float *lds;
 
@@ -1008,7 +1013,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
         // then final the moment the column accepts: no second rollout), and the early stop keeps the passes that are
         // rejected anyway -- most of a Reservoir search -- from writing much.  `complete`: this column's last try ran to
         // the end of the horizon.  (Two step sizes per pass, HVAC: nothing is written, the accepted one is rolled out again.)
-        constexpr bool kStoreWhileSearching = NA == 1;
+        constexpr bool kStoreWhileSearching = NA == 1;      // (no env of the current tree searches one step size per pass)
         // ... but not the passes that are all but certain to be rejected: the step size a column accepts rarely moves to
         // an EARLIER position from one iteration to the next (Reservoir, cfg5: never below index 3 of 11; tools/probes/
         // cfg5_trace.py), so the passes before the SMALLEST index any column of the wave accepted last time only answer
