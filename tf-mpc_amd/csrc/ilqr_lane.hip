@@ -782,7 +782,10 @@ __global__ __launch_bounds__(64, 4) void ilqr_group_solve_kernel(TfmpcEnv genv, 
     const int my_alpha_idx = (gl < cfg.n_alphas) ? gl : cfg.n_alphas - 1;
     const float my_alpha = cfg.alphas[my_alpha_idx];
     float *scratch = a.scratch + (size_t)blockIdx.x * ScratchSink<N, M>::rows(T) * 64;
-    const ScratchSink<N, M> sink{scratch + threadIdx.x, T, gl < cfg.n_alphas};
+    // every lane of the group writes its column, also lanes 11 .. 15 (they repeat the last step size and their column is
+    // never adopted): the 16 lanes of a group are ONE 64-byte sector per scratch row -- 11 of 16 would be a partial-sector
+    // write (read-modify-write in the memory system)
+    const ScratchSink<N, M> sink{scratch + threadIdx.x, T, true};
     Store st{lane_lds + grp, T};
 
     const int b = blockIdx.x * GROUPS + grp;
