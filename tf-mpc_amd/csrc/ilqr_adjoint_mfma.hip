@@ -238,9 +238,10 @@ __device__ __forceinline__ void stv(bf16_t *p, int n, int q, bool keep, const fl
             }
         }
 }
-// ---- the solver's OWN trajectory buffers are WAVE-major: [time step][column][tile][lane quarter] pieces of a lane's four rows, so a
-// load / store instruction of the wave moves one contiguous KB (half a KB in 16-bit containers) instead of sixteen
-// 64-byte segments 12.8 KB apart.  Instance-major arrays (the ABI's inputs and outputs) are touched once each: the start
+// ---- the solver's OWN trajectory buffers are WAVE-major: [time step][column][tile][lane quarter] 16-byte pieces (a lane's four
+// rows of one tile; `lane` below is the piece index column * 4 NT + quarter, + 4 per tile).  A time step of the wave is one
+// contiguous 2 KB (two tiles; half of that in 16-bit containers) instead of sixteen 64-byte segments 12.8 KB apart, and
+// the 128 bytes of ONE column are contiguous, so that a store masked by column writes whole 64-byte sectors.  Instance-major arrays (the ABI's inputs and outputs) are touched once each: the start
 // rollout reads u_init, the end of the kernel copies the nominal trajectory out.  Measured (tools/probes/traj_layout_probe.hip,
 // same access sequence without the arithmetic): scattered 64-byte stores sustain 3.5 TB/s, contiguous ones 6.1 TB/s --
 // a storing pass of the instance-major layout took 0.37 ms, longer than its arithmetic (0.15 ms).
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
 
     // trajectories of this wave, wave-major (see ldw): two buffers of states / actions / stage costs in the wave's slice
     // of the workspace, the nominal one is [flip]; at the end the nominal trajectory is copied (16-bit containers:
-    // widened) into the instance-major output arrays.  Then the selector bytes [t][lane]: 4 NT bits each.
+    // widened) into the instance-major output arrays.  Then the selector bytes [t][column][lane quarter]: 4 NT bits each.
     const size_t kXs = (size_t)(T + 1) * NT * kTileElems, kUs = (size_t)T * NT * kTileElems, kCs = (size_t)(T + 1) * kCostLd;
     unsigned char *const wave_ws = static_cast<unsigned char *>(a.wave_ws) + (size_t)blockIdx.x * adjoint_mfma_wave_bytes(NT, T);
     TT *xbuf[2], *ubuf[2], *cbuf[2];
