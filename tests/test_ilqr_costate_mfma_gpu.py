@@ -79,8 +79,9 @@ def test_reservoir_columns_finish_at_different_times(force_kernel, n, T, B, iter
 
 @pytest.mark.parametrize("n,B", [(24, 4200), (10, 4100), (24, 40), (10, 40), (4, 3)])
 def test_default_dispatch(force_kernel, n, B):
-    """A shared env goes to the 16-per-wave kernel without any forcing at n <= 16 (any batch size) and from 4097 instances
-    at n > 16; smaller large-n batches stay on the register-resident kernels: on Reservoir all equal the wave kernel bit for bit."""
+    """A shared env goes to the 16-per-wave kernel without any forcing at n <= 16 (any batch size), on Reservoir at any n, and
+    on HVAC at n > 16 from 4097 instances (smaller large-n HVAC batches stay on the register-resident kernels): on Reservoir
+    every kernel equals the wave kernel bit for bit, whichever is dispatched."""
     env, x0 = _env("reservoir", n, B, 3)
     solver = iLQR(env, max_iterations=4)
     u0 = solver.random_actions(10, B, seed=2)

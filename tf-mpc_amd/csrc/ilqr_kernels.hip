@@ -134,7 +134,10 @@ __global__ __launch_bounds__(kWave) void ilqr_derivatives_kernel(TfmpcEnv env, i
 // (n = 16, 12, 6 / 4 at B = 1 ... 256: 3.0-5.4 ms against 3.4-5.8 for the register-resident kernels).  For n > 16 one of its waves
 // takes ~1.3x as long as a one-instance wave, so it pays once the register-resident kernels need a second round of
 // waves (4 per SIMD x 1024 SIMDs): B = 4096 6.9 / 11.3 ms against 8.2 / 12.6, B = 6144 12.3 / 19.0 against 8.6 / 12.8
-// (HVAC / Reservoir, T = 100, 12 iterations; tools/costate_mfma_check.py).
+// (HVAC / Reservoir, T = 100, 12 iterations; tools/costate_mfma_check.py).  End of round 2 (wave-major buffers, bf16 operand
+// split, two step sizes per pass; tools/costate_dispatch_sweep.py, n = 32): Reservoir 7.0-7.1 ms at B = 256 ... 4096
+// against 8.4-11.0 for the register-resident kernel -- the 16-per-wave kernel at EVERY batch size; HVAC 6.7-6.8 ms
+// against 4.5-6.75 -- the threshold stays.
 constexpr int kCostateMfmaMinBatchLarge = 4097, kCostateMfmaMinBatchSmall = 1;
 constexpr int kBlockedFrom = 12;         // state dimension from which the register-blocked products pay
 
@@ -526,7 +529,8 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
         const bool forced_lean = option_is(kOptIlqrKernel, "lean") || option_is(kOptIlqrKernel, "lean1");
         const bool forced_mfma = option_is(kOptIlqrKernel, "costate_mfma");
         if (!forced_wave && !forced_lean && ilqr_adjoint_mfma_supported(*env, *cfg) &&
-            (forced_mfma || cfg->storage_bf16 || B >= (n > 16 ? kCostateMfmaMinBatchLarge : kCostateMfmaMinBatchSmall)))
+            (forced_mfma || cfg->storage_bf16 ||
+             B >= ((n > 16 && env->kind != TFMPC_ENV_RESERVOIR) ? kCostateMfmaMinBatchLarge : kCostateMfmaMinBatchSmall)))
             return ilqr_adjoint_mfma_launch(*env, *cfg, aa, st);
         if (!forced_wave && ilqr_adjoint_supported(*env, *cfg)) return ilqr_adjoint_launch(*env, *cfg, aa, st);
     }
