@@ -51,5 +51,6 @@ for kind, NA, sweep_w, reroll in (("hvac", 2, 1.0, True), ("reservoir", 1, 1.5, 
     fixed = total(tr, lambda s, prev, acc, act: np.arange(B), NA, sweep_w, reroll)
     pred = total(tr, lambda s, prev, acc, act: np.argsort(np.where(act, prev, 99), kind="stable")[:act.sum() + (-act.sum()) % 16], NA, sweep_w, reroll)
     best = total(tr, lambda s, prev, acc, act: np.argsort(np.where(act, np.where(acc >= 0, acc, 11), 99), kind="stable")[:act.sum() + (-act.sum()) % 16], NA, sweep_w, reroll)
-    print(f"{kind}: fixed groups {fixed / B:.1f} steps/instance, regrouped by last accepted index {pred / B:.1f} "
-          f"({fixed / pred:.2f}x), by the true index (bound) {best / B:.1f} ({fixed / best:.2f}x)")
+    per = lambda tot: tot / (B / 16) / 12               # wave-steps per wave and iteration (12 iterations)
+    print(f"{kind}: fixed groups {per(fixed):.0f} wave-steps per iteration, regrouped by last accepted index {per(pred):.0f} "
+          f"({fixed / pred:.2f}x), by the true index (bound) {per(best):.0f} ({fixed / best:.2f}x)")
