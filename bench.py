@@ -265,7 +265,9 @@ def other_config_rates():
     flop = its * T * bw_step + max(its - B, 0.0) * T * fw_step
     tf = flop / (line["ms_per_batch"] * 1e-3) / 1e12
     line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
-                        "algorithmic_flop": flop, "traffic": None}
+                        "algorithmic_flop": flop,
+                        # PMC: profiles/r02_large_tile_pmc.json, taken at 8 192 instances x 2.02 iterations (tools/large_tile_once.py)
+                        "traffic": pmc_traffic("ilqr_lq_mfma32_kernel", 8192 * 2.02, its)}
     line["kernel"] = "ilqr_lq_mfma32_kernel (2 x 2 tiles of bf16x3, trajectories in HBM); round-2 start: wave kernel, 1 123 ms"
     res["cfg5_literal_dims_ilqr_lq_n32_m16"] = line
     del solver, x0d
@@ -277,7 +279,8 @@ def other_config_rates():
     res["lqr_n32_m16"] = {"ms_per_batch": dt * 1e3, "solves_per_s": 8192 / dt, "batch": 8192, "horizon": 50,
                           "kernel": _hip_kernel_name(32, 16, 50),
                           "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                                       "frac": tf / PEAK_F32_TFLOPS, "algorithmic_flop_per_solve": lqr_flops_per_solve(32, 16, 50)}}
+                                       "frac": tf / PEAK_F32_TFLOPS, "algorithmic_flop_per_solve": lqr_flops_per_solve(32, 16, 50),
+                                       "traffic": pmc_traffic("lqr_mfma32x16_kernel", 8192, 8192)}}
     return res
 
 
