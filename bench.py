@@ -233,7 +233,7 @@ def other_config_rates():
         "roofline": roofline_hbm(1820 * its, dt, None)}
     del ws, outs, data
     # cfg5: n = m = 32, T = 100 -> read x, u 25.7 KB + write x, u, c 26.1 KB = 51.8 KB per iteration
-    for kind, kernel_tag in (("hvac", "ilqr_adjoint_mfma_kernel<3"), ("reservoir", "ilqr_adjoint_mfma_kernel<4")):
+    for kind, kernel_tag in (("hvac", "ilqr_adjoint_mfma_kernel<3, 2"), ("reservoir", "ilqr_adjoint_mfma_kernel<4, 2")):     # two-tile instantiations
         n, T, B = 32, 100, 32768
         if kind == "hvac":
             env, x0 = HVAC.load(dict(problems.hvac_config(n, seed=5))), np.full((B, n, 1), 10.0, dtype=np.float32)
@@ -243,14 +243,16 @@ def other_config_rates():
         res[f"cfg5_{kind}_ilqr_n32"] = ilqr_line(solver, x0, T, solver.random_actions(T, B, seed=5), 3,
                                                  alg_bytes=4 * (2 * (T + 1) * n + 2 * T * n + (T + 1)), pmc=(kernel_tag, 32768 * 12))
     # the reference's own env configs (hvac6.config.json n = 6, res4.config.json n = 4) at a large batch
-    for name, env, x0r in (("hvac6", HVAC.load(dict(problems.HVAC6_CONFIG)), problems.HVAC6_X0),
-                           ("res4", Reservoir.load(dict(problems.RES4_CONFIG)), problems.RES4_X0)):
+    for name, env, x0r, kernel_tag in (("hvac6", HVAC.load(dict(problems.HVAC6_CONFIG)), problems.HVAC6_X0, "ilqr_adjoint_mfma_kernel<3, 1"),
+                                       ("res4", Reservoir.load(dict(problems.RES4_CONFIG)), problems.RES4_X0, "ilqr_adjoint_mfma_kernel<4, 1")):
         B, T = 16384, 100
         n = len(x0r)
         x0 = (np.array(x0r, dtype=np.float32)[None] * rng.uniform(0.9, 1.1, size=(B, 1, 1))).astype(np.float32)
         solver = iLQR(env, max_iterations=12)
+        # PMC: profiles/r02_small_env_pmc.json (tools/small_env_once.py, 16 384 instances x 12 iterations)
         res[f"{name}_reference_config_ilqr"] = ilqr_line(solver, x0, T, solver.random_actions(T, B, seed=1), 2,
-                                                         alg_bytes=4 * (2 * (T + 1) * n + 2 * T * n + (T + 1)))
+                                                         alg_bytes=4 * (2 * (T + 1) * n + 2 * T * n + (T + 1)),
+                                                         pmc=(kernel_tag, 16384 * 12))
     # configs[4] at its literal dims (n = 32, m = 16, T = 100, B = 32 768) as iLQR on the generalised LQ env
     n, m, T, B = 32, 16, 100, 32768
     F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=6)
