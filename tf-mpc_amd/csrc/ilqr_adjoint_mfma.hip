@@ -929,7 +929,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
     {
         const float a0[1] = {0.0f};
         float J[1];
-        rollout(std::false_type{}, std::true_type{}, one_t{}, a0, a.u_init + b * T * m, live, xbuf[0], ubuf[0], cbuf[0], J);
+        // EVERY column stores its start trajectory, the empty ones of the last wave too (they run the last instance's
+        // data): the sweeps below read every column's nominal buffer, and with several instances per matrix-core column
+        // (n <= 8) a NaN left in the workspace by an earlier use would reach the live rows of the same column through
+        // the block-diagonal operand's zeros (0 x NaN).  Found by tools/probes/fuzz_costate.py / nan_workspace.py.
+        rollout(std::false_type{}, std::true_type{}, one_t{}, a0, a.u_init + b * T * m, true, xbuf[0], ubuf[0], cbuf[0], J);
     }
 
     float mu = 0.0f, delta = 1.0f;
