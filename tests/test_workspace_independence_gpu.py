@@ -102,3 +102,40 @@ def test_lqr_kernels(n, m, T, B):
     lqr = LQR(F * 0.5, f, C, c)
     x0d = lqr._prep_x0(x0)
     _check(lambda ws: lqr.solve_device(x0d, T, workspace=ws))
+
+
+def test_concurrent_streams_do_not_interfere():
+    """Solves of different families in flight on different streams (each with its own workspace) return the bits of the same
+    solves run one after the other: no kernel keeps state outside the buffers it is handed."""
+    rng = np.random.default_rng(9)
+    F, f, C, c, x0 = problems.make_lqr_batch_fast(3000, 16, 8, seed=2)
+    lqr = LQR(F * 0.4, f, C, c)
+    x0d = lqr._prep_x0(x0)
+    res = iLQR(_costate_env("reservoir", 20), max_iterations=6)
+    xr = rng.uniform(20.0, 60.0, size=(700, 20, 1)).astype(np.float32)
+    ur = res.random_actions(40, 700, seed=1)
+    nav = iLQR(Navigation.load(problems.NAV_CONFIG), max_iterations=8)
+    xn = torch.as_tensor(rng.uniform(0, 10, size=(900, 2, 1)).astype(np.float32), device="cuda")
+    un = nav.random_actions(30, 900, seed=2)
+    xr = torch.as_tensor(xr, device="cuda")
+    jobs = [lambda ws: lqr.solve_device(x0d, 40, workspace=ws),
+            lambda ws: res.solve_device(xr, 40, u_init=ur, workspace=ws),
+            lambda ws: nav.solve_device(xn, 30, u_init=un, workspace=ws)]
+    serial = []
+    for job in jobs:
+        out = job(None)
+        torch.cuda.synchronize()
+        serial.append({k: out[k].clone() for k in KEYS if k in out})
+    streams = [torch.cuda.Stream() for _ in jobs]
+    ws = [None] * len(jobs)
+    outs = [None] * len(jobs)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for i, (job, st) in enumerate(zip(jobs, streams)):
+            with torch.cuda.stream(st):
+                outs[i] = job(ws[i])
+                ws[i] = outs[i]["workspace"]
+    torch.cuda.synchronize()
+    for ref, out in zip(serial, outs):
+        for k in ref:
+            assert _same(ref[k], out[k]), k
