@@ -38,6 +38,9 @@ BUDGET = 5.0
 ALPHAS = np.geomspace(1.0, 1e-3, 11)
 
 
+MIN_DECIDED = 0.5          # share of the action entries that must have moved with a clear-cut selector (the fuzz lowers it)
+
+
 def _case(kind, n, B):
     rng = np.random.default_rng(1000 + n)
     if kind == "hvac":
@@ -108,7 +111,7 @@ def _check_iteration(o64, o32, xs_dev, us_dev, out_next, tag):
     sel_dev_high = du > 0
     sel_64_high = k64 > 0
     decided = moved & (np.abs(k64) > 0) & (margin > 1e-3)
-    assert decided.mean() > 0.5, (tag, decided.mean())
+    assert decided.mean() > MIN_DECIDED, (tag, decided.mean())
     assert np.array_equal(sel_dev_high[decided], sel_64_high[decided]), \
         (tag, "selector", int((sel_dev_high[decided] != sel_64_high[decided]).sum()), int(decided.sum()))
     # step size the device accepted: du = alpha * (bound - u)
