@@ -341,7 +341,10 @@ def dry_run_cpu(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from tfmpc.parallel import gather_trajectories
-    B, n, m, T = 64 + rank, 4, 2, 5            # uneven shards on purpose
+    from tfmpc.parallel import shard_bounds
+    n, m, T, B_total = 4, 2, 5, 64 * world + 1   # uneven block split on purpose: the first rank gets one instance more
+    lo_, hi_ = shard_bounds(B_total, world, rank)
+    B = hi_ - lo_
 
     def fence():
         if world > 1:
@@ -356,7 +359,8 @@ def dry_run_cpu(args):
     fence()
     elapsed = time.perf_counter() - t0
     states = torch.full((B, T + 1, n, 1), float(rank))
-    gathered = gather_trajectories(states, torch.zeros(B, T, m, 1), torch.zeros(B, T + 1)) if world > 1 else None
+    # total= : the shard sizes follow from the block split, so the gather is the ONLY collective of the data path
+    gathered = gather_trajectories(states, torch.zeros(B, T, m, 1), torch.zeros(B, T + 1), total=B_total) if world > 1 else None
     total = torch.tensor([float(B)])
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64)
@@ -458,21 +462,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # under a launcher (torch.distributed.run: RANK / WORLD_SIZE set) the run goes through RCCL even with ONE rank, so
+    # that the multi-GPU path -- process group, barriers, the gather -- can be rehearsed on a one-GPU box
+    use_dist = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # The secondary numbers (`extra`) run in a CHILD process, started here -- before this process touches the GPU (no
     # exec after GPU initialisation) -- and idle until the headline measurement is over: whatever happens in one of the
     # secondary kernels, the headline line is printed.
-    extras_child = spawn_extras(args) if (world == 1 and not args.no_extra) else None
+    extras_child = spawn_extras(args) if (world == 1 and not use_dist and not args.no_extra) else None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if use_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from tfmpc import _hip
-    from tfmpc.parallel import gather_trajectories
+    from tfmpc.parallel import gather_buffers, gather_trajectories
     from tfmpc.solvers.lqr import LQR
     import problems
 
@@ -493,7 +501,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -501,8 +509,9 @@ def main():
     # variant of the kernel, reported beside the default (bf16x3) -- not part of `value`.  Measured BEFORE the warm-up
     # and the timed steps: a process's first ~40 launches run 5-8 % slower than its steady state (1.92 -> 1.78 ms on one
     # box, tools/probes/stream_effect_headline.py), so what has to run anyway runs first.
-    f32_ms = None
-    if world == 1:
+    f32_ms, f32_launches = None, 0
+    lqr_mfma_override = _hip.get_option("TFMPC_LQR_MFMA")     # an A/B run may have exported a variant: then the headline IS that variant
+    if world == 1 and not use_dist and lqr_mfma_override is None:
         with _hip.option("TFMPC_LQR_MFMA", "f32"):
             for _ in range(3):
                 step()
@@ -513,9 +522,13 @@ def main():
             e1.record()
             torch.cuda.synchronize()
         f32_ms = e0.elapsed_time(e1) / max(1, args.steps // 2)
+        f32_launches = 3 + max(1, args.steps // 2)
 
     for _ in range(args.warmup):
         out = step()
+    # the receive buffers of the final gather are allocated up front (rank 0), where running out of memory fails the job
+    # at start-up; the gather itself is then ONE collective and nothing else (sizes follow from the block split)
+    recv = gather_buffers(out["states"], out["actions"], out["costs"], total=B * world) if use_dist else None
     fence()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
@@ -531,17 +544,17 @@ def main():
     # the one collective of the path: gather the result trajectories on rank 0 (outside
     # the timed region: it happens once per job, not per step).  gather_trajectories fails on ALL ranks or none.
     gathered, gather_error, gather_ms = None, None, None
-    if world > 1:
+    if use_dist:
         fence()
         g0 = time.perf_counter()
         try:
-            gathered = gather_trajectories(out["states"], out["actions"], out["costs"])
+            gathered = gather_trajectories(out["states"], out["actions"], out["costs"], total=B * world, recv=recv)
         except RuntimeError as exc:
             gather_error = repr(exc)
         fence()
         gather_ms = (time.perf_counter() - g0) * 1e3
 
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -577,6 +590,9 @@ def main():
                          "algorithmic_bytes_per_iteration": lqr_bytes_per_solve(n, m, T),
                          "hbm_frac_at_algorithmic_bytes": lqr_bytes_per_solve(n, m, T) * B / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
             "status_flagged_instances": status_bad,
+            # launches of this process before the timed region: the declared warm-up + the strict-variant pass above
+            "untimed_launches_before_timing": args.warmup + f32_launches,
+            "lqr_mfma_option": lqr_mfma_override or "default (bf16x3)",
         }
         if f32_ms is not None:
             flop_s = flops / (f32_ms * 1e-3) / 1e12
@@ -587,9 +603,14 @@ def main():
         if gather_ms is not None:
             from tfmpc.parallel import gather_bytes_per_rank
             per_rank = gather_bytes_per_rank(out["states"], out["actions"], out["costs"])
-            line["gather"] = {"collective": "ONE dist.gather (RCCL) of the packed trajectories onto rank 0, after the timed steps",
+            line["gather"] = {"collective": "ONE dist.gather (RCCL) of the packed trajectories onto rank 0, after the timed steps; "
+                                            "shard sizes follow from the block split (no size exchange), receive buffers "
+                                            "allocated at start-up",
+                              "backend": dist.get_backend(), "world_size": world,
                               "ms": gather_ms, "bytes_per_rank": per_rank, "bytes_total": per_rank * world,
-                              "GB_per_s_into_rank0": per_rank * (world - 1) / (gather_ms * 1e-3) / 1e9}
+                              "GB_per_s_into_rank0": per_rank * (world - 1) / (gather_ms * 1e-3) / 1e9,
+                              "checked": bool(gathered is not None and torch.equal(gathered[0][-B:], out["states"]))
+                              if world == 1 else None}
         if gather_error is not None:
             line["gather_error"] = gather_error
         if world == 1 and not args.no_cpu_baseline:
@@ -598,7 +619,7 @@ def main():
             line["extra"] = collect_extras(extras_child)
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -44,11 +44,14 @@ extern "C" {
 /* Library / device information ------------------------------------------------ */
 int tfmpc_version(void);
 /* Kernel-variant overrides for A/B timing and tests.  The environment variables TFMPC_LQR_KERNEL
- * (generic | lane | block), TFMPC_LQR_MFMA (f32 | bf16x3) and TFMPC_ILQR_KERNEL (wave | lane | lane1 |
- * lean | lean1 | costate_mfma) are read ONCE per process, at the first use of the library; afterwards only
+ * (generic | lane | block), TFMPC_LQR_MFMA (f32 | bf16x3), TFMPC_ILQR_KERNEL (wave | lane | lane1 |
+ * lean | lean1 | costate_mfma) and TFMPC_COSTATE_WAVES (1 | 2: waves per sixteen-instance group of the HVAC /
+ * Reservoir kernel) are read ONCE per process, at the first use of the library; afterwards only
  * this call changes them (value NULL or "" = back to the dispatcher's own choice).  Returns TFMPC_ERR_ARG
  * for an unknown name.  Process-wide; not meant to be flipped while other threads launch. */
 int tfmpc_set_option(const char *name, const char *value);
+/* The current override of `name` as a string in buf[len] ("" = none), so that a caller can restore what it replaces. */
+int tfmpc_get_option(const char *name, char *buf, int len);
 /* Name of the kernel variant the dispatcher would pick for an LQR shape
  * ("generic_wave", "mfma_16x8", ...).  Host-only; never touches the GPU. */
 const char *tfmpc_lqr_kernel_name(int n, int m, int T);

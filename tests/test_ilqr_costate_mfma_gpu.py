@@ -102,7 +102,8 @@ def test_hvac_tracks_the_wave_kernel(force_kernel, n, T, B):
     rel = ((w["states"] - f["states"]).abs().flatten(1).max(dim=1).values /
            w["states"].abs().flatten(1).max(dim=1).values)
     close = rel < 2e-6                                            # fp32 rounding through <= 6 iterations
-    assert float(close.float().mean()) >= 0.9, float(rel.max())   # the rest: a bang-bang decision flipped
+    # the rest: a bang-bang decision flipped (at most a tenth of the batch; one instance of a tiny batch)
+    assert int((~close).sum()) <= max(1, B // 10), float(rel.max())
     assert bool((w["iterations"] == f["iterations"])[close].all())
     tw, tf_ = w["costs"].sum(dim=1), f["costs"].sum(dim=1)
     assert float(((tw - tf_).abs() / tw.abs()).max()) < 1e-3       # flipped or not, the solutions are equally good

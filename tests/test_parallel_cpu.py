@@ -30,7 +30,25 @@ def _fake_solve(x0, T, m):
     return states, actions, costs
 
 
-def _worker(rank, world, port, B, n, m, T, out_path):
+class _CountingCollectives:
+    """Counts the collectives a call issues (the single-gather contract of SURVEY.md 8e is checked, not assumed)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def __enter__(self):
+        self.saved = {name: getattr(dist, name) for name in ("gather", "all_gather", "all_reduce", "broadcast", "barrier")}
+        for name, fn in self.saved.items():
+            setattr(dist, name, (lambda fn_, name_: lambda *a, **k: (self.calls.append(name_), fn_(*a, **k))[1])(fn, name))
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self.saved.items():
+            setattr(dist, name, fn)
+        return False
+
+
+def _worker(rank, world, port, B, n, m, T, out_path, with_total=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -38,7 +56,21 @@ def _worker(rank, world, port, B, n, m, T, out_path):
         mine = parallel.shard(x0)
         lo, hi = parallel.shard_bounds(B, world, rank)
         assert mine.shape[0] == hi - lo
-        res = parallel.gather_trajectories(*_fake_solve(mine, T, m))
+        if with_total:
+            shards = _fake_solve(mine, T, m)
+            recv = parallel.gather_buffers(*shards, total=B)
+            assert (recv is not None) == (rank == 0)
+            with _CountingCollectives() as counted:
+                res = parallel.gather_trajectories(*shards, total=B, recv=recv)
+            assert counted.calls == ["gather"], counted.calls          # ONE collective, nothing else
+            try:                                                       # a shard of the wrong size is refused BEFORE any collective
+                with _CountingCollectives() as counted:
+                    parallel.gather_trajectories(*_fake_solve(torch.cat([mine, x0[:1]]), T, m), total=B)
+                raise AssertionError("a shard that is not the block split's was accepted")
+            except ValueError:
+                assert counted.calls == []
+        else:
+            res = parallel.gather_trajectories(*_fake_solve(mine, T, m))
         if rank == 0:
             full = _fake_solve(x0, T, m)
             ok = all(torch.equal(a, b) for a, b in zip(res, full))
@@ -80,3 +112,13 @@ def test_two_rank_gather_with_an_empty_shard(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), B, n, m, T, out_path), nprocs=2, join=True)
     res = torch.load(out_path)
     assert res["ok"] and res["shapes"][0] == (B, T + 1, n, 1)
+
+
+def test_two_rank_gather_is_one_collective_when_the_global_batch_is_known(tmp_path):
+    """`total=`: the shard sizes follow from the block split, so the data path is literally ONE dist.gather -- no size
+    exchange, no agreement step (counted) -- also with shards that differ by one instance and with an empty shard."""
+    for B in (37, 1, 64):
+        out_path = str(tmp_path / f"rank0_{B}.pt")
+        mp.spawn(_worker, args=(2, _free_port(), B, 6, 3, 9, out_path, True), nprocs=2, join=True)
+        res = torch.load(out_path)
+        assert res["ok"] and res["shapes"][0] == (B, 10, 6, 1)

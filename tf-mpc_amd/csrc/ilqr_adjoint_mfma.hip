@@ -39,6 +39,7 @@
 #include "../../include/tfmpc_hip.h"
 #include "ilqr_adjoint.h"
 #include "mfma_bf16x3.h"
+#include "options.h"
 #include "trig.h"
 #include "wave_ops.h"
 
@@ -65,6 +66,53 @@ __device__ __forceinline__ f32x2 abs2(f32x2 a) { return f32x2{fabsf(a.x), fabsf(
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 __device__ __forceinline__ float sgnf_(float y) { return (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f); }
+
+// Ordering fence between cross-lane producer / consumer phases of ONE wave (LDS and global memory): the waits of a
+// workgroup-scope fence without the s_barrier.  wave_ops.h's wsync() is __syncthreads(), which is the same thing while a
+// workgroup is one wave but a real barrier in the two-wave groups below, whose waves are in different phases.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// ---- LDS-DMA input ring (round 3) ---------------------------------------------------------------------------------
+// The inputs of a time step (the nominal actions and the selector byte of a rollout; the nominal state, action and stage
+// cost of the sweep) used to be prefetched into a REGISTER ring.  At 250 registers the compiler rotates such a ring
+// through copies at the loop's back edge, and the copies wait for the loads just issued (s_waitcnt vmcnt(0) once per
+// trip): the prefetch distance was gone, an HBM round trip was exposed every two steps, and round 2's counters show the
+// HVAC waves parked in s_waitcnt for 52 % of their cycles.  Now the loads are LDS-DMA (global_load_lds: HBM -> LDS
+// without passing registers), issued kRingDepth - 1 steps ahead into a ring of LDS slots, and a step begins with
+// s_waitcnt vmcnt(N), N = the loads of the YOUNGER steps, which stay in flight.  Both the issue and the wait are inline
+// assembly the compiler knows nothing about: it cannot merge, copy or hoist them, and it inserts no vmcnt(0) of its
+// own in front of LDS reads (which it does, once per loop trip, for the __builtin_amdgcn_global_load_lds form).  Its
+// own waits stay correct: an extra outstanding load can only make a compiler-placed vmcnt(N) wait longer.  M0 (the
+// LDS base of the DMA) is saved and restored around each issue.
+#define TFMPC_LDS __attribute__((address_space(3)))
+__device__ __forceinline__ unsigned lds_addr_of(const void *p) { return (unsigned)(uintptr_t)(const TFMPC_LDS void *)p; }
+__device__ __forceinline__ void dma16(const void *g, unsigned lds)          // 16 bytes per lane -> lds + 16 lane
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void dma4(const void *g, unsigned lds)           // 4 bytes per lane -> lds + 4 lane
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void dma1(const void *g, unsigned lds)           // 1 byte per lane -> the low byte of lds + 4 lane
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// a slot's LDS reads have delivered before the slot is refilled
+__device__ __forceinline__ void lds_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // Exchange across the lane quarters that hold the other rows of a column, on gfx950's row swaps:
 // v_permlane16_swap a, b swaps row 1 of a with row 0 of b and row 3 of a with row 2 of b (rows of 16 lanes);
@@ -432,7 +480,7 @@ __device__ __forceinline__ void load_operand(int n, int i, int q, F el, MatOp<2,
     static_assert(PK == 1, "instances are packed into ONE tile");
     const int lane = lane_id();
     bool exact = true;
-    wsync();                                     // the previous phase's reads of `rest` are done
+    wave_sync();                                 // the previous phase's reads of `rest` are done
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         u32x4 m, l;
@@ -441,7 +489,7 @@ __device__ __forceinline__ void load_operand(int n, int i, int q, F el, MatOp<2,
         rest[(2 * a + 1) * kWave + lane] = l;
         exact = exact && ((m[0] | m[1] | m[2] | m[3] | l[0] | l[1] | l[2] | l[3]) & 0x7FFF7FFFu) == 0u;     // +-0 parts only
     }
-    wsync();
+    wave_sync();
     A.rest = rest;
     A.exact = __all(exact);
 }
@@ -462,12 +510,12 @@ __device__ __forceinline__ void lds_rows(const float *lds, int slot, int qo, flo
 }
 constexpr int kSlotALow = 6, kSlotAHigh = 7;          // action bounds (both envs)
 
-template <int KIND, int NT> struct EnvM;
+template <int KIND, int NT, bool LEAN = false> struct EnvM;
 
 // ---------------------------------------------------------------------------------- HVAC ----
 // x' = x + rcap (heating + [A x + c0])   with  A = G - diag(gsum + k_out + k_hall),  c0 = k_out t_out + k_hall t_hall
 // (hvac/__init__.py:69-89, :131-149);  Q_x = l_x + V_x - u am CAP w + A^T w,  w = rcap V_x;  Q_u = COST am + am CAP (TEMP - x) w
-template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
+template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_HVAC, NT, LEAN> {
     static constexpr int NV = 4 * NT;
     static constexpr float CAP_AIR = 1.006f, COST_AIR = 1.0f, TEMP_AIR = 40.0f, TIME_DELTA = 1.0f;
     static constexpr float PENALTY = 20000.0f, SET_POINT_PENALTY = 10.0f;
@@ -492,7 +540,7 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
         }
         return v;
     }
-    using Operand = MatOp<NT, false>;
+    using Operand = MatOp<NT, LEAN>;                    // LEAN (two-wave groups, 128 registers): non-leading parts in LDS
     template <int PK>
     __device__ __forceinline__ void load_forward(const TfmpcEnv &g, int i, int q, Operand &A, u32x4 *rest) const
     {
@@ -565,18 +613,46 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
 #pragma unroll
         for (int e = 0; e < NV; e += 2) unpr(gx, e, grad_x(pr(x, e), e));
     }
+    // x' = x + rcap (air CAP (TEMP - x) + [A x + c0]) with the two outer operations fused (one rounding each instead of
+    // two: 4 packed instructions per row pair instead of 6; round 3 -- this env was never bit-tied to the wave kernels)
     __device__ __forceinline__ void step(const Operand &A, const float (&x)[NV], const float (&u)[NV], int qo,
                                          float (&xn)[NV]) const
     {
         float acc[NV];
         lds_rows<NT>(lds, kC0, qo, acc);
+#ifndef TFMPC_PROBE_NO_MATRIX_PRODUCT      // probe builds (tools/probes/cfg5_phases.py): what the bf16x3 product costs a step
         mat_apply(A, x, acc);
+#endif
 #pragma unroll
         for (int e = 0; e < NV; e += 2) {
             const f32x2 X = pr(x, e);
             const f32x2 air = pr(u, e) * pr(am, e);                                       // :72
-            const f32x2 heating = air * CAP_AIR * (TEMP_AIR - X);                         // :74
-            unpr(xn, e, X + pr(rcap, e) * (heating + pr(acc, e)));                        // :80-88
+            const f32x2 h = air * (TEMP_AIR - X);                                         // :74 (x CAP_AIR in the next line)
+            unpr(xn, e, fma2(pr(rcap, e), fma2(h, splat(CAP_AIR), pr(acc, e)), X));       // :80-88
+        }
+    }
+    // A line-search rollout only needs J = sum of all stage costs: the costs of a lane's rows are accumulated straight
+    // into two running pairs (no per-row cost values, no per-step column sum); the column sum is taken when the pass
+    // ends or tests its early exit.  max(0, lo - x) + max(0, x - hi) = max(lo - x, x - hi, 0) needs lo <= hi: `ordered`.
+    static constexpr bool kFusedSearchCost = true;
+    __device__ __forceinline__ bool bounds_ordered() const
+    {
+        bool ok = true;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) ok = ok && lo[e] <= hi[e];
+        return __all(ok);
+    }
+    __device__ __forceinline__ void cost_accumulate(const float (&x)[NV], const float (&u)[NV], int, f32x2 (&jacc)[2]) const
+    {
+#pragma unroll
+        for (int e = 0; e < NV; e += 2) {
+            const f32x2 X = pr(x, e), LO = pr(lo, e), HI = pr(hi, e);
+            const f32x2 a = LO - X, b = X - HI, d = (LO + HI) / 2 - X;
+            const f32x2 oob = {fmaxf(fmaxf(a.x, b.x), 0.0f), fmaxf(fmaxf(a.y, b.y), 0.0f)};
+            f32x2 acc = jacc[(e >> 1) & 1];
+            acc = fma2(splat(PENALTY), oob, acc);                                         // :97-100
+            acc = f32x2{fmaf(SET_POINT_PENALTY, fabsf(d.x), acc.x), fmaf(SET_POINT_PENALTY, fabsf(d.y), acc.y)};   // :101-105
+            jacc[(e >> 1) & 1] = fma2(pr(u, e), pr(am, e), acc);                          // :93 (COST_AIR == 1)
         }
     }
     __device__ __forceinline__ void adjoint(const Operand &A, const float (&xh)[NV], const float (&uh)[NV],
@@ -600,7 +676,7 @@ template <int NT> struct EnvM<TFMPC_ENV_HVAC, NT> {
 
 // ----------------------------------------------------------------------------- RESERVOIR ----
 // element-wise expressions in the order of ilqr_adjoint.hip / envs.h (reservoir/__init__.py:47-105)
-template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
+template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_RESERVOIR, NT, LEAN> {
     static constexpr int NV = 4 * NT;
     static constexpr int kRain = 0, kDii = 1, kLP = 2, kHP = 3, kSP = 4;      // LDS slots
     // see EnvM<HVAC>.  Two tiles, round 2: with a column's rows contiguous in the buffers the single-step-size search that
@@ -685,6 +761,9 @@ template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
         }
     }
     __device__ __forceinline__ void final_costs(const float (&x)[NV], int qo, float (&c)[NV]) const { stage_costs(x, x, qo, c); }   // :81-83
+    static constexpr bool kFusedSearchCost = false;       // the per-row costs keep the wave kernels' expression (and bits)
+    __device__ __forceinline__ bool bounds_ordered() const { return true; }
+    __device__ __forceinline__ void cost_accumulate(const float (&)[NV], const float (&)[NV], int, f32x2 (&)[2]) const {}
     __device__ __forceinline__ void grads(const float (&x)[NV], int qo, float (&gx)[NV]) const
     {
         float LP[NV], HP[NV], SP[NV];
@@ -747,6 +826,15 @@ template <int NT> struct EnvM<TFMPC_ENV_RESERVOIR, NT> {
 __device__ int *g_cfg5_trace = nullptr;
 #endif
 
+#ifdef TFMPC_PHASE_PROBE
+__device__ unsigned long long *g_cfg5_phases = nullptr;
+#define TFMPC_PHASE_BEGIN() const unsigned long long phase_t0_ = __builtin_amdgcn_s_memtime()
+#define TFMPC_PHASE_END(i) do { __builtin_amdgcn_s_waitcnt(0); phase_acc[i] += __builtin_amdgcn_s_memtime() - phase_t0_; ++phase_cnt[i]; } while (0)
+#else
+#define TFMPC_PHASE_BEGIN() do {} while (0)
+#define TFMPC_PHASE_END(i) do {} while (0)
+#endif
+
 // bytes of one wave's slice of the wave-major workspace (sized for fp32 containers; the 16-bit ones use half of each buffer)
 __host__ __device__ constexpr size_t adjoint_mfma_wave_bytes(int NT, int T)
 {
@@ -754,13 +842,32 @@ __host__ __device__ constexpr size_t adjoint_mfma_wave_bytes(int NT, int T)
             (size_t)T * kWave + 255) & ~(size_t)255;
 }
 
-template <int KIND, int NT, int VW, int PK, bool BF16 = false>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 && PK == 1 ? 3 : 2, NT == 1 && PK == 1 ? 3 : 2))) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
+// ---- round 3: groups of NW waves, one step-size chain per wave ----------------------------------------------------------
+// A wave alone issues an instruction every ~8.5 cycles on this code (a dependent, in-order stream at 230-250 registers), two
+// per SIMD one every ~4.9 between them -- and B = 32 768 instances are only 2 048 sixteen-column groups, two per SIMD.  The
+// second step size of a line-search pass used to ride in the same wave (two chains per lane: instruction-level
+// parallelism an in-order wave barely uses, and twice the registers).  With NW = 2 the sixteen columns of a group are
+// shared by a WORKGROUP of two waves: wave w of the group rolls out step size NW p + w of pass p (one chain per lane,
+// <= 128 registers: four waves per SIMD), stops on its own once all of ITS columns are above J_hat, and the two meet at
+// a barrier per pass to exchange J through LDS; the state machine runs replicated in both waves on the same inputs.
+// The costate sweep, the start rollout and the stored rollout of the accepted step size run on wave 0 (their result
+// reaches wave 1 through HBM / L1 of the same CU behind the barrier); the other groups' waves fill the SIMD meanwhile.
+template <int NW>
+__device__ __forceinline__ void group_sync()
+{
+    if (NW == 1) wave_sync();
+    else __syncthreads();
+}
+
+template <int KIND, int NT, int VW, int PK, bool BF16 = false, int NW = 1>
+__global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW > 1 ? 4 : (NT == 1 && PK == 1 ? 3 : 2), NW > 1 ? 4 : (NT == 1 && PK == 1 ? 3 : 2)))) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
 {
     constexpr int NV = 4 * NT;
     using TT = typename std::conditional<BF16, bf16_t, float>::type;      // element type of the trajectories in HBM
     static_assert(PK == 1 || NT == 1, "instances are packed into ONE tile");
+    static_assert(NW == 1 || NW == 2, "one or two waves per sixteen-column group");
     const int lane = lane_id(), j = lane & 15, q = lane >> 4, n = genv.n, m = n, T = a.T;
+    const int wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // this wave within its group
     // PK instances per column (n <= 16 / PK): lane quarter q belongs to sub-instance q / (4 / PK) and holds its rows
     // 4 ql .. 4 ql + 3, ql = q mod (4 / PK).  Everything below indexes rows with ql; only the MFMA operands know q.
     const int ql = q & (4 / PK - 1);
@@ -769,26 +876,40 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
     // writes whole 64-byte sectors instead of 16-byte pieces 256 bytes apart
     const int wl = j * NT * 4 + q;                      // [column][tile][lane quarter]: + 4 per tile (ldw / stw)
     const int b_raw = (blockIdx.x * kCols + j) * PK + q / (4 / PK);
-    const bool live = b_raw < a.B;                       // the last wave may carry empty columns: they compute on the
+    const bool live = b_raw < a.B;                       // the last group may carry empty columns: they compute on the
     const size_t b = live ? b_raw : a.B - 1;             // last instance's data and store nothing
     __shared__ __attribute__((aligned(16))) float rows[kRowSlots * kRowLd];
-    __shared__ u32x4 op_rest[NT == 2 ? 4 * kWave : 1];         // MatOp<2, true>: the non-leading parts of the operand
-    EnvM<KIND, NT> env;
-    env.load(genv, lane, ql, rows);
+    __shared__ u32x4 op_rest_all[NW][NT == 2 ? 4 * kWave : 1];  // MatOp<2, true>: the non-leading parts of the operand, per wave
+    __shared__ float x_sweep[NW > 1 ? 4 : 1][kWave];           // wave 0 -> the others: J_hat, dV1, g_norm, max |k|
+    __shared__ float x_pass[2][NW][2][kWave];                  // [pass parity][wave][J | cut short][lane]
+    u32x4 *const op_rest = op_rest_all[wv];
+    // the LDS-DMA input ring of this wave (fp32 containers): [slot][x tiles | u tiles][lane] 16-byte pieces, the stage
+    // cost and the selector byte of a slot.  Depth 3 with two tiles keeps 8 groups per CU inside the 160 KB.
+    constexpr bool kLdsRing = !BF16;
+    constexpr int kRingDepth = NT == 2 ? 3 : 4;
+    __shared__ f32x4 ring_v_all[NW][kLdsRing ? kRingDepth : 1][2 * NT][kWave];
+    __shared__ float ring_c_all[NW][kLdsRing ? kRingDepth : 1][kWave];
+    __shared__ unsigned ring_k_all[NW][kLdsRing ? kRingDepth : 1][kWave];    // (a sub-dword LDS-DMA still strides the lanes by 4 bytes)
+    f32x4 (*const ring_v)[2 * NT][kWave] = ring_v_all[wv];
+    float (*const ring_c)[kWave] = ring_c_all[wv];
+    unsigned (*const ring_k)[kWave] = ring_k_all[wv];
+    EnvM<KIND, NT, (NW > 1)> env;
+    env.load(genv, lane, ql, rows);                      // (every wave of the group writes the same values)
     if (lane < kRowLd) {
         rows[kSlotALow * kRowLd + lane] = (lane < m) ? genv.low[lane] : 0.0f;
         rows[kSlotAHigh * kRowLd + lane] = (lane < m) ? genv.high[lane] : 0.0f;
     }
-    wsync();
+    group_sync<NW>();
     const bool early_exit = cfg.c1 == 0.0f && env.costs_nonnegative();     // see `rollout`
+    const bool fused_cost = EnvM<KIND, NT, (NW > 1)>::kFusedSearchCost && env.bounds_ordered();
 
-    // trajectories of this wave, wave-major (see ldw): two buffers of states / actions / stage costs in the wave's slice
+    // trajectories of this group, wave-major (see ldw): two buffers of states / actions / stage costs in the group's slice
     // of the workspace, the nominal one is [flip]; at the end the nominal trajectory is copied (16-bit containers:
     // widened) into the instance-major output arrays.  Then the selector bytes [t][column][lane quarter]: 4 NT bits each.
     const size_t kXs = (size_t)(T + 1) * NT * kTileElems, kUs = (size_t)T * NT * kTileElems, kCs = (size_t)(T + 1) * kCostLd;
     unsigned char *const wave_ws = static_cast<unsigned char *>(a.wave_ws) + (size_t)blockIdx.x * adjoint_mfma_wave_bytes(NT, T);
     TT *xbuf[2], *ubuf[2], *cbuf[2];
-    const int ccol = j * PK + q / (4 / PK);             // this lane's instance within the wave
+    const int ccol = j * PK + q / (4 / PK);             // this lane's instance within the group
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         xbuf[i] = reinterpret_cast<TT *>(wave_ws + (size_t)i * (kXs + kUs + kCs) * sizeof(float));
@@ -802,20 +923,24 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
     // One rollout of every column from x0.  SEARCH: u_t = clip(u_hat_t + alpha k_t) (ilqr.py:193-197), else the
     // injected start actions (:53-82).  The bang-bang gain is k_t = bound - u_hat_t (:140-141), so the sweep leaves ONE
     // BIT per action (which bound) and the rollout rebuilds k_t from u_hat_t with the sweep's own expression.
-    // A wave alone waits ~3 000 cycles on every HBM / L2 round trip and only two waves share a SIMD, so the inputs of
-    // step t + kAhead are requested before step t is computed (a register ring, the time loop unrolled by kAhead).
-    constexpr int kAheadRoll = NT == 2 ? 2 : 4, kAhead = 2;        // rollouts / costate sweep (two tiles: the ring is 8 registers per step ahead)
+    // The inputs of step t + kAhead are requested before step t is computed (a register ring, the time loop unrolled by kAhead).
+    // (two tiles: the ring is 8 registers per step ahead; two-wave groups have 128 registers and four waves per SIMD to hide a load behind)
+    constexpr int kAheadRoll = NW > 1 ? (NT == 2 ? 1 : 2) : (NT == 2 ? 2 : 4), kAhead = NW > 1 && NT == 2 ? 1 : 2;        // rollouts / costate sweep
     // STORE: the trajectory is written (rows of columns with `keep`).  The line search only needs J: its rollouts store
     // nothing, and the one step size a column settles on is rolled out again with STORE (same arithmetic, same bits)
     // -- every speculative rollout writing its 25 KB per instance made the solve HBM-write-bound.
-    // NA = 2 (the HVAC line search): TWO step sizes in one pass -- the inputs u_hat_t and the selector byte are loaded once,
-    // and the two independent state chains give a wave something to issue while the other chain waits on its LDS
-    // reads and MFMA results (only two waves share a SIMD at BASELINE's batch).
+    // NA = 2 (one-wave groups): TWO step sizes in one pass -- the inputs u_hat_t and the selector byte are loaded once.
     // A line-search rollout that stores nothing exists to answer "is J(alpha) <= J_hat?" (ilqr.py:339-353 with c1 = 0:
     // z >= 0 <=> J_hat - J >= 0 on either branch of :342-346).  Stage costs are >= 0 on both envs, so the partial sum only
     // grows: once it is above `reject_above` (= J_hat) in every column that is still trying (`trying`), the answer is
     // "no" whatever follows, and the pass stops -- the first, too long step sizes of a Reservoir search blow the cost
-    // up within 5 .. 40 of the 100 steps.  Same decisions, so same results, bit for bit.
+    // up within 5 .. 40 of the 100 steps.
+    // Round 3: such a rollout does not form the stage cost of a step at all.  Every lane adds the costs of ITS rows into two
+    // running pairs (`jacc`; HVAC: fused multiply-adds straight from the penalty terms, EnvM::cost_accumulate), and the
+    // sum over a column's lanes is taken when the pass ends or tests its early exit (once per kAheadRoll steps) -- the
+    // per-step column reduction (two lane exchanges, ~20 instructions and their hazard no-ops per chain-step) is gone.  J(alpha) is
+    // then summed in a different order than the stored pass and the wave kernels sum theirs (a decision can differ only
+    // where |J - J_hat| is at rounding level, ~1e-7 relative); the trajectories a pass stores are computed as before.
 #ifdef TFMPC_CFG5_TRACE
     int trace_fa[2] = {-1, -1};
 #endif
@@ -824,20 +949,27 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
                        bool trying = false, float reject_above = 0.0f, bool may_stop = false, bool *stopped_out = nullptr) {
         constexpr bool SEARCH = decltype(search)::value, STORE = decltype(store)::value;
         constexpr int NA = decltype(n_alpha)::value;
+        constexpr bool DEFER = SEARCH && !STORE;            // only J matters: lane-partial cost sums
         static_assert(!STORE || NA == 1, "only a single rollout is stored");
-        typename EnvM<KIND, NT>::Operand A;
+        typename EnvM<KIND, NT, (NW > 1)>::Operand A;
         env.fence();
         env.template load_forward<PK>(genv, opaque(j), opaque(q), A, op_rest);
-        float x[NA][NV], ur[kAheadRoll][NV], J[NA];
-        unsigned kb[kAheadRoll];
+        constexpr bool RING = SEARCH && kLdsRing;           // wave-major fp32 inputs: the LDS-DMA ring; else a register ring
+        constexpr int kSlots = RING ? 1 : kAheadRoll, kLoads = NT + 1;      // kLoads: DMA instructions per step
+        float x[NA][NV], ur[kSlots][NV], J[NA];
+        f32x2 jacc[NA][2];
+        unsigned kb[kSlots];
         ldv<NT, VW>(x0p, n, ql, x[0]);
         if (STORE) stw<NT>(xs, 0, wl, keep, x[0]);
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             J[k] = 0.0f;
+            jacc[k][0] = jacc[k][1] = splat(0.0f);
 #pragma unroll
             for (int e = 0; e < NV; ++e) x[k][e] = x[0][e];
         }
+        // the column's partial cost of a deferred pass: this lane's pairs, then the lanes of the column
+        auto partial = [&](int k) { return tile_sum<PK>((jacc[k][0].x + jacc[k][0].y) + (jacc[k][1].x + jacc[k][1].y)); };
         auto request = [&](int t, float (&u_)[NV], unsigned &k_) {
             if constexpr (SEARCH) {
                 ldw<NT>(uh, t, wl, u_);
@@ -846,12 +978,32 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
                 ldv<NT, VW>(uh + (size_t)t * m, m, ql, u_);                 // the injected start actions: instance-major
             }
         };
+        // LDS-DMA ring: the actions of step t (this lane's 16-byte pieces, as ldw addresses them) and the selector byte
+        auto issue = [&](int slot, int t) {
+            if constexpr (RING) {
+                lds_reads_done();
+                const float *src = reinterpret_cast<const float *>(uh) + (size_t)t * NT * kTileElems + 4 * wl;
 #pragma unroll
-        for (int d = 0; d < kAheadRoll; ++d) {
-            kb[d] = 0;
+                for (int b = 0; b < NT; ++b) dma16(src + 16 * b, lds_addr_of(&ring_v[slot][b][0]));
+                dma1(ksel + (size_t)t * kWave, lds_addr_of(&ring_k[slot][0]));
+            }
+        };
+        // Either ring is refilled UNCONDITIONALLY (the time index clamped to the horizon; the last steps re-read step
+        // T - 1): the register ring because behind a condition the compiler merges "old value or loaded value" through
+        // copies, the LDS ring because its waits count the loads of the younger steps.
+        int slot = 0;                                       // LDS ring: the slot of the current step
+        if constexpr (RING) {
 #pragma unroll
-            for (int e = 0; e < NV; ++e) ur[d][e] = 0.0f;
-            if (d < T) request(d, ur[d], kb[d]);
+            for (int d = 0; d < kRingDepth - 1; ++d)
+                if (T > 0) issue(d, d < T ? d : T - 1);
+        } else {
+#pragma unroll
+            for (int d = 0; d < kAheadRoll; ++d) {
+                kb[d] = 0;
+#pragma unroll
+                for (int e = 0; e < NV; ++e) ur[d][e] = 0.0f;
+                if (T > 0) request(d < T ? d : T - 1, ur[d], kb[d]);
+            }
         }
         bool stopped = false;
 #ifdef TFMPC_CFG5_TRACE
@@ -861,7 +1013,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
             if (SEARCH && early_exit && may_stop) {
                 bool open = false;                       // a trying column whose partial cost may still end at or below J_hat
 #pragma unroll
-                for (int k = 0; k < NA; ++k) open = open || (trying && !(J[k] > reject_above));
+                for (int k = 0; k < NA; ++k) open = open || (trying && !((DEFER ? partial(k) : J[k]) > reject_above));
                 if (!__any(open)) { stopped = true; break; }
             }
 #pragma unroll
@@ -871,14 +1023,29 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
                 if (t < T) {
                     const int qo = opaque(ql);
                     float u[NA][NV];
+                    const int dd = RING ? 0 : d;                // the register ring's slot of this unrolled step
+                    if constexpr (RING) {
+                        // step t + depth - 1 goes into the slot the previous step has just read; then the loads of THIS
+                        // step have landed once at most the (depth - 1) younger steps' are outstanding
+                        const int ahead = t + kRingDepth - 1;
+                        issue(slot == 0 ? kRingDepth - 1 : slot - 1, ahead < T ? ahead : T - 1);
+                        wait_vmem<(kRingDepth - 1) * kLoads>();
+#pragma unroll
+                        for (int b = 0; b < NT; ++b) {
+                            const f32x4 v = ring_v[slot][b][lane];
+                            ur[0][4 * b] = v[0]; ur[0][4 * b + 1] = v[1]; ur[0][4 * b + 2] = v[2]; ur[0][4 * b + 3] = v[3];
+                        }
+                        kb[0] = ring_k[slot][lane] & 0xFFu;
+                        slot = slot + 1 == kRingDepth ? 0 : slot + 1;
+                    }
                     if (SEARCH) {
                         float alow[NV], ahigh[NV];
                         lds_rows<NT>(rows, kSlotALow, qo, alow);
                         lds_rows<NT>(rows, kSlotAHigh, qo, ahigh);
 #pragma unroll
                         for (int e = 0; e < NV; e += 2) {
-                            const f32x2 uh_e = pr(ur[d], e);
-                            const f32x2 bound = {((kb[d] >> e) & 1u) ? alow[e] : ahigh[e], ((kb[d] >> (e + 1)) & 1u) ? alow[e + 1] : ahigh[e + 1]};
+                            const f32x2 uh_e = pr(ur[dd], e);
+                            const f32x2 bound = {((kb[dd] >> e) & 1u) ? alow[e] : ahigh[e], ((kb[dd] >> (e + 1)) & 1u) ? alow[e + 1] : ahigh[e + 1]};
                             const f32x2 kt = bound - uh_e;                                                   // :140-141
 #pragma unroll
                             for (int k = 0; k < NA; ++k) {
@@ -889,23 +1056,41 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
                         }
                     } else {
 #pragma unroll
-                        for (int e = 0; e < NV; ++e) u[0][e] = ur[d][e];
+                        for (int e = 0; e < NV; ++e) u[0][e] = ur[dd][e];
                     }
-                    if (t + kAheadRoll < T) request(t + kAheadRoll, ur[d], kb[d]);
+                    if constexpr (!RING) {
+                        // the refill is issued AFTER the slot's last use (a scheduling fence on either side)
+                        __builtin_amdgcn_sched_barrier(0);
+                        request(t + kAheadRoll < T ? t + kAheadRoll : T - 1, ur[dd], kb[dd]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
 #pragma unroll
                     for (int k = 0; k < NA; ++k) {
-                        float cp[NV], xn[NV];
-                        env.stage_costs(x[k], u[k], qo, cp);
-                        const float c = col_sum<NT, PK>(cp);
-                        env.step(A, x[k], u[k], qo, xn);
-                        J[k] += c;
+                        float xn[NV];
+                        if constexpr (DEFER) {
+                            if (fused_cost) {                                   // (wave-uniform)
+                                env.cost_accumulate(x[k], u[k], qo, jacc[k]);
+                            } else {
+                                float cp[NV];
+                                env.stage_costs(x[k], u[k], qo, cp);
+#pragma unroll
+                                for (int e = 0; e < NV; e += 2) jacc[k][(e >> 1) & 1] += pr(cp, e);
+                            }
+                            env.step(A, x[k], u[k], qo, xn);
 #ifdef TFMPC_CFG5_TRACE
-                        if (SEARCH && trace_fa[k] < 0 && J[k] > reject_above) trace_fa[k] = t;
+                            if (trace_fa[k] < 0 && partial(k) > reject_above) trace_fa[k] = t;
 #endif
-                        if (STORE) {
-                            stw<NT>(us, t, wl, keep, u[k]);
-                            stw<NT>(xs, t + 1, wl, keep, xn);
-                            if (keep && ql == 0) stc(cs + (size_t)t * kCostLd, c);
+                        } else {
+                            float cp[NV];
+                            env.stage_costs(x[k], u[k], qo, cp);
+                            const float c = col_sum<NT, PK>(cp);
+                            env.step(A, x[k], u[k], qo, xn);
+                            J[k] += c;
+                            if (STORE) {
+                                stw<NT>(us, t, wl, keep, u[k]);
+                                stw<NT>(xs, t + 1, wl, keep, xn);
+                                if (keep && ql == 0) stc(cs + (size_t)t * kCostLd, c);
+                            }
                         }
 #pragma unroll
                         for (int e = 0; e < NV; ++e) x[k][e] = xn[e];
@@ -917,38 +1102,56 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
         for (int k = 0; k < NA; ++k) {
             float cp[NV];
             env.final_costs(x[k], opaque(ql), cp);
-            const float fc = col_sum<NT, PK>(cp);
-            if (STORE && keep && ql == 0) stc(cs + (size_t)T * kCostLd, fc);
-            J_out[k] = stopped ? J[k] : J[k] + fc;       // stopped: already above J_hat in every column that asked
+            if constexpr (DEFER) {
+                // stopped: already above J_hat in every column that asked
+                float fl = (cp[0] + cp[1]) + (cp[2] + cp[3]);
+                if constexpr (NT == 2) fl += (cp[4] + cp[5]) + (cp[6] + cp[7]);
+                const float own = (jacc[k][0].x + jacc[k][0].y) + (jacc[k][1].x + jacc[k][1].y);
+                J_out[k] = tile_sum<PK>(stopped ? own : own + fl);
+            } else {
+                const float fc = col_sum<NT, PK>(cp);
+                if (STORE && keep && ql == 0) stc(cs + (size_t)T * kCostLd, fc);
+                J_out[k] = stopped ? J[k] : J[k] + fc;
+            }
         }
         if (stopped_out) *stopped_out = stopped;
-        if (STORE) wsync();                 // costs are written by lane quarter 0 and read by all four in the next sweep
+        if (STORE) wave_sync();             // costs are written by lane quarter 0 and read by all four in the next sweep
     };
     using one_t = std::integral_constant<int, 1>;
 
-    {
+#ifdef TFMPC_PHASE_PROBE
+    unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, phase_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long kernel_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    if (wv == 0) {
+        TFMPC_PHASE_BEGIN();
         const float a0[1] = {0.0f};
         float J[1];
-        // EVERY column stores its start trajectory, the empty ones of the last wave too (they run the last instance's
+        // EVERY column stores its start trajectory, the empty ones of the last group too (they run the last instance's
         // data): the sweeps below read every column's nominal buffer, and with several instances per matrix-core column
         // (n <= 8) a NaN left in the workspace by an earlier use would reach the live rows of the same column through
         // the block-diagonal operand's zeros (0 x NaN).  Found by tools/probes/fuzz_costate.py / nan_workspace.py.
         rollout(std::false_type{}, std::true_type{}, one_t{}, a0, a.u_init + b * T * m, true, xbuf[0], ubuf[0], cbuf[0], J);
+        TFMPC_PHASE_END(0);
     }
 
     float mu = 0.0f, delta = 1.0f;
     int status = 0, attempts = 0, iteration = 0, last_index = 0;     // last_index: position of the step size accepted last
+    int parity = 0;                                                  // of the exchange buffer x_pass
     bool done = !live || cfg.max_iterations <= 0;
     while (__any(!done)) {
         TT *const xhat = xbuf[flip], *const uhat = ubuf[flip], *const chat = cbuf[flip];
         TT *const xc = xbuf[flip ^ 1], *const uc = ubuf[flip ^ 1], *const cc = cbuf[flip ^ 1];
-        // ---- backward (ilqr.py:94-172 on the bang-bang branch): costate recursion, all columns ------------
-        float rJ, dV1, g_norm, kmax;
-        {
-            typename EnvM<KIND, NT>::Operand A;
+        // ---- backward (ilqr.py:94-172 on the bang-bang branch): costate recursion, all columns (wave 0) ----
+        float rJ = 0.0f, dV1 = 0.0f, g_norm = 0.0f, kmax = 0.0f;
+        if (wv == 0) {
+            TFMPC_PHASE_BEGIN();
+            typename EnvM<KIND, NT, (NW > 1)>::Operand A;
             env.fence();
             env.template load_backward<PK>(genv, opaque(j), opaque(q), A, op_rest);
-            float vx[NV], xT[NV], p1[NV], ka[NV], xr[kAhead][NV], ur[kAhead][NV], lr[kAhead];
+            constexpr bool RING = kLdsRing;
+            constexpr int kSlots = RING ? 1 : kAhead, kLoads = 2 * NT + 1;
+            float vx[NV], xT[NV], p1[NV], ka[NV], xr[kSlots][NV], ur[kSlots][NV], lr[kSlots];
             ldw<NT>(xhat, T, wl, xT);
             env.grads(xT, opaque(ql), vx);                     // V_x = l_x^f
 #pragma unroll
@@ -960,12 +1163,31 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
                 ldw<NT>(uhat, t, wl, u_);
                 l_ = ldc(chat + (size_t)t * kCostLd);
             };
+            auto issue = [&](int slot, int t) {                // LDS-DMA ring: x_hat_t, u_hat_t, l_t (see `rollout`)
+                if constexpr (RING) {
+                    lds_reads_done();
+                    const float *sx = reinterpret_cast<const float *>(xhat) + (size_t)t * NT * kTileElems + 4 * wl;
+                    const float *su = reinterpret_cast<const float *>(uhat) + (size_t)t * NT * kTileElems + 4 * wl;
 #pragma unroll
-            for (int d = 0; d < kAhead; ++d) {
-                lr[d] = 0.0f;
+                    for (int b = 0; b < NT; ++b) dma16(sx + 16 * b, lds_addr_of(&ring_v[slot][b][0]));
 #pragma unroll
-                for (int e = 0; e < NV; ++e) { xr[d][e] = 0.0f; ur[d][e] = 0.0f; }
-                if (T - 1 - d >= 0) request(T - 1 - d, xr[d], ur[d], lr[d]);
+                    for (int b = 0; b < NT; ++b) dma16(su + 16 * b, lds_addr_of(&ring_v[slot][NT + b][0]));
+                    dma4(reinterpret_cast<const float *>(chat) + (size_t)t * kCostLd, lds_addr_of(&ring_c[slot][0]));
+                }
+            };
+            int slot = 0;
+            if constexpr (RING) {
+#pragma unroll
+                for (int d = 0; d < kRingDepth - 1; ++d)
+                    if (T > 0) issue(d, T - 1 - d >= 0 ? T - 1 - d : 0);
+            } else {
+#pragma unroll
+                for (int d = 0; d < kAhead; ++d) {
+                    lr[d] = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) { xr[d][e] = 0.0f; ur[d][e] = 0.0f; }
+                    if (T > 0) request(T - 1 - d >= 0 ? T - 1 - d : 0, xr[d], ur[d], lr[d]);      // (unconditional refills: see `rollout`)
+                }
             }
             for (int t0 = T - 1; t0 >= 0; t0 -= kAhead) {
 #pragma unroll
@@ -974,11 +1196,29 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
                     __builtin_amdgcn_sched_barrier(0);      // the unrolled steps are not interleaved (registers)
                     if (t >= 0) {
                         const int qo = opaque(ql);
+                        const int dd = RING ? 0 : d;
+                        if constexpr (RING) {
+                            const int ahead = t - (kRingDepth - 1);
+                            issue(slot == 0 ? kRingDepth - 1 : slot - 1, ahead >= 0 ? ahead : 0);
+                            wait_vmem<(kRingDepth - 1) * kLoads>();
+#pragma unroll
+                            for (int b = 0; b < NT; ++b) {
+                                const f32x4 vx_ = ring_v[slot][b][lane], vu_ = ring_v[slot][NT + b][lane];
+                                xr[0][4 * b] = vx_[0]; xr[0][4 * b + 1] = vx_[1]; xr[0][4 * b + 2] = vx_[2]; xr[0][4 * b + 3] = vx_[3];
+                                ur[0][4 * b] = vu_[0]; ur[0][4 * b + 1] = vu_[1]; ur[0][4 * b + 2] = vu_[2]; ur[0][4 * b + 3] = vu_[3];
+                            }
+                            lr[0] = ring_c[slot][lane];
+                            slot = slot + 1 == kRingDepth ? 0 : slot + 1;
+                        }
                         float xh[NV], uh[NV];
 #pragma unroll
-                        for (int e = 0; e < NV; ++e) { xh[e] = xr[d][e]; uh[e] = ur[d][e]; }
-                        const float l = lr[d];
-                        if (t - kAhead >= 0) request(t - kAhead, xr[d], ur[d], lr[d]);
+                        for (int e = 0; e < NV; ++e) { xh[e] = xr[dd][e]; uh[e] = ur[dd][e]; }
+                        const float l = lr[dd];
+                        if constexpr (!RING) {
+                            __builtin_amdgcn_sched_barrier(0);          // (see `rollout`)
+                            request(t - kAhead >= 0 ? t - kAhead : 0, xr[dd], ur[dd], lr[dd]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                         float Qx[NV], Qu[NV], gm[NV], alow[NV], ahigh[NV];
                         env.adjoint(A, xh, uh, vx, qo, Qx, Qu);
                         lds_rows<NT>(rows, kSlotALow, qo, alow);
@@ -993,8 +1233,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
                             const f32x2 akt = abs2(kt);
                             unpr(ka, e, max2(pr(ka, e), akt));
                             const f32x2 den = abs2(pr(uh, e)) + 1.0f;
-                            gm[e] = akt.x / den.x;
-                            gm[e + 1] = akt.y / den.y;
+                            // |k| / (|u| + 1) (:243-245) with the hardware reciprocal (1 ulp) instead of an IEEE division
+                            // (8 per step were ~130 instructions): g_norm is only ever compared with atol
+                            gm[e] = akt.x * __builtin_amdgcn_rcpf(den.x);
+                            gm[e + 1] = akt.y * __builtin_amdgcn_rcpf(den.y);
                             vx[e] = Qx[e];                                                          // V_x <- Q_x
                             vx[e + 1] = Qx[e + 1];
                         }
@@ -1007,23 +1249,29 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
             kmax = col_max<NT, PK>(ka);
             dV1 = col_sum<NT, PK>(p1);
             g_norm = T > 0 ? gsum / (float)T : 0.0f;
+            TFMPC_PHASE_END(1);
+            if constexpr (NW > 1) { x_sweep[0][lane] = rJ; x_sweep[1][lane] = dV1; x_sweep[2][lane] = g_norm; x_sweep[3][lane] = kmax; }
+        }
+        if constexpr (NW > 1) {
+            __syncthreads();                 // the sweep's selector bytes (HBM) and its four results (LDS) are visible to the group
+            if (wv != 0) { rJ = x_sweep[0][lane]; dV1 = x_sweep[1][lane]; g_norm = x_sweep[2][lane]; kmax = x_sweep[3][lane]; }
         }
         const bool converged_g = !done && g_norm < cfg.atol;                   // :243-248
-        // ---- line search rounds (ilqr.py:317-355): every searching column tries its next step size ------
+        // ---- line search rounds (ilqr.py:317-355): every searching column tries its next step size(s) ------
         const bool searching = !done && !converged_g;
         bool accept = false;
         float residual = 0.0f, alpha_last = 0.0f;          // alpha_last: the step size of this column's last rollout
-        constexpr int NA = EnvM<KIND, NT>::kSearchAlphas;
-        // One step size per pass: the pass WRITES the candidate of every column that is trying it (a column's buffer is
+        constexpr int NA = NW > 1 ? 1 : EnvM<KIND, NT, (NW > 1)>::kSearchAlphas;       // step sizes per wave and pass
+        constexpr int NAP = NA * NW;                                          // ... per group and pass
+        // One step size per pass in a one-wave group: the pass WRITES the candidate of every column that is trying it (a column's buffer is
         // then final the moment the column accepts: no second rollout), and the early stop keeps the passes that are
         // rejected anyway -- most of a Reservoir search -- from writing much.  `complete`: this column's last try ran to
-        // the end of the horizon.  (Two step sizes per pass, HVAC: nothing is written, the accepted one is rolled out again.)
-        constexpr bool kStoreWhileSearching = NA == 1;      // (no env of the current tree searches one step size per pass)
+        // the end of the horizon.  (Several step sizes per pass: nothing is written, the accepted one is rolled out again.)
+        constexpr bool kStoreWhileSearching = NAP == 1;     // (no env of the current tree searches one step size per pass)
         // ... but not the passes that are all but certain to be rejected: the step size a column accepts rarely moves to
         // an EARLIER position from one iteration to the next (Reservoir, cfg5: never below index 3 of 11; tools/probes/
         // cfg5_trace.py), so the passes before the SMALLEST index any column of the wave accepted last time only answer
-        // "J(alpha) <= J_hat?" and write nothing -- a third of the kernel's stores went into candidates that were thrown
-        // away (cfg5 Reservoir 19.1 -> 17.9 ms; with a margin of one position: 19.4 -> 19.1).  A column that accepts in
+        // "J(alpha) <= J_hat?" and write nothing.  A column that accepts in
         // such a pass after all is rolled out again below (`complete` stays false): the results do not depend on the guess.
         int store_from = 0;
         if (kStoreWhileSearching) {
@@ -1032,37 +1280,55 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
                 if (__any(searching && last_index == v)) { store_from = v; break; }
         }
         bool complete = false;
-        for (int ai = 0; ai < cfg.n_alphas && __any(searching && !accept); ai += NA) {
-            float al[NA], J[NA];
+        for (int ai = 0; ai < cfg.n_alphas && __any(searching && !accept); ai += NAP) {
+            float al[NA], J[NA], Jall[NAP];
+            const int mine = ai + wv * NA;                                     // this wave's first step size of the pass
 #pragma unroll
-            for (int k = 0; k < NA; ++k) al[k] = cfg.alphas[ai + k < cfg.n_alphas ? ai + k : ai];
+            for (int k = 0; k < NA; ++k) al[k] = cfg.alphas[mine + k < cfg.n_alphas ? mine + k : ai];
             const bool trying_now = searching && !accept;
             bool stopped = false;
             const bool storing = kStoreWhileSearching && ai >= store_from;         // wave-uniform
-            if (storing)
-                rollout(std::true_type{}, std::integral_constant<bool, kStoreWhileSearching>{}, std::integral_constant<int, NA>{}, al,
-                        uhat, trying_now, xc, uc, cc, J, trying_now, rJ, true, &stopped);
-            else
-                rollout(std::true_type{}, std::false_type{}, std::integral_constant<int, NA>{}, al,
-                        uhat, false, xc, uc, cc, J, trying_now, rJ, true, &stopped);
+            if (mine < cfg.n_alphas) {                                         // (else: nothing left for this wave in the last pass)
+                TFMPC_PHASE_BEGIN();
+                if (storing)
+                    rollout(std::true_type{}, std::integral_constant<bool, kStoreWhileSearching>{}, std::integral_constant<int, NA>{}, al,
+                            uhat, trying_now, xc, uc, cc, J, trying_now, rJ, true, &stopped);
+                else
+                    rollout(std::true_type{}, std::false_type{}, std::integral_constant<int, NA>{}, al,
+                            uhat, false, xc, uc, cc, J, trying_now, rJ, true, &stopped);
+                TFMPC_PHASE_END(2);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NA; ++k) J[k] = 0.0f;
+            }
+            if (NW > 1) {                                                      // the group's J(alpha) of this pass, in step-size order
+                x_pass[parity][wv][0][lane] = J[0];
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < NW; ++w) Jall[w] = x_pass[parity][w][0][lane];
+                parity ^= 1;
+            } else {
+#pragma unroll
+                for (int k = 0; k < NA; ++k) Jall[k] = J[k];
+            }
             if (trying_now) complete = storing && !stopped;
 #pragma unroll
-            for (int k = 0; k < NA; ++k) {                                     // in the reference's order
+            for (int k = 0; k < NAP; ++k) {                                    // in the reference's order
                 const bool trying = searching && !accept && ai + k < cfg.n_alphas;
-                const float alpha = al[k];
+                const float alpha = cfg.alphas[ai + k < cfg.n_alphas ? ai + k : ai];
                 // residual = max |alpha k_t| (:206, before clipping) = alpha max |k_t|: rounding is monotone and alpha >= 0
                 const float res = alpha * kmax;
                 const float delta_J = -alpha * (dV1 + alpha * 0.0f);           // :339 (dV2 == 0 here)
-                const float dcost = rJ - J[k];
+                const float dcost = rJ - Jall[k];
                 const float z = (delta_J > 0.0f) ? dcost / delta_J : sgnf_(dcost); // :342-346
                 if (trying) {
                     residual = res;
                     alpha_last = alpha;
                     if (z >= cfg.c1) { accept = true; last_index = ai + k; }   // :351-353
 #ifdef TFMPC_CFG5_TRACE
-                    if (g_cfg5_trace && q == 0 && live && iteration + attempts < 16 && ai + k < 11) {
+                    if (NW == 1 && g_cfg5_trace && q == 0 && live && iteration + attempts < 16 && ai + k < 11) {
                         int *tr = g_cfg5_trace + ((size_t)b * 16 + iteration + attempts) * 12;
-                        tr[1 + ai + k] = trace_fa[k] < 0 ? T + 1 : trace_fa[k];
+                        tr[1 + ai + k] = trace_fa[k % 2] < 0 ? T + 1 : trace_fa[k % 2];
                         if (accept) tr[0] = ai + k;
                     }
 #endif
@@ -1072,9 +1338,13 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
         const bool small_step = searching && residual < cfg.atol;              // :253-257
         const bool take = searching && (small_step || accept);                 // (:253 takes the last rollout even if rejected)
         if (__any(take && !complete)) {     // (also: the last step size tried was cut short and :253 takes it all the same)
-            const float al[1] = {alpha_last};
-            float J[1];
-            rollout(std::true_type{}, std::true_type{}, one_t{}, al, uhat, take && !complete, xc, uc, cc, J);
+            if (wv == 0) {
+                TFMPC_PHASE_BEGIN();
+                const float al[1] = {alpha_last};
+                float J[1];
+                rollout(std::true_type{}, std::true_type{}, one_t{}, al, uhat, take && !complete, xc, uc, cc, J);
+                TFMPC_PHASE_END(3);
+            }
         }
         if (take) flip ^= 1;                                                   // the candidate becomes the nominal
         if (converged_g || small_step) done = true;                            // converged
@@ -1088,11 +1358,13 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
             if (++attempts >= cfg.max_attempts || !(mu < 1e30f)) { status |= TFMPC_ST_MAX_ATTEMPTS; done = true; }
         }
     }
-    // the nominal trajectory of every column goes out to the instance-major output arrays (16-bit containers: widened)
+    // the nominal trajectory of every column goes out to the instance-major output arrays (16-bit containers: widened);
+    // the waves of a group take alternate time steps
+    group_sync<NW>();                                      // wave 0's last stored rollout is visible to the group
     {
         const TT *xsrc = xbuf[flip], *usrc = ubuf[flip], *csrc = cbuf[flip];
         float *xdst = a.states + b * (T + 1) * n, *udst = a.actions + b * T * m, *cdst = a.costs + b * (T + 1);
-        for (int t = 0; t <= T; ++t) {
+        for (int t = wv; t <= T; t += NW) {
             float v[NV];
             ldw<NT>(xsrc, t, wl, v);
             stv<NT, VW>(xdst + (size_t)t * n, n, ql, live, v);
@@ -1103,8 +1375,15 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
             if (ql == 0) { const float c = ldc(csrc + (size_t)t * kCostLd); if (live) gst(cdst + t, c); }
         }
     }
+#ifdef TFMPC_PHASE_PROBE
+    if (g_cfg5_phases && wv == 0 && lane == 0) {
+        unsigned long long *out = g_cfg5_phases + (size_t)blockIdx.x * 16;
+        for (int i = 0; i < 4; ++i) { out[i] = phase_acc[i]; out[8 + i] = phase_cnt[i]; }
+        out[5] = __builtin_amdgcn_s_memtime() - kernel_t0;
+    }
+#endif
     if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
-    if (ql == 0 && live) {
+    if (wv == 0 && ql == 0 && live) {
         const float cT = ldc(cbuf[flip] + (size_t)T * kCostLd);
         if (!(cT == cT)) status |= TFMPC_ST_NAN;
         a.iterations[b] = iteration;
@@ -1113,6 +1392,15 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NT == 1 &
 }
 
 }  // namespace
+
+#ifdef TFMPC_PHASE_PROBE
+// probe builds only (tools/probes/cfg5_phases.py): cycles a group spends per phase, [group][8] 64-bit counters:
+// 0 start rollout, 1 sweep, 2 search passes, 3 stored rollout, 4 copy-out, 5 whole kernel, 6 search rollouts, 7 sweeps
+extern "C" int tfmpc_debug_cfg5_phases(unsigned long long *device_buffer)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cfg5_phases), &device_buffer, sizeof(device_buffer));
+}
+#endif
 
 #ifdef TFMPC_CFG5_TRACE
 extern "C" int tfmpc_debug_cfg5_trace(int *device_buffer)
@@ -1151,11 +1439,29 @@ int ilqr_adjoint_mfma_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, co
     const int vw = (env.n % 4 == 0 && aligned(15u)) ? 4 : ((env.n % 2 == 0 && aligned(7u)) ? 2 : 1);
     // instances per column: one up to n = 32 (two tiles) or 16, two for n <= 8, four for n <= 4
     const int pk = env.n <= 4 ? 4 : (env.n <= 8 ? 2 : 1);
-    const dim3 block(kWave), grid((a.B + kCols * pk - 1) / (kCols * pk));
+    // waves per sixteen-column group (see the kernel): one; TFMPC_COSTATE_WAVES=2 selects the two-wave form (measured slower)
+#ifdef TFMPC_COSTATE_PAIR
+    const int nw = option_int(kOptCostateWaves, 1) == 2 ? 2 : 1;
+#else
+    constexpr int nw = 1;               // the two-wave form is compiled only with -DTFMPC_COSTATE_PAIR (measured 1.4-1.5x slower)
+#endif
+    const dim3 block(kWave * nw), grid((a.B + kCols * pk - 1) / (kCols * pk));
+#ifdef TFMPC_COSTATE_PAIR
+#define TFMPC_LAUNCH_PAIR(KIND, NT_, PK_, VW_, BF_)                                                                            \
+    if (nw == 2) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, VW_, PK_, BF_, 2>), grid, block, 0, stream, env, cfg, a); \
+    else
+#else
+#define TFMPC_LAUNCH_PAIR(KIND, NT_, PK_, VW_, BF_)
+#endif
+#define TFMPC_LAUNCH_AM4(KIND, NT_, PK_, VW_, BF_)                                                                             \
+    do {                                                                                                                       \
+        TFMPC_LAUNCH_PAIR(KIND, NT_, PK_, VW_, BF_)                                                                            \
+        hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, VW_, PK_, BF_, 1>), grid, block, 0, stream, env, cfg, a);      \
+    } while (0)
 #define TFMPC_LAUNCH_AM3(KIND, NT_, PK_, VW_)                                                                                  \
     do {                                                                                                                       \
-        if (cfg.storage_bf16) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, VW_, PK_, true>), grid, block, 0, stream, env, cfg, a); \
-        else hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, VW_, PK_, false>), grid, block, 0, stream, env, cfg, a);  \
+        if (cfg.storage_bf16) TFMPC_LAUNCH_AM4(KIND, NT_, PK_, VW_, true);                                                     \
+        else TFMPC_LAUNCH_AM4(KIND, NT_, PK_, VW_, false);                                                                     \
     } while (0)
 #define TFMPC_LAUNCH_AM2(KIND, NT_, PK_)                                                                                        \
     do {                                                                                                                       \
@@ -1175,6 +1481,8 @@ int ilqr_adjoint_mfma_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, co
 #undef TFMPC_LAUNCH_AM
 #undef TFMPC_LAUNCH_AM2
 #undef TFMPC_LAUNCH_AM3
+#undef TFMPC_LAUNCH_AM4
+#undef TFMPC_LAUNCH_PAIR
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
 }
 

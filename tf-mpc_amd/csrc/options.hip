@@ -11,7 +11,7 @@ namespace tfmpc {
 namespace {
 
 constexpr int kMaxLen = 32;
-const char *const kNames[kOptCount] = {"TFMPC_LQR_KERNEL", "TFMPC_LQR_MFMA", "TFMPC_ILQR_KERNEL"};
+const char *const kNames[kOptCount] = {"TFMPC_LQR_KERNEL", "TFMPC_LQR_MFMA", "TFMPC_ILQR_KERNEL", "TFMPC_COSTATE_WAVES"};
 
 struct Table {
     char value[kOptCount][kMaxLen];
@@ -64,6 +64,23 @@ extern "C" int tfmpc_set_option(const char *name, const char *value)
         std::lock_guard<std::mutex> g(t.lock);
         t.value[i][0] = 0;
         if (value) std::strncat(t.value[i], value, kMaxLen - 1);
+        return TFMPC_OK;
+    }
+    return TFMPC_ERR_ARG;
+}
+
+
+// the current override of `name` copied into buf (empty string = no override): lets a caller restore what it replaces
+extern "C" int tfmpc_get_option(const char *name, char *buf, int len)
+{
+    using namespace tfmpc;
+    if (!name || !buf || len <= 0) return TFMPC_ERR_ARG;
+    Table &t = table();
+    for (int i = 0; i < kOptCount; ++i) {
+        if (std::strcmp(name, kNames[i]) != 0) continue;
+        std::lock_guard<std::mutex> g(t.lock);
+        buf[0] = 0;
+        std::strncat(buf, t.value[i], (size_t)len - 1);
         return TFMPC_OK;
     }
     return TFMPC_ERR_ARG;

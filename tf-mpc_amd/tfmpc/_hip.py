@@ -24,6 +24,7 @@ _P, _I, _L, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t
 _SIGNATURES = {
     "tfmpc_version": (ctypes.c_int, []),
     "tfmpc_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    "tfmpc_get_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]),
     "tfmpc_lqr_kernel_name": (ctypes.c_char_p, [_I, _I, _I]),
     "tfmpc_lqr_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "tfmpc_lqr_backward_f32": (_I, [_I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L,
@@ -87,7 +88,11 @@ def load():
                 "There is no CPU fallback.")
         lib = ctypes.CDLL(_LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(lib, name)
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                raise RuntimeError(f"tfmpc: {_LIB_PATH} does not export {name}: the library is older than this "
+                                   "package (rebuild it: make -C tf-mpc_amd/csrc)") from None
             fn.restype = res
             fn.argtypes = args
         _lib = lib
@@ -103,27 +108,39 @@ def require_gpu():
     return lib
 
 
+def get_option(name):
+    """The current override of a kernel-variant option (``None`` = the dispatcher's own choice): what the environment
+    variable of that name held at the library's first use, or the last ``set_option``."""
+    buf = ctypes.create_string_buffer(64)
+    if load().tfmpc_get_option(name.encode(), buf, len(buf)) != 0:
+        raise ValueError(f"tfmpc: unknown option {name!r}")
+    return buf.value.decode() or None
+
+
 def set_option(name, value):
     """``tfmpc_set_option``: force a kernel variant (``value=None`` = the dispatcher's own choice).  The library
-    reads the environment variables of the same names once, at its first use; afterwards only this call counts."""
+    reads the environment variables of the same names once, at its first use; afterwards only this call counts.
+    Returns the override it replaced (``None`` if there was none), so a caller can put it back."""
+    previous = get_option(name)
     rc = load().tfmpc_set_option(name.encode(), None if value is None else str(value).encode())
     if rc != 0:
         raise ValueError(f"tfmpc: unknown option {name!r}")
+    return previous
 
 
 class option:
-    """``with _hip.option("TFMPC_LQR_MFMA", "f32"): ...`` -- variant override for the duration of a block
-    (restores "no override", not a previous override)."""
+    """``with _hip.option("TFMPC_LQR_MFMA", "f32"): ...`` -- variant override for the duration of a block; on exit the
+    override that was active before the block (e.g. one exported in the environment) is restored."""
 
     def __init__(self, name, value):
-        self.name, self.value = name, value
+        self.name, self.value, self.previous = name, value, None
 
     def __enter__(self):
-        set_option(self.name, self.value)
+        self.previous = set_option(self.name, self.value)
         return self
 
     def __exit__(self, *exc):
-        set_option(self.name, None)
+        set_option(self.name, self.previous)
         return False
 
 

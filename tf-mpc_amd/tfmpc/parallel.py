@@ -22,32 +22,71 @@ def shard(tensor, world_size=None, rank=None):
     return tensor[lo:hi]
 
 
-def gather_trajectories(states, actions, costs, dst=0, group=None):
+def gather_buffers(states, actions, costs, total, dst=0, group=None):
+    """The receive buffers of ``gather_trajectories(..., total=total)`` on rank ``dst`` (``None`` elsewhere): allocate
+    them when the job starts, where running out of memory is an ordinary start-up error, instead of in front of the
+    collective."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    world = dist.get_world_size(group)
+    if dist.get_rank() != dst:
+        return None
+    per = states.shape[1:].numel() + actions.shape[1:].numel() + costs.shape[1:].numel()
+    bmax = max(hi - lo for lo, hi in (shard_bounds(total, world, r) for r in range(world)))
+    return [torch.empty((bmax, per), device=states.device, dtype=states.dtype) for _ in range(world)]
+
+
+def gather_trajectories(states, actions, costs, dst=0, group=None, total=None, recv=None):
     """Gather per-rank result shards ``states[b,T+1,n,1]``, ``actions[b,T,m,1]``,
     ``costs[b,T+1,...]`` on GLOBAL rank ``dst`` as ONE collective over a single packed
-    buffer.  Shards may differ in size by one instance.  Returns the concatenated
-    tensors on ``dst`` and ``None`` elsewhere.
+    buffer.  Returns the concatenated tensors on ``dst`` and ``None`` elsewhere.
 
-    Every rank takes the same sequence of collectives whatever happens locally: buffers are
-    allocated first, the ranks then agree (one 4-byte all_reduce) that all allocations
-    succeeded, and only then enter the gather -- an out-of-memory on the destination raises
-    ``RuntimeError`` on EVERY rank instead of leaving the others inside the collective."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    ``total`` = the global number of instances of a block-sharded batch (``shard`` / ``shard_bounds``): every rank
+    then knows every shard's size, and the ONLY communication is one ``dist.gather`` of the packed rows (padded to
+    the largest shard, which is at most one row more than the smallest) -- SURVEY.md 8(e)'s single RCCL gather.
+    ``recv`` = buffers from ``gather_buffers`` (else they are allocated here; an allocation failure then raises on
+    that rank only).
+
+    Without ``total`` the shards may be of any sizes: an 8-byte ``all_gather`` of the sizes and a 4-byte
+    ``all_reduce`` by which the ranks agree that every buffer could be allocated precede the gather, so that an
+    out-of-memory raises ``RuntimeError`` on EVERY rank instead of leaving the others inside the collective."""
+    if not (dist.is_available() and dist.is_initialized()):
         return states, actions, costs
     world = dist.get_world_size(group)
     is_dst = dist.get_rank() == dst                          # `dst` is a global rank, as dist.gather takes it
     b = states.shape[0]
     ns, na, nc = states.shape[1:].numel(), actions.shape[1:].numel(), costs.shape[1:].numel()   # valid for an empty shard too
     per = ns + na + nc
+
+    def pack(bmax):
+        packed = torch.zeros((bmax, per), device=states.device, dtype=states.dtype)
+        packed[:b] = torch.cat([states.reshape(b, ns), actions.reshape(b, na), costs.reshape(b, nc)], dim=1)
+        return packed
+
+    def unpack(recv_, all_b):
+        full = torch.cat([r[:nb] for r, nb in zip(recv_, all_b)], dim=0)
+        B = full.shape[0]
+        return (full[:, :ns].reshape(B, *states.shape[1:]), full[:, ns:ns + na].reshape(B, *actions.shape[1:]),
+                full[:, ns + na:].reshape(B, *costs.shape[1:]))
+
+    if total is not None:
+        all_b = [hi - lo for lo, hi in (shard_bounds(total, world, r) for r in range(world))]
+        mine = all_b[dist.get_rank(group)]
+        if b != mine:                                        # a caller's error, raised before anything is sent
+            raise ValueError(f"gather_trajectories: this rank holds {b} instances, the block split of {total} gives it {mine}")
+        packed = pack(max(all_b))
+        if is_dst and recv is None:
+            recv = [torch.empty_like(packed) for _ in range(world)]
+        dist.gather(packed, recv if is_dst else None, dst=dst, group=group)          # the one collective
+        return unpack(recv, all_b) if is_dst else None
+
     sizes = torch.tensor([b], device=states.device, dtype=torch.int64)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes, group=group)          # 8 bytes per rank; sizes only
     all_b = [int(s.item()) for s in all_sizes]
-    bmax = max(all_b)
-    packed, recv, error = None, None, None
+    packed, error = None, None
     try:
-        packed = torch.zeros((bmax, per), device=states.device, dtype=states.dtype)
-        packed[:b] = torch.cat([states.reshape(b, ns), actions.reshape(b, na), costs.reshape(b, nc)], dim=1)
+        packed = pack(max(all_b))
         recv = [torch.empty_like(packed) for _ in range(world)] if is_dst else None
     except RuntimeError as exc:                              # e.g. out of memory for the receive buffers
         error = exc
@@ -56,12 +95,7 @@ def gather_trajectories(states, actions, costs, dst=0, group=None):
     if int(ok.item()) == 0:
         raise RuntimeError(f"gather_trajectories: buffer allocation failed on at least one rank ({error!r} here)")
     dist.gather(packed, recv, dst=dst, group=group)        # the one data-path collective
-    if not is_dst:
-        return None
-    full = torch.cat([r[:nb] for r, nb in zip(recv, all_b)], dim=0)
-    B = full.shape[0]
-    return (full[:, :ns].reshape(B, *states.shape[1:]), full[:, ns:ns + na].reshape(B, *actions.shape[1:]),
-            full[:, ns + na:].reshape(B, *costs.shape[1:]))
+    return unpack(recv, all_b) if is_dst else None
 
 
 def gather_bytes_per_rank(states, actions, costs):

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Device assembly of ONLY the cfg5 instantiations (n = 32: two tiles, 16-byte pieces, fp32 containers) of
+# tf-mpc_amd/csrc/ilqr_adjoint_mfma.hip, for register / instruction budgeting without a GPU:
+#   tools/probes/asm_cfg5.sh [out.s]     then  python tools/probes/asm_loops.py out.s <kernel substring>
+set -e
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+OUT=${1:-/tmp/asm/cfg5.s}
+mkdir -p $(dirname $OUT)
+SRC=$ROOT/tf-mpc_amd/csrc/_asm_cfg5_tmp.hip
+python3 - "$ROOT/tf-mpc_amd/csrc/ilqr_adjoint_mfma.hip" "$SRC" <<'PY'
+import sys, re
+s = open(sys.argv[1]).read()
+a = s.index('#ifdef TFMPC_COSTATE_PAIR\n#define TFMPC_LAUNCH_PAIR')
+b = s.index('#undef TFMPC_LAUNCH_PAIR')
+few = '''    if (env.kind == TFMPC_ENV_HVAC) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<TFMPC_ENV_HVAC, 2, 4, 1, false, 1>), grid, block, 0, stream, env, cfg, a);
+    else hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<TFMPC_ENV_RESERVOIR, 2, 4, 1, false, 1>), grid, block, 0, stream, env, cfg, a);
+    (void)vw; (void)pk;
+'''
+open(sys.argv[2], 'w').write(s[:a] + few + s[b:])
+PY
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -S --cuda-device-only -o $OUT $SRC 2>&1 | grep -v "warning: argument unused" || true
+rm -f $SRC
+python3 - $OUT <<'PY'
+import re, sys
+txt = open(sys.argv[1]).read()
+for m in re.finditer(r'\.name:\s+(\S*ilqr_adjoint_mfma_kernel\S*)\n(?:.*\n)*?\s+\.sgpr_spill_count:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)', txt):
+    t = re.search(r'ILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELi(\d)E', m.group(1))
+    print("KIND", t.group(1), "NT", t.group(2), "NW", t.group(6), "| vgpr", m.group(3), "vgpr spills", m.group(4), "sgpr spills", m.group(2))
+PY

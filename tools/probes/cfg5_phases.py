@@ -1,0 +1,35 @@
+"""Where a cfg5 group's time goes (probe build: tools/probes/build_probe.sh ilqr_adjoint_mfma.hip, loaded through
+TFMPC_LIB): s_memtime cycles per phase of ilqr_adjoint_mfma_kernel -- start rollout, costate sweeps, line-search passes,
+stored rollouts -- per group, averaged; and the same at ONE group per SIMD (B = 16 384) and a single group (B = 16)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("TFMPC_LIB", os.path.join(ROOT, "tools/probes/ab/lib_probe.so"))
+for _p in ('tf-mpc_amd', 'tests', ''): sys.path.insert(0, os.path.join(ROOT, _p))
+import numpy as np, torch, problems
+from tfmpc import _hip
+from tfmpc.envs.hvac import HVAC
+from tfmpc.envs.reservoir import Reservoir
+from tfmpc.solvers.ilqr import iLQR
+n, T = 32, 100
+lib = _hip.load()
+lib.tfmpc_debug_cfg5_phases.argtypes = [ctypes.c_void_p]
+names = ["start rollout", "sweeps", "search passes", "stored rollouts"]
+for B in [int(v) for v in sys.argv[1:]] or (32768, 16384, 16):
+    rng = np.random.default_rng(4)
+    for kind in ("hvac", "reservoir"):
+        if kind == "hvac":
+            env = HVAC.load(dict(problems.hvac_config(n, seed=5))); x0 = np.full((B, n, 1), 10.0, dtype=np.float32)
+        else:
+            env = Reservoir.load(dict(problems.reservoir_config(n, seed=5))); x0 = rng.uniform(50, 75, size=(B, n, 1)).astype(np.float32)
+        s = iLQR(env, max_iterations=12); u0 = s.random_actions(T, B, seed=5)
+        groups = (B + 15) // 16
+        buf = torch.zeros((groups, 16), dtype=torch.int64, device="cuda")
+        assert lib.tfmpc_debug_cfg5_phases(buf.data_ptr()) == 0
+        out = s.solve_device(x0, T, u_init=u0); torch.cuda.synchronize()
+        out = s.solve_device(x0, T, u_init=u0, workspace=out["workspace"]); torch.cuda.synchronize()
+        p = buf.cpu().numpy().astype(np.float64)
+        tot = p[:, 5].mean()
+        print(f"{kind} B={B}: kernel {tot / 1e3:.0f} k ticks per group (s_memtime ticks)")
+        for i, nm in enumerate(names):
+            c = p[:, 8 + i].mean()
+            print(f"   {nm:16s} {100 * p[:, i].mean() / tot:5.1f} %   {c:6.1f} calls, {p[:, i].mean() / max(c, 1):9.0f} ticks per call")
