@@ -223,7 +223,8 @@ int tfmpc_ilqr_forward_f32(const TfmpcEnv *env, int B, int T, const float *x, co
 
 /* Scratch of tfmpc_ilqr_solve_f32, a function of the shape alone (the env kind is not known here): per instance the
  * gains K, k and one candidate trajectory; for n = m = 2 a line-search block per wavefront; for n = m <= 32 the two
- * wave-major trajectory buffers of the 16-instances-per-wave HVAC / Reservoir kernel.  256-byte aligned base. */
+ * wave-major trajectory buffers of the 16-instances-per-wave HVAC / Reservoir kernel.  The workspace handed to
+ * tfmpc_ilqr_solve_f32 must be 256-byte aligned (TFMPC_ERR_WORKSPACE otherwise). */
 size_t tfmpc_ilqr_workspace_bytes(int B, int n, int m, int T);
 
 /* iLQR.solve (ilqr.py:214-283) in ONE launch: each wave runs its instance's whole
@@ -238,6 +239,33 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
                          float *states, float *actions, float *costs,
                          int32_t *iterations, int32_t *status,
                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* tfmpc_ilqr_solve_f32 with the DECISION TRACE of the solve (what the reference prints per pass through the body of
+ * ilqr.py:238-270 -- `[BACKWARD] J_hat`, `[SOLVE] g_norm`, `[FORWARD] J`, the progress bar's J / g_norm / residual,
+ * ilqr.py:243-279 -- and what its regularisation schedule holds): one row of TFMPC_TRACE_COLS floats per backward
+ * pass + line search of an instance, in the order they happen, trace[B][trace_rows][TFMPC_TRACE_COLS]; rows beyond
+ * trace_rows are dropped.  trace_len[B] = the number of passes the instance made (may exceed trace_rows).
+ * Columns: see TFMPC_TR_*.  trace == NULL: identical to tfmpc_ilqr_solve_f32.  With a trace the solve runs on a
+ * kernel that records one (the HVAC / Reservoir shared-env kernel, the 2-D lane-group kernel, else the generic
+ * wave kernel): same algorithm, possibly another kernel than the untraced call would pick. */
+#define TFMPC_TRACE_COLS 10
+#define TFMPC_TR_ITERATION 0  /* the reference's loop index `iteration` (ilqr.py:227) of this pass            */
+#define TFMPC_TR_MU 1         /* mu handed to _backward (ilqr.py:240), before a local Cholesky-failure bump   */
+#define TFMPC_TR_DELTA 2      /* delta at that point                                                          */
+#define TFMPC_TR_J_HAT 3      /* cost of the nominal trajectory as the backward pass sums it (ilqr.py:164)    */
+#define TFMPC_TR_G_NORM 4     /* ilqr.py:243                                                                  */
+#define TFMPC_TR_ALPHA_INDEX 5 /* position (0-based) in the step-size list of the LAST rollout of the line search;
+                                 -1 when the pass ended on g_norm < atol before any rollout                  */
+#define TFMPC_TR_ALPHA 6      /* that step size                                                               */
+#define TFMPC_TR_J 7          /* its total cost J (ilqr.py:205-210)                                           */
+#define TFMPC_TR_ACCEPTED 8   /* 1 = z >= c1 (ilqr.py:351-353), 0 = all step sizes rejected, -1 = no line search */
+#define TFMPC_TR_RESIDUAL 9   /* ilqr.py:206 of that rollout (-1 without line search)                         */
+int tfmpc_ilqr_solve_trace_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B, int T,
+                               const float *x0, const float *u_init,
+                               float *states, float *actions, float *costs,
+                               int32_t *iterations, int32_t *status,
+                               float *trace, int trace_rows, int32_t *trace_len,
+                               void *workspace, size_t workspace_bytes, void *stream);
 
 /* projected_newton_qp (tfmpc/utils/optimization.py:6-101): B independent box QPs
  * min 1/2 x^T H x + q^T x, low <= x <= high.  H[B][m][m], q/low/high/x0[B][m];

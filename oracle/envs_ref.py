@@ -70,8 +70,19 @@ class OracleEnv:
             return self._final_cost(self._t(state)).numpy().reshape(())
 
     # -- diffenv.py:13-32 -------------------------------------------------------
-    def get_linear_transition(self, states, actions):
+    # The reference differentiates the whole time axis at once (GradientTape.batch_jacobian, diffenv.py:21-22); so does
+    # the restatement: torch.func's jacrev / hessian of the single-step functions, vmapped over the T steps (the same
+    # reverse-mode derivatives as a per-step loop of torch.autograd.functional.jacobian, which `_loop=True` still runs --
+    # tests/test_oracle_pinning.py holds the two against each other -- at a fiftieth of the time).
+    def get_linear_transition(self, states, actions, _loop=False):
         n, m = self.state_size, self.action_size
+        if not _loop and len(states) > 0:
+            X, U = self._t(np.stack(states)), self._t(np.stack(actions))
+            with torch.no_grad():
+                f = torch.func.vmap(self._transition)(X, U)
+            jx, ju = torch.func.vmap(torch.func.jacrev(self._transition, argnums=(0, 1)))(X, U)
+            T = X.shape[0]
+            return TransitionApprox(f.numpy(), jx.reshape(T, n, n).numpy(), ju.reshape(T, n, m).numpy())
         fs, fxs, fus = [], [], []
         for x, u in zip(states, actions):
             x, u = self._t(x), self._t(u)
@@ -83,15 +94,25 @@ class OracleEnv:
         return TransitionApprox(np.stack(fs), np.stack(fxs), np.stack(fus))
 
     # -- diffenv.py:34-83 -------------------------------------------------------
-    def get_quadratic_cost(self, states, actions):
+    def get_quadratic_cost(self, states, actions, _loop=False):
         n, m = self.state_size, self.action_size
+
+        def scalar_cost(x, u):
+            return self._cost(x, u).reshape(())
+
+        if not _loop and len(states) > 0:
+            X, U = self._t(np.stack(states)), self._t(np.stack(actions))
+            T = X.shape[0]
+            with torch.no_grad():
+                l = torch.func.vmap(scalar_cost)(X, U)
+            gx, gu = torch.func.vmap(torch.func.jacrev(scalar_cost, argnums=(0, 1)))(X, U)
+            (hxx, hxu), (hux, huu) = torch.func.vmap(torch.func.jacfwd(torch.func.jacrev(scalar_cost, argnums=(0, 1)), argnums=(0, 1)))(X, U)
+            return CostApprox(l.numpy(), gx.reshape(T, n, 1).numpy(), gu.reshape(T, m, 1).numpy(),
+                              hxx.reshape(T, n, n).numpy(), huu.reshape(T, m, m).numpy(),
+                              hux.reshape(T, m, n).numpy(), hxu.reshape(T, n, m).numpy())
         out = [[] for _ in range(7)]
         for x, u in zip(states, actions):
             x, u = self._t(x), self._t(u)
-
-            def scalar_cost(x, u):
-                return self._cost(x, u).reshape(())
-
             l = scalar_cost(x, u)
             gx, gu = torch.autograd.functional.jacobian(scalar_cost, (x, u))
             (hxx, hxu), (hux, huu) = torch.autograd.functional.hessian(scalar_cost, (x, u))

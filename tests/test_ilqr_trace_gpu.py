@@ -1,0 +1,164 @@
+"""Whole-solve DECISION-TRACE parity of the fused iLQR kernels (``-m gpu``): ``tfmpc_ilqr_solve_trace_f32`` /
+``iLQR.solve(..., trace=True)`` returns, per instance, what the reference logs per pass through the body of
+/root/reference/tfmpc/solvers/ilqr.py:238-279 (mu, delta, J_hat, g_norm, the step size the line search ended on, its
+J and residual, accepted or not).  Here that trace is compared, pass by pass, with the FREE-RUNNING fp32 restatement of
+the reference (oracle/ilqr_ref.py through tests/trace_oracle.py, which also reports each pass's decision margin): wherever
+every comparison of a pass has a clear margin the device must have taken the same decisions with the same numbers, up to
+the first near-tie (after which two fp32 programs may legitimately part ways); and where the whole traces agree, the final
+trajectory must agree with the fp64 restatement inside the fp32 budget (5 x the fp32 restatement's own error).
+
+BASELINE configs[3] (Navigation, n = m = 2, T = 50: the 16-lanes-per-instance kernel) on 256 instances;
+configs[4] (HVAC n = m = 32, T = 100, 12 iterations: the 16-instances-per-wave kernel) on 64 instances;
+the generic wave kernel on the reference's own hvac6 config.  Reservoir's costate sweep has exact ties in every pass
+(Q_u,i = x_i (V_x,i+1 - V_x,i)), so its trace is compared up to the first divergence only.
+PARITY UNPINNED for numeric iLQR outputs: the reference holds no numeric iLQR answer -- "vs own restatement"."""
+
+import numpy as np
+import pytest
+import torch
+
+import problems
+import trace_oracle
+from tfmpc import _hip
+from tfmpc.envs.hvac import HVAC
+from tfmpc.envs.navigation import Navigation
+from tfmpc.envs.reservoir import Reservoir
+from tfmpc.solvers.ilqr import iLQR, trace_records
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(dev_rows, ref_rows, atol=5e-3):
+    """Pass-by-pass comparison of one instance.  Returns (agreeing passes, 'full' | 'tie' | 'mismatch: ...').
+    g_norm and residual are quantities the solver compares with `atol`: they are held to 0.5 % or 0.2 % of atol."""
+    n = 0
+    for p, ref in enumerate(ref_rows):
+        if ref["margin"] < 1.0:
+            return n, "tie"                      # a near-tie in the restatement: either side is right from here on
+        if p >= len(dev_rows):
+            return n, f"mismatch: the device made {len(dev_rows)} passes, the restatement at least {p + 1}"
+        d = dev_rows[p]
+        for key in ("iteration", "alpha_index", "accepted"):
+            if d[key] != ref[key]:
+                return n, f"mismatch: pass {p} {key}: device {d[key]}, restatement {ref[key]} (margin {ref['margin']:.1f})"
+        for key, rtol, floor in (("mu", 1e-5, 1e-12), ("delta", 1e-6, 1e-12), ("J_hat", 2e-4, 1e-6), ("g_norm", 5e-3, 2e-3 * atol),
+                                 ("J", 2e-4, 1e-6), ("residual", 5e-3, 2e-3 * atol)):
+            if ref[key] is None:
+                continue
+            if abs(d[key] - ref[key]) > max(rtol * abs(ref[key]), floor):
+                return n, f"mismatch: pass {p} {key}: device {d[key]!r}, restatement {ref[key]!r}"
+        n += 1
+    if len(dev_rows) != len(ref_rows):
+        return n, f"mismatch: the device made {len(dev_rows)} passes, the restatement {len(ref_rows)}"
+    return n, "full"
+
+
+def _device(env, x0, u0, T, max_iterations, rows=160, **kw):
+    solver = iLQR(env, max_iterations=max_iterations, **kw)
+    out = solver.solve_device(x0, T, u_init=u0, trace_rows=rows)
+    plain = solver.solve_device(x0, T, u_init=u0)
+    torch.cuda.synchronize()
+    assert int(out["trace_len"].max()) <= rows
+    return out, plain
+
+
+def _check(kind, cfg, env, x0, u0, T, max_iterations, min_full, n64, same_kernel_untraced=True):
+    out, plain = _device(env, x0, u0, T, max_iterations)
+    if same_kernel_untraced:                     # the trace is a by-product: the traced and the plain launch agree bit for bit
+        for key in ("states", "actions", "costs", "iterations", "status"):
+            assert torch.equal(out[key], plain[key]), key
+    dev = trace_records(out["trace"], out["trace_len"])
+    its = out["iterations"].cpu().numpy()
+    ref32 = trace_oracle.run_many(kind, cfg, x0, u0, T, "float32", max_iterations)
+    verdicts = [_compare(dev[b], ref32[b][0]) for b in range(len(x0))]
+    mism = [(b, v) for b, (n, v) in enumerate(verdicts) if v.startswith("mismatch")]
+    assert not mism, mism[:5]
+    full = [b for b, (n, v) in enumerate(verdicts) if v == "full"]
+    passes = sum(n for n, v in verdicts)
+    print(f"{kind}: {len(full)} of {len(x0)} whole traces agree, {passes} passes compared in all, "
+          f"{sum(1 for n, v in verdicts if v == 'tie')} instances end at a near-tie")
+    assert len(full) >= min_full * len(x0), (len(full), len(x0))
+    assert passes >= 0.6 * sum(len(r[0]) for r in ref32), passes           # most passes lie before an instance's first near-tie
+    for b in full:                               # same decisions all the way: same iteration count
+        assert its[b] == ref32[b][4], (b, its[b], ref32[b][4])
+    # final trajectories inside the fp32 budget where the fp64 restatement takes the same decisions too
+    some = full[:n64]
+    ref64 = trace_oracle.run_many(kind, cfg, x0[some], u0[some], T, "float64", max_iterations)
+    compared = 0
+    for i, b in enumerate(some):
+        r64, r32 = ref64[i], ref32[b]
+        same = len(r64[0]) == len(r32[0]) and all(a["alpha_index"] == c["alpha_index"] and a["accepted"] == c["accepted"]
+                                                    and a["iteration"] == c["iteration"] for a, c in zip(r64[0], r32[0]))
+        if not same:
+            continue
+        compared += 1
+        for key, j in (("states", 1), ("actions", 2), ("costs", 3)):
+            got = out[key][b].cpu().numpy().astype(np.float64).reshape(r64[j].shape)
+            scale = max(np.abs(r64[j]).max(), 1.0)
+            budget = max(5 * np.abs(r32[j] - r64[j]).max(), 2e-6 * scale)
+            assert np.abs(got - r64[j]).max() <= budget, (b, key, np.abs(got - r64[j]).max(), budget)
+    assert compared >= max(1, len(some) // 2), (compared, len(some))
+    return verdicts
+
+
+def test_navigation_whole_solve_traces():
+    """BASELINE configs[3]: 256 instances through the lane-group kernel, default hyper-parameters (up to 100 iterations)."""
+    cfg = problems.NAV_CONFIG
+    env = Navigation.load(cfg)
+    rng = np.random.default_rng(4)
+    B, T = 256, 50
+    x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
+    u0 = np.stack([problems.scalar_uniform_actions(T, [-1, -1], [1, 1], rng) for _ in range(B)]).astype(np.float32)
+    _check("navigation", cfg, env, x0, u0, T, 100, min_full=0.9, n64=48)     # (measured: 248 of 256, 2101 passes)
+
+
+def test_hvac_cfg5_whole_solve_traces():
+    """BASELINE configs[4]: HVAC n = m = 32, T = 100, 12 iterations, 64 instances = four groups of the 16-per-wave kernel."""
+    n, T, B = 32, 100, 64
+    cfg = dict(problems.hvac_config(n, seed=5))
+    env = HVAC.load(dict(cfg))
+    rng = np.random.default_rng(11)
+    x0 = rng.uniform(8.0, 25.0, size=(B, n, 1)).astype(np.float32)
+    u0 = iLQR(env).random_actions(T, B, seed=5).cpu().numpy().astype(np.float32)
+    _hip.set_option("TFMPC_ILQR_KERNEL", "costate_mfma")
+    try:
+        _check("hvac", cfg, env, x0, u0, T, 12, min_full=0.15, n64=8)   # (measured: 16 of 64 without any near-tie in 12 iterations, 553 of 768 passes compared)
+    finally:
+        _hip.set_option("TFMPC_ILQR_KERNEL", None)
+
+
+def test_reservoir_cfg5_traces_up_to_the_first_tie():
+    n, T, B = 32, 100, 16
+    cfg = dict(problems.reservoir_config(n, seed=5))
+    env = Reservoir.load(dict(cfg))
+    rng = np.random.default_rng(12)
+    x0 = rng.uniform(50.0, 75.0, size=(B, n, 1)).astype(np.float32)
+    u0 = iLQR(env).random_actions(T, B, seed=5).cpu().numpy().astype(np.float32)
+    out, plain = _device(env, x0, u0, T, 3)
+    for key in ("states", "actions", "costs", "iterations"):
+        assert torch.equal(out[key], plain[key]), key
+    dev = trace_records(out["trace"], out["trace_len"])
+    ref32 = trace_oracle.run_many("reservoir", cfg, x0, u0, T, "float32", 3)
+    first = 0
+    for b in range(B):
+        d, r = dev[b][0], ref32[b][0][0]
+        # the first pass starts from the same trajectory: J_hat and the gradient norm agree to rounding; the step size
+        # depends on bang-bang selector ties and is compared where the restatement's margin is clear
+        assert abs(d["J_hat"] - r["J_hat"]) <= 2e-4 * abs(r["J_hat"]) and abs(d["g_norm"] - r["g_norm"]) <= 5e-3 * r["g_norm"]
+        first += int(d["alpha_index"] == r["alpha_index"])
+    assert first >= B // 2, first
+
+
+def test_wave_kernel_trace_on_the_reference_hvac6_config():
+    """The generic wave kernel (any env): its trace against the restatement on the reference's own small HVAC config."""
+    cfg = dict(problems.HVAC6_CONFIG)
+    n, T, B = 6, 40, 24
+    env = HVAC.load(dict(cfg))
+    rng = np.random.default_rng(13)
+    x0 = rng.uniform(8.0, 25.0, size=(B, n, 1)).astype(np.float32)
+    u0 = iLQR(env).random_actions(T, B, seed=6).cpu().numpy().astype(np.float32)
+    _hip.set_option("TFMPC_ILQR_KERNEL", "wave")
+    try:
+        _check("hvac", cfg, env, x0, u0, T, 10, min_full=0.3, n64=6)
+    finally:
+        _hip.set_option("TFMPC_ILQR_KERNEL", None)

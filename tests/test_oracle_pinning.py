@@ -301,3 +301,27 @@ def test_golden_files_are_reproducible(golden):
     x, u, c, it = s.solve(g["x03"][:, None], int(g["T3"]), u_init=g["u_init3"][..., None])
     assert it == int(g["sol_iteration3"])
     assert np.array_equal(x, g["sol_states3"]) and np.array_equal(c, g["sol_costs3"])
+
+
+def test_vectorised_derivatives_equal_the_per_step_loop():
+    """oracle/envs_ref.py differentiates all time steps at once (torch.func, as the reference's batch_jacobian does,
+    diffenv.py:21-22, 45-72); the per-step torch.autograd.functional loop it replaced stays as `_loop=True`: every
+    field of both approximations agrees to rounding on all five envs."""
+    import problems
+    from oracle import envs_ref
+    rng = np.random.default_rng(0)
+    nav = problems.NAV_CONFIG
+    F, f, C, c, _ = problems.make_lqr_batch_fast(1, 4, 2, seed=1)
+    cases = [(envs_ref.HVAC(**problems.hvac_config(8, seed=1)), 8, 8),
+             (envs_ref.Reservoir(**problems.reservoir_config(5, seed=1)), 5, 5),
+             (envs_ref.Navigation(nav["goal"], nav["deceleration"]["center"], nav["deceleration"]["decay"], nav["low"], nav["high"]), 2, 2),
+             (envs_ref.NavigationLQR([[5.5], [-9.0]], 5.0, -1.0, 1.0), 2, 2),
+             (envs_ref.LQEnv(F[0], f[0][:, None], C[0], c[0][:, None]), 4, 2)]
+    for env, n, m in cases:
+        X = [rng.uniform(5, 60, size=(n, 1)) for _ in range(6)]
+        U = [rng.uniform(0, 1, size=(m, 1)) for _ in range(6)]
+        for name in ("get_linear_transition", "get_quadratic_cost"):
+            fast, loop = getattr(env, name)(X, U), getattr(env, name)(X, U, _loop=True)
+            for a, b, field in zip(fast, loop, fast._fields):
+                assert a.shape == b.shape, (type(env).__name__, name, field)
+                assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max()), (type(env).__name__, name, field)

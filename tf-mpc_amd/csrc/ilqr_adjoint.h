@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "../../include/tfmpc_hip.h"
+#include "ilqr_trace.h"
 
 namespace tfmpc {
 
@@ -16,6 +17,7 @@ struct AdjointSolveArgs {
     int32_t *iterations, *status;
     float *wsk, *wsx, *wsu, *wsc;        // gains k[T][m], candidate x[T+1][n], u[T][m], costs[T+1]
     void *wave_ws;                       // 16-per-wave kernel: its wave-major trajectory buffers (ilqr_adjoint_mfma_workspace_bytes)
+    TraceArgs trace;                     // 16-per-wave kernel only: the optional decision trace
 };
 
 bool ilqr_adjoint_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg);

@@ -1261,6 +1261,11 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
         const bool searching = !done && !converged_g;
         bool accept = false;
         float residual = 0.0f, alpha_last = 0.0f;          // alpha_last: the step size of this column's last rollout
+        float J_last = 0.0f;                               // ... and its cost, position: the decision trace
+        int index_last = -1;
+        const bool active = !done;
+        const float mu_pass = mu, delta_pass = delta;
+        const int row_pass = iteration + attempts;
         constexpr int NA = NW > 1 ? 1 : EnvM<KIND, NT, (NW > 1)>::kSearchAlphas;       // step sizes per wave and pass
         constexpr int NAP = NA * NW;                                          // ... per group and pass
         // One step size per pass in a one-wave group: the pass WRITES the candidate of every column that is trying it (a column's buffer is
@@ -1324,6 +1329,8 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
                 if (trying) {
                     residual = res;
                     alpha_last = alpha;
+                    J_last = Jall[k];
+                    index_last = ai + k;
                     if (z >= cfg.c1) { accept = true; last_index = ai + k; }   // :351-353
 #ifdef TFMPC_CFG5_TRACE
                     if (NW == 1 && g_cfg5_trace && q == 0 && live && iteration + attempts < 16 && ai + k < 11) {
@@ -1346,6 +1353,9 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
                 TFMPC_PHASE_END(3);
             }
         }
+        if (a.trace.rows && active && live && wv == 0 && ql == 0)             // one lane per instance (tfmpc_ilqr_solve_trace_f32)
+            trace_write(a.trace, b, row_pass, iteration, mu_pass, delta_pass, rJ, g_norm, index_last, alpha_last, J_last,
+                        searching ? (accept ? 1 : 0) : -1, searching ? residual : -1.0f);
         if (take) flip ^= 1;                                                   // the candidate becomes the nominal
         if (converged_g || small_step) done = true;                            // converged
         else if (searching && accept) {                                        // :259-266

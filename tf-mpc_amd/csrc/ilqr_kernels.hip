@@ -10,6 +10,7 @@
 #include "ilqr_adjoint.h"
 #include "ilqr_core.h"
 #include "ilqr_lq_mfma.h"
+#include "ilqr_trace.h"
 #include "lqr_kernels.h"
 #include "options.h"
 
@@ -20,8 +21,9 @@ bool ilqr_lane_supported(const TfmpcEnv &env);
 int ilqr_lane_solve_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, int B, int T, const float *x0,
                            const float *u_init, float *states, float *actions, float *costs, int32_t *iterations,
                            int32_t *status, float *wsK, float *wsk, float *wsx, float *wsu, float *wsc, void *extra,
-                           hipStream_t stream);
+                           const TraceArgs &trace, hipStream_t stream);
 size_t ilqr_lane_extra_workspace_bytes(int B, int n, int m, int T);
+bool ilqr_lane_group_fits(int T);       // the 16-lanes-per-instance kernel (the one that records a decision trace) serves this horizon
 
 // ---- model providers for backward_pass ------------------------------------------
 template <int KIND>
@@ -198,6 +200,7 @@ struct SolveArgs {
     int32_t *iterations, *status;
     float *wsK, *wsk, *wsx, *wsu, *wsc;     // per-instance scratch: gains and the candidate trajectory
     int only_flagged;                       // second-chance launch: solve only instances with kIlqrRetryBit set
+    TraceArgs trace;                        // optional decision trace (tfmpc_ilqr_solve_trace_f32)
 };
 
 // iLQR.solve (ilqr.py:214-283): the whole iteration loop of one instance in one wave.
@@ -247,14 +250,19 @@ __global__ __launch_bounds__(kWave) void ilqr_solve_kernel(TfmpcEnv env, TfmpcIl
                 wsync();
             }
             if (give_up) break;
-            if (r.g_norm < cfg.atol) { converged = true; break; }          // :243-248
+            if (r.g_norm < cfg.atol) {                                     // :243-248
+                if (lane == 0) trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, r.J, r.g_norm, -1, 0.0f, 0.0f, -1, -1.0f);
+                converged = true;
+                break;
+            }
             wsync();
             // _forward (:317-355): backtracking line search over the step sizes
             bool accept = false;
-            float residual = 0.0f;
+            float residual = 0.0f, J = 0.0f;
+            int ai_last = -1;
             for (int ai = 0; ai < cfg.n_alphas; ++ai) {
                 const float alpha = cfg.alphas[ai];
-                float J;
+                ai_last = ai;
                 forward_pass<KIND, !kAdjoint>(s, e, T, alpha, xhat, uhat, Kg, kg, xc, uc, cc, J, residual);
                 const float delta_J = -alpha * (r.dV1 + alpha * r.dV2);    // :339
                 const float dcost = r.J - J;
@@ -263,6 +271,9 @@ __global__ __launch_bounds__(kWave) void ilqr_solve_kernel(TfmpcEnv env, TfmpcIl
                 if (z >= cfg.c1) { accept = true; break; }                 // :351-353
             }
             const bool small_step = residual < cfg.atol;                  // :253-257 (taken even if rejected)
+            if (lane == 0)
+                trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, r.J, r.g_norm, ai_last,
+                            ai_last >= 0 ? cfg.alphas[ai_last] : 0.0f, J, accept ? 1 : 0, residual);
             if (small_step || accept) {
                 for (int idx = lane; idx < (T + 1) * n; idx += kWave) xhat[idx] = xc[idx];
                 for (int idx = lane; idx < T * m; idx += kWave) uhat[idx] = uc[idx];
@@ -452,53 +463,87 @@ int tfmpc_ilqr_forward_f32(const TfmpcEnv *env, int B, int T, const float *x, co
     return launched();
 }
 
+// The ONE description of the solve workspace (tfmpc_ilqr_workspace_bytes sizes it, tfmpc_ilqr_solve_trace_f32 carves it):
+// five per-instance slabs -- gains K[T][m][n], k[T][m] and a candidate trajectory x[T+1][n], u[T][m], c[T+1] -- then, each
+// from a 256-byte boundary, the line-search scratch of the 2-D lane-group kernel and the wave-major trajectory buffers of
+// the 16-instances-per-wave HVAC / Reservoir kernel.  Offsets in bytes from a 256-byte aligned base.
+struct IlqrWsLayout {
+    size_t K, k, x, u, c, lane, wave, total;
+    IlqrWsLayout(int B, int n, int m, int T)
+    {
+        const size_t f = sizeof(float);
+        K = 0;
+        k = K + (size_t)B * T * m * n * f;
+        x = k + (size_t)B * T * m * f;
+        u = x + (size_t)B * (T + 1) * n * f;
+        c = u + (size_t)B * T * m * f;
+        lane = round256(c + (size_t)B * (T + 1) * f);
+        wave = lane + round256(ilqr_lane_extra_workspace_bytes(B, n, m, T));
+        total = wave + ilqr_adjoint_mfma_workspace_bytes(B, n, m, T);
+    }
+    static size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
+};
+
 size_t tfmpc_ilqr_workspace_bytes(int B, int n, int m, int T)
 {
     if (B <= 0 || n <= 0 || m <= 0 || T < 0) return 0;
-    const size_t per = (size_t)T * m * n + (size_t)T * m + (size_t)(T + 1) * n + (size_t)T * m + (size_t)(T + 1);
-    const size_t slabs = ((size_t)B * per * sizeof(float) + 255) & ~(size_t)255;
-    const size_t lane = (ilqr_lane_extra_workspace_bytes(B, n, m, T) + 255) & ~(size_t)255;   // 2-D envs: line-search scratch
-    return slabs + lane + ilqr_adjoint_mfma_workspace_bytes(B, n, m, T);   // n == m <= 32: wave-major trajectories (16 per wave)
+    return IlqrWsLayout(B, n, m, T).total;
 }
 
 int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B, int T, const float *x0,
                          const float *u_init, float *states, float *actions, float *costs, int32_t *iterations,
                          int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
 {
+    return tfmpc_ilqr_solve_trace_f32(env, cfg, B, T, x0, u_init, states, actions, costs, iterations, status, nullptr, 0,
+                                      nullptr, workspace, workspace_bytes, stream);
+}
+
+int tfmpc_ilqr_solve_trace_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B, int T, const float *x0,
+                               const float *u_init, float *states, float *actions, float *costs, int32_t *iterations,
+                               int32_t *status, float *trace, int trace_rows, int32_t *trace_len, void *workspace,
+                               size_t workspace_bytes, void *stream)
+{
     int rc = check_env(env);
     if (rc != TFMPC_OK) return rc;
     if (!cfg || B < 0 || T < 0 || cfg->n_alphas < 1 || cfg->n_alphas > TFMPC_MAX_ALPHAS || cfg->max_iterations < 1)
         return TFMPC_ERR_ARG;
+    if (trace && (trace_rows < 1 || !trace_len)) return TFMPC_ERR_ARG;
     if (B == 0) return TFMPC_OK;
     if (!x0 || !states || !costs || !iterations || !status || (T > 0 && (!u_init || !actions))) return TFMPC_ERR_ARG;
     const int n = env->n, m = env->m;
-    if (!workspace || workspace_bytes < tfmpc_ilqr_workspace_bytes(B, n, m, T)) return TFMPC_ERR_WORKSPACE;
-    float *w = static_cast<float *>(workspace);
+    const IlqrWsLayout lay(B, n, m, T);
+    if (!workspace || workspace_bytes < lay.total || (reinterpret_cast<uintptr_t>(workspace) & 255u)) return TFMPC_ERR_WORKSPACE;
+    char *const base = static_cast<char *>(workspace);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const TraceArgs tr{trace, trace_len, trace ? trace_rows : 0};
+    const bool traced = trace != nullptr;
+    if (traced && hipMemsetAsync(trace_len, 0, (size_t)B * sizeof(int32_t), st) != hipSuccess) return TFMPC_ERR_LAUNCH;
     SolveArgs a{};
     a.B = B; a.T = T; a.x0 = x0; a.u_init = u_init;
     a.states = states; a.actions = actions; a.costs = costs; a.iterations = iterations; a.status = status;
-    a.wsK = w; w += (size_t)B * T * m * n;
-    a.wsk = w; w += (size_t)B * T * m;
-    a.wsx = w; w += (size_t)B * (T + 1) * n;
-    a.wsu = w; w += (size_t)B * T * m;
-    a.wsc = w;
-    char *const after_slabs = static_cast<char *>(workspace) + (((size_t)B * ((size_t)T * m * n + (size_t)T * m + (size_t)(T + 1) * n + (size_t)T * m + (size_t)(T + 1)) * sizeof(float) + 255) & ~(size_t)255);
-    char *const after_lane = after_slabs + ((ilqr_lane_extra_workspace_bytes(B, n, m, T) + 255) & ~(size_t)255);
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    a.wsK = reinterpret_cast<float *>(base + lay.K);
+    a.wsk = reinterpret_cast<float *>(base + lay.k);
+    a.wsx = reinterpret_cast<float *>(base + lay.x);
+    a.wsu = reinterpret_cast<float *>(base + lay.u);
+    a.wsc = reinterpret_cast<float *>(base + lay.c);
+    a.trace = tr;
+    char *const after_slabs = base + lay.lane;
+    char *const after_lane = base + lay.wave;
     {
         // tiny 2-D envs: 16 lanes per instance with a speculative parallel line search (ilqr_lane.hip) at EVERY batch
         // size -- also for one instance it has the shorter critical path (Navigation, T = 50, B = 1: 2.3 ms against
         // 7.2 ms for the wave kernel; tools/small_batch_lane_vs_wave.py).  TFMPC_ILQR_KERNEL=lane|lane1|wave forces.
         const bool forced_wave = option_is(kOptIlqrKernel, "wave");
-        if (ilqr_lane_supported(*env) && !forced_wave && !cfg->storage_bf16)
+        if (ilqr_lane_supported(*env) && !forced_wave && !cfg->storage_bf16 && (!traced || ilqr_lane_group_fits(T)))
             return ilqr_lane_solve_launch(*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status,
                                           a.wsK, a.wsk, a.wsx, a.wsu, a.wsc,
-                                          after_slabs, st);
+                                          after_slabs, tr, st);
     }
     {
         // LQ env on the matrix cores (ilqr_lq_mfma.hip); instances it cannot finish (mu > 0 needed)
         // come back flagged and are re-solved from scratch by the wave kernel right behind it
-        const bool forced_wave = option_is(kOptIlqrKernel, "wave");
+        // (the matrix-core LQ kernels record no decision trace: a traced solve goes to the wave kernel)
+        const bool forced_wave = option_is(kOptIlqrKernel, "wave") || traced;
         if (!forced_wave && !cfg->storage_bf16 && ilqr_lq_box_mfma_supported(*env, T)) {
             // control-limited LQ problems: box-QP in registers, the complete solve loop in one kernel
             IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk, a.wsu};
@@ -521,7 +566,7 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
         // HVAC / Reservoir at n <= 32: register-resident costate kernel (ilqr_adjoint.hip),
         // bit-identical to the generic wave kernel below (TFMPC_ILQR_KERNEL=wave selects that one)
         const bool forced_wave = option_is(kOptIlqrKernel, "wave");
-        const AdjointSolveArgs aa{B, T, x0, u_init, states, actions, costs, iterations, status, a.wsk, a.wsx, a.wsu, a.wsc, after_lane};
+        const AdjointSolveArgs aa{B, T, x0, u_init, states, actions, costs, iterations, status, a.wsk, a.wsx, a.wsu, a.wsc, after_lane, tr};
         // a batch that shares one env: 16 instances per wave with the coupling-matrix products on the matrix
         // cores (ilqr_adjoint_mfma.hip); TFMPC_ILQR_KERNEL=costate_mfma forces it, lean / lean1 the kernels above.
         // storage_bf16: that kernel keeps its trajectories in REAL 16-bit containers (the wave kernel below emulates
@@ -529,10 +574,10 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
         const bool forced_lean = option_is(kOptIlqrKernel, "lean") || option_is(kOptIlqrKernel, "lean1");
         const bool forced_mfma = option_is(kOptIlqrKernel, "costate_mfma");
         if (!forced_wave && !forced_lean && ilqr_adjoint_mfma_supported(*env, *cfg) &&
-            (forced_mfma || cfg->storage_bf16 ||
+            (forced_mfma || cfg->storage_bf16 || traced ||
              B >= ((n > 16 && env->kind != TFMPC_ENV_RESERVOIR) ? kCostateMfmaMinBatchLarge : kCostateMfmaMinBatchSmall)))
             return ilqr_adjoint_mfma_launch(*env, *cfg, aa, st);
-        if (!forced_wave && ilqr_adjoint_supported(*env, *cfg)) return ilqr_adjoint_launch(*env, *cfg, aa, st);
+        if (!forced_wave && !traced && ilqr_adjoint_supported(*env, *cfg)) return ilqr_adjoint_launch(*env, *cfg, aa, st);
     }
     const size_t smem = ilqr_solve_smem_bytes(env->kind, n, m, env->n_zones);
     if (env->kind == TFMPC_ENV_LQ && n >= kBlockedFrom) {      // the only dense env that comes in large shapes

@@ -14,6 +14,7 @@
 
 #include "envs.h"
 #include "lqr_kernels.h"
+#include "ilqr_trace.h"
 #include "options.h"
 #include "small_linalg.h"
 
@@ -353,6 +354,7 @@ struct SolveArgsLane {
     int32_t *iterations, *status;
     float *wsK, *wsk, *wsx, *wsu, *wsc;
     float *scratch;          // group kernel only: one block of candidate trajectories per wavefront
+    TraceArgs trace;         // group kernel only: the optional decision trace
 };
 
 template <int KIND, int N, int M, class Store, bool PRE = false>
@@ -845,7 +847,11 @@ __global__ __launch_bounds__(64, 4) void ilqr_group_solve_kernel(TfmpcEnv genv, 
                     if (retry >= 40) { give_up = true; break; }
                 }
                 if (give_up) break;
-                if (r.g_norm < cfg.atol) { converged = true; break; }            // :243-248
+                if (r.g_norm < cfg.atol) {                                       // :243-248
+                    if (leader) trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, r.J, r.g_norm, -1, 0.0f, 0.0f, -1, -1.0f);
+                    converged = true;
+                    break;
+                }
                 // all step sizes at once, one per lane (ilqr.py:322-353), candidates into the scratch columns
                 float J, residual;
                 TFMPC_PROBE_START();
@@ -860,6 +866,11 @@ __global__ __launch_bounds__(64, 4) void ilqr_group_solve_kernel(TfmpcEnv genv, 
                 const int chosen = accept ? (__ffs(mask) - 1) : cfg.n_alphas - 1;     // first accepted, else the last tried
                 const float res_chosen = __shfl(residual, grp * G + chosen, 64);
                 const bool small_step = res_chosen < cfg.atol;                   // :253-257
+                if (a.trace.rows) {
+                    const float J_chosen = __shfl(J, grp * G + chosen, 64);
+                    if (leader) trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, r.J, r.g_norm, chosen,
+                                            cfg.alphas[chosen], J_chosen, accept ? 1 : 0, res_chosen);
+                }
                 if (small_step || accept) {
                     // adopt the chosen lane's candidate: its scratch column becomes the nominal trajectory
                     TFMPC_PROBE_START();
@@ -903,6 +914,8 @@ __global__ __launch_bounds__(64, 4) void ilqr_group_solve_kernel(TfmpcEnv genv, 
     }
 }
 
+bool ilqr_lane_group_fits(int T) { return GroupStore<2, 2, 4, 3>::bytes(T) <= 64 * 1024; }
+
 bool ilqr_lane_supported(const TfmpcEnv &env)
 {
     if (env.n != 2 || env.m != 2) return false;
@@ -937,11 +950,12 @@ static int group_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const S
 int ilqr_lane_solve_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, int B, int T, const float *x0,
                            const float *u_init, float *states, float *actions, float *costs, int32_t *iterations,
                            int32_t *status, float *wsK, float *wsk, float *wsx, float *wsu, float *wsc, void *extra,
-                           hipStream_t stream)
+                           const TraceArgs &trace, hipStream_t stream)
 {
     SolveArgsLane a{B, T, x0, u_init, states, actions, costs, iterations, status, wsK, wsk, wsx, wsu, wsc};
+    a.trace = trace;
     {
-        const bool per_lane = option_is(kOptIlqrKernel, "lane1");
+        const bool per_lane = option_is(kOptIlqrKernel, "lane1") && !trace.rows;      // (only the group kernel records a trace)
         const size_t glds = GroupStore<2, 2, 4, 3>::bytes(T);
         if (!per_lane && glds <= 64 * 1024) {
             a.scratch = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(extra) + 255) & ~(uintptr_t)255);

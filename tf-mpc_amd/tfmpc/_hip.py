@@ -42,6 +42,7 @@ for _name in ("backward", "forward", "solve"):       # twins for a non-symmetric
 ENV_LQ, ENV_NAVLQR, ENV_NAVIGATION, ENV_HVAC, ENV_RESERVOIR = range(5)
 ENV_MAX_PARAMS = 10
 MAX_ALPHAS = 16
+TRACE_COLS = 10          # TFMPC_TRACE_COLS
 
 
 class TfmpcEnv(ctypes.Structure):
@@ -69,6 +70,7 @@ _SIGNATURES.update({
     "tfmpc_ilqr_forward_f32": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P]),
     "tfmpc_ilqr_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "tfmpc_ilqr_solve_f32": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "tfmpc_ilqr_solve_trace_f32": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _P]),
     "tfmpc_boxqp_f32": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 })
 

@@ -30,6 +30,28 @@ from tfmpc.envs.diffenv import CostApprox, FinalCostApprox, TransitionApprox
 from tfmpc.utils import trajectory
 
 
+TRACE_COLUMNS = ("iteration", "mu", "delta", "J_hat", "g_norm", "alpha_index", "alpha", "J", "accepted", "residual")
+
+
+def trace_records(trace, trace_len):
+    """The device trace of ``solve_device(trace_rows=...)`` as lists of dicts, one list per instance and one dict per
+    pass -- the fields the oracle's ``ILQRRef.trace`` holds (oracle/ilqr_ref.py; reference: ilqr.py:238-279).  A pass that
+    ended on ``g_norm < atol`` made no line search: ``alpha_index``, ``alpha``, ``J``, ``accepted``, ``residual`` are None."""
+    tr = trace.detach().cpu().numpy()
+    ln = trace_len.detach().cpu().numpy()
+    out = []
+    for b in range(tr.shape[0]):
+        rows = []
+        for r in tr[b, :min(int(ln[b]), tr.shape[1])]:
+            searched = r[8] >= 0
+            rows.append(dict(iteration=int(r[0]), mu=float(r[1]), delta=float(r[2]), J_hat=float(r[3]), g_norm=float(r[4]),
+                             alpha_index=int(r[5]) if searched else None, alpha=float(r[6]) if searched else None,
+                             J=float(r[7]) if searched else None, accepted=bool(r[8] > 0) if searched else None,
+                             residual=float(r[9]) if searched else None))
+        out.append(rows)
+    return out
+
+
 def _f32(a, device):
     if isinstance(a, torch.Tensor):
         return a.detach().to(device=device, dtype=torch.float32)
@@ -246,10 +268,14 @@ class iLQR:
         return states, actions, costs, J, residual
 
     # -- fused solve, device tensors in/out -----------------------------------------------------
-    def solve_device(self, x0, T, u_init=None, seed=None, workspace=None):
+    def solve_device(self, x0, T, u_init=None, seed=None, workspace=None, trace_rows=0):
         """ONE kernel launch for B whole iLQR solves.  Returns a dict of device tensors:
         ``states[B,T+1,n,1]``, ``actions[B,T,m,1]``, ``costs[B,T+1]``, ``iterations[B]``
-        (the reference's returned loop index) and ``status[B]``.  Never synchronises."""
+        (the reference's returned loop index) and ``status[B]``.  Never synchronises.
+
+        ``trace_rows > 0``: also the decision trace of every instance -- ``trace[B, trace_rows, TRACE_COLS]`` (one row
+        per backward pass + line search, columns ``TRACE_COLUMNS``; rows never written are NaN) and ``trace_len[B]``
+        (passes made): what the reference logs per pass of ilqr.py:238-279 (``tfmpc_ilqr_solve_trace_f32``)."""
         lib = _hip.require_gpu()
         T = int(T)
         n, m = self.env.state_size, self.env.action_size
@@ -280,18 +306,40 @@ class iLQR:
             workspace = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
         env, keep = self.env.c_env()
         cfg = self._c_config()
-        rc = lib.tfmpc_ilqr_solve_f32(ctypes.byref(env), ctypes.byref(cfg), B, T, _hip.ptr(x0), _hip.ptr(u),
-                                      _hip.ptr(states), _hip.ptr(actions), _hip.ptr(costs), _hip.ptr(iterations),
-                                      _hip.ptr(status), _hip.ptr(workspace),
-                                      workspace.numel() * workspace.element_size(), _hip.stream())
-        _hip.check(rc, "tfmpc_ilqr_solve_f32")
+        trace = trace_len = None
+        if trace_rows > 0:
+            trace = torch.full((B, int(trace_rows), _hip.TRACE_COLS), float("nan"), dtype=torch.float32, device=dev)
+            trace_len = torch.zeros((B,), dtype=torch.int32, device=dev)
+        rc = lib.tfmpc_ilqr_solve_trace_f32(ctypes.byref(env), ctypes.byref(cfg), B, T, _hip.ptr(x0), _hip.ptr(u),
+                                            _hip.ptr(states), _hip.ptr(actions), _hip.ptr(costs), _hip.ptr(iterations),
+                                            _hip.ptr(status), _hip.ptr(trace), int(trace_rows), _hip.ptr(trace_len),
+                                            _hip.ptr(workspace), workspace.numel() * workspace.element_size(), _hip.stream())
+        _hip.check(rc, "tfmpc_ilqr_solve_trace_f32")
         self.last_status = status
-        return dict(states=states.unsqueeze(-1), actions=actions.unsqueeze(-1), costs=costs, iterations=iterations,
-                    status=status, batched=batched, workspace=workspace)
+        out = dict(states=states.unsqueeze(-1), actions=actions.unsqueeze(-1), costs=costs, iterations=iterations,
+                   status=status, batched=batched, workspace=workspace)
+        if trace is not None:
+            out.update(trace=trace, trace_len=trace_len)
+        return out
 
     # -- ilqr.py:214-283 ---------------------------------------------------------------------
-    def solve(self, x0, T, show_progress=True, u_init=None, seed=None):
-        out = self.solve_device(x0, T, u_init=u_init, seed=seed)
+    def solve(self, x0, T, show_progress=True, u_init=None, seed=None, trace=False):
+        """``(Trajectory, iteration)`` as the reference returns them (ilqr.py:281-283).  ``trace=True`` also records what
+        the reference logs while it solves (ilqr.py:243-279: per pass ``J_hat``, ``g_norm``, the step size the line
+        search ended on, its ``J`` and ``residual``, ``mu`` / ``delta``) into ``self.last_trace`` -- a list of dicts
+        per instance (``tfmpc.solvers.ilqr.trace_records``); with ``show_progress`` the progress bar's postfix
+        (``J``, ``g_norm``, ``residual``, ilqr.py:279) of an unbatched solve is printed per pass to stderr."""
+        rows = 0
+        if trace:       # an iteration makes at most max_attempts rejected passes; almost all make one or two
+            rows = int(self.max_iterations) + int(self.max_attempts) + 1
+        out = self.solve_device(x0, T, u_init=u_init, seed=seed, trace_rows=rows)
+        if trace:
+            self.last_trace = trace_records(out["trace"], out["trace_len"])
+            if show_progress and not out["batched"]:
+                import sys
+                for r in self.last_trace[0]:
+                    res = "" if r["residual"] is None else f", residual={r['residual']:.4f}"
+                    print(f"[iLQR] iteration {r['iteration']}: J={r['J_hat']:.4f}, g_norm={r['g_norm']:.4f}{res}", file=sys.stderr)
         if out["batched"]:
             return trajectory.Trajectory(out["states"], out["actions"], out["costs"]), out["iterations"].cpu().numpy()
         traj = trajectory.Trajectory(out["states"][0], out["actions"][0], out["costs"][0])
