@@ -107,6 +107,27 @@ int tfmpc_lqr_solve_f32(int B, int n, int m, int T,
                         float *K, float *k, float *V, float *v, float *cst,
                         int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The policy (K_t, k_t) and the value function (V_t, v_t, const_t) of lqr.py:107-129 in 16-BIT containers (SURVEY.md 8f
+ * N4: they are 9 x the bytes of the trajectory -- 81.8 KB per solve at n = 16, m = 8, T = 50, 40.9 KB like this).
+ * K16, k16, V16, v16, cst16: bf16 arrays (uint16_t) in the layouts of K, k, V, v, cst, any may be NULL; every value is
+ * the fp32 result rounded to nearest even, i.e. exactly what rounding tfmpc_lqr_solve_f32's outputs would give.  The
+ * trajectory (states, actions, costs: fp32) is rolled out with the fp32 gains and is identical to
+ * tfmpc_lqr_solve_f32's.  `workspace`: tfmpc_lqr_workspace_bytes (the fp32 gains live there).  Shapes the lane /
+ * workgroup kernels serve go to the wave kernel; TFMPC_ERR_UNSUPPORTED beyond its LDS limit (n = m ~ 48). */
+int tfmpc_lqr_solve_bf16out_f32(int B, int n, int m, int T,
+                                const float *F, long strideF, const float *f, long stride_f,
+                                const float *C, long strideC, const float *c, long stride_c,
+                                const float *x0,
+                                float *states, float *actions, float *costs,
+                                uint16_t *K16, uint16_t *k16, uint16_t *V16, uint16_t *v16, uint16_t *cst16,
+                                int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+/* LQR.backward alone, 16-bit outputs (same contract; `workspace` as above). */
+int tfmpc_lqr_backward_bf16out_f32(int B, int n, int m, int T,
+                                   const float *F, long strideF, const float *f, long stride_f,
+                                   const float *C, long strideC, const float *c, long stride_c,
+                                   uint16_t *K16, uint16_t *k16, uint16_t *V16, uint16_t *v16, uint16_t *cst16,
+                                   int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+
 
 /* The same three calls for a C that is not symmetric (see PRECONDITION above). */
 int tfmpc_lqr_backward_general_f32(int B, int n, int m, int T,

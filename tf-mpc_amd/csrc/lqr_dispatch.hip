@@ -72,6 +72,9 @@ int run(const LqrArgs &a, bool bw, bool fw, bool general, void *stream)
     if (general) return lqr_generic_launch(a, bw, fw, s);
     if (want_mfma(a.n, a.m)) return lqr_mfma_launch(a, bw, fw, s);
     if (want_mfma32(a.n, a.m)) return lqr_mfma32_launch(a, bw, fw, s);
+    // 16-bit policy / value outputs (tfmpc_lqr_*_bf16out_f32) are written by the two kernels above and the wave kernel
+    if (a.K16 || a.k16 || a.V16 || a.v16 || a.cst16)
+        return lqr_generic_smem_bytes(a.n, a.m) <= kMaxLdsBytes ? lqr_generic_launch(a, bw, fw, s) : TFMPC_ERR_UNSUPPORTED;
     if (want_lane(a.n, a.m, a.B)) return lqr_lane_launch(a, bw, fw, s);
     if (want_block(a.n, a.m, a.B)) return lqr_block_launch(a, bw, fw, s);
     return lqr_generic_launch(a, bw, fw, s);
@@ -102,13 +105,17 @@ size_t tfmpc_lqr_workspace_bytes(int B, int n, int m, int T)
     return (size_t)B * T * m * (n + 1) * sizeof(float);
 }
 
+
 }  // extern "C"
 
 namespace {
 
+struct Out16 { uint16_t *K, *k, *V, *v, *cst; };
+
 int backward_impl(bool general, int B, int n, int m, int T, const float *F, long strideF, const float *f,
                   long stride_f, const float *C, long strideC, const float *c, long stride_c,
-                  float *K, float *k, float *V, float *v, float *cst, int32_t *status, void *stream)
+                  float *K, float *k, float *V, float *v, float *cst, int32_t *status, void *stream,
+                  const Out16 &o16 = Out16{})
 {
     int rc = check_common(B, n, m, T, F, f, C, c, general);
     if (rc != TFMPC_OK) return rc;
@@ -119,6 +126,7 @@ int backward_impl(bool general, int B, int n, int m, int T, const float *F, long
     a.sF = strideF; a.sf = stride_f; a.sC = strideC; a.sc = stride_c;
     a.K = K; a.k = k; a.sK = (long)T * m * n; a.sk = (long)T * m;
     a.V = V; a.v = v; a.cst = cst; a.status = status;
+    a.K16 = o16.K; a.k16 = o16.k; a.V16 = o16.V; a.v16 = o16.v; a.cst16 = o16.cst;
     return run(a, true, false, general, stream);
 }
 
@@ -144,7 +152,7 @@ int solve_impl(bool general, int B, int n, int m, int T, const float *F, long st
                long stride_f, const float *C, long strideC, const float *c, long stride_c,
                const float *x0, float *states, float *actions, float *costs, float *K, float *k,
                float *V, float *v, float *cst, int32_t *status, void *workspace,
-               size_t workspace_bytes, void *stream)
+               size_t workspace_bytes, void *stream, const Out16 &o16 = Out16{})
 {
     int rc = check_common(B, n, m, T, F, f, C, c, general);
     if (rc != TFMPC_OK) return rc;
@@ -164,6 +172,7 @@ int solve_impl(bool general, int B, int n, int m, int T, const float *F, long st
     a.K = K; a.k = k; a.sK = (long)T * m * n; a.sk = (long)T * m;
     a.V = V; a.v = v; a.cst = cst;
     a.states = states; a.actions = actions; a.costs = costs; a.status = status;
+    a.K16 = o16.K; a.k16 = o16.k; a.V16 = o16.V; a.v16 = o16.v; a.cst16 = o16.cst;
     return run(a, true, true, general, stream);
 }
 
@@ -198,5 +207,31 @@ int tfmpc_lqr_solve_f32(TFMPC_LQR_SOLVE_PARAMS) { return solve_impl(false, TFMPC
 int tfmpc_lqr_backward_general_f32(TFMPC_LQR_BACKWARD_PARAMS) { return backward_impl(true, TFMPC_LQR_BACKWARD_ARGS); }
 int tfmpc_lqr_forward_general_f32(TFMPC_LQR_FORWARD_PARAMS) { return forward_impl(true, TFMPC_LQR_FORWARD_ARGS); }
 int tfmpc_lqr_solve_general_f32(TFMPC_LQR_SOLVE_PARAMS) { return solve_impl(true, TFMPC_LQR_SOLVE_ARGS); }
+
+// Policy / value-function outputs in 16-bit containers (lqr.py:107-129 is what they hold)
+int tfmpc_lqr_solve_bf16out_f32(int B, int n, int m, int T, const float *F, long strideF, const float *f, long stride_f,
+                                const float *C, long strideC, const float *c, long stride_c, const float *x0,
+                                float *states, float *actions, float *costs, uint16_t *K16, uint16_t *k16, uint16_t *V16,
+                                uint16_t *v16, uint16_t *cst16, int32_t *status, void *workspace, size_t workspace_bytes,
+                                void *stream)
+{
+    return solve_impl(false, B, n, m, T, F, strideF, f, stride_f, C, strideC, c, stride_c, x0, states, actions, costs,
+                      nullptr, nullptr, nullptr, nullptr, nullptr, status, workspace, workspace_bytes, stream,
+                      Out16{K16, k16, V16, v16, cst16});
+}
+
+int tfmpc_lqr_backward_bf16out_f32(int B, int n, int m, int T, const float *F, long strideF, const float *f, long stride_f,
+                                   const float *C, long strideC, const float *c, long stride_c, uint16_t *K16,
+                                   uint16_t *k16, uint16_t *V16, uint16_t *v16, uint16_t *cst16, int32_t *status,
+                                   void *workspace, size_t workspace_bytes, void *stream)
+{
+    // the sweep still needs its fp32 gains (K_t feeds V_t): they live in the caller's scratch
+    if (B > 0 && T > 0 && (!workspace || workspace_bytes < tfmpc_lqr_workspace_bytes(B, n, m, T))) return TFMPC_ERR_WORKSPACE;
+    float *w = static_cast<float *>(workspace);
+    return backward_impl(false, B, n, m, T, F, strideF, f, stride_f, C, strideC, c, stride_c, w,
+                         w ? w + (size_t)B * T * m * n : nullptr, nullptr, nullptr, nullptr, status, stream,
+                         Out16{K16, k16, V16, v16, cst16});
+}
+
 
 }  // extern "C"

@@ -137,11 +137,13 @@ __global__ __launch_bounds__(kWave) void lqr_generic_kernel(LqrArgs a)
                 const float x = -s.aug[r * lda + m + 1 + j];
                 s.K[r * ldn + j] = x;
                 if (Kg) Kg[(size_t)t * m * n + idx] = x;
+                if (a.K16) a.K16[((size_t)b * T + t) * m * n + idx] = lqr_to_bf16(x);
             });
             for (int r = lane; r < m; r += kWave) {
                 const float x = -s.aug[r * lda + m];
                 s.k[r] = x;
                 if (kg) kg[(size_t)t * m + r] = x;
+                if (a.k16) a.k16[((size_t)b * T + t) * m + r] = lqr_to_bf16(x);
             }
             wsync();
             // K^T Q_uu  [n][m]                                         (lqr.py:95)
@@ -191,13 +193,16 @@ __global__ __launch_bounds__(kWave) void lqr_generic_kernel(LqrArgs a)
                 const float x = s.Vn[i * ldn + j];
                 s.V[i * ldn + j] = x;
                 if (a.V) a.V[((size_t)b * T + t) * n * n + idx] = x;
+                if (a.V16) a.V16[((size_t)b * T + t) * n * n + idx] = lqr_to_bf16(x);
             });
             for (int i = lane; i < n; i += kWave) {
                 const float x = s.vn[i];
                 s.v[i] = x;
                 if (a.v) a.v[((size_t)b * T + t) * n + i] = x;
+                if (a.v16) a.v16[((size_t)b * T + t) * n + i] = lqr_to_bf16(x);
             }
             if (a.cst && lane == 0) a.cst[(size_t)b * T + t] = cst;
+            if (a.cst16 && lane == 0) a.cst16[(size_t)b * T + t] = lqr_to_bf16(cst);
             wsync();
         }
 

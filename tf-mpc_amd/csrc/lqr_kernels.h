@@ -14,6 +14,14 @@ namespace tfmpc {
 // gfx950: 160 KiB of LDS per CU, all of it addressable by one workgroup.
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 
+// fp32 -> bf16, round to nearest even on the bits (NaN stays NaN: the quiet bit survives the shift)
+__host__ __device__ inline uint16_t lqr_to_bf16(float x)
+{
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
 struct LqrArgs {
     int B, n, m, T;
     const float *F, *f, *C, *c, *x0;
@@ -21,6 +29,9 @@ struct LqrArgs {
     float *K, *k;                 // [B][T][m][n], [B][T][m]  (read by forward-only launches)
     long sK, sk;                  // batch strides of K, k
     float *V, *v, *cst;           // optional value-function outputs
+    // optional 16-bit (bf16, round to nearest even) copies of the policy / value-function outputs, in the layouts of
+    // K, k, V, v, cst (tfmpc_lqr_*_bf16out_f32; served by the matrix-core kernels and the wave kernel)
+    uint16_t *K16, *k16, *V16, *v16, *cst16;
     float *states, *actions, *costs;
     int32_t *status;
 };

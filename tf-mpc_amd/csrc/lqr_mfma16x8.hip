@@ -290,6 +290,12 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
                     if (ka < m && 2 * jc + 1 < n) Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] = kv.y;
                     if (lane < m) kg[(size_t)t * m + lane] = lds[kKs + 24 * 8 + lane];
                 }
+                if (a.K16) {                               // 16-bit copy of the policy (the rollout reads the fp32 gains)
+                    uint16_t *Ko = a.K16 + ((size_t)b * T + t) * (m * n);
+                    if (ka < m && 2 * jc < n) Ko[ka * n + 2 * jc] = lqr_to_bf16(kv.x);
+                    if (ka < m && 2 * jc + 1 < n) Ko[ka * n + 2 * jc + 1] = lqr_to_bf16(kv.y);
+                }
+                if (a.k16 && lane < m) a.k16[((size_t)b * T + t) * m + lane] = lqr_to_bf16(lds[kKs + 24 * 8 + lane]);
             }
             if (VALUE) {
                 // const += 1/2 k^T Q_uu k + k^T q_u + 1/2 f^T V f + f^T v with Q_uu k = -q_u
@@ -308,6 +314,19 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
                         if (EXACT || 4 * q + r < n) vo[4 * q + r] = vd[r];
                 }
                 if (a.cst && lane == 0) a.cst[(size_t)b * T + t] = cst;
+                if (a.V16) {
+                    uint16_t *Vo = a.V16 + ((size_t)b * T + t) * (n * n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (EXACT || (4 * q + r < n && i < n)) Vo[(4 * q + r) * n + i] = lqr_to_bf16(Vd[r]);
+                }
+                if (a.v16 && i == M) {
+                    uint16_t *vo = a.v16 + ((size_t)b * T + t) * n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (EXACT || 4 * q + r < n) vo[4 * q + r] = lqr_to_bf16(vd[r]);
+                }
+                if (a.cst16 && lane == 0) a.cst16[(size_t)b * T + t] = lqr_to_bf16(cst);
             }
             __syncthreads();
         }
@@ -492,7 +511,7 @@ bool lqr_mfma_supported(int n, int m) { return n >= 1 && m >= 1 && n <= N && m <
 
 int lqr_mfma_launch(const LqrArgs &a, bool backward, bool forward, hipStream_t stream)
 {
-    const bool value = a.V || a.v || a.cst;
+    const bool value = a.V || a.v || a.cst || a.V16 || a.v16 || a.cst16;
     if (backward && forward) return value ? launch<true, true, true>(a, stream) : launch<true, true, false>(a, stream);
     if (backward) return value ? launch<true, false, true>(a, stream) : launch<true, false, false>(a, stream);
     return launch<false, true, false>(a, stream);

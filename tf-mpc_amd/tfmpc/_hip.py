@@ -33,6 +33,10 @@ _SIGNATURES = {
                                    _P, _L, _P, _L, _P, _P, _P, _P, _P]),
     "tfmpc_lqr_solve_f32": (_I, [_I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P,
                                  _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "tfmpc_lqr_solve_bf16out_f32": (_I, [_I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P,
+                                         _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "tfmpc_lqr_backward_bf16out_f32": (_I, [_I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L,
+                                            _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
 }
 
 

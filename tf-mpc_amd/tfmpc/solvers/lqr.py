@@ -205,10 +205,14 @@ class LQR:
         return states, actions, costs
 
     # -- fused backward + forward, device tensors in/out ----------------------------
-    def solve_device(self, x0, T, want_policy=False, want_value=False, workspace=None):
+    def solve_device(self, x0, T, want_policy=False, want_value=False, workspace=None, storage_bf16=False):
         """One kernel launch for ``B`` solves; returns a dict of device tensors
         (``states[B,T+1,n,1]``, ``actions[B,T,m,1]``, ``costs[B,T+1,1,1]``,
-        ``status[B]`` and, on request, ``K, k, V, v, const``).  Never synchronises."""
+        ``status[B]`` and, on request, ``K, k, V, v, const``).  Never synchronises.
+
+        ``storage_bf16=True``: the requested policy / value-function tensors come back as ``torch.bfloat16`` (half the
+        bytes of the path's largest outputs, lqr.py:107-129; each value = the fp32 result rounded to nearest even,
+        ``tfmpc_lqr_solve_bf16out_f32``); the trajectory stays fp32 and is the one the fp32 gains give."""
         lib = _hip.require_gpu()
         T = int(T)
         n, m = self.state_size, self.action_size
@@ -222,18 +226,22 @@ class LQR:
                    actions=torch.empty((Bk, T, m, 1), device=dev),
                    costs=torch.empty((Bk, T + 1, 1, 1), device=dev),
                    status=torch.zeros((Bk,), dtype=torch.int32, device=dev))
+        odt = torch.bfloat16 if storage_bf16 else torch.float32
+        if storage_bf16 and self._suffix != "_f32":
+            raise NotImplementedError("16-bit outputs are served for symmetric C (the fast kernels and the wave kernel)")
         if want_policy:
-            out.update(K=torch.empty((Bk, T, m, n), device=dev), k=torch.empty((Bk, T, m, 1), device=dev))
+            out.update(K=torch.empty((Bk, T, m, n), device=dev, dtype=odt), k=torch.empty((Bk, T, m, 1), device=dev, dtype=odt))
         if want_value:
-            out.update(V=torch.empty((Bk, T, n, n), device=dev), v=torch.empty((Bk, T, n, 1), device=dev),
-                       const=torch.empty((Bk, T, 1, 1), device=dev))
+            out.update(V=torch.empty((Bk, T, n, n), device=dev, dtype=odt), v=torch.empty((Bk, T, n, 1), device=dev, dtype=odt),
+                       const=torch.empty((Bk, T, 1, 1), device=dev, dtype=odt))
         ws_bytes = 0
-        if not want_policy:
+        if not want_policy or storage_bf16:
             ws_bytes = int(lib.tfmpc_lqr_workspace_bytes(Bk, n, m, T))
             if workspace is None or workspace.numel() * workspace.element_size() < ws_bytes:
                 workspace = torch.empty((max(ws_bytes, 4) + 3) // 4, dtype=torch.float32, device=dev)
             ws_bytes = workspace.numel() * workspace.element_size()
-        rc = getattr(lib, "tfmpc_lqr_solve" + self._suffix)(Bk, n, m, T, *self._ptr_args(), _hip.ptr(x0),
+        entry = "tfmpc_lqr_solve_bf16out_f32" if storage_bf16 else "tfmpc_lqr_solve" + self._suffix
+        rc = getattr(lib, entry)(Bk, n, m, T, *self._ptr_args(), _hip.ptr(x0),
                                      _hip.ptr(out["states"]), _hip.ptr(out["actions"]), _hip.ptr(out["costs"]),
                                      _hip.ptr(out.get("K")), _hip.ptr(out.get("k")), _hip.ptr(out.get("V")),
                                      _hip.ptr(out.get("v")), _hip.ptr(out.get("const")), _hip.ptr(out["status"]),
