@@ -135,3 +135,35 @@ def test_four_groups_per_wave_equal_the_per_lane_kernel(force_kernel, kind, T):
         torch.cuda.synchronize()
     for key in ("iterations", "status", "states", "actions", "costs"):
         assert torch.equal(out[None][key], out["lane1"][key]), key
+
+
+def test_two_variable_boxqp_closed_form_against_the_restatement():
+    """The lane kernels' box-QP for two actions (closed form over the nine candidate active sets, iteration as fall-back;
+    reached through tfmpc_boxqp_f32 at m = 2) against oracle/boxqp_ref.py (optimization.py:6-101 restated) on 4 000 random
+    strictly convex QPs -- minimiser in the interior, on edges, in corners -- plus degenerate ones: a multiplier that is
+    exactly zero on a bound, a zero-width box, a nearly singular H."""
+    from oracle import boxqp_ref
+    from tfmpc.utils import optimization
+    rng = np.random.default_rng(21)
+    B = 4000
+    A = rng.normal(size=(B, 2, 2))
+    H = A @ A.transpose(0, 2, 1) + 0.05 * np.eye(2)
+    H[:50] = np.array([[1.0, 0.999], [0.999, 1.0]])                       # nearly singular
+    q = rng.normal(scale=3.0, size=(B, 2, 1))
+    low = -np.abs(rng.normal(size=(B, 2, 1))) - 0.1
+    high = np.abs(rng.normal(size=(B, 2, 1))) + 0.1
+    low[100:150, 1] = high[100:150, 1] = 0.3                               # zero-width box in the second variable
+    # exactly zero multiplier: the unconstrained minimiser sits ON the upper bound of the first variable
+    xs = np.linalg.solve(H[200:260], -q[200:260])
+    high[200:260, 0] = xs[:, 0]
+    low[200:260, 0] = xs[:, 0] - 1.0
+    x0 = (low + high) / 2
+    x, _, free, clamped = optimization.projected_newton_qp(H, q, low, high, x0)
+    x, free = x.cpu().numpy()[..., 0], free.cpu().numpy()[..., 0]
+    bad = 0
+    for b in range(B):
+        xr, _, fr, _ = boxqp_ref.projected_newton_qp(H[b], q[b], low[b], high[b], x0[b], dtype=np.float64)
+        scale = max(1.0, np.abs(xr).max())
+        assert np.abs(x[b] - xr[:, 0]).max() <= 2e-4 * scale, (b, x[b], xr[:, 0])
+        bad += int(not np.array_equal(free[b], fr[:, 0]))
+    assert bad <= B // 200, bad          # the free set may differ only where a multiplier or a distance is at the 1e-6 tolerance

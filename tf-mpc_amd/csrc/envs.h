@@ -267,6 +267,26 @@ template <> struct Env<TFMPC_ENV_NAVLQR> {
 };
 
 // --------------------------------------------------------------- NAVIGATION ---
+// The deceleration factor of one zone (envs/navigation/__init__.py:61-74), shared by EVERY kernel that evaluates the
+// env (wave kernels here, lane kernels in ilqr_lane.hip) so that all of them round identically: hardware square
+// root and exponential (1 ulp each; exp(a) = exp2(a log2 e)) and reciprocals by v_rcp_f32 + one Newton step -- the
+// sequential rollouts of the lane kernels are bound by the length of this instruction stream (libm's expf / sqrtf and
+// IEEE divisions were ~100 of a rollout step's ~170 instructions).
+__device__ __forceinline__ float env_rcp(float x)
+{
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float nav_zone_lambda(float r2, float decay, float *r_out, float *ex_out)
+{
+    const float r = __builtin_amdgcn_sqrtf(r2);
+    const float ex = __builtin_amdgcn_exp2f(-decay * r * 1.44269504088896340736f);
+    if (r_out) { *r_out = r; *ex_out = ex; }
+    return 2.0f * env_rcp(1.0f + ex) - 1.0f;
+}
+// h_z = d lambda_z / d r = 2 d e^{-d r} / (1 + e^{-d r})^2
+__device__ __forceinline__ float nav_zone_slope(float decay, float ex) { return 2.0f * decay * ex * env_rcp((1.0f + ex) * (1.0f + ex)); }
+
 template <> struct Env<TFMPC_ENV_NAVIGATION> {
     // true iff every second derivative of cost and final cost is identically zero
     static constexpr bool kPiecewiseLinearCost = false;
@@ -279,25 +299,24 @@ template <> struct Env<TFMPC_ENV_NAVIGATION> {
         for (int z = 0; z < Z; ++z) {
             float r2 = 0.0f;
             for (int i = 0; i < n; ++i) { const float dlt = x[i] - center[z * n + i]; r2 = fmaf(dlt, dlt, r2); }
-            const float ex = expf(-decay[z] * sqrtf(r2));
-            lam *= 2.0f / (1.0f + ex) - 1.0f;
+            lam *= nav_zone_lambda(r2, decay[z], nullptr, nullptr);
         }
         if (grad) {
             for (int i = 0; i < n; ++i) grad[i] = 0.0f;
             for (int z = 0; z < Z; ++z) {
                 float r2 = 0.0f;
                 for (int i = 0; i < n; ++i) { const float dlt = x[i] - center[z * n + i]; r2 = fmaf(dlt, dlt, r2); }
-                const float r = sqrtf(r2);
-                const float ex = expf(-decay[z] * r);
-                const float h = 2.0f * decay[z] * ex / ((1.0f + ex) * (1.0f + ex));
+                float r, ex;
+                nav_zone_lambda(r2, decay[z], &r, &ex);
+                const float h = nav_zone_slope(decay[z], ex);
                 float others = 1.0f;
                 for (int y = 0; y < Z; ++y) {
                     if (y == z) continue;
                     float q2 = 0.0f;
                     for (int i = 0; i < n; ++i) { const float dlt = x[i] - center[y * n + i]; q2 = fmaf(dlt, dlt, q2); }
-                    others *= 2.0f / (1.0f + expf(-decay[y] * sqrtf(q2))) - 1.0f;
+                    others *= nav_zone_lambda(q2, decay[y], nullptr, nullptr);
                 }
-                for (int i = 0; i < n; ++i) grad[i] += h * (x[i] - center[z * n + i]) / r * others;
+                for (int i = 0; i < n; ++i) grad[i] += h * (x[i] - center[z * n + i]) * env_rcp(r) * others;
             }
         }
         return lam;

@@ -23,7 +23,9 @@ int ilqr_lane_solve_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, int 
                            int32_t *status, float *wsK, float *wsk, float *wsx, float *wsu, float *wsc, void *extra,
                            const TraceArgs &trace, hipStream_t stream);
 size_t ilqr_lane_extra_workspace_bytes(int B, int n, int m, int T);
-bool ilqr_lane_group_fits(int T);       // the 16-lanes-per-instance kernel (the one that records a decision trace) serves this horizon
+bool ilqr_lane_group_fits(int T);
+int boxqp_lane2_launch(int B, const float *H, const float *q, const float *low, const float *high, const float *x0,
+                       float *x, float *free_mask, int32_t *status, hipStream_t stream);   // m = 2: one QP per lane       // the 16-lanes-per-instance kernel (the one that records a decision trace) serves this horizon
 
 // ---- model providers for backward_pass ------------------------------------------
 template <int KIND>
@@ -600,6 +602,8 @@ int tfmpc_boxqp_f32(int B, int m, const float *H, const float *q, const float *l
     if (B < 0 || m <= 0) return TFMPC_ERR_ARG;
     if (B == 0) return TFMPC_OK;
     if (!H || !q || !low || !high || !x0 || !x) return TFMPC_ERR_ARG;
+    if (m == 2 && !option_is(kOptIlqrKernel, "wave"))       // the lane kernels' own QP (closed form for two variables)
+        return boxqp_lane2_launch(B, H, q, low, high, x0, x, free_mask, status, static_cast<hipStream_t>(stream));
     const size_t smem = (ilqr_smem_floats(1, m) + (size_t)m * odd_ld(m) + m) * sizeof(float);
     if (smem > kMaxLdsBytes) return TFMPC_ERR_UNSUPPORTED;
     int rc = prep(boxqp_kernel, smem);

@@ -34,6 +34,10 @@ struct LaneModel {                 // quadratic expansion at one (x, u)
     float lx[N], lu[M], l;
 };
 
+// 1 / x to ~1 ulp: the hardware reciprocal and one Newton step (three instructions; an IEEE division is ten, and a
+// lane kernel is bound by the LENGTH of its dependent instruction stream, ~10 cycles per instruction)
+__device__ __forceinline__ float lane_rcp(float x) { return env_rcp(x); }       // envs.h
+
 template <int KIND, int N, int M> struct LaneEnv;
 
 template <int N>
@@ -111,10 +115,7 @@ struct LaneEnv<TFMPC_ENV_NAVIGATION, N, N> {             // envs/navigation/__in
         float r2 = 0.0f;
 #pragma unroll
         for (int i = 0; i < N; ++i) { const float d = x[i] - center[z * N + i]; r2 = fmaf(d, d, r2); }
-        const float r = sqrtf(r2);
-        const float ex = expf(-decay[z] * r);
-        if (r_out) { *r_out = r; *ex_out = ex; }
-        return 2.0f / (1.0f + ex) - 1.0f;
+        return nav_zone_lambda(r2, decay[z], r_out, ex_out);          // envs.h: the same expression in every kernel
     }
     __device__ float deceleration(const float *x, float *grad) const
     {
@@ -126,12 +127,12 @@ struct LaneEnv<TFMPC_ENV_NAVIGATION, N, N> {             // envs/navigation/__in
             for (int z = 0; z < zones; ++z) {
                 float r, ex;
                 zone_lambda(x, z, &r, &ex);
-                const float h = 2.0f * decay[z] * ex / ((1.0f + ex) * (1.0f + ex));
+                const float h = nav_zone_slope(decay[z], ex);
                 float others = 1.0f;
                 for (int y = 0; y < zones; ++y)
                     if (y != z) others *= zone_lambda(x, y, nullptr, nullptr);
 #pragma unroll
-                for (int i = 0; i < N; ++i) grad[i] += h * (x[i] - center[z * N + i]) / r * others;
+                for (int i = 0; i < N; ++i) grad[i] += h * (x[i] - center[z * N + i]) * env_rcp(r) * others;
             }
         }
         return lam;
@@ -217,6 +218,22 @@ __device__ __forceinline__ float qp_value(const Mat<M, M> &H, const float *q, co
 template <int M, int W>
 __device__ __forceinline__ int solve_free(const Mat<M, M> &H, const bool *fre, const Mat<M, W> &rhs, Mat<M, W> &out)
 {
+    if constexpr (M == 2) {
+        // two variables: the elimination written out (same pivots, same positivity test as gauss_jordan<.., false>;
+        // a clamped variable is an identity row), two or three divisions instead of the generic in-register sweep
+        const bool f0 = fre[0], f1 = fre[1];
+        const float h00 = f0 ? H(0, 0) : 1.0f, h11 = f1 ? H(1, 1) : 1.0f;
+        const float h01 = (f0 && f1) ? H(0, 1) : 0.0f, h10 = (f0 && f1) ? H(1, 0) : 0.0f;
+        const float inv0 = lane_rcp(h00), p2 = fmaf(-h10, h01 * inv0, h11), inv1 = lane_rcp(p2);
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const float r0 = f0 ? rhs(0, j) : 0.0f, r1 = f1 ? rhs(1, j) : 0.0f;
+            const float y1 = fmaf(-h10, r0 * inv0, r1) * inv1;
+            out(1, j) = y1;
+            out(0, j) = fmaf(-h01 * inv0, y1, r0 * inv0);
+        }
+        return (!(h00 > 0.0f) || !(p2 > 0.0f)) ? 1 : 0;
+    }
     Mat<M, M + W> aug;
 #pragma unroll
     for (int i = 0; i < M; ++i) {
@@ -237,6 +254,76 @@ template <int M>
 __device__ inline int boxqp_lane(const Mat<M, M> &H, const float *q, const float *lo, const float *hi, float *x, bool *fre)
 {
     const float rtol = 1e-8f, step_dec = 0.6f, min_step = 1e-22f, armijo = 0.1f, eps = 1e-6f;
+    if constexpr (M == 2) {
+        // Two actions (BASELINE configs[3]; round 3): a strictly convex QP over a box has ONE Karush-Kuhn-Tucker point,
+        // and with two variables there are nine places it can be -- the interior (both free), four edges (one variable
+        // on a bound, the other free), four corners.  Each candidate is a handful of operations; the one that is
+        // feasible with the right multiplier signs IS the minimiser the projected-Newton iteration of
+        // optimization.py:24-99 converges to, and its free set is what the clamp rule (:121-127) gives there.  The
+        // iteration itself (up to 100 passes of gradient, clamp set, elimination, Armijo loop with IEEE divisions) was
+        // 130 k of the 259 k cycles of a cfg4 iLQR iteration.  Candidates are accepted only with a margin of `eps`
+        // (= the rule's own tolerance, and the gradient tolerance 1e-6 of :13-17) on every comparison, and only if
+        // exactly one qualifies; anything closer to a tie, and any H that is not positive definite, is left to the
+        // iteration below (which also reports TFMPC_ST_NOT_PD as before).
+        const float h00 = H(0, 0), h01 = H(0, 1), h10 = H(1, 0), h11 = H(1, 1);
+        const float inv0 = lane_rcp(h00), p2 = fmaf(-h10, h01 * inv0, h11);   // the pivots of the first factorisation
+        if (h00 > 0.0f && p2 > 0.0f && h11 > 0.0f) {
+            const float inv1 = lane_rcp(h11);
+            // a candidate: variable i on bound b_i (s_i = -1 lower, +1 upper) or free (s_i = 0); ok = feasible with
+            // the right multiplier signs, every comparison with a margin of eps
+            auto candidate = [&](int s0, int s1, float &a0, float &a1) {
+                const float b0 = s0 > 0 ? hi[0] : lo[0], b1 = s1 > 0 ? hi[1] : lo[1];
+                if (s0 == 0 && s1 == 0) {                                            // H x = -q
+                    a1 = (h10 * (q[0] * inv0) - q[1]) * lane_rcp(p2);
+                    a0 = -(q[0] + h01 * a1) * inv0;
+                    return a0 > lo[0] + eps && a0 < hi[0] - eps && a1 > lo[1] + eps && a1 < hi[1] - eps;
+                }
+                if (s0 != 0 && s1 == 0) {
+                    a0 = b0;
+                    a1 = -(q[1] + h10 * b0) * inv1;
+                    const float g0 = fmaf(h00, b0, fmaf(h01, a1, q[0]));
+                    return a1 > lo[1] + eps && a1 < hi[1] - eps && (s0 > 0 ? g0 < -eps : g0 > eps);
+                }
+                if (s0 == 0 && s1 != 0) {
+                    a1 = b1;
+                    a0 = -(q[0] + h01 * b1) * inv0;
+                    const float g1 = fmaf(h10, a0, fmaf(h11, b1, q[1]));
+                    return a0 > lo[0] + eps && a0 < hi[0] - eps && (s1 > 0 ? g1 < -eps : g1 > eps);
+                }
+                a0 = b0; a1 = b1;
+                const float g0 = fmaf(h00, b0, fmaf(h01, b1, q[0])), g1 = fmaf(h10, b0, fmaf(h11, b1, q[1]));
+                return (s0 > 0 ? g0 < -eps : g0 > eps) && (s1 > 0 ? g1 < -eps : g1 > eps);
+            };
+            float a0, a1;
+            // the usual case first: the unconstrained minimiser, else the active set its violations suggest -- a
+            // candidate that passes IS the solution (the KKT point is unique), so nothing else needs looking at
+            if (candidate(0, 0, a0, a1)) { x[0] = a0; x[1] = a1; fre[0] = fre[1] = true; return 0; }
+            {
+                const int s0 = a0 <= lo[0] + eps ? -1 : (a0 >= hi[0] - eps ? 1 : 0);
+                const int s1 = a1 <= lo[1] + eps ? -1 : (a1 >= hi[1] - eps ? 1 : 0);
+                float c0, c1;
+                if ((s0 != 0 || s1 != 0) && candidate(s0, s1, c0, c1)) {
+                    x[0] = c0; x[1] = c1; fre[0] = s0 == 0; fre[1] = s1 == 0;
+                    return 0;
+                }
+            }
+            // rare: all nine, accepted only if exactly one qualifies
+            float cx0 = 0.0f, cx1 = 0.0f;
+            int cs0 = 0, cs1 = 0, hits = 0;
+#pragma unroll
+            for (int s0 = -1; s0 <= 1; ++s0)
+#pragma unroll
+                for (int s1 = -1; s1 <= 1; ++s1) {
+                    float c0, c1;
+                    if (candidate(s0, s1, c0, c1)) { cx0 = c0; cx1 = c1; cs0 = s0; cs1 = s1; hits += 1; }
+                }
+            if (hits == 1) {
+                x[0] = cx0; x[1] = cx1;
+                fre[0] = cs0 == 0; fre[1] = cs1 == 0;
+                return 0;
+            }
+        }
+    }
     float value = qp_value<M>(H, q, x), old_value = value;
 #pragma unroll
     for (int i = 0; i < M; ++i) fre[i] = true;
@@ -912,6 +999,39 @@ __global__ __launch_bounds__(64, 4) void ilqr_group_solve_kernel(TfmpcEnv genv, 
 #endif
         }
     }
+}
+
+// projected_newton_qp (optimization.py:6-101) for two variables, one QP per LANE: the stand-alone entry point
+// tfmpc_boxqp_f32 at m = 2 runs the very function the lane kernels call in their backward pass (closed form + iteration)
+__global__ __launch_bounds__(64) void boxqp_lane2_kernel(int B, const float *H, const float *q, const float *low,
+                                                         const float *high, const float *x0, float *x, float *free_mask,
+                                                         int32_t *status)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    Mat<2, 2> Hm;
+    float qv[2], lo[2], hi[2], xv[2];
+    bool fre[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        Hm(i, 0) = H[(size_t)b * 4 + 2 * i]; Hm(i, 1) = H[(size_t)b * 4 + 2 * i + 1];
+        qv[i] = q[(size_t)b * 2 + i]; lo[i] = low[(size_t)b * 2 + i]; hi[i] = high[(size_t)b * 2 + i];
+        xv[i] = x0[(size_t)b * 2 + i];
+    }
+    const int rc = boxqp_lane<2>(Hm, qv, lo, hi, xv, fre);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        x[(size_t)b * 2 + i] = xv[i];
+        if (free_mask) free_mask[(size_t)b * 2 + i] = fre[i] ? 1.0f : 0.0f;
+    }
+    if (status) status[b] = rc;
+}
+
+int boxqp_lane2_launch(int B, const float *H, const float *q, const float *low, const float *high, const float *x0,
+                       float *x, float *free_mask, int32_t *status, hipStream_t stream)
+{
+    hipLaunchKernelGGL(boxqp_lane2_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, B, H, q, low, high, x0, x, free_mask, status);
+    return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
 }
 
 bool ilqr_lane_group_fits(int T) { return GroupStore<2, 2, 4, 3>::bytes(T) <= 64 * 1024; }
