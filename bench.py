@@ -59,38 +59,59 @@ def lqr_bytes_per_solve(n, m, T):
     return 4 * (n * d + n + d * d + d + n) + 4 * ((T + 1) * n + T * m + (T + 1))
 
 
+# which kernel source a profiled kernel lives in (its PMC summary is only quoted while that file is unchanged)
+KERNEL_SOURCES = {"mfma": ["lqr_mfma16x8.hip", "wave_ldlt8.h", "mfma_bf16x3.h"], "ilqr_group_solve": ["ilqr_lane.hip", "envs.h"],
+                  "ilqr_adjoint_mfma": ["ilqr_adjoint_mfma.hip", "trig.h"], "ilqr_lq_mfma_kernel": ["ilqr_lq_mfma.hip", "wave_ldlt8.h"],
+                  "ilqr_lq_box_mfma": ["ilqr_lq_box_mfma.hip", "wave_ldlt8.h"], "ilqr_lq_mfma32": ["ilqr_lq_mfma32.hip", "wave_ldlt.h"],
+                  "lqr_mfma32x16": ["lqr_mfma32x16.hip", "wave_ldlt.h"]}
+
+
+def _summary_is_current(summary, key):
+    """A committed PMC summary is quoted only while the sources of its kernel hash to what it recorded
+    (tools/source_stamp.py): traffic from a profile of an older kernel would be a number about other code."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import source_stamp
+    return source_stamp.matches(summary.get("csrc_sha16"), KERNEL_SOURCES.get(key, []))
+
+
 def measured_traffic(kernel, batch):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/*_pmc_summary.json, collected with tools/pmc_passes.sh on this same command:
-    separate --pmc passes, FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes).
-    bench.py cannot run rocprofv3 on itself, so the number is read back, scaled per instance."""
+    """(HBM bytes per launch of the dominant kernel, where the number comes from) -- from the committed PMC passes
+    (profiles/*_pmc_summary.json, collected with tools/pmc_passes.sh on this same command: separate --pmc passes,
+    FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes).  bench.py cannot run rocprofv3 on itself, so the
+    number is read back, scaled per instance -- and only from a summary stamped with the CURRENT kernel sources."""
     import glob
-    best = None
+    best, best_path = None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
         try:
             d = json.load(open(path))
         except Exception:
             continue
         if kernel.split("_")[0] in d.get("kernel", "") and "hbm_bytes_per_launch" in d:
-            best = d
+            best, best_path = d, path
     if best is None:
-        return None
+        return None, "no PMC summary under profiles/"
+    if not _summary_is_current(best, "mfma"):
+        return None, f"{os.path.basename(best_path)} was taken on other kernel sources (csrc_sha16 differs): not quoted"
     per_instance = best["hbm_bytes_per_launch"]["total_corrected"] / float(best.get("batch_per_launch", BATCH))
-    return per_instance * batch
+    return per_instance * batch, f"profiles/{os.path.basename(best_path)} (kernel sources unchanged since)"
 
 
 def pmc_traffic(kernel_substring, per_launch_units, units):
-    """HBM bytes of one launch of a secondary kernel, from the committed PMC summaries of this round
-    (profiles/r02_*_pmc.json, written by tools/pmc_kernel.sh: separate --pmc passes, FETCH_SIZE x2 + WRITE_SIZE as
-    MI355X_MICROARCH.md prescribes), scaled to `units` work units (the summary was taken at `per_launch_units`)."""
+    """HBM bytes of one launch of a secondary kernel, from the newest committed PMC summary of that kernel
+    (profiles/r*_pmc.json, written by tools/pmc_kernel.sh: separate --pmc passes, FETCH_SIZE x2 + WRITE_SIZE as
+    MI355X_MICROARCH.md prescribes), scaled to `units` work units (the summary was taken at `per_launch_units`).
+    None when the newest summary was taken on other sources of that kernel (tools/source_stamp.py)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_*_pmc.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
             continue
         for name, c in d.get("counters_per_launch", {}).items():
             if kernel_substring in name and "hbm_bytes_per_launch" in c:
+                key = next((k for k in KERNEL_SOURCES if k in kernel_substring or kernel_substring in k), None)
+                if not _summary_is_current(d, key):
+                    return None
                 return c["hbm_bytes_per_launch"]["total_corrected"] * units / float(per_launch_units)
     return None
 
@@ -565,6 +586,7 @@ def main():
     if rank == 0:
         total_solves = B * world * args.steps
         value = total_solves / elapsed
+        traffic, traffic_source = measured_traffic(kernel, B)
         flops = lqr_flops_per_solve(n, m, T) * B
         achieved = flops / (kernel_ms * 1e-3) / 1e12
         line = {
@@ -581,7 +603,7 @@ def main():
                        "kernel": kernel},
             "timestep_iterations_per_s": value * T,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": measured_traffic(kernel, B),
+                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_unit": "HBM bytes per launch (PMC, profiles/)",
                          "traffic_note": "algorithmic bytes + the gain round trip: K_t, k_t (27.2 KB per solve) are produced "
                                          "backwards and consumed forwards, written once and read once = 3.57 GB per launch "

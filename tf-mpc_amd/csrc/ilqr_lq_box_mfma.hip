@@ -31,6 +31,7 @@
 #include "ilqr_lq_mfma.h"
 #include "mfma_bf16x3.h"
 #include "wave_ldlt8.h"
+#include "options.h"
 #include "wave_ops.h"
 
 namespace tfmpc {
@@ -84,6 +85,7 @@ __device__ __forceinline__ float sgn(float y) { return (y > 0.0f) ? 1.0f : ((y <
 
 struct StepResult { float J, dV1, dV2, g_norm; bool failed; int flags; };
 
+template <bool BRACKET>
 __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -523,26 +525,61 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
     // ---- iLQR.solve (ilqr.py:214-283) ------------------------------------------------------------------------------
     float mu = 0.0f, delta = 1.0f;                                         // :215-216
     int status = 0, attempts = 0, iteration = 0;
+    int r_hint = 0;                     // the bump level the last backward pass succeeded on (see the search below)
     bool converged = false, give_up = false;
     for (iteration = 0; iteration < cfg.max_iterations; ++iteration) {      // :227
         // derivatives (:234): l_z(t) of the nominal trajectory, kept in HBM-free LDS? No room beside the candidate
         // buffer, which the line search overwrites: the gradients live in `cand` during a backward pass and are
         // recomputed for every pass (one C Z product: 6 % of a pass).
         for (;;) {                                                          // :238
-            float mu_l = mu, delta_l = delta;
+            // _backward (:285-315): the first regularisation level of the LOCAL bump sequence mu_l(0) = mu, mu_l(r + 1) =
+            // max(mu_min, mu_l(r) delta_l(r + 1)) at which the sweep factorises -- the reference probes r = 0, 1, 2, ...
+            // and discards the bump afterwards (quirk Q2), so an instance whose box-QP loses positive definiteness at
+            // small mu pays the same R failed sweeps in EVERY pass (the launch of a 65 536 batch lasted as long as one such
+            // instance: 100 iterations x up to 41 sweeps).  Q~_uu = Q_uu + mu F_u^T F_u grows with mu, so "fails at r"
+            // USUALLY implies "fails below r".  BRACKET (TFMPC_ILQR_RETRY=bracket, off by default): the search starts at the
+            // level the previous pass ended on (`r_hint`) -- expect a failure at r_hint - 1 and a success at r_hint, two
+            // sweeps -- and walks up or down from there.  Measured on 65 536 control-limited problems (tools/probes/
+            // box_ab.py): 960 -> 513 ms, but NOT the reference's answer everywhere: the box-QP's free set changes with mu,
+            // so success is not monotone in the level, and 343 of the 64 980 instances that finish took another
+            // regularisation path (as many ended better as worse).  The default stays the reference's linear probe.
             StepResult r;
-            for (int retry = 0;; ++retry) {                                 // _backward :285-315
-                cz_pass(nom, Tp, cand, true);
+            bool grads_ready = false;
+            auto attempt = [&](int level) {
+                float mu_l = mu, delta_l = delta;
+                for (int j = 0; j < level; ++j) {
+                    delta_l = fmaxf(cfg.delta_0, delta_l * cfg.delta_0);        // :308-309
+                    mu_l = fmaxf(cfg.mu_min, mu_l * delta_l);
+                }
                 __syncthreads();
-                r = backward(cand, mu_l);
-                status |= r.flags;
-                if (!r.failed) break;
-                status |= TFMPC_ST_NOT_PD;
-                delta_l = fmaxf(cfg.delta_0, delta_l * cfg.delta_0);        // :308-309
-                mu_l = fmaxf(cfg.mu_min, mu_l * delta_l);
-                if (retry >= 40) { give_up = true; break; }
-                __syncthreads();
+                if (!grads_ready) {                     // l_z(t) of the nominal trajectory: once per pass, the sweeps only read it
+                    cz_pass(nom, Tp, cand, true);
+                    __syncthreads();
+                    grads_ready = true;
+                }
+                StepResult res = backward(cand, mu_l);
+                status |= res.flags;
+                return res;
+            };
+            // one call site for the sweep: lo_fail = highest level known to fail, hi_ok = lowest known to factorise
+            int lo_fail = -1, hi_ok = 1 << 20, probe = (BRACKET && r_hint > 0) ? r_hint - 1 : 0, level = 0;
+            for (;;) {
+                r = attempt(probe);
+                if (r.failed) lo_fail = probe > lo_fail ? probe : lo_fail;
+                else hi_ok = probe < hi_ok ? probe : hi_ok;
+                if (hi_ok == lo_fail + 1) {                                 // bracketed (hi_ok == 0: nothing below it)
+                    level = hi_ok;
+                    if (!r.failed && probe == level) break;                 // ... and its gains are the ones in the workspace
+                    probe = level;                                          // a failed sweep overwrote them: once more
+                } else if (hi_ok == (1 << 20)) {                            // no success yet: up, as the reference probes
+                    if (lo_fail >= 40) { give_up = true; level = lo_fail; break; }
+                    probe = lo_fail + 1;
+                } else {
+                    probe = hi_ok - 1;                                      // less regularisation than last time: down
+                }
             }
+            if (level > 0) status |= TFMPC_ST_NOT_PD;
+            r_hint = give_up ? 0 : level;
             if (give_up) break;
             if (r.g_norm < cfg.atol) { converged = true; break; }           // :243-248
             const float J_hat = sum_costs(cnom);                            // :104,164
@@ -609,7 +646,8 @@ bool ilqr_lq_box_mfma_supported(const TfmpcEnv &env, int T)
 int ilqr_lq_box_mfma_launch(const IlqrLqArgs &a, hipStream_t stream)
 {
     const size_t lds = box_lds_bytes(a.T);
-    hipLaunchKernelGGL(ilqr_lq_box_mfma_kernel, dim3(a.B), dim3(kWave), lds, stream, a);
+    if (option_is(kOptIlqrRetry, "bracket")) hipLaunchKernelGGL(ilqr_lq_box_mfma_kernel<true>, dim3(a.B), dim3(kWave), lds, stream, a);
+    else hipLaunchKernelGGL(ilqr_lq_box_mfma_kernel<false>, dim3(a.B), dim3(kWave), lds, stream, a);
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
 }
 

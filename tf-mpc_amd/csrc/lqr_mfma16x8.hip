@@ -94,7 +94,9 @@ constexpr int kDppHalfMirror = 0x141; // lane i <-> 7 - i inside each 8-lane hal
 // embedded in the 16 x 8 tile grid: states n..15 and actions m..7 are zero rows/columns of
 // F~ and C~, with a unit diagonal on the padded part of C_uu so the elimination stays regular
 // (the padded gains come out exactly 0).
-template <bool BACKWARD, bool FORWARD, bool VALUE, bool EXACT, bool BF3>
+// OUT16: the 16-bit copies of the policy / value outputs (LqrArgs::K16 ...) are compiled into separate instantiations, so
+// that the default kernels carry none of their code
+template <bool BACKWARD, bool FORWARD, bool VALUE, bool EXACT, bool BF3, bool OUT16 = false>
 __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
@@ -290,12 +292,12 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
                     if (ka < m && 2 * jc + 1 < n) Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] = kv.y;
                     if (lane < m) kg[(size_t)t * m + lane] = lds[kKs + 24 * 8 + lane];
                 }
-                if (a.K16) {                               // 16-bit copy of the policy (the rollout reads the fp32 gains)
+                if (OUT16 && a.K16) {                      // 16-bit copy of the policy (the rollout reads the fp32 gains)
                     uint16_t *Ko = a.K16 + ((size_t)b * T + t) * (m * n);
                     if (ka < m && 2 * jc < n) Ko[ka * n + 2 * jc] = lqr_to_bf16(kv.x);
                     if (ka < m && 2 * jc + 1 < n) Ko[ka * n + 2 * jc + 1] = lqr_to_bf16(kv.y);
                 }
-                if (a.k16 && lane < m) a.k16[((size_t)b * T + t) * m + lane] = lqr_to_bf16(lds[kKs + 24 * 8 + lane]);
+                if (OUT16 && a.k16 && lane < m) a.k16[((size_t)b * T + t) * m + lane] = lqr_to_bf16(lds[kKs + 24 * 8 + lane]);
             }
             if (VALUE) {
                 // const += 1/2 k^T Q_uu k + k^T q_u + 1/2 f^T V f + f^T v with Q_uu k = -q_u
@@ -314,19 +316,19 @@ __global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
                         if (EXACT || 4 * q + r < n) vo[4 * q + r] = vd[r];
                 }
                 if (a.cst && lane == 0) a.cst[(size_t)b * T + t] = cst;
-                if (a.V16) {
+                if (OUT16 && a.V16) {
                     uint16_t *Vo = a.V16 + ((size_t)b * T + t) * (n * n);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (EXACT || (4 * q + r < n && i < n)) Vo[(4 * q + r) * n + i] = lqr_to_bf16(Vd[r]);
                 }
-                if (a.v16 && i == M) {
+                if (OUT16 && a.v16 && i == M) {
                     uint16_t *vo = a.v16 + ((size_t)b * T + t) * n;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (EXACT || 4 * q + r < n) vo[4 * q + r] = lqr_to_bf16(vd[r]);
                 }
-                if (a.cst16 && lane == 0) a.cst16[(size_t)b * T + t] = lqr_to_bf16(cst);
+                if (OUT16 && a.cst16 && lane == 0) a.cst16[(size_t)b * T + t] = lqr_to_bf16(cst);
             }
             __syncthreads();
         }
@@ -490,16 +492,16 @@ bool use_bf16x3()
     return !option_is(kOptLqrMfma, "f32");
 }
 
-template <bool BW, bool FW, bool VAL>
+template <bool BW, bool FW, bool VAL, bool O16 = false>
 int launch(const LqrArgs &a, hipStream_t stream)
 {
     const bool exact = a.n == N && a.m == M;
     const bool bf3 = BW && use_bf16x3();
     const dim3 grid(a.B), block(kWave);
-    if (exact && bf3) hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, true, true>), grid, block, 0, stream, a);
-    else if (exact) hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, true, false>), grid, block, 0, stream, a);
-    else if (bf3) hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, false, false>), grid, block, 0, stream, a);
+    if (exact && bf3) hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, true, true, O16>), grid, block, 0, stream, a);
+    else if (exact) hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, true, false, O16>), grid, block, 0, stream, a);
+    else if (bf3) hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, false, true, O16>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, false, false, O16>), grid, block, 0, stream, a);
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
 }
 
@@ -511,7 +513,11 @@ bool lqr_mfma_supported(int n, int m) { return n >= 1 && m >= 1 && n <= N && m <
 
 int lqr_mfma_launch(const LqrArgs &a, bool backward, bool forward, hipStream_t stream)
 {
-    const bool value = a.V || a.v || a.cst || a.V16 || a.v16 || a.cst16;
+    if (a.K16 || a.k16 || a.V16 || a.v16 || a.cst16) {       // 16-bit outputs: the value-function code is compiled in
+        if (backward && forward) return launch<true, true, true, true>(a, stream);
+        if (backward) return launch<true, false, true, true>(a, stream);
+    }
+    const bool value = a.V || a.v || a.cst;
     if (backward && forward) return value ? launch<true, true, true>(a, stream) : launch<true, true, false>(a, stream);
     if (backward) return value ? launch<true, false, true>(a, stream) : launch<true, false, false>(a, stream);
     return launch<false, true, false>(a, stream);

@@ -65,7 +65,7 @@ constexpr int kLdsFloats = (kSweepFloats > (kTC + 1) * kZld ? kSweepFloats : (kT
 
 struct Tile2x2 { f32x4 t[2][2]; };
 
-template <bool BACKWARD, bool FORWARD, bool VALUE>
+template <bool BACKWARD, bool FORWARD, bool VALUE, bool OUT16 = false>      // OUT16: see lqr_mfma16x8.hip
 __global__ __launch_bounds__(kWave, 2) void lqr_mfma32x16_kernel(LqrArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
@@ -298,14 +298,14 @@ __global__ __launch_bounds__(kWave, 2) void lqr_mfma32x16_kernel(LqrArgs a)
                 }
                 if (lane < m) kg[(size_t)t * m + lane] = lds[kkv + lane];
             }
-            if (a.K16) {                                   // 16-bit copy of the policy (the rollout reads the fp32 gains)
+            if (OUT16 && a.K16) {                          // 16-bit copy of the policy (the rollout reads the fp32 gains)
                 uint16_t *Ko = a.K16 + ((size_t)b * T + t) * (m * n);
                 for (int idx = lane; idx < M * N; idx += kWave) {
                     const int ka = idx >> 5, j = idx & 31;
                     if (ka < m && j < n) Ko[ka * n + j] = lqr_to_bf16(lds[kKs + idx]);
                 }
             }
-            if (a.k16 && lane < m) a.k16[((size_t)b * T + t) * m + lane] = lqr_to_bf16(lds[kkv + lane]);
+            if (OUT16 && a.k16 && lane < m) a.k16[((size_t)b * T + t) * m + lane] = lqr_to_bf16(lds[kkv + lane]);
             if (VALUE) {
                 // const += 1/2 k^T Q_uu k + k^T q_u + 1/2 f^T V f + f^T v with Q_uu k = -q_u (lqr.py:113-121)
                 cst += 0.5f * quk + 0.5f * fw + fv;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kWave, 2) void lqr_mfma32x16_kernel(LqrArgs a)
                             if (16 * a_ + 4 * q + r < n) vo[16 * a_ + 4 * q + r] = vd[a_][r];
                 }
                 if (a.cst && lane == 0) a.cst[(size_t)b * T + t] = cst;
-                if (a.V16) {
+                if (OUT16 && a.V16) {
                     uint16_t *Vo = a.V16 + ((size_t)b * T + t) * (n * n);
 #pragma unroll
                     for (int a_ = 0; a_ < 2; ++a_)
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(kWave, 2) void lqr_mfma32x16_kernel(LqrArgs a)
                                 if (row < n && col < n) Vo[row * n + col] = lqr_to_bf16(Vd[a_][b_][r]);
                             }
                 }
-                if (a.v16 && i == 0) {
+                if (OUT16 && a.v16 && i == 0) {
                     uint16_t *vo = a.v16 + ((size_t)b * T + t) * n;
 #pragma unroll
                     for (int a_ = 0; a_ < 2; ++a_)
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kWave, 2) void lqr_mfma32x16_kernel(LqrArgs a)
                         for (int r = 0; r < 4; ++r)
                             if (16 * a_ + 4 * q + r < n) vo[16 * a_ + 4 * q + r] = lqr_to_bf16(vd[a_][r]);
                 }
-                if (a.cst16 && lane == 0) a.cst16[(size_t)b * T + t] = lqr_to_bf16(cst);
+                if (OUT16 && a.cst16 && lane == 0) a.cst16[(size_t)b * T + t] = lqr_to_bf16(cst);
             }
             __syncthreads();
         }
@@ -493,10 +493,10 @@ __global__ __launch_bounds__(kWave, 2) void lqr_mfma32x16_kernel(LqrArgs a)
     if (a.status && lane == 0) a.status[b] = status;
 }
 
-template <bool BW, bool FW, bool VAL>
+template <bool BW, bool FW, bool VAL, bool O16 = false>
 int launch(const LqrArgs &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL((lqr_mfma32x16_kernel<BW, FW, VAL>), dim3(a.B), dim3(kWave), 0, stream, a);
+    hipLaunchKernelGGL((lqr_mfma32x16_kernel<BW, FW, VAL, O16>), dim3(a.B), dim3(kWave), 0, stream, a);
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
 }
 
@@ -510,7 +510,11 @@ bool lqr_mfma32_supported(int n, int m)
 
 int lqr_mfma32_launch(const LqrArgs &a, bool backward, bool forward, hipStream_t stream)
 {
-    const bool value = a.V || a.v || a.cst || a.V16 || a.v16 || a.cst16;
+    if (a.K16 || a.k16 || a.V16 || a.v16 || a.cst16) {
+        if (backward && forward) return launch<true, true, true, true>(a, stream);
+        if (backward) return launch<true, false, true, true>(a, stream);
+    }
+    const bool value = a.V || a.v || a.cst;
     if (backward && forward) return value ? launch<true, true, true>(a, stream) : launch<true, true, false>(a, stream);
     if (backward) return value ? launch<true, false, true>(a, stream) : launch<true, false, false>(a, stream);
     return launch<false, true, false>(a, stream);

@@ -41,8 +41,14 @@ __device__ __forceinline__ void ldlt8_solve_neg(f32x2 (&M2)[4], float (&X)[8], i
         if (ps == 0) M2[pp][1] = fmaf(nl[p + 1][p], Mp, M2[pp][1]);
         const f32x2 Mpp = {Mp, Mp};
 #pragma unroll
-        for (int k = pp + 1; k < 4; ++k)
+        for (int k = pp + 1; k < 4; ++k) {
+#ifdef TFMPC_LDLT_SCALAR_FMA        // A/B: two v_fma_f32 instead of one v_pk_fma_f32
+            M2[k][0] = fmaf(nl[2 * k][p], Mp, M2[k][0]);
+            M2[k][1] = fmaf(nl[2 * k + 1][p], Mp, M2[k][1]);
+#else
             M2[k] = __builtin_elementwise_fma(f32x2{nl[2 * k][p], nl[2 * k + 1][p]}, Mpp, M2[k]);
+#endif
+        }
     }
 #pragma unroll
     for (int s = 7; s >= 1; --s) {
@@ -50,8 +56,14 @@ __device__ __forceinline__ void ldlt8_solve_neg(f32x2 (&M2)[4], float (&X)[8], i
         const f32x2 Nss = {Ns, Ns};
         if (s & 1) N2[s >> 1][0] = fmaf(nl[s][s - 1], Ns, N2[s >> 1][0]);
 #pragma unroll
-        for (int k = 0; k < (s >> 1); ++k)
+        for (int k = 0; k < (s >> 1); ++k) {
+#ifdef TFMPC_LDLT_SCALAR_FMA
+            N2[k][0] = fmaf(nl[s][2 * k], Ns, N2[k][0]);
+            N2[k][1] = fmaf(nl[s][2 * k + 1], Ns, N2[k][1]);
+#else
             N2[k] = __builtin_elementwise_fma(f32x2{nl[s][2 * k], nl[s][2 * k + 1]}, Nss, N2[k]);
+#endif
+        }
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) X[r] = N2[r >> 1][r & 1];

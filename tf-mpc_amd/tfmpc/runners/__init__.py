@@ -70,14 +70,22 @@ class Runner:
 class CapturedEpisode:
 
     def __init__(self, runner, initial_state, horizon, noise):
-        env, agent = runner.env, runner.agent
+        import copy
+        if getattr(getattr(runner.agent, "solver", None), "_generic_env", False):
+            raise ValueError("Runner.capture: a solver on a TorchEnv drives its iterations from the host (it reads "
+                             "results back between launches) and cannot run inside a graph capture")
+        # the capture works on PRIVATE shallow copies of the env and the agent: device mode, the start actions of this
+        # batch shape and the injected static noise buffers would otherwise leak into a later eager run() of the
+        # caller's objects
+        env, agent = copy.copy(runner.env), copy.copy(runner.agent)
         dev = env._device()
-        self.runner, self.horizon = runner, int(horizon)
+        self.runner, self.horizon = Runner(env, agent), int(horizon)
         self.x0 = torch.as_tensor(initial_state, dtype=torch.float32).to(dev).clone()
         self.noise = [torch.as_tensor(s, dtype=torch.float32).to(dev).clone() for s in noise]
         if len(self.noise) != self.horizon:
             raise ValueError("capture needs one noise draw per control step")
         agent.on_device = True
+        agent.reset()
         agent.prepare_start_actions(self.x0.shape[0] if self.x0.dim() == 3 else None)
         env._injected = self.noise                      # the static buffers themselves: replays read what __call__ copied in
         side = torch.cuda.Stream()
@@ -100,7 +108,13 @@ class CapturedEpisode:
         if initial_state is not None:
             self.x0.copy_(torch.as_tensor(initial_state, dtype=torch.float32), non_blocking=True)
         if noise is not None:
+            noise = list(noise)
+            if len(noise) != len(self.noise):
+                raise ValueError(f"a captured episode of {len(self.noise)} steps needs {len(self.noise)} noise draws, got {len(noise)}")
             for dst, src in zip(self.noise, noise):
-                dst.copy_(torch.as_tensor(src, dtype=torch.float32), non_blocking=True)
+                src = torch.as_tensor(src, dtype=torch.float32)
+                if tuple(src.shape) != tuple(dst.shape):
+                    raise ValueError(f"noise draw of shape {tuple(src.shape)}, captured with {tuple(dst.shape)}")
+                dst.copy_(src, non_blocking=True)
         self.graph.replay()
         return Trajectory(*self.tensors), self.iterations.cpu().numpy()         # (the conversions synchronise)

@@ -63,7 +63,10 @@ def _as_column(t, size):
 
 class LQR:
 
-    def __init__(self, F, f, C, c, device=None):
+    def __init__(self, F, f, C, c, device=None, symmetric=None):
+        """``symmetric``: ``None`` (default) checks once whether ``C`` is symmetric -- the fast kernels' precondition,
+        include/tfmpc_hip.h -- which costs two temporaries and a host read-back; ``True`` / ``False`` states it and
+        skips the check (construction is then free of synchronisation, e.g. inside a stream capture)."""
         self.device = torch.device(device) if device is not None else _hip.default_device()
         F, f, C, c = (_as_f32(a, self.device) for a in (F, f, C, c))
         n, d = F.shape[-2], F.shape[-1]
@@ -80,8 +83,13 @@ class LQR:
         self.batch_size = batches.pop() if batches else None
         self.last_status = None
         # asymmetry beyond fp32 rounding of a symmetric matrix -> the reference's term-by-term recursion
-        asym = (self.C - self.C.transpose(-1, -2)).abs().amax()
-        self.symmetric_cost = bool(asym <= 1e-6 * self.C.abs().amax())
+        if symmetric is not None:
+            self.symmetric_cost = bool(symmetric)
+        elif self.C.numel() == 0:                      # an empty shard (parallel.shard of a small batch)
+            self.symmetric_cost = True
+        else:
+            asym = (self.C - self.C.transpose(-1, -2)).abs().amax()
+            self.symmetric_cost = bool(asym <= 1e-6 * self.C.abs().amax())
         self._suffix = "_f32" if self.symmetric_cost else "_general_f32"
 
     # -- reference properties (lqr.py:24-34) -----------------------------------

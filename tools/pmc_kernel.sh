@@ -18,7 +18,7 @@ for C in "SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pass$i" -- python3 $SCRIPT "$@" > "$OUT/pass$i.log" 2>&1
 done
-python3 - "$OUT" "$MATCH" <<'PY' > "$OUT/summary.json"
+GRAFT_REPO_ROOT=$ROOT python3 - "$OUT" "$MATCH" <<'PY' > "$OUT/summary.json"
 import csv, glob, json, os, sys
 from collections import defaultdict
 out, match = sys.argv[1], sys.argv[2]
@@ -38,6 +38,12 @@ stats = {}
 for f in glob.glob(os.path.join(out, "stats", "*", "*_kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
         if match in r["Name"]: stats[r["Name"][:120]] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6}
-print(json.dumps({"kernel_stats": stats, "counters_per_launch": summary}, indent=1))
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "tools"))
+try:
+    import source_stamp
+    src = source_stamp.stamp()
+except Exception:
+    src = None
+print(json.dumps({"kernel_stats": stats, "counters_per_launch": summary, "csrc_sha16": src}, indent=1))
 PY
 cat "$OUT/summary.json"

@@ -46,6 +46,9 @@ if "FETCH_SIZE" in avg or "WRITE_SIZE" in avg:
 if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "SQ_BUSY_CU_CYCLES" in avg:
     # MFMA_BUSY counts cycles summed over SIMDs; BUSY_CU_CYCLES cycles summed over CUs (x4 SIMDs)
     summary["mfma_busy_frac_of_simd_time"] = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * avg["SQ_BUSY_CU_CYCLES"])
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import source_stamp
+summary["csrc_sha16"] = source_stamp.stamp()      # the kernel sources this profile belongs to (bench.py checks it)
 summary["batch_per_launch"] = 65536
 summary["note"] = ("rocprofv3 passes of tools/pmc_passes.sh on bench.py (B=65536 per launch, --no-extra): the kernel-trace "
                    "stats pass runs bench.py's default step counts, the --pmc passes 4 steps; FETCH_SIZE/WRITE_SIZE in KiB, "
