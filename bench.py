@@ -123,50 +123,112 @@ def roofline_hbm(alg_bytes, seconds, traffic):
 
 
 def ilqr_api_rate(n, m, T, B, reps=5):
-    """Secondary number (not `value`): the same shape driven through tfmpc.solvers.ilqr.iLQR.solve
-    on the LQ env (whole iteration loops in one launch, matrix-core kernel).  F is scaled to
-    spectral radius ~1: iLQR's OPEN-LOOP start rollout of a rho ~ 5 system overflows fp32 long
-    before T = 50, in any implementation.  Iterations counted = reference loop index + 1.
+    """Secondary number (not `value`), first-class since round 3: BASELINE.json's headline shape driven through
+    tfmpc.solvers.ilqr.iLQR.solve on the LQ env (whole iteration loops in one launch, matrix-core kernel).
+    Problems: the reference's make_lqr distribution (tests/problems.py:make_lqr_batch_spd: C by make_spd_matrix's formula,
+    eigenvalues ~1e-3 .. n + m) with ONE change: F is scaled by 0.25 (spectral radius ~1.3 instead of ~5).  iLQR's start is
+    an OPEN-LOOP rollout of the given actions (ilqr.py:53-82), and at rho ~ 5 an open-loop rollout amplifies a rounding
+    error 5^50 times over T = 50 -- it overflows fp32 in any implementation, also from the optimal actions.  Start
+    actions: the LQR-optimal open-loop actions of each instance (LQR.solve on the same problem) perturbed by 5 % of
+    their size -- a warm start near the optimum, as an MPC re-solve gives -- so every instance needs the full Newton
+    step and the line search (mean ~2 iterations).  Iterations counted = reference loop index + 1.
     Roofline: algorithmic flop = backward passes x T x 45.0 kflop + rollouts x T x 2.2 kflop with
     backward passes = iterations and rollouts >= iterations - 1 (a converged instance ends on a backward pass)."""
     import problems
+    from tfmpc import _hip
     from tfmpc.envs.lq import LQEnv
     from tfmpc.solvers.ilqr import iLQR
-    F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=4321)
+    from tfmpc.solvers.lqr import LQR
+    F, f, C, c, x0 = problems.make_lqr_batch_spd(B, n, m, seed=4321)
+    F = 0.25 * F
     x0 = torch.as_tensor(x0[..., None].astype(np.float32), device="cuda")
-    u0 = torch.zeros(B, T, m, 1, device="cuda")
+    opt = LQR(F, f, C, c).solve_device(x0, T)["actions"]
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    u0 = (opt + 0.05 * opt.abs().amax(dim=(1, 2, 3), keepdim=True) * torch.randn(opt.shape, device="cuda", generator=gen)).contiguous()
 
-    def run(solver):
+    def run(solver, reps_):
         out = solver.solve_device(x0, T, u_init=u0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(reps):
+        for _ in range(reps_):
             out = solver.solve_device(x0, T, u_init=u0, workspace=out["workspace"])
         torch.cuda.synchronize()
-        return out, (time.perf_counter() - t0) / reps
+        return out, (time.perf_counter() - t0) / reps_
 
-    out, dt = run(iLQR(LQEnv(0.25 * F, f, C, c)))
+    out, dt = run(iLQR(LQEnv(F, f, C, c)), reps)
     its = float((out["iterations"].double() + 1).sum())
     flop = its * T * 45.0e3 + max(its - B, 0.0) * T * 2.2e3
     tf = flop / dt / 1e12
     res = {"iterations_per_s": its / dt, "ms_per_batch": dt * 1e3, "mean_iterations": its / B,
            "flagged_instances": int((out["status"] != 0).sum()),
-           "workload": f"iLQR.solve on LQEnv(0.25 F, f, C, c), n={n} m={m} T={T} B={B}, zero initial actions",
+           "workload": f"iLQR.solve on LQEnv(0.25 F, f, C, c) of make_lqr's distribution, n={n} m={m} T={T} B={B}, start = LQR-optimal actions + 5 % noise",
            "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
                         "algorithmic_flop": flop, "traffic": pmc_traffic("ilqr_lq_mfma_kernel", 65536, B),
-                        "kernel": "ilqr_lq_mfma_kernel (profiles/r02_ilqr_api_kernel_stats.csv)"}}
-    # the same problems with CONTROL LIMITS: box-QP at every backward step, regularisation loop in the kernel
-    reps = 1
-    out, dt = run(iLQR(LQEnv(0.25 * F, f, C, c, low=-0.5, high=0.5)))
-    its = float((out["iterations"].double() + 1).sum())
-    st = out["status"]
-    res["control_limited"] = {"workload": f"same problems, actions in [-0.5, 0.5] (ilqr.py:136-138,364-387: box-QP at every step), B={B}",
-                              "ms_per_batch": dt * 1e3, "solves_per_s": B / dt, "iterations_per_s": its / dt, "mean_iterations": its / B,
-                              "max_iterations": int(out["iterations"].max()) + 1,
-                              "instances_with_cholesky_retries": int(((st & 2) != 0).sum()),
-                              "instances_at_attempt_cap": int(((st & 16) != 0).sum()),
-                              "kernel": "ilqr_lq_box_mfma_kernel (profiles/r02_box_kernel_stats.csv); round 1: wave kernel, 2.3 k solves/s at B=8192"}
+                        "kernel": "ilqr_lq_mfma_kernel (profiles/r03_ilqr_api_kernel_stats.csv: tools/ilqr_api_once.py under rocprofv3)"}}
+    # CONTROL LIMITS: box-QP at every backward step, regularisation loop in the kernel.  On the well-conditioned generator
+    # (tests/problems.py:make_lqr_batch_fast, eigenvalues of C in [1, 2]; zero start actions) as in rounds 1-2: with
+    # make_spd_matrix's spectrum and a +-0.5 box three quarters of the instances exhaust the regularisation attempts (the
+    # reference would loop on them without bound, ilqr.py:238-270) -- a statement about those problems, not a benchmark.
+    Fw, fw, Cw, cw, x0w = problems.make_lqr_batch_fast(B, n, m, seed=4321)
+    x0 = torch.as_tensor(x0w[..., None].astype(np.float32), device="cuda")
+    u0 = torch.zeros(B, T, m, 1, device="cuda")
+    F, f, C, c = 0.25 * Fw, fw, Cw, cw
+
+    def limited(tag):
+        out_, dt_ = run(iLQR(LQEnv(F, f, C, c, low=-0.5, high=0.5)), 1)
+        its_ = float((out_["iterations"].double() + 1).sum())
+        st, it = out_["status"], (out_["iterations"] + 1).float()
+        return {"ms_per_batch": dt_ * 1e3, "solves_per_s": B / dt_, "iterations_per_s": its_ / dt_, "mean_iterations": its_ / B,
+                "iterations_p50_p90_p99_max": [float(torch.quantile(it, q)) for q in (0.5, 0.9, 0.99, 1.0)],
+                "instances_with_cholesky_retries": int(((st & 2) != 0).sum()),
+                "instances_at_attempt_cap": int(((st & 16) != 0).sum()), "regularisation_search": tag}
+
+    res["control_limited"] = limited("linear probe 0, 1, 2, ... (ilqr.py:285-315; the default)")
+    res["control_limited"]["workload"] = f"LQEnv(0.25 F, f, C, c) of the well-conditioned generator, zero start, actions in [-0.5, 0.5] (ilqr.py:136-138,364-387: box-QP at every step), B={B}"
+    res["control_limited"]["kernel"] = "ilqr_lq_box_mfma_kernel; round 1: wave kernel, 2.3 k solves/s at B=8192"
+    with _hip.option("TFMPC_ILQR_RETRY", "bracket"):
+        res["control_limited"]["bracket_search_variant"] = limited(
+            "TFMPC_ILQR_RETRY=bracket: around the previous pass's level (another regularisation path on ~0.5 % of the instances, DESIGN.md 3.6)")
     return res
+
+
+def torchenv_rate(B=1024, T=40):
+    """Secondary number: an arbitrary differentiable env given as torch functions (`TorchEnv`; here the
+    Navigation env of nav.config.json written in plain torch) -- derivatives by torch.func on the GPU, the backward pass in
+    the HIP kernel, line-search rollouts as batched torch ops, the iteration loop driven from the host
+    (tfmpc/solvers/ilqr.py:_solve_host_driven).  Iterations per second of one batched solve."""
+    import problems
+    from tfmpc.envs.torchenv import TorchEnv
+    from tfmpc.solvers.ilqr import iLQR
+    cfg = problems.NAV_CONFIG
+    goal = torch.tensor(np.array(cfg["goal"], dtype=np.float32).reshape(-1), device="cuda")
+    centers = torch.tensor(np.array(cfg["deceleration"]["center"], dtype=np.float32).reshape(-1, 2), device="cuda")
+    decay = torch.tensor(np.array(cfg["deceleration"]["decay"], dtype=np.float32).reshape(-1), device="cuda")
+
+    def transition(x, u):
+        r = torch.linalg.norm(x[None, :] - centers, dim=1)
+        lam = torch.prod(2.0 / (1.0 + torch.exp(-decay * r)) - 1.0)
+        return x + lam * u
+
+    def cost(x, u):
+        return torch.sum((x - goal) ** 2)
+
+    env = TorchEnv(transition, cost, lambda x: torch.sum((x - goal) ** 2), 2, 2,
+                   low=np.array(cfg["low"], dtype=np.float32).reshape(-1, 1), high=np.array(cfg["high"], dtype=np.float32).reshape(-1, 1))
+    solver = iLQR(env, max_iterations=10)
+    rng = np.random.default_rng(4)
+    x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
+    u0 = solver.random_actions(T, B, seed=4)
+    solver.solve_device(x0, T, u_init=u0)                        # warm-up: torch.func traces, allocator
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = solver.solve_device(x0, T, u_init=u0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    its = float((out["iterations"].double() + 1).sum())
+    return {"iterations_per_s": its / dt, "ms_per_batch": dt * 1e3, "mean_iterations": its / B, "batch": B, "horizon": T,
+            "workload": "Navigation (nav.config.json) as torch functions through TorchEnv: host-driven loop, <= 10 iterations",
+            "note": "bound by the host loop (a few hundred small torch launches per iteration); the built-in envs run fused"}
 
 
 def other_config_rates():
@@ -219,7 +281,8 @@ def other_config_rates():
     u0 = solver.random_actions(50, Bn, seed=4)
     res["cfg4_navigation_ilqr"] = ilqr_line(solver, x0, 50, u0, 2, alg_bytes=1820, pmc=("ilqr_group_solve", 142719))
     res["cfg4_navigation_ilqr"]["note"] = ("one launch lasts as long as its slowest instance (median 8 iterations, p99 20, max 87: "
-                                           "profiles/r02_cfg4_iteration_histogram.json); several batches in flight fill the chip")
+                                           "profiles/r02_cfg4_iteration_histogram.json); several batches in flight fill the chip; round 3: "
+                                           "closed-form two-variable box-QP, hardware sqrt / exp2 / rcp in the env")
     # The FIRST eight streams a process creates run this loop 40 % slower than any later eight (5.9 vs 4.2 ms per batch on
     # the same box, whatever precedes them: fresh or reused memory, idle or busy GPU -- tools/probes/repro_cfg4_bench2.py;
     # with GPU_MAX_HW_QUEUES=8: 4.9 vs 3.9): an artefact of how ROCm binds streams to hardware queues, not of the solver.
@@ -270,7 +333,7 @@ def other_config_rates():
         n = len(x0r)
         x0 = (np.array(x0r, dtype=np.float32)[None] * rng.uniform(0.9, 1.1, size=(B, 1, 1))).astype(np.float32)
         solver = iLQR(env, max_iterations=12)
-        # PMC: profiles/r02_small_env_pmc.json (tools/small_env_once.py, 16 384 instances x 12 iterations)
+        # PMC: profiles/r0x_small_env_pmc.json (tools/small_env_once.py, 16 384 instances x 12 iterations)
         res[f"{name}_reference_config_ilqr"] = ilqr_line(solver, x0, T, solver.random_actions(T, B, seed=1), 2,
                                                          alg_bytes=4 * (2 * (T + 1) * n + 2 * T * n + (T + 1)),
                                                          pmc=(kernel_tag, 16384 * 12))
@@ -447,6 +510,10 @@ def extras_only(args):
     try:
         extra["ilqr_api"] = ilqr_api_rate(n, m, T, B)
         extra["other_configs"] = other_config_rates()
+        try:
+            extra["torchenv_generic_env"] = torchenv_rate()
+        except Exception as exc:                              # noqa: BLE001
+            extra["torchenv_generic_env"] = {"error": repr(exc)}
     except Exception as exc:                                  # noqa: BLE001
         extra["other_configs_error"] = repr(exc)
     if not args.no_cpu_baseline:

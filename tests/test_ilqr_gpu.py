@@ -241,13 +241,21 @@ def test_fused_solve_tracks_the_fp32_restatement_on_navigation():
     x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
     u0 = np.stack([problems.scalar_uniform_actions(T, [-1, -1], [1, 1], rng) for _ in range(B)]).astype(np.float32)
     traj, its = iLQR(env).solve(x0, T, u_init=u0)
-    same = 0
+    import trace_oracle
+    clear = 0
     for b in range(B):
         o = ilqr_ref.ILQRRef(oenv, dtype=np.float32)
-        x, u, c, it = o.solve(x0[b], T, u_init=u0[b])
-        assert abs(traj.total_cost[b] - c.sum()) <= 2e-2 * abs(c.sum()), b
-        same += int(it == its[b])
-    assert same >= B // 2
+        records, x, u, c, it = trace_oracle.solve_with_margins(o, x0[b], T, u0[b])
+        if min(r["margin"] for r in records) >= 1.0:
+            # every decision of the restatement has a clear margin (tests/trace_oracle.py): the device takes the same
+            # ones -- same iteration count, same cost to fp32 accuracy (round 3; the whole traces are compared pass by
+            # pass on 256 instances in tests/test_ilqr_trace_gpu.py)
+            clear += 1
+            assert it == its[b], (b, it, its[b])
+            assert abs(traj.total_cost[b] - c.sum()) <= 1e-4 * abs(c.sum()), b
+        else:
+            assert abs(traj.total_cost[b] - c.sum()) <= 2e-2 * abs(c.sum()), b      # a near-tie somewhere: either side is right
+    assert clear >= (3 * B) // 4, clear
 
 
 def test_batched_solve_equals_single_solves_and_shapes():

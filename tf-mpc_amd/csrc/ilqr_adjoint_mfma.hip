@@ -838,8 +838,11 @@ __device__ unsigned long long *g_cfg5_phases = nullptr;
 // bytes of one wave's slice of the wave-major workspace (sized for fp32 containers; the 16-bit ones use half of each buffer)
 __host__ __device__ constexpr size_t adjoint_mfma_wave_bytes(int NT, int T)
 {
+    // ... + one time step's worth of "nowhere" (kTrashFloats): the stored rollout issues EVERY store on every step -- lanes
+    // of columns that do not keep the candidate write there -- so that the number of vector-memory operations of a step
+    // is a constant the LDS-DMA ring's s_waitcnt vmcnt(N) can count (see `rollout`)
     return (2 * ((size_t)(T + 1) * NT * kTileElems + (size_t)T * NT * kTileElems + (size_t)(T + 1) * kCostLd) * sizeof(float) +
-            (size_t)T * kWave + 255) & ~(size_t)255;
+            (size_t)T * kWave + 255 + ((size_t)NT * kTileElems + kCostLd) * sizeof(float)) & ~(size_t)255;
 }
 
 // ---- round 3: groups of NW waves, one step-size chain per wave ----------------------------------------------------------
@@ -917,6 +920,8 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
         cbuf[i] = ubuf[i] + kUs + ccol;
     }
     unsigned char *const ksel = wave_ws + 2 * (kXs + kUs + kCs) * sizeof(float) + (j * 4 + q);     // [t][column][lane quarter]
+    // the trash slot behind the selector bytes (16-byte aligned): one tile set + one cost row
+    TT *const trash = reinterpret_cast<TT *>(wave_ws + ((2 * (kXs + kUs + kCs) * sizeof(float) + (size_t)T * kWave + 15) & ~(size_t)15));
     const float *const x0p = a.x0 + b * n;
     int flip = 0;
 
@@ -1029,7 +1034,13 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
                         // step have landed once at most the (depth - 1) younger steps' are outstanding
                         const int ahead = t + kRingDepth - 1;
                         issue(slot == 0 ? kRingDepth - 1 : slot - 1, ahead < T ? ahead : T - 1);
-                        wait_vmem<(kRingDepth - 1) * kLoads>();
+                        // (a stored rollout also issues kStores stores per step, unconditionally: they are younger than the
+                        // loads waited for and stay in flight too -- counted without them, every step waited for the previous
+                        // step's stores to be acknowledged by the memory system, ~2 us: the stored rollout, one chain, took as
+                        // long as a search pass with two)
+                        // (the stores of the last depth - 2 steps are counted: that many exist from step depth - 2 on)
+                        if (STORE && t >= kRingDepth - 2) wait_vmem<(kRingDepth - 1) * kLoads + (kRingDepth - 2) * (2 * NT + 1)>();
+                        else wait_vmem<(kRingDepth - 1) * kLoads>();
 #pragma unroll
                         for (int b = 0; b < NT; ++b) {
                             const f32x4 v = ring_v[slot][b][lane];
@@ -1087,9 +1098,17 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
                             env.step(A, x[k], u[k], qo, xn);
                             J[k] += c;
                             if (STORE) {
-                                stw<NT>(us, t, wl, keep, u[k]);
-                                stw<NT>(xs, t + 1, wl, keep, xn);
-                                if (keep && ql == 0) stc(cs + (size_t)t * kCostLd, c);
+                                if constexpr (RING) {
+                                    // every store is issued on every step (columns that do not keep the candidate write to
+                                    // the trash slot): kStores per step, which the ring's wait counts
+                                    stw<NT>(keep ? us : trash, keep ? t : 0, wl, true, u[k]);
+                                    stw<NT>(keep ? xs : trash, keep ? t + 1 : 0, wl, true, xn);
+                                    stc(keep ? cs + (size_t)t * kCostLd : trash + NT * kTileElems + ccol, c);
+                                } else {
+                                    stw<NT>(us, t, wl, keep, u[k]);
+                                    stw<NT>(xs, t + 1, wl, keep, xn);
+                                    if (keep && ql == 0) stc(cs + (size_t)t * kCostLd, c);
+                                }
                             }
                         }
 #pragma unroll
