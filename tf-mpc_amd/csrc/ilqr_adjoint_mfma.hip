@@ -846,15 +846,21 @@ __host__ __device__ constexpr size_t adjoint_mfma_wave_bytes(int NT, int T)
 }
 
 // ---- round 3: groups of NW waves, one step-size chain per wave ----------------------------------------------------------
-// A wave alone issues an instruction every ~8.5 cycles on this code (a dependent, in-order stream at 230-250 registers), two
-// per SIMD one every ~4.9 between them -- and B = 32 768 instances are only 2 048 sixteen-column groups, two per SIMD.  The
-// second step size of a line-search pass used to ride in the same wave (two chains per lane: instruction-level
-// parallelism an in-order wave barely uses, and twice the registers).  With NW = 2 the sixteen columns of a group are
-// shared by a WORKGROUP of two waves: wave w of the group rolls out step size NW p + w of pass p (one chain per lane,
-// <= 128 registers: four waves per SIMD), stops on its own once all of ITS columns are above J_hat, and the two meet at
-// a barrier per pass to exchange J through LDS; the state machine runs replicated in both waves on the same inputs.
-// The costate sweep, the start rollout and the stored rollout of the accepted step size run on wave 0 (their result
-// reaches wave 1 through HBM / L1 of the same CU behind the barrier); the other groups' waves fill the SIMD meanwhile.
+// The second step size of a line-search pass used to ride in the same wave: two chains per lane.  An in-order wave does
+// not overlap them -- tools/probes/matvec_bf16x3_probe.hip: the split + 12-MFMA block of a chain-step takes 448 cycles
+// for one chain and 880 for two in one wave -- so the second chain only pays off through the shared loads and the
+// clip's shared half.  With NW = 2 the sixteen columns of a group are shared by a WORKGROUP of two waves: wave w rolls out
+// step size NW p + w of pass p (one chain per lane), stops on its own once all of ITS columns are above J_hat, and the
+// two meet at a barrier per pass to exchange J through LDS; the state machine runs replicated in both waves on the same
+// inputs.  The costate sweep, the start rollout and the stored rollout of the accepted step size run on wave 0 (their
+// result reaches wave 1 through HBM / the L1 of the same CU behind the barrier).
+// Where it pays: launches that leave SIMDs idle (<= 512 groups: small batches, the packed tiny envs) -- a pass takes
+// about half as long there (ilqr_adjoint_mfma_launch lists the timings).  With a group per SIMD or more the one-wave
+// form is the faster one: the second wave's registers and LDS ring cost residency (cfg5: 13.4 -> 19 ms).  The verdict
+// of round 2 had asked for an eight-columns-per-wave form to reach four waves per SIMD at cfg5: this IS that split (half
+// the element-wise state per wave) without wasting half of every matrix instruction, and the measurement says no:
+// at 128 registers the costate sweep spills ~120-330 registers (31.8 / 41.6 ms), at the register count it wants
+// two groups no longer fit a SIMD.
 template <int NW>
 __device__ __forceinline__ void group_sync()
 {
@@ -863,7 +869,7 @@ __device__ __forceinline__ void group_sync()
 }
 
 template <int KIND, int NT, int VW, int PK, bool BF16 = false, int NW = 1>
-__global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW > 1 ? 4 : (NT == 1 && PK == 1 ? 3 : 2), NW > 1 ? 4 : (NT == 1 && PK == 1 ? 3 : 2)))) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
+__global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW > 1 && NT == 1 ? 4 : (NT == 1 && PK == 1 ? 3 : 2), NW > 1 && NT == 1 ? 4 : (NT == 1 && PK == 1 ? 3 : 2)))) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
 {
     constexpr int NV = 4 * NT;
     using TT = typename std::conditional<BF16, bf16_t, float>::type;      // element type of the trajectories in HBM
@@ -1469,19 +1475,20 @@ int ilqr_adjoint_mfma_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, co
     // instances per column: one up to n = 32 (two tiles) or 16, two for n <= 8, four for n <= 4
     const int pk = env.n <= 4 ? 4 : (env.n <= 8 ? 2 : 1);
     // waves per sixteen-column group (see the kernel): one; TFMPC_COSTATE_WAVES=2 selects the two-wave form (measured slower)
-#ifdef TFMPC_COSTATE_PAIR
-    const int nw = option_int(kOptCostateWaves, 1) == 2 ? 2 : 1;
-#else
-    constexpr int nw = 1;               // the two-wave form is compiled only with -DTFMPC_COSTATE_PAIR (measured 1.4-1.5x slower)
-#endif
+    // waves per sixteen-column group (see the kernel).  Two waves -- one step size each instead of two chains in one wave's
+    // instruction stream, which an in-order wave does not overlap (tools/probes/matvec_bf16x3_probe.hip: two chains in
+    // a wave take twice one chain's time) -- shorten a line-search pass wherever the chip has idle SIMDs: measured
+    // (MI355X, 12 iterations, T = 100) n = 32: B = 1 024 6.5 -> 5.4-5.6 ms, B = 4 096 6.6 -> 5.9-6.1 ms, res4 / hvac6 at
+    // B = 16 384 (256 / 512 groups) 3.83 -> 3.19 / 4.35 -> 4.16 ms; from one group per SIMD on (n = 32, B = 16 384: 9.2 ->
+    // 10.0 ms; cfg5's B = 32 768: 13.4 -> 19 ms) the one-wave form wins: it needs half the registers per column.
+    // TFMPC_COSTATE_WAVES=1|2 forces a form.
+    const int groups = (a.B + kCols * pk - 1) / (kCols * pk);
+    const int forced = option_int(kOptCostateWaves, 0);
+    const int nw = forced == 1 ? 1 : (forced == 2 ? 2 : (groups <= 512 ? 2 : 1));
     const dim3 block(kWave * nw), grid((a.B + kCols * pk - 1) / (kCols * pk));
-#ifdef TFMPC_COSTATE_PAIR
 #define TFMPC_LAUNCH_PAIR(KIND, NT_, PK_, VW_, BF_)                                                                            \
     if (nw == 2) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, VW_, PK_, BF_, 2>), grid, block, 0, stream, env, cfg, a); \
     else
-#else
-#define TFMPC_LAUNCH_PAIR(KIND, NT_, PK_, VW_, BF_)
-#endif
 #define TFMPC_LAUNCH_AM4(KIND, NT_, PK_, VW_, BF_)                                                                             \
     do {                                                                                                                       \
         TFMPC_LAUNCH_PAIR(KIND, NT_, PK_, VW_, BF_)                                                                            \
