@@ -522,7 +522,11 @@ template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_HVAC, NT, LEAN> {
     static constexpr int kC0 = 0;                       // LDS slot
     // step sizes per line-search pass: two independent chains give a wave something to issue while the other chain waits
     // (cfg5 HVAC: 20.1 -> 16.6 ms in round 1; one step size per pass with stored candidates, re-tried in round 2: 18.0 vs 14.1 ms)
+#ifdef TFMPC_SEARCH_ALPHAS            // A/B builds: step sizes per line-search pass of a one-wave group
+    static constexpr int kSearchAlphas = TFMPC_SEARCH_ALPHAS;
+#else
     static constexpr int kSearchAlphas = 2;
+#endif
     float lo[NV], hi[NV], am[NV], rcap[NV];
     const float *lds;
 
@@ -684,7 +688,11 @@ template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_RESERVOIR, NT, LEAN> {
     // search that writes nothing and rolls the accepted size out again (41 GB, 4.66 G instructions, 23 spilled registers)
     // take the same time on a box with fast memory (13.8 vs 13.4 ms); the one that moves fewer bytes is kept -- cfg5
     // Reservoir varied by 20 % between boxes while it was the heavier on HBM.
+#ifdef TFMPC_SEARCH_ALPHAS            // A/B builds: step sizes per line-search pass of a one-wave group
+    static constexpr int kSearchAlphas = TFMPC_SEARCH_ALPHAS;
+#else
     static constexpr int kSearchAlphas = 2;
+#endif
     float rcap[NV], lo[NV], hi[NV];                  // 1 / max_res_cap: x / cap is x times the rounded reciprocal everywhere
     const float *lds;
 
