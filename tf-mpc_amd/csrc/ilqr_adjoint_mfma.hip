@@ -525,7 +525,9 @@ template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_HVAC, NT, LEAN> {
 #ifdef TFMPC_SEARCH_ALPHAS            // A/B builds: step sizes per line-search pass of a one-wave group
     static constexpr int kSearchAlphas = TFMPC_SEARCH_ALPHAS;
 #else
-    static constexpr int kSearchAlphas = 2;
+    // round 3 (LDS ring: no registers for the prefetch; lane-partial cost sums): THREE chains per pass at two tiles
+    // 13.6 - 14.0 -> 13.0 - 13.1 ms (four: 15.1; one, storing its candidate: 19.0 - 19.8), same box
+    static constexpr int kSearchAlphas = NT == 2 ? 3 : 2;
 #endif
     float lo[NV], hi[NV], am[NV], rcap[NV];
     const float *lds;
@@ -961,7 +963,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
     // then summed in a different order than the stored pass and the wave kernels sum theirs (a decision can differ only
     // where |J - J_hat| is at rounding level, ~1e-7 relative); the trajectories a pass stores are computed as before.
 #ifdef TFMPC_CFG5_TRACE
-    int trace_fa[2] = {-1, -1};
+    int trace_fa[4] = {-1, -1, -1, -1};
 #endif
     auto rollout = [&](auto search, auto store, auto n_alpha, const float (&alpha)[decltype(n_alpha)::value], auto uh,
                        bool keep, TT *xs, TT *us, TT *cs, float (&J_out)[decltype(n_alpha)::value],
@@ -1026,7 +1028,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
         }
         bool stopped = false;
 #ifdef TFMPC_CFG5_TRACE
-        trace_fa[0] = trace_fa[1] = -1;
+        trace_fa[0] = trace_fa[1] = trace_fa[2] = trace_fa[3] = -1;
 #endif
         for (int t0 = 0; t0 < T; t0 += kAheadRoll) {
             if (SEARCH && early_exit && may_stop) {
@@ -1368,7 +1370,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
 #ifdef TFMPC_CFG5_TRACE
                     if (NW == 1 && g_cfg5_trace && q == 0 && live && iteration + attempts < 16 && ai + k < 11) {
                         int *tr = g_cfg5_trace + ((size_t)b * 16 + iteration + attempts) * 12;
-                        tr[1 + ai + k] = trace_fa[k % 2] < 0 ? T + 1 : trace_fa[k % 2];
+                        tr[1 + ai + k] = trace_fa[k % 4] < 0 ? T + 1 : trace_fa[k % 4];
                         if (accept) tr[0] = ai + k;
                     }
 #endif

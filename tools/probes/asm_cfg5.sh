@@ -10,7 +10,7 @@ SRC=$ROOT/tf-mpc_amd/csrc/_asm_cfg5_tmp.hip
 python3 - "$ROOT/tf-mpc_amd/csrc/ilqr_adjoint_mfma.hip" "$SRC" <<'PY'
 import sys, re
 s = open(sys.argv[1]).read()
-a = s.index('#ifdef TFMPC_COSTATE_PAIR\n#define TFMPC_LAUNCH_PAIR')
+a = s.index('#define TFMPC_LAUNCH_PAIR(KIND')
 b = s.index('#undef TFMPC_LAUNCH_PAIR')
 few = '''    if (env.kind == TFMPC_ENV_HVAC) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<TFMPC_ENV_HVAC, 2, 4, 1, false, 1>), grid, block, 0, stream, env, cfg, a);
     else hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<TFMPC_ENV_RESERVOIR, 2, 4, 1, false, 1>), grid, block, 0, stream, env, cfg, a);
