@@ -919,6 +919,12 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
         rows[kSlotAHigh * kRowLd + lane] = (lane < m) ? genv.high[lane] : 0.0f;
     }
     group_sync<NW>();
+#ifdef TFMPC_STAGGER
+    // A/B builds: every other group starts late, so that the store-heavy phase of one half of the chip (the stored rollout
+    // of a full cfg5 batch asks for ~6 TB/s when all groups run it at once) meets the line-search passes of the other
+    if (blockIdx.x & 1)
+        for (int i = 0; i < TFMPC_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     const bool early_exit = cfg.c1 == 0.0f && env.costs_nonnegative();     // see `rollout`
     const bool fused_cost = EnvM<KIND, NT, (NW > 1)>::kFusedSearchCost && env.bounds_ordered();
 
