@@ -166,3 +166,15 @@ def test_trajectory_str_and_repr_reproduce_the_readme_tables(name, x0):
     assert r.group(1) == m.group(1)                                        # "-1.   0.5  3.6" / "0. 0."
     assert np.allclose(np.array(r.group(2).split(), float), np.array(m.group(2).split(), float), atol=1e-4)
     assert abs(float(r.group(3)) - float(m.group(3))) <= 2e-4
+
+
+def test_trace_log_lines_follow_the_reference_log_messages():
+    """`trace_log_lines`: the per-pass lines of the reference's trace.log (ilqr.py:229-257, 301-303, 332-333) from decision records."""
+    from tfmpc.solvers.ilqr import trace_log_lines
+    records = [dict(iteration=0, mu=0.0, delta=0.0, J_hat=12.5, g_norm=0.4, alpha_index=2, alpha=0.25, J=11.0, accepted=True, residual=1.5),
+               dict(iteration=1, mu=0.0, delta=0.0, J_hat=11.0, g_norm=1e-5, alpha_index=None, alpha=None, J=None, accepted=None,
+                    residual=None)]
+    lines = trace_log_lines(records)
+    assert lines[0] == "[SOLVE] >>>>>>> Iteration = 0 <<<<<<<" and lines[4] == "[SOLVE] >>>>>>> Iteration = 1 <<<<<<<"
+    assert lines[3].startswith("[FORWARD] num_iter = 3, alpha = 0.25, J = 11.0000") and lines[3].endswith("accept = True")
+    assert lines[-1] == "[SOLVE] CONVERGED: g_norm < atol" and len(lines) == 8

@@ -135,7 +135,15 @@ def ilqr(env, online, horizon, atol, max_iterations, logdir, num_samples, num_wo
         with runners.Runner(model, controller)(x0, horizon) as r:
             trajectory = r.run()
     else:
-        trajectory, _ = solver.solve(x0, horizon, seed=seed)
+        # -v: what the reference logs while it solves (ilqr.py:41-43 -> <logdir>/trace.log; :279 progress postfix), from the
+        # decision trace of the fused solve
+        trajectory, _ = solver.solve(x0, horizon, seed=seed, trace=verbose >= 1, show_progress=num_samples <= 1)
+        if verbose >= 1:
+            with open(os.path.join(logdir, "trace.log"), "w") as file:
+                for b, records in enumerate(solver.last_trace):
+                    if len(solver.last_trace) > 1:
+                        file.write(f"[SAMPLE] {b}\n")
+                    file.write("\n".join(ilqr_solver.trace_log_lines(records)) + "\n")
 
     runs = [trajectory] if not trajectory.batched else [trajectory.instance(b) for b in range(num_samples)]
     for i, run in enumerate(runs):

@@ -52,6 +52,25 @@ def trace_records(trace, trace_len):
     return out
 
 
+def trace_log_lines(records):
+    """One instance's trace (``trace_records(...)[b]``) as the lines the reference writes to ``<logdir>/trace.log`` while it
+    solves (ilqr.py:229, 244-257, 301-303, 332-333): iteration banner, ``[BACKWARD] J_hat``, ``[SOLVE] g_norm``, the
+    ``[FORWARD]`` line of the step size the line search ended on, the convergence messages."""
+    lines, last = [], None
+    for r in records:
+        if r["iteration"] != last:
+            lines.append(f"[SOLVE] >>>>>>> Iteration = {r['iteration']} <<<<<<<")
+            last = r["iteration"]
+        lines.append(f"[BACKWARD] mu = {r['mu']}, delta = {r['delta']}, J_hat = {r['J_hat']:.4f}")
+        lines.append(f"[SOLVE] g_norm = {r['g_norm']:.6f}")
+        if r["accepted"] is None:
+            lines.append("[SOLVE] CONVERGED: g_norm < atol")
+            continue
+        lines.append(f"[FORWARD] num_iter = {r['alpha_index'] + 1}, alpha = {r['alpha']}, J = {r['J']:.4f}, residual = {r['residual']}, "
+                     f"accept = {r['accepted']}")
+    return lines
+
+
 def _f32(a, device):
     if isinstance(a, torch.Tensor):
         return a.detach().to(device=device, dtype=torch.float32)
