@@ -45,8 +45,8 @@ extern "C" {
 int tfmpc_version(void);
 /* Kernel-variant overrides for A/B timing and tests.  The environment variables TFMPC_LQR_KERNEL
  * (generic | lane | block), TFMPC_LQR_MFMA (f32 | bf16x3), TFMPC_ILQR_KERNEL (wave | lane | lane1 |
- * lean | lean1 | costate_mfma), TFMPC_COSTATE_WAVES (1 | 2: waves per sixteen-instance group of the HVAC /
- * Reservoir kernel) and TFMPC_ILQR_RETRY (bracket: the control-limited LQ kernel looks for the regularisation level
+ * lean | lean1 | costate_mfma), TFMPC_COSTATE_WAVES (1 | 2 | 4 | 8: waves per sixteen-instance group of the HVAC /
+ * Reservoir kernel; default: the form that brings the launch to about two waves per SIMD) and TFMPC_ILQR_RETRY (bracket: the control-limited LQ kernel looks for the regularisation level
  * of a failed factorisation around the level of its previous pass instead of probing 0, 1, 2, ... as ilqr.py:285-315
  * does -- half the time of a large batch, another regularisation path on ~0.5 % of the instances) are read ONCE per process, at the first use of the library; afterwards only
  * this call changes them (value NULL or "" = back to the dispatcher's own choice).  Returns TFMPC_ERR_ARG

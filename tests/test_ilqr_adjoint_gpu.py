@@ -118,7 +118,7 @@ def test_per_instance_parameters(force_kernel):
     u0 = iLQR(env).random_actions(T, B, seed=1)
     for b in range(B):
         single = iLQR(envs[b], max_iterations=4)
-        force_kernel(None)
+        force_kernel("lean")
         fast = single.solve_device(x0[b:b + 1], T, u_init=u0[b:b + 1])
         force_kernel("wave")
         wave = single.solve_device(x0[b:b + 1], T, u_init=u0[b:b + 1])

@@ -194,3 +194,37 @@ def test_sixteen_bit_trajectory_containers(force_kernel, kind, n, B):
     # a perturbation of the solve, not a different one (Reservoir is bang-bang: its line-search decisions flip under a
     # perturbation of any size, so individual solves move by tens of per cent at equal quality)
     assert float(((tf_ - tr).abs() / tr.abs()).median()) <= (0.05 if kind == "hvac" else 0.3)
+
+
+@pytest.mark.parametrize("kind,n,T,B", [("reservoir", 32, 37, 70), ("hvac", 32, 37, 70), ("reservoir", 4, 50, 300), ("hvac", 6, 50, 150),
+                                        ("reservoir", 12, 3, 40), ("hvac", 16, 9, 33), ("reservoir", 8, 100, 64)])
+def test_every_group_form_returns_the_same_bits(force_kernel, kind, n, T, B):
+    """Waves per sixteen-column group (TFMPC_COSTATE_WAVES = 1 | 2 | 4 | 8; the launcher picks by batch size): one step size
+    per wave in a line-search pass, the stored rollout of the accepted one as one SEGMENT of the horizon per wave from the
+    accepted chain's checkpoints.  Same expressions on the same inputs in every form: identical bits, traces included
+    (also for horizons shorter than the number of waves and not divisible by it)."""
+    env, x0 = _env(kind, n, B, n + 1)
+    solver = iLQR(env, max_iterations=5)
+    u0 = solver.random_actions(T, B, seed=n)
+    force_kernel("costate_mfma")
+    outs = {}
+    for waves in ("1", "2", "4", "8"):
+        with _hip.option("TFMPC_COSTATE_WAVES", waves):
+            o = solver.solve_device(x0, T, u_init=u0, trace_rows=8)
+            torch.cuda.synchronize()
+            outs[waves] = {k: v.clone() for k, v in o.items() if torch.is_tensor(v) and k != "workspace"}
+    def decisions(o):        # (the J of a REJECTED last try is a partial sum up to where its pass was cut short: that depends on the form)
+        tr = o["trace"].clone()
+        tr[..., 7] = torch.where(tr[..., 8] > 0, tr[..., 7], torch.zeros_like(tr[..., 7]))
+        rows = torch.arange(tr.shape[1], device=tr.device)[None, :, None] < o["trace_len"][:, None, None]
+        return torch.where(rows, tr, torch.zeros_like(tr))
+    # HVAC: the multi-wave forms keep part of the matrix operand in LDS and add the six partial products in another order
+    # than the one-wave form (fp32 rounding: a decision can flip): identical among themselves, close to the one-wave form
+    base = "2" if kind == "hvac" else "1"
+    for waves in ("2", "4", "8"):
+        for key in ("iterations", "status", "states", "actions", "costs", "trace_len"):
+            assert torch.equal(outs[waves][key], outs[base][key]), (waves, key)
+        assert torch.equal(decisions(outs[waves]), decisions(outs[base])), waves
+    if kind == "hvac":
+        c1, c2 = outs["1"]["costs"].sum(dim=1), outs["2"]["costs"].sum(dim=1)
+        assert int(((c1 - c2).abs() > 1e-4 * c1.abs()).sum()) <= max(1, B // 10)

@@ -845,6 +845,11 @@ __device__ unsigned long long *g_cfg5_phases = nullptr;
 #define TFMPC_PHASE_END(i) do {} while (0)
 #endif
 
+// Multi-wave groups (round 3): every line-search chain leaves the states it passes through at the segment boundaries of the
+// horizon (kMaxGroupWaves - 1 of them) in the workspace, one tile set each, fp32; the stored rollout of the accepted step
+// size then runs as one segment per wave, each from its checkpoint (see the kernel).
+constexpr int kMaxGroupWaves = 8;
+__host__ __device__ constexpr size_t adjoint_mfma_checkpoint_floats(int NT) { return (size_t)kMaxGroupWaves * (kMaxGroupWaves - 1) * NT * kTileElems; }
 // bytes of one wave's slice of the wave-major workspace (sized for fp32 containers; the 16-bit ones use half of each buffer)
 __host__ __device__ constexpr size_t adjoint_mfma_wave_bytes(int NT, int T)
 {
@@ -852,7 +857,8 @@ __host__ __device__ constexpr size_t adjoint_mfma_wave_bytes(int NT, int T)
     // of columns that do not keep the candidate write there -- so that the number of vector-memory operations of a step
     // is a constant the LDS-DMA ring's s_waitcnt vmcnt(N) can count (see `rollout`)
     return (2 * ((size_t)(T + 1) * NT * kTileElems + (size_t)T * NT * kTileElems + (size_t)(T + 1) * kCostLd) * sizeof(float) +
-            (size_t)T * kWave + 255 + ((size_t)NT * kTileElems + kCostLd) * sizeof(float)) & ~(size_t)255;
+            (size_t)T * kWave + 255 + ((size_t)NT * kTileElems + kCostLd) * sizeof(float) +
+            adjoint_mfma_checkpoint_floats(NT) * sizeof(float)) & ~(size_t)255;
 }
 
 // ---- round 3: groups of NW waves, one step-size chain per wave ----------------------------------------------------------
@@ -884,7 +890,8 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
     constexpr int NV = 4 * NT;
     using TT = typename std::conditional<BF16, bf16_t, float>::type;      // element type of the trajectories in HBM
     static_assert(PK == 1 || NT == 1, "instances are packed into ONE tile");
-    static_assert(NW == 1 || NW == 2, "one or two waves per sixteen-column group");
+    static_assert(NW == 1 || NW == 2 || NW == 4 || NW == 8, "waves per sixteen-column group");
+    static_assert(NW <= kMaxGroupWaves, "checkpoint tiles");
     const int lane = lane_id(), j = lane & 15, q = lane >> 4, n = genv.n, m = n, T = a.T;
     const int wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // this wave within its group
     // PK instances per column (n <= 16 / PK): lane quarter q belongs to sub-instance q / (4 / PK) and holds its rows
@@ -944,6 +951,9 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
     unsigned char *const ksel = wave_ws + 2 * (kXs + kUs + kCs) * sizeof(float) + (j * 4 + q);     // [t][column][lane quarter]
     // the trash slot behind the selector bytes (16-byte aligned): one tile set + one cost row
     TT *const trash = reinterpret_cast<TT *>(wave_ws + ((2 * (kXs + kUs + kCs) * sizeof(float) + (size_t)T * kWave + 15) & ~(size_t)15));
+    // the checkpoint tiles behind the trash slot: [chain of the pass][segment boundary - 1][tile][lane] 16-byte pieces, fp32
+    float *const ckpt = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(trash) + ((size_t)NT * kTileElems + kCostLd) * sizeof(float));
+    const int t_seg = NW > 1 ? (T + NW - 1) / NW : T;    // segment w of a stored rollout: steps [w t_seg, min((w + 1) t_seg, T))
     const float *const x0p = a.x0 + b * n;
     int flip = 0;
 
@@ -973,7 +983,12 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
 #endif
     auto rollout = [&](auto search, auto store, auto n_alpha, const float (&alpha)[decltype(n_alpha)::value], auto uh,
                        bool keep, TT *xs, TT *us, TT *cs, float (&J_out)[decltype(n_alpha)::value],
-                       bool trying = false, float reject_above = 0.0f, bool may_stop = false, bool *stopped_out = nullptr) {
+                       bool trying = false, float reject_above = 0.0f, bool may_stop = false, bool *stopped_out = nullptr,
+                       float *ck_out = nullptr, int t_lo = 0, int t_hi_ = -1, const float *ck_in = nullptr) {
+        // ck_out (line-search chains of a multi-wave group): the state at every segment boundary goes to the workspace, columns
+        // that are trying only.  [t_lo, t_hi) + ck_in (stored rollout of a multi-wave group): ONE segment of the horizon, from
+        // the accepted chain's checkpoint -- the state the one-piece rollout reaches there, bit for bit.
+        const int t_hi = t_hi_ < 0 ? T : t_hi_;
         constexpr bool SEARCH = decltype(search)::value, STORE = decltype(store)::value;
         constexpr int NA = decltype(n_alpha)::value;
         constexpr bool DEFER = SEARCH && !STORE;            // only J matters: lane-partial cost sums
@@ -987,7 +1002,14 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
         f32x2 jacc[NA][2];
         unsigned kb[kSlots];
         ldv<NT, VW>(x0p, n, ql, x[0]);
-        if (STORE) stw<NT>(xs, 0, wl, keep, x[0]);
+        if (STORE && t_lo > 0) {
+            float xc_[NV];
+            ldw<NT>(ck_in, 0, wl, xc_);
+#pragma unroll
+            for (int e = 0; e < NV; ++e) x[0][e] = keep ? xc_[e] : x[0][e];       // (lanes without a checkpoint compute on finite values)
+        }
+        if (STORE && t_lo == 0) stw<NT>(xs, 0, wl, keep, x[0]);
+        int ck_next = t_seg, ck_slot = 0;                   // ck_out: the next boundary and its tile
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             J[k] = 0.0f;
@@ -1022,7 +1044,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
         if constexpr (RING) {
 #pragma unroll
             for (int d = 0; d < kRingDepth - 1; ++d)
-                if (T > 0) issue(d, d < T ? d : T - 1);
+                if (t_hi > t_lo) issue(d, t_lo + d < t_hi ? t_lo + d : t_hi - 1);
         } else {
 #pragma unroll
             for (int d = 0; d < kAheadRoll; ++d) {
@@ -1036,7 +1058,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
 #ifdef TFMPC_CFG5_TRACE
         trace_fa[0] = trace_fa[1] = trace_fa[2] = trace_fa[3] = -1;
 #endif
-        for (int t0 = 0; t0 < T; t0 += kAheadRoll) {
+        for (int t0 = t_lo; t0 < t_hi; t0 += kAheadRoll) {
             if (SEARCH && early_exit && may_stop) {
                 bool open = false;                       // a trying column whose partial cost may still end at or below J_hat
 #pragma unroll
@@ -1047,21 +1069,28 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
             for (int d = 0; d < kAheadRoll; ++d) {
                 const int t = t0 + d;
                 __builtin_amdgcn_sched_barrier(0);          // the unrolled steps are not interleaved (registers)
-                if (t < T) {
+                if (t < t_hi) {
                     const int qo = opaque(ql);
                     float u[NA][NV];
                     const int dd = RING ? 0 : d;                // the register ring's slot of this unrolled step
+                    if (NW > 1 && DEFER && ck_out && t == ck_next) {    // (wave-uniform; uncounted stores only make the ring's waits longer)
+#pragma unroll
+                        for (int k = 0; k < NA; ++k) stw<NT>(ck_out + ((size_t)k * (kMaxGroupWaves - 1) + ck_slot) * NT * kTileElems, 0, wl, trying, x[k]);
+                        ck_next += t_seg;
+                        ++ck_slot;
+                    }
                     if constexpr (RING) {
                         // step t + depth - 1 goes into the slot the previous step has just read; then the loads of THIS
                         // step have landed once at most the (depth - 1) younger steps' are outstanding
                         const int ahead = t + kRingDepth - 1;
-                        issue(slot == 0 ? kRingDepth - 1 : slot - 1, ahead < T ? ahead : T - 1);
+                        issue(slot == 0 ? kRingDepth - 1 : slot - 1, ahead < t_hi ? ahead : t_hi - 1);
                         // (a stored rollout also issues kStores stores per step, unconditionally: they are younger than the
                         // loads waited for and stay in flight too -- counted without them, every step waited for the previous
                         // step's stores to be acknowledged by the memory system, ~2 us: the stored rollout, one chain, took as
                         // long as a search pass with two)
-                        // (the stores of the last depth - 2 steps are counted: that many exist from step depth - 2 on)
-                        if (STORE && t >= kRingDepth - 2) wait_vmem<(kRingDepth - 1) * kLoads + (kRingDepth - 2) * (2 * NT + 1)>();
+                        // (the loads of THIS step were issued at the start of step t - (depth - 1), BEFORE that step's stores: the
+                        // stores of the last depth - 1 steps are younger and stay in flight; that many exist from step depth - 1 on)
+                        if (STORE && t - t_lo >= kRingDepth - 1) wait_vmem<(kRingDepth - 1) * (kLoads + 2 * NT + 1)>();
                         else wait_vmem<(kRingDepth - 1) * kLoads>();
 #pragma unroll
                         for (int b = 0; b < NT; ++b) {
@@ -1151,7 +1180,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
                 J_out[k] = tile_sum<PK>(stopped ? own : own + fl);
             } else {
                 const float fc = col_sum<NT, PK>(cp);
-                if (STORE && keep && ql == 0) stc(cs + (size_t)T * kCostLd, fc);
+                if (STORE && keep && ql == 0 && t_hi == T) stc(cs + (size_t)T * kCostLd, fc);
                 J_out[k] = stopped ? J[k] : J[k] + fc;
             }
         }
@@ -1241,7 +1270,10 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
                         if constexpr (RING) {
                             const int ahead = t - (kRingDepth - 1);
                             issue(slot == 0 ? kRingDepth - 1 : slot - 1, ahead >= 0 ? ahead : 0);
-                            wait_vmem<(kRingDepth - 1) * kLoads>();
+                            // (the selector store of a step is younger than the loads issued at that step's start: the stores
+                            // of the last depth - 1 steps stay in flight -- uncounted, every wait also asked for one load of the NEXT step)
+                            if (RING && t <= T - kRingDepth) wait_vmem<(kRingDepth - 1) * (kLoads + 1)>();
+                            else wait_vmem<(kRingDepth - 1) * kLoads>();
 #pragma unroll
                             for (int b = 0; b < NT; ++b) {
                                 const f32x4 vx_ = ring_v[slot][b][lane], vu_ = ring_v[slot][NT + b][lane];
@@ -1281,7 +1313,11 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
                             vx[e] = Qx[e];                                                          // V_x <- Q_x
                             vx[e + 1] = Qx[e + 1];
                         }
-                        if (!done) gst(ksel + (size_t)t * kWave, (unsigned char)sel);
+                        if constexpr (RING) {       // issued on every step (the waits count it): a finished column writes to the trash slot
+                            gst(done ? reinterpret_cast<unsigned char *>(trash) + lane : ksel + (size_t)t * kWave, (unsigned char)sel);
+                        } else {
+                            if (!done) gst(ksel + (size_t)t * kWave, (unsigned char)sel);
+                        }
                         rJ += l;
                         gsum += col_max<NT, PK>(gm);
                     }
@@ -1326,6 +1362,12 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
                 if (__any(searching && last_index == v)) { store_from = v; break; }
         }
         bool complete = false;
+        // multi-wave groups on fp32 containers: the stored rollout runs as one segment of the horizon per wave (see `rollout`)
+#ifdef TFMPC_NO_ROLLOUT_SEGMENTS       // A/B builds
+        constexpr bool kSegments = false;
+#else
+        constexpr bool kSegments = kLdsRing && NW > 1;
+#endif
         for (int ai = 0; ai < cfg.n_alphas && __any(searching && !accept); ai += NAP) {
             float al[NA], J[NA], Jall[NAP];
             const int mine = ai + wv * NA;                                     // this wave's first step size of the pass
@@ -1341,7 +1383,8 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
                             uhat, trying_now, xc, uc, cc, J, trying_now, rJ, true, &stopped);
                 else
                     rollout(std::true_type{}, std::false_type{}, std::integral_constant<int, NA>{}, al,
-                            uhat, false, xc, uc, cc, J, trying_now, rJ, true, &stopped);
+                            uhat, false, xc, uc, cc, J, trying_now, rJ, true, &stopped,
+                            kSegments ? ckpt + (size_t)wv * NA * (kMaxGroupWaves - 1) * NT * kTileElems : nullptr);
                 TFMPC_PHASE_END(2);
             } else {
 #pragma unroll
@@ -1386,10 +1429,20 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
         const bool small_step = searching && residual < cfg.atol;              // :253-257
         const bool take = searching && (small_step || accept);                 // (:253 takes the last rollout even if rejected)
         if (__any(take && !complete)) {     // (also: the last step size tried was cut short and :253 takes it all the same)
-            if (wv == 0) {
+            const float al[1] = {alpha_last};
+            float J[1];
+            // (a column taken WITHOUT having accepted -- :253 on a rejected, possibly cut-short last try -- has no checkpoints)
+            if (kSegments && !__any(take && !accept)) {
                 TFMPC_PHASE_BEGIN();
-                const float al[1] = {alpha_last};
-                float J[1];
+                const int lo = wv * t_seg, hi = lo + t_seg < T ? lo + t_seg : T;
+                const int kacc = take ? index_last % NAP : 0;                 // the accepted chain of its pass
+                if (lo < hi)
+                    rollout(std::true_type{}, std::true_type{}, one_t{}, al, uhat, take && !complete, xc, uc, cc, J, false, 0.0f, false, nullptr,
+                            nullptr, lo, hi, ckpt + ((size_t)kacc * (kMaxGroupWaves - 1) + (wv > 0 ? wv - 1 : 0)) * NT * kTileElems);
+                TFMPC_PHASE_END(3);
+                group_sync<NW>();                  // every segment is visible to wave 0's sweep
+            } else if (wv == 0) {
+                TFMPC_PHASE_BEGIN();
                 rollout(std::true_type{}, std::true_type{}, one_t{}, al, uhat, take && !complete, xc, uc, cc, J);
                 TFMPC_PHASE_END(3);
             }
@@ -1490,20 +1543,24 @@ int ilqr_adjoint_mfma_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, co
     const int vw = (env.n % 4 == 0 && aligned(15u)) ? 4 : ((env.n % 2 == 0 && aligned(7u)) ? 2 : 1);
     // instances per column: one up to n = 32 (two tiles) or 16, two for n <= 8, four for n <= 4
     const int pk = env.n <= 4 ? 4 : (env.n <= 8 ? 2 : 1);
-    // waves per sixteen-column group (see the kernel): one; TFMPC_COSTATE_WAVES=2 selects the two-wave form (measured slower)
-    // waves per sixteen-column group (see the kernel).  Two waves -- one step size each instead of two chains in one wave's
-    // instruction stream, which an in-order wave does not overlap (tools/probes/matvec_bf16x3_probe.hip: two chains in
-    // a wave take twice one chain's time) -- shorten a line-search pass wherever the chip has idle SIMDs: measured
-    // (MI355X, 12 iterations, T = 100) n = 32: B = 1 024 6.5 -> 5.4-5.6 ms, B = 4 096 6.6 -> 5.9-6.1 ms, res4 / hvac6 at
-    // B = 16 384 (256 / 512 groups) 3.83 -> 3.19 / 4.35 -> 4.16 ms; from one group per SIMD on (n = 32, B = 16 384: 9.2 ->
-    // 10.0 ms; cfg5's B = 32 768: 13.4 -> 19 ms) the one-wave form wins: it needs half the registers per column.
-    // TFMPC_COSTATE_WAVES=1|2 forces a form.
+    // Waves per sixteen-column group (see the kernel).  One step size per wave instead of several chains in one wave's
+    // instruction stream, and the stored rollout as one segment of the horizon per wave: a group's iteration is a chain of
+    // dependent 100-step phases, and wherever the chip has idle SIMDs more waves per group shorten it.  The form that
+    // brings the launch to ~2 waves per SIMD (2 048 waves) wins (MI355X, 12 iterations, T = 100, tools/probes/group_waves_sweep.py;
+    // ms by waves 1 / 2 / 4 / 8): hvac6 B = 16 384 (512 groups) 3.98 / 3.51 / 2.46 / 3.10; res4 B = 16 384 (256 groups) 3.68 /
+    // 2.69 / 2.03 / 1.89, B = 65 536 (1 024 groups) 4.03 / 3.84 / 5.15 / 7.30; n = 32 Reservoir B = 256 6.50 / 4.86 / 3.46 / 3.05,
+    // B = 8 192 (512 groups) 6.92 / 6.43 / 4.99 / 6.31; two tiles (n > 16) beyond 512 groups: one wave (B = 16 384: 8.48 / 9.77 HVAC,
+    // 7.53 / 7.84 Reservoir -- a two-tile wave needs the registers of a whole SIMD half).  TFMPC_COSTATE_WAVES=1|2|4|8 forces a form.
     const int groups = (a.B + kCols * pk - 1) / (kCols * pk);
     const int forced = option_int(kOptCostateWaves, 0);
-    const int nw = forced == 1 ? 1 : (forced == 2 ? 2 : (groups <= 512 ? 2 : 1));
+    int nw = (forced == 1 || forced == 2 || forced == 4 || forced == 8) ? forced
+             : (groups <= 256 ? 8 : (groups <= 512 ? 4 : (groups <= 1024 && env.n <= 16 ? 2 : 1)));
+    if (cfg.storage_bf16 && nw > 2) nw = 2;                          // (16-bit containers: the one- and two-wave forms)
     const dim3 block(kWave * nw), grid((a.B + kCols * pk - 1) / (kCols * pk));
 #define TFMPC_LAUNCH_PAIR(KIND, NT_, PK_, VW_, BF_)                                                                            \
     if (nw == 2) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, VW_, PK_, BF_, 2>), grid, block, 0, stream, env, cfg, a); \
+    else if (!BF_ && nw == 4) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, VW_, PK_, false, 4>), grid, block, 0, stream, env, cfg, a); \
+    else if (!BF_ && nw == 8) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, VW_, PK_, false, 8>), grid, block, 0, stream, env, cfg, a); \
     else
 #define TFMPC_LAUNCH_AM4(KIND, NT_, PK_, VW_, BF_)                                                                             \
     do {                                                                                                                       \

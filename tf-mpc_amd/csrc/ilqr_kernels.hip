@@ -141,8 +141,9 @@ __global__ __launch_bounds__(kWave) void ilqr_derivatives_kernel(TfmpcEnv env, i
 // (HVAC / Reservoir, T = 100, 12 iterations; tools/costate_mfma_check.py).  End of round 2 (wave-major buffers, bf16 operand
 // split, two step sizes per pass; tools/costate_dispatch_sweep.py, n = 32): Reservoir 7.0-7.1 ms at B = 256 ... 4096
 // against 8.4-11.0 for the register-resident kernel -- the 16-per-wave kernel at EVERY batch size; HVAC 6.7-6.8 ms
-// against 4.5-6.75 -- the threshold stays.
-constexpr int kCostateMfmaMinBatchLarge = 4097, kCostateMfmaMinBatchSmall = 1;
+// against 4.5-6.75 -- the threshold stayed.  Round 3 (groups of up to eight waves, ilqr_adjoint_mfma_launch): HVAC n = 32
+// 3.28-3.39 ms at B = 16 ... 4096 against 4.48-6.85 -- the 16-per-wave kernel at every batch size on both envs.
+constexpr int kCostateMfmaMinBatchLarge = 1, kCostateMfmaMinBatchSmall = 1;
 constexpr int kBlockedFrom = 12;         // state dimension from which the register-blocked products pay
 
 struct BackwardArgs {

@@ -7,7 +7,7 @@ import numpy as np, torch, problems
 from tfmpc.envs.hvac import HVAC
 from tfmpc.envs.reservoir import Reservoir
 from tfmpc.solvers.ilqr import iLQR
-n, T, B = 32, 100, 32768
+n, T, B = 32, 100, int(os.environ.get("CFG5_B", 32768))
 bf16 = len(sys.argv) > 1 and sys.argv[1] == "bf16"          # 16-bit trajectory containers (storage_bf16)
 rng = np.random.default_rng(4)
 for kind in ("hvac", "reservoir"):
