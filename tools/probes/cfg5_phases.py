@@ -14,15 +14,21 @@ n, T = 32, 100
 lib = _hip.load()
 lib.tfmpc_debug_cfg5_phases.argtypes = [ctypes.c_void_p]
 names = ["start rollout", "sweeps", "search passes", "stored rollouts"]
+SMALL = os.environ.get("PHASES_SMALL")                      # the reference's own configs (hvac6, res4) instead of n = 32
 for B in [int(v) for v in sys.argv[1:]] or (32768, 16384, 16):
     rng = np.random.default_rng(4)
-    for kind in ("hvac", "reservoir"):
-        if kind == "hvac":
+    for kind in (("hvac6", "res4") if SMALL else ("hvac", "reservoir")):
+        if kind == "hvac6":
+            env = HVAC.load(dict(problems.HVAC6_CONFIG)); x0 = np.tile(np.array(problems.HVAC6_X0, dtype=np.float32)[None], (B, 1, 1))
+        elif kind == "res4":
+            env = Reservoir.load(dict(problems.RES4_CONFIG)); x0 = np.tile(np.array(problems.RES4_X0, dtype=np.float32)[None], (B, 1, 1))
+        elif kind == "hvac":
             env = HVAC.load(dict(problems.hvac_config(n, seed=5))); x0 = np.full((B, n, 1), 10.0, dtype=np.float32)
         else:
             env = Reservoir.load(dict(problems.reservoir_config(n, seed=5))); x0 = rng.uniform(50, 75, size=(B, n, 1)).astype(np.float32)
         s = iLQR(env, max_iterations=12); u0 = s.random_actions(T, B, seed=5)
-        groups = (B + 15) // 16
+        per = 16 * (4 if env.state_size <= 4 else (2 if env.state_size <= 8 else 1))
+        groups = (B + per - 1) // per
         buf = torch.zeros((groups, 16), dtype=torch.int64, device="cuda")
         assert lib.tfmpc_debug_cfg5_phases(buf.data_ptr()) == 0
         out = s.solve_device(x0, T, u_init=u0); torch.cuda.synchronize()
