@@ -885,7 +885,10 @@ __device__ __forceinline__ void group_sync()
 }
 
 template <int KIND, int NT, int VW, int PK, bool BF16 = false, int NW = 1>
-__global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW > 1 && NT == 1 ? 4 : (NT == 1 && PK == 1 ? 3 : 2), NW > 1 && NT == 1 ? 4 : (NT == 1 && PK == 1 ? 3 : 2)))) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
+#ifndef TFMPC_GROUP_EU
+#define TFMPC_GROUP_EU 4               // A/B builds: the register target (waves per SIMD) of the multi-wave one-tile forms
+#endif
+__global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW > 1 && NT == 1 ? (NW > 2 ? TFMPC_GROUP_EU : 4) : (NT == 1 && PK == 1 ? 3 : 2), NW > 1 && NT == 1 ? (NW > 2 ? TFMPC_GROUP_EU : 4) : (NT == 1 && PK == 1 ? 3 : 2)))) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
 {
     constexpr int NV = 4 * NT;
     using TT = typename std::conditional<BF16, bf16_t, float>::type;      // element type of the trajectories in HBM
