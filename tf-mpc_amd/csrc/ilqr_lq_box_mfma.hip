@@ -85,6 +85,12 @@ __device__ __forceinline__ float sgn(float y) { return (y > 0.0f) ? 1.0f : ((y <
 
 struct StepResult { float J, dV1, dV2, g_norm; bool failed; int flags; };
 
+#ifdef TFMPC_BOX_PROBE
+// probe builds only (tools/probes/box_lifetime.py): per instance, sweeps / rollouts in total and in passes that REPEAT the
+// previous pass (after a rejected line search the next pass probes the previous pass's levels shifted by one: see the solve loop)
+__device__ int *g_box_counts = nullptr;
+#endif
+
 template <bool BRACKET>
 __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a)
 {
@@ -527,7 +533,13 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
     int status = 0, attempts = 0, iteration = 0;
     int r_hint = 0;                     // the bump level the last backward pass succeeded on (see the search below)
     bool converged = false, give_up = false;
+#ifdef TFMPC_BOX_PROBE
+    int n_sweeps = 0, n_sweeps_rep = 0, n_roll = 0, n_roll_rep = 0, repeats = 0;
+#endif
     for (iteration = 0; iteration < cfg.max_iterations; ++iteration) {      // :227
+#ifdef TFMPC_BOX_PROBE
+        repeats = 0;
+#endif
         // derivatives (:234): l_z(t) of the nominal trajectory, kept in HBM-free LDS? No room beside the candidate
         // buffer, which the line search overwrites: the gradients live in `cand` during a backward pass and are
         // recomputed for every pass (one C Z product: 6 % of a pass).
@@ -558,6 +570,9 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
                     grads_ready = true;
                 }
                 StepResult res = backward(cand, mu_l);
+#ifdef TFMPC_BOX_PROBE
+                ++n_sweeps; if (repeats > 0) ++n_sweeps_rep;
+#endif
                 status |= res.flags;
                 return res;
             };
@@ -589,6 +604,9 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
                 const float alpha = cfg.alphas[ai];
                 float J;
                 forward(alpha, J, residual);
+#ifdef TFMPC_BOX_PROBE
+                ++n_roll; if (repeats > 0) ++n_roll_rep;
+#endif
                 const float delta_J = -alpha * (r.dV1 + alpha * r.dV2);     // :339
                 const float dcost = J_hat - J;
                 const float z = (delta_J > 0.0f) ? dcost / delta_J : sgn(dcost);   // :342-346
@@ -605,6 +623,9 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
                 mu = (mu * delta > cfg.mu_min) ? mu * delta : 0.0f;
                 break;
             }
+#ifdef TFMPC_BOX_PROBE
+            if (repeats > 0) --repeats; else repeats = level;           // a rejected pass at level r is followed by r identical ones
+#endif
             delta = fmaxf(cfg.delta_0, delta * cfg.delta_0);                // :267-270
             mu = fmaxf(cfg.mu_min, mu * delta);
             if (++attempts >= cfg.max_attempts || !(mu < 1e30f)) { give_up = true; break; }
@@ -625,6 +646,9 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
         if (!(cT == cT)) status |= TFMPC_ST_NAN;
         a.iterations[b] = iteration;
         a.status[b] = status;
+#ifdef TFMPC_BOX_PROBE
+        if (g_box_counts) { int *o = g_box_counts + (size_t)b * 4; o[0] = n_sweeps; o[1] = n_sweeps_rep; o[2] = n_roll; o[3] = n_roll_rep; }
+#endif
     }
 }
 
@@ -635,6 +659,13 @@ size_t box_lds_bytes(int T)
 }
 
 }  // namespace
+
+#ifdef TFMPC_BOX_PROBE
+extern "C" int tfmpc_debug_box_counts(int *device_buffer)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_box_counts), &device_buffer, sizeof(device_buffer));
+}
+#endif
 
 // Bounded actions (gym's Box.is_bounded(), ilqr.py:136) or any finite bound (the rollout clips against it, :197).
 bool ilqr_lq_box_mfma_supported(const TfmpcEnv &env, int T)

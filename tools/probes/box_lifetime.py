@@ -1,0 +1,32 @@
+"""Control-limited kernel, 65 536 problems: where the sweeps and rollouts of the long-running instances go (probe build:
+hipcc ... -DTFMPC_BOX_PROBE ilqr_lq_box_mfma.hip, loaded through TFMPC_LIB).  A rejected line search is followed by a pass
+that probes the SAME regularisation levels shifted by one (mu <- max(mu_min, mu delta) is the local bump's own step, ilqr.py:267-270
+vs :308-309) on the SAME nominal trajectory: counted here as 'repeats'."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("TFMPC_LIB", os.path.join(ROOT, "tools/probes/ab/lib_boxprobe.so"))
+for _p in ('tf-mpc_amd', 'tests', ''): sys.path.insert(0, os.path.join(ROOT, _p))
+import numpy as np, torch, problems
+from tfmpc import _hip
+from tfmpc.envs.lq import LQEnv
+from tfmpc.solvers.ilqr import iLQR
+B = 65536
+F, f, C, c, x0 = problems.make_lqr_batch_fast(B, 16, 8, seed=4321)
+s = iLQR(LQEnv(0.25 * F, f, C, c, low=-0.5, high=0.5))
+u0 = torch.zeros(B, 50, 8, 1, device="cuda")
+x0 = x0[..., None].astype(np.float32)
+lib = _hip.load()
+lib.tfmpc_debug_box_counts.argtypes = [ctypes.c_void_p]
+buf = torch.zeros((B, 4), dtype=torch.int32, device="cuda")
+assert lib.tfmpc_debug_box_counts(buf.data_ptr()) == 0
+out = s.solve_device(x0, 50, u_init=u0); torch.cuda.synchronize()
+c = buf.cpu().numpy().astype(np.int64)
+it = out["iterations"].cpu().numpy() + 1
+st = out["status"].cpu().numpy()
+work = c[:, 0] + 0.4 * c[:, 2]                       # a rollout + its cost pass ~ 0.4 sweeps
+order = np.argsort(-work)
+print("sweeps: total", c[:, 0].sum(), "of which repeats", c[:, 1].sum(), "| rollouts: total", c[:, 2].sum(), "of which repeats", c[:, 3].sum())
+for name, sel in (("top 64 by work", order[:64]), ("top 1 %", order[:B // 100]), ("top 10 %", order[:B // 10]), ("all", order)):
+    print(f"{name:15s}: sweeps per instance {c[sel, 0].mean():8.1f} (repeats {c[sel, 1].mean():8.1f}), rollouts {c[sel, 2].mean():8.1f} (repeats {c[sel, 3].mean():8.1f}), "
+          f"iterations {it[sel].mean():6.1f}, capped {int(((st[sel] & 16) != 0).sum())}")
+print("work quantiles (sweep equivalents): p50", np.quantile(work, 0.5), "p90", np.quantile(work, 0.9), "p99", np.quantile(work, 0.99), "p99.9", np.quantile(work, 0.999), "max", work.max())
