@@ -228,7 +228,8 @@ def torchenv_rate(B=1024, T=40):
     its = float((out["iterations"].double() + 1).sum())
     return {"iterations_per_s": its / dt, "ms_per_batch": dt * 1e3, "mean_iterations": its / B, "batch": B, "horizon": T,
             "workload": "Navigation (nav.config.json) as torch functions through TorchEnv: host-driven loop, <= 10 iterations",
-            "note": "bound by the host loop (a few hundred small torch launches per iteration); the built-in envs run fused"}
+            "note": "the rollout and derivative blocks of the loop are replayed as hipGraphs (iLQR(env, graphs=True)); "
+                    "the built-in envs run fused"}
 
 
 def other_config_rates():

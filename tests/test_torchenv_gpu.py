@@ -213,3 +213,43 @@ def test_generic_hvac_two_iterations_match_the_oracle():
         for got, r64, r32, what in ((tg.states[b], x64, x32, "states"), (tg.actions[b], u64, u32, "actions"), (tg.costs[b], c64, c32, "costs")):
             allowed = 5 * max(np.abs(r32.astype(np.float64) - r64).max(), 1e-6 * np.abs(r64).max())
             assert np.abs(got - r64).max() <= allowed, (b, what, np.abs(got - r64).max(), allowed)
+
+
+def test_graph_replay_of_the_generic_path_changes_nothing():
+    """`iLQR(env, graphs=True)` (the default) replays the rollout and derivative blocks of the host-driven loop as hipGraphs:
+    same launches on the same inputs, so every output must equal the eager loop's bit for bit -- also when the batch
+    changes between solves (a new capture per shape)."""
+    cfg = problems.NAV_CONFIG
+    env = _navigation_torch(cfg)
+    rng = np.random.default_rng(3)
+    for B, T in ((33, 12), (7, 9), (33, 12)):
+        x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
+        outs = {}
+        for graphs in (False, True):
+            solver = outs.setdefault(("solver", graphs), iLQR(env, max_iterations=6, graphs=graphs))
+            u0 = solver.random_actions(T, B, seed=B)
+            outs[graphs] = solver.solve_device(x0, T, u_init=u0)
+        assert not any(g.eager for g in outs[("solver", True)]._graphed.values())      # both blocks were captured
+        for key in ("states", "actions", "costs", "iterations", "status"):
+            assert torch.equal(outs[False][key], outs[True][key]), (B, T, key)
+
+
+def test_an_env_that_cannot_be_captured_runs_eagerly():
+    """A transition function that copies from the host on every call cannot be recorded into a graph: the block falls back to
+    eager execution (once, remembered) and the solve returns what the eager solver returns."""
+    g_host = np.array([8.0, 9.0], dtype=np.float32)
+
+    def transition(x, u):
+        return x + u + 0.0 * torch.as_tensor(g_host, device=x.device).sum()          # host-to-device copy inside the env
+
+    g = torch.as_tensor(g_host, device="cuda")
+    env = TorchEnv(transition, lambda x, u: ((x - g) ** 2).sum() + 0.1 * (u ** 2).sum(), lambda x: ((x - g) ** 2).sum(), 2, 2)
+    x0 = np.random.default_rng(1).uniform(0, 10, size=(5, 2, 1)).astype(np.float32)
+    outs = {}
+    for graphs in (False, True):
+        solver = iLQR(env, max_iterations=3, graphs=graphs)
+        outs[graphs] = solver.solve_device(x0, 6, u_init=solver.random_actions(6, 5, seed=2))
+        if graphs:
+            assert solver._graphed["rollouts"].eager
+    for key in ("states", "actions", "costs", "iterations"):
+        assert torch.equal(outs[False][key], outs[True][key]), key

@@ -71,6 +71,47 @@ def trace_log_lines(records):
     return lines
 
 
+class _Graphed:
+    """A block of torch work on fixed shapes, captured once as a hipGraph (``torch.cuda.CUDAGraph``) and replayed: the
+    generic-env path's line-search rollouts are T steps of a dozen small element-wise launches each, its derivatives a few
+    hundred -- launch-bound from the host.  ``fn(*tensors) -> tuple of tensors``; inputs are copied into static buffers, the
+    outputs are the graph's static tensors (valid until the next call).  A block that cannot be captured (a host
+    synchronisation or data-dependent control flow inside the user's env functions) runs eagerly from then on."""
+
+    def __init__(self, fn):
+        self.fn, self.key, self.graph, self.inputs, self.outputs, self.eager = fn, None, None, None, None, False
+
+    def __call__(self, *args):
+        if self.eager or not args[0].is_cuda:
+            return self.fn(*args)
+        key = tuple((tuple(a.shape), a.dtype) for a in args)
+        if key != self.key:
+            try:
+                self._capture(args, key)
+            except Exception:
+                torch.cuda.synchronize()
+                self.eager, self.graph = True, None
+                return self.fn(*args)
+        for dst, src in zip(self.inputs, args):
+            dst.copy_(src)
+        self.graph.replay()
+        return self.outputs
+
+    def _capture(self, args, key):
+        self.inputs = [a.clone() for a in args]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                  # warm-up: torch.func traces, allocator, lazy initialisation
+                self.fn(*self.inputs)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.outputs = self.fn(*self.inputs)
+        self.graph, self.key = graph, key
+
+
 def _f32(a, device):
     if isinstance(a, torch.Tensor):
         return a.detach().to(device=device, dtype=torch.float32)
@@ -95,6 +136,9 @@ class iLQR:
         self.max_attempts = kwargs.get("max_attempts", 64)
         # build-only: keep trajectories / gains in HBM at bf16 precision (fp32 arithmetic); wave kernels only
         self.storage_bf16 = bool(kwargs.get("storage_bf16", False))
+        # build-only, generic envs (TorchEnv): replay the rollout / derivative blocks of the host-driven loop as hipGraphs
+        self.graphs = bool(kwargs.get("graphs", True))
+        self._graphed = {}
 
         self._config = kwargs
         self.last_status = None
@@ -106,13 +150,21 @@ class iLQR:
     def device(self):
         return self.env._device()
 
+    def _bound(self, name):
+        # (one host-to-device copy per solver, not per use: the rollouts of a generic env are replayed as a hipGraph)
+        cache = self.__dict__.setdefault("_bounds", {})
+        key = (name, str(self.device))
+        if key not in cache:
+            cache[key] = torch.as_tensor(np.asarray(getattr(self.env.action_space, name), dtype=np.float32), device=self.device)
+        return cache[key]
+
     @property
     def low(self):
-        return torch.as_tensor(self.env.action_space.low, device=self.device)
+        return self._bound("low")
 
     @property
     def high(self):
-        return torch.as_tensor(self.env.action_space.high, device=self.device)
+        return self._bound("high")
 
     # -- helpers --------------------------------------------------------------------------
     def _alphas(self):
@@ -432,6 +484,24 @@ class iLQR:
         J = co.sum(dim=1)
         return (st, ac, co, J, res) if batched else (st[0], ac[0], co[0], J[0], res[0])
 
+    def _rollouts_graphed(self, xh, uh, K, k, alphas):
+        if not self.graphs:
+            return self._line_search_rollouts(xh, uh, K, k, alphas)
+        g = self._graphed.setdefault("rollouts", _Graphed(self._line_search_rollouts))
+        return g(xh, uh, K, k, alphas)
+
+    def _derivatives_graphed(self, xh, uh):
+        if not self.graphs:
+            return self.derivatives(xh.unsqueeze(-1), uh.unsqueeze(-1))
+
+        def flat(x, u):
+            tm, cm, fm = self.derivatives(x.unsqueeze(-1), u.unsqueeze(-1))
+            return tuple(tm) + tuple(cm) + tuple(fm)
+        g = self._graphed.setdefault("derivatives", _Graphed(flat))
+        out = g(xh, uh)
+        nt, nc = len(TransitionApprox._fields), len(CostApprox._fields)
+        return TransitionApprox(*out[:nt]), CostApprox(*out[nt:nt + nc]), FinalCostApprox(*out[nt + nc:])
+
     def _solve_host_driven(self, x0, u, batched):
         dev = self.device
         B, T, m = u.shape
@@ -451,7 +521,7 @@ class iLQR:
             if not bool(active.any()):
                 break
             iterations[active] = it
-            tm, cm, fm = self.derivatives(xh.unsqueeze(-1), uh.unsqueeze(-1))
+            tm, cm, fm = self._derivatives_graphed(xh, uh)
             J_hat = ch.sum(dim=1)
             pending = active.clone()                       # still inside the `while True` of ilqr.py:238
             converged = torch.zeros_like(active)
@@ -483,7 +553,7 @@ class iLQR:
                 g_norm = (k.abs() / (uh.abs() + 1.0)).amax(dim=2).mean(dim=1)          # ilqr.py:243
                 conv_g = pending & (g_norm < self.atol)
                 ls = pending & ~conv_g
-                xs, us, cs, res = self._line_search_rollouts(xh, uh, K, k, alphas)
+                xs, us, cs, res = self._rollouts_graphed(xh, uh, K.contiguous(), k.contiguous(), alphas)
                 J = cs.sum(dim=2)                                                        # [B, A]
                 delta_J = -alphas[None] * (dV1[:, None] + alphas[None] * dV2[:, None])   # :339
                 dcost = J_hat[:, None] - J
