@@ -607,12 +607,20 @@ template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_HVAC, NT, LEAN> {
 #pragma unroll
         for (int e = 0; e < NV; e += 2) unpr(c, e, penalties(pr(x, e), e));               // :112-129
     }
+    // PENALTY (above - below) - SET_POINT_PENALTY sgn(mid - x), hvac :97-105 differentiated, without comparisons: the violation
+    // v = x - clamp(x, lo, hi) is 0 inside the band and carries the side's sign outside, and c sgn(v) = med3(v 2^126, -c, c) for
+    // c > 0 (the product saturates to +-inf or stays an exact 0; a violation below 1e-33 degrees would fall short of c).  The same
+    // values as the compare-and-select form, in 11 instead of 20 instructions per row pair.
     __device__ __forceinline__ f32x2 grad_x(f32x2 x, int e) const
     {
+        static_assert(PENALTY > 0.0f && SET_POINT_PENALTY > 0.0f, "c sgn(v) as a median needs c > 0");
+        constexpr float kBig = 0x1p+126f;
         const f32x2 LO = pr(lo, e), HI = pr(hi, e);
-        const f32x2 mid = (LO + HI) / 2, d = mid - x;
-        const f32x2 below = {LO.x > x.x ? 1.0f : 0.0f, LO.y > x.y ? 1.0f : 0.0f}, above = {x.x > HI.x ? 1.0f : 0.0f, x.y > HI.y ? 1.0f : 0.0f};
-        return PENALTY * (-below + above) - SET_POINT_PENALTY * f32x2{sgnf_(d.x), sgnf_(d.y)};
+        const f32x2 mid = (LO + HI) / 2;
+        const f32x2 v = (x - f32x2{__builtin_amdgcn_fmed3f(x.x, LO.x, HI.x), __builtin_amdgcn_fmed3f(x.y, LO.y, HI.y)}) * kBig;
+        const f32x2 w = (x - mid) * kBig;
+        return f32x2{__builtin_amdgcn_fmed3f(v.x, -PENALTY, PENALTY), __builtin_amdgcn_fmed3f(v.y, -PENALTY, PENALTY)} +
+               f32x2{__builtin_amdgcn_fmed3f(w.x, -SET_POINT_PENALTY, SET_POINT_PENALTY), __builtin_amdgcn_fmed3f(w.y, -SET_POINT_PENALTY, SET_POINT_PENALTY)};
     }
     __device__ __forceinline__ void grads(const float (&x)[NV], int, float (&gx)[NV]) const
     {
@@ -1346,7 +1354,15 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
         const bool active = !done;
         const float mu_pass = mu, delta_pass = delta;
         const int row_pass = iteration + attempts;
-        constexpr int NA = NW > 1 ? 1 : EnvM<KIND, NT, (NW > 1)>::kSearchAlphas;       // step sizes per wave and pass
+        // step sizes per wave and pass: a four-wave group of two-tile waves rolls out two per wave -- eight per pass, as an eight-wave
+        // group does, on the 2 048 wave slots that 512 groups leave (n = 32, B = 8 192: HVAC 5.59 -> 4.89 ms, Reservoir 4.99 -> 4.78; with one
+        // tile the second chain costs what the saved passes bring: hvac6 2.46 -> 2.43, n = 16 HVAC 2.26 -> 2.40)
+#ifndef TFMPC_GROUP4_ALPHAS
+#define TFMPC_GROUP4_ALPHAS (NT == 2 ? 2 : 1)
+#endif
+        constexpr int NA = NW == 1 ? EnvM<KIND, NT, false>::kSearchAlphas : (NW == 4 ? TFMPC_GROUP4_ALPHAS : 1);
+        static_assert(NA * NW <= kMaxGroupWaves || NW == 1, "checkpoint tiles of a pass");
+        static_assert(NW == 1 || NA <= 2, "the exchange buffer holds two values per wave");
         constexpr int NAP = NA * NW;                                          // ... per group and pass
         // One step size per pass in a one-wave group: the pass WRITES the candidate of every column that is trying it (a column's buffer is
         // then final the moment the column accepts: no second rollout), and the early stop keeps the passes that are
@@ -1394,10 +1410,13 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
                 for (int k = 0; k < NA; ++k) J[k] = 0.0f;
             }
             if (NW > 1) {                                                      // the group's J(alpha) of this pass, in step-size order
-                x_pass[parity][wv][0][lane] = J[0];
+#pragma unroll
+                for (int k = 0; k < NA; ++k) x_pass[parity][wv][k][lane] = J[k];
                 __syncthreads();
 #pragma unroll
-                for (int w = 0; w < NW; ++w) Jall[w] = x_pass[parity][w][0][lane];
+                for (int w = 0; w < NW; ++w)
+#pragma unroll
+                    for (int k = 0; k < NA; ++k) Jall[w * NA + k] = x_pass[parity][w][k][lane];
                 parity ^= 1;
             } else {
 #pragma unroll
