@@ -1519,6 +1519,14 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
 
 }  // namespace
 
+// ---- host side.  The instantiations are spread over EIGHT translation units (Makefile: this file compiled with
+// -DTFMPC_AM_PART=0..7 = (HVAC | Reservoir) x (two tiles | one tile with 1, 2, 4 instances per column), 18 kernels each, built in
+// parallel); part 0 also carries the host functions.  Without the macro (tools/probes) everything is one unit.
+#ifndef TFMPC_AM_PART
+#define TFMPC_AM_PART -1
+#endif
+
+#if TFMPC_AM_PART <= 0
 #ifdef TFMPC_PHASE_PROBE
 // probe builds only (tools/probes/cfg5_phases.py): cycles a group spends per phase, [group][8] 64-bit counters:
 // 0 start rollout, 1 sweep, 2 search passes, 3 stored rollout, 4 copy-out, 5 whole kernel, 6 search rollouts, 7 sweeps
@@ -1553,6 +1561,72 @@ bool ilqr_adjoint_mfma_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg
     return true;
 }
 
+#endif      // TFMPC_AM_PART <= 0
+
+#define TFMPC_LAUNCH_PAIR(KIND, NT_, PK_, VW_, BF_)                                                                            \
+    if (nw == 2) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, VW_, PK_, BF_, 2>), grid, block, 0, stream, env, cfg, a); \
+    else if (!BF_ && nw == 4) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, VW_, PK_, false, 4>), grid, block, 0, stream, env, cfg, a); \
+    else if (!BF_ && nw == 8) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, VW_, PK_, false, 8>), grid, block, 0, stream, env, cfg, a); \
+    else
+#define TFMPC_LAUNCH_AM4(KIND, NT_, PK_, VW_, BF_)                                                                             \
+    do {                                                                                                                       \
+        TFMPC_LAUNCH_PAIR(KIND, NT_, PK_, VW_, BF_)                                                                            \
+        hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, VW_, PK_, BF_, 1>), grid, block, 0, stream, env, cfg, a);      \
+    } while (0)
+#define TFMPC_LAUNCH_AM3(KIND, NT_, PK_, VW_)                                                                                  \
+    do {                                                                                                                       \
+        if (cfg.storage_bf16) TFMPC_LAUNCH_AM4(KIND, NT_, PK_, VW_, true);                                                     \
+        else TFMPC_LAUNCH_AM4(KIND, NT_, PK_, VW_, false);                                                                     \
+    } while (0)
+#define TFMPC_LAUNCH_AM2(KIND, NT_, PK_)                                                                                        \
+    do {                                                                                                                       \
+        if (vw == 4) TFMPC_LAUNCH_AM3(KIND, NT_, PK_, 4);                                                                      \
+        else if (vw == 2) TFMPC_LAUNCH_AM3(KIND, NT_, PK_, 2);                                                                 \
+        else TFMPC_LAUNCH_AM3(KIND, NT_, PK_, 1);                                                                              \
+    } while (0)
+#define TFMPC_AM_PART_FN(P, KIND, NT_, PK_)                                                                                     \
+    int ilqr_adjoint_mfma_launch_part##P(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const AdjointSolveArgs &a, hipStream_t stream, \
+                                         int vw, int nw, dim3 grid, dim3 block)                                                 \
+    {                                                                                                                          \
+        TFMPC_LAUNCH_AM2(KIND, NT_, PK_);                                                                                      \
+        return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;                                                  \
+    }
+#define TFMPC_AM_PART_DECL(P)                                                                                                  \
+    int ilqr_adjoint_mfma_launch_part##P(const TfmpcEnv &, const TfmpcIlqrConfig &, const AdjointSolveArgs &, hipStream_t, int, int, dim3, dim3);
+TFMPC_AM_PART_DECL(0) TFMPC_AM_PART_DECL(1) TFMPC_AM_PART_DECL(2) TFMPC_AM_PART_DECL(3)
+TFMPC_AM_PART_DECL(4) TFMPC_AM_PART_DECL(5) TFMPC_AM_PART_DECL(6) TFMPC_AM_PART_DECL(7)
+#if TFMPC_AM_PART < 0 || TFMPC_AM_PART == 0
+TFMPC_AM_PART_FN(0, TFMPC_ENV_HVAC, 2, 1)
+#endif
+#if TFMPC_AM_PART < 0 || TFMPC_AM_PART == 1
+TFMPC_AM_PART_FN(1, TFMPC_ENV_HVAC, 1, 1)
+#endif
+#if TFMPC_AM_PART < 0 || TFMPC_AM_PART == 2
+TFMPC_AM_PART_FN(2, TFMPC_ENV_HVAC, 1, 2)
+#endif
+#if TFMPC_AM_PART < 0 || TFMPC_AM_PART == 3
+TFMPC_AM_PART_FN(3, TFMPC_ENV_HVAC, 1, 4)
+#endif
+#if TFMPC_AM_PART < 0 || TFMPC_AM_PART == 4
+TFMPC_AM_PART_FN(4, TFMPC_ENV_RESERVOIR, 2, 1)
+#endif
+#if TFMPC_AM_PART < 0 || TFMPC_AM_PART == 5
+TFMPC_AM_PART_FN(5, TFMPC_ENV_RESERVOIR, 1, 1)
+#endif
+#if TFMPC_AM_PART < 0 || TFMPC_AM_PART == 6
+TFMPC_AM_PART_FN(6, TFMPC_ENV_RESERVOIR, 1, 2)
+#endif
+#if TFMPC_AM_PART < 0 || TFMPC_AM_PART == 7
+TFMPC_AM_PART_FN(7, TFMPC_ENV_RESERVOIR, 1, 4)
+#endif
+#undef TFMPC_AM_PART_FN
+#undef TFMPC_AM_PART_DECL
+#undef TFMPC_LAUNCH_AM2
+#undef TFMPC_LAUNCH_AM3
+#undef TFMPC_LAUNCH_AM4
+#undef TFMPC_LAUNCH_PAIR
+
+#if TFMPC_AM_PART <= 0
 int ilqr_adjoint_mfma_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const AdjointSolveArgs &a, hipStream_t stream)
 {
     auto aligned = [&](unsigned mask) {
@@ -1579,42 +1653,18 @@ int ilqr_adjoint_mfma_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, co
              : (groups <= 256 ? 8 : (groups <= 512 ? 4 : (groups <= 1024 && env.n <= 16 ? 2 : 1)));
     if (cfg.storage_bf16 && nw > 2) nw = 2;                          // (16-bit containers: the one- and two-wave forms)
     const dim3 block(kWave * nw), grid((a.B + kCols * pk - 1) / (kCols * pk));
-#define TFMPC_LAUNCH_PAIR(KIND, NT_, PK_, VW_, BF_)                                                                            \
-    if (nw == 2) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, VW_, PK_, BF_, 2>), grid, block, 0, stream, env, cfg, a); \
-    else if (!BF_ && nw == 4) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, VW_, PK_, false, 4>), grid, block, 0, stream, env, cfg, a); \
-    else if (!BF_ && nw == 8) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, VW_, PK_, false, 8>), grid, block, 0, stream, env, cfg, a); \
-    else
-#define TFMPC_LAUNCH_AM4(KIND, NT_, PK_, VW_, BF_)                                                                             \
-    do {                                                                                                                       \
-        TFMPC_LAUNCH_PAIR(KIND, NT_, PK_, VW_, BF_)                                                                            \
-        hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<KIND, NT_, VW_, PK_, BF_, 1>), grid, block, 0, stream, env, cfg, a);      \
-    } while (0)
-#define TFMPC_LAUNCH_AM3(KIND, NT_, PK_, VW_)                                                                                  \
-    do {                                                                                                                       \
-        if (cfg.storage_bf16) TFMPC_LAUNCH_AM4(KIND, NT_, PK_, VW_, true);                                                     \
-        else TFMPC_LAUNCH_AM4(KIND, NT_, PK_, VW_, false);                                                                     \
-    } while (0)
-#define TFMPC_LAUNCH_AM2(KIND, NT_, PK_)                                                                                        \
-    do {                                                                                                                       \
-        if (vw == 4) TFMPC_LAUNCH_AM3(KIND, NT_, PK_, 4);                                                                      \
-        else if (vw == 2) TFMPC_LAUNCH_AM3(KIND, NT_, PK_, 2);                                                                 \
-        else TFMPC_LAUNCH_AM3(KIND, NT_, PK_, 1);                                                                              \
-    } while (0)
-#define TFMPC_LAUNCH_AM(KIND)                                                                                                  \
-    do {                                                                                                                       \
-        if (env.n > 16) TFMPC_LAUNCH_AM2(KIND, 2, 1);                                                                          \
-        else if (pk == 1) TFMPC_LAUNCH_AM2(KIND, 1, 1);                                                                        \
-        else if (pk == 2) TFMPC_LAUNCH_AM2(KIND, 1, 2);                                                                        \
-        else TFMPC_LAUNCH_AM2(KIND, 1, 4);                                                                                     \
-    } while (0)
-    if (env.kind == TFMPC_ENV_HVAC) TFMPC_LAUNCH_AM(TFMPC_ENV_HVAC);
-    else TFMPC_LAUNCH_AM(TFMPC_ENV_RESERVOIR);
-#undef TFMPC_LAUNCH_AM
-#undef TFMPC_LAUNCH_AM2
-#undef TFMPC_LAUNCH_AM3
-#undef TFMPC_LAUNCH_AM4
-#undef TFMPC_LAUNCH_PAIR
-    return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
+    const int part = (env.kind == TFMPC_ENV_HVAC ? 0 : 4) + (env.n > 16 ? 0 : (pk == 1 ? 1 : (pk == 2 ? 2 : 3)));
+    switch (part) {
+    case 0: return ilqr_adjoint_mfma_launch_part0(env, cfg, a, stream, vw, nw, grid, block);
+    case 1: return ilqr_adjoint_mfma_launch_part1(env, cfg, a, stream, vw, nw, grid, block);
+    case 2: return ilqr_adjoint_mfma_launch_part2(env, cfg, a, stream, vw, nw, grid, block);
+    case 3: return ilqr_adjoint_mfma_launch_part3(env, cfg, a, stream, vw, nw, grid, block);
+    case 4: return ilqr_adjoint_mfma_launch_part4(env, cfg, a, stream, vw, nw, grid, block);
+    case 5: return ilqr_adjoint_mfma_launch_part5(env, cfg, a, stream, vw, nw, grid, block);
+    case 6: return ilqr_adjoint_mfma_launch_part6(env, cfg, a, stream, vw, nw, grid, block);
+    default: return ilqr_adjoint_mfma_launch_part7(env, cfg, a, stream, vw, nw, grid, block);
+    }
 }
+#endif      // TFMPC_AM_PART <= 0
 
 }  // namespace tfmpc

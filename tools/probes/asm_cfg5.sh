@@ -6,20 +6,12 @@ set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=${1:-/tmp/asm/cfg5.s}
 mkdir -p $(dirname $OUT)
-SRC=$ROOT/tf-mpc_amd/csrc/_asm_cfg5_tmp.hip
-python3 - "$ROOT/tf-mpc_amd/csrc/ilqr_adjoint_mfma.hip" "$SRC" <<'PY'
-import sys, re
-s = open(sys.argv[1]).read()
-a = s.index('#define TFMPC_LAUNCH_PAIR(KIND')
-b = s.index('#undef TFMPC_LAUNCH_PAIR')
-few = '''    if (env.kind == TFMPC_ENV_HVAC) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<TFMPC_ENV_HVAC, 2, 4, 1, false, 1>), grid, block, 0, stream, env, cfg, a);
-    else hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<TFMPC_ENV_RESERVOIR, 2, 4, 1, false, 1>), grid, block, 0, stream, env, cfg, a);
-    (void)vw; (void)pk;
-'''
-open(sys.argv[2], 'w').write(s[:a] + few + s[b:])
-PY
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -S --cuda-device-only -o $OUT $SRC 2>&1 | grep -v "warning: argument unused" || true
-rm -f $SRC
+# (the file is built as eight translation units: part 0 = HVAC, two tiles, part 4 = Reservoir, two tiles -- every VW / container / group form)
+for P in 0 4; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -DTFMPC_AM_PART=$P -S --cuda-device-only \
+      -o $OUT.p$P $ROOT/tf-mpc_amd/csrc/ilqr_adjoint_mfma.hip 2>&1 | grep -v "warning: argument unused" | grep -v "pass-failed\|__global__\|\^\|warnings generated" || true
+done
+cat $OUT.p0 $OUT.p4 > $OUT; rm -f $OUT.p0 $OUT.p4
 python3 - $OUT <<'PY'
 import re, sys
 txt = open(sys.argv[1]).read()
