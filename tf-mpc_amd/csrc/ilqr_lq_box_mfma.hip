@@ -55,6 +55,13 @@ __device__ __forceinline__ float dpp(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
+// the value lane J of the caller's own group of 8 adjacent lanes holds (ds_swizzle in bit mode: lane <- (lane & 0x18) | J within
+// each half of the wave; no LDS memory involved)
+template <int J>
+__device__ __forceinline__ float group_lane(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (J << 5) | 0x18));
+}
 constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141;
 // sum / max over each group of 8 adjacent lanes (every lane of the group gets the result)
 __device__ __forceinline__ float sum8(float v)
@@ -266,6 +273,12 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
     // In: Hrow (row r8 of the regularised H), Mreg (column c32 of the regularised [Q~_ux | H | .]), q_r, lo_r, hi_r.
     // Out: x_r (the solution k), Kcol (column c32 of K for the last factorised free set).  Returns 0 ok,
     // TFMPC_ST_QP_MAXITER, or -1: a factorisation failed (ilqr.py:305 raises mu).
+#ifdef TFMPC_BOX_PROBE
+    int qp_iterations = 0, armijo_trials = 0;
+    unsigned long long cyc_qp = 0, cyc_sweeps = 0, cyc_rollouts = 0;
+#endif
+    float step_round0 = 1.0f;            // 0.6^(lane >> 3), formed by repeated products like the sequential backtracking loop's
+    for (int e = 0; e < (lane >> 3); ++e) step_round0 *= 0.6f;
     auto boxqp8 = [&](const float (&Hrow)[8], const float (&Mreg)[8], float q_r, float lo_r, float hi_r, float &x_r,
                       float (&Kcol)[8]) -> int {
         const float rtol = 1e-8f, step_dec = 0.6f, min_step = 1e-22f, armijo = 0.1f, eps = 1e-6f;       // :13-17
@@ -286,6 +299,9 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
 #pragma unroll
         for (int e = 0; e < 8; ++e) Kcol[e] = 0.0f;
         for (int it = 0; it < 100; ++it) {                                                               // :24
+#ifdef TFMPC_BOX_PROBE
+            ++qp_iterations;
+#endif
             if (it > 0 && (old_value - value) < rtol * fabsf(old_value)) return 0;                      // :27-29
             old_value = value;
             float g = q_r;                                                                               // :34
@@ -330,20 +346,44 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
             sr = clamped ? 0.0f : sr - x_r;
             const float sdotg = sum8(sr * g);                                                            // :75
             if (sdotg >= 0.0f) return 0;                                                                 // :77-79
-            float step = 1.0f, xc, vc;                                                                   // :82-95
+            // Backtracking line search (:82-95), EIGHT step sizes at a time.  The reference tries step = 1, 0.6, 0.36, ... one after
+            // the other until (value(step) - value) / (step s.g) >= armijo, or the step falls below min_step; measured on 65 536
+            // control-limited problems (tools/probes/box_lifetime.py) that is 5.8 trials per QP iteration, 21 per time step of a sweep,
+            // and with a wave-uniform iterate every trial paid 8 v_readlane + the objective: 60 % of the whole solve.  The eight
+            // 8-lane groups of the wave hold the same QP, so group p evaluates trial 8 r + p of round r: its own step (the same
+            // repeated products by 0.6 as the sequential loop forms), its own clipped point, the objective with the point's
+            // entries fetched by ds_swizzle (lane j of the lane's own group) and added in the same order j = 0 .. 7 -- every
+            // trial's numbers are the sequential loop's, bit for bit -- and the first group in trial order that passes (or is
+            // forced by min_step) wins.  Its point goes to every group (ds_bpermute) and becomes the wave-uniform iterate.
+            float xc = x_r, vc = value, stepg = step_round0;
             for (;;) {
-                xc = fminf(fmaxf(fmaf(step, sr, x_r), lo_r), hi_r);
-                bcast(xc);
-                vc = objective(xc);
-                if (!((vc - old_value) / (step * sdotg) < armijo)) break;
-                step *= step_dec;
-                if (step < min_step) {
-                    xc = fminf(fmaxf(fmaf(step, sr, x_r), lo_r), hi_r);
-                    bcast(xc);
-                    vc = objective(xc);
+#ifdef TFMPC_BOX_PROBE
+                ++armijo_trials;
+#endif
+                const float xg = fminf(fmaxf(fmaf(stepg, sr, x_r), lo_r), hi_r);
+                float hx = 0.0f;
+                hx = fmaf(Hrow[0], group_lane<0>(xg), hx);
+                hx = fmaf(Hrow[1], group_lane<1>(xg), hx);
+                hx = fmaf(Hrow[2], group_lane<2>(xg), hx);
+                hx = fmaf(Hrow[3], group_lane<3>(xg), hx);
+                hx = fmaf(Hrow[4], group_lane<4>(xg), hx);
+                hx = fmaf(Hrow[5], group_lane<5>(xg), hx);
+                hx = fmaf(Hrow[6], group_lane<6>(xg), hx);
+                hx = fmaf(Hrow[7], group_lane<7>(xg), hx);
+                const float vg = sum8(xg * fmaf(0.5f, hx, q_r));
+                const bool forced = stepg < min_step;                          // (the sequential loop evaluates this step and stops)
+                const bool pass = forced || !((vg - old_value) / (stepg * sdotg) < armijo);
+                const unsigned long long won = __ballot(pass);
+                if (won != 0ull) {
+                    const int first = __builtin_ctzll(won) & ~7;              // first lane of the winning group
+                    xc = __int_as_float(__builtin_amdgcn_ds_bpermute((first + r8) << 2, __float_as_int(xg)));
+                    vc = readlane(vg, first);
                     break;
                 }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) stepg *= step_dec;                // the next eight trials
             }
+            bcast(xc);
             x_r = xc;                                                                                    // :98-99 (xs == x already)
             value = vc;
         }
@@ -351,12 +391,21 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
     };
 
     // ---- regularised backward pass (ilqr.py:94-172) over the nominal trajectory `nom` with gradients Lz -------------
+#ifdef TFMPC_BOX_PROBE
+    int probe_steps = 0;                 // time steps the current sweep has run
+#endif
     auto backward = [&](const float *Lz, float mu) -> StepResult {
         StepResult res{0.0f, 0.0f, 0.0f, 0.0f, false, 0};
+#ifdef TFMPC_BOX_PROBE
+        probe_steps = 0;
+#endif
         f32x4 Vd = Cd00, vd = {0.f, 0.f, 0.f, 0.f};
         if (i == M) vd = *reinterpret_cast<const f32x4 *>(&Lz[T * kZld + 4 * q]);     // V_x = l_x^f
         float gsum = 0.0f;
         for (int t = T - 1; t >= 0; --t) {
+#ifdef TFMPC_BOX_PROBE
+            ++probe_steps;
+#endif
             const bool vxx_nonzero = __any(Vd[0] != 0.0f || Vd[1] != 0.0f || Vd[2] != 0.0f || Vd[3] != 0.0f);   // :137
             f32x4 W0 = {0.f, 0.f, 0.f, 0.f}, W1 = {0.f, 0.f, 0.f, 0.f};
             {
@@ -414,7 +463,13 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
                     if (r8 == e) k_r = ke;
                 }
             } else if (vxx_nonzero) {
+#ifdef TFMPC_BOX_PROBE
+                const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+#endif
                 const int rc = boxqp8(Hrow, Mreg, Qu_r, low_r - uh_r, high_r - uh_r, k_r, Kcol);       // :364-371
+#ifdef TFMPC_BOX_PROBE
+                cyc_qp += __builtin_amdgcn_s_memtime() - tq0;
+#endif
                 if (rc < 0) { res.failed = true; return res; }
                 res.flags |= rc;
             } else {
@@ -534,7 +589,7 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
     int r_hint = 0;                     // the bump level the last backward pass succeeded on (see the search below)
     bool converged = false, give_up = false;
 #ifdef TFMPC_BOX_PROBE
-    int n_sweeps = 0, n_sweeps_rep = 0, n_roll = 0, n_roll_rep = 0, repeats = 0;
+    int n_sweeps = 0, n_sweeps_rep = 0, n_roll = 0, n_roll_rep = 0, repeats = 0, n_failed = 0, steps_failed = 0, steps_ok = 0;
 #endif
     for (iteration = 0; iteration < cfg.max_iterations; ++iteration) {      // :227
 #ifdef TFMPC_BOX_PROBE
@@ -569,9 +624,14 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
                     __syncthreads();
                     grads_ready = true;
                 }
+#ifdef TFMPC_BOX_PROBE
+                const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
                 StepResult res = backward(cand, mu_l);
 #ifdef TFMPC_BOX_PROBE
+                cyc_sweeps += __builtin_amdgcn_s_memtime() - ts0;
                 ++n_sweeps; if (repeats > 0) ++n_sweeps_rep;
+                if (res.failed) { ++n_failed; steps_failed += probe_steps; } else steps_ok += probe_steps;
 #endif
                 status |= res.flags;
                 return res;
@@ -603,8 +663,12 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
             for (int ai = 0; ai < cfg.n_alphas; ++ai) {                     // _forward :317-355
                 const float alpha = cfg.alphas[ai];
                 float J;
+#ifdef TFMPC_BOX_PROBE
+                const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
+#endif
                 forward(alpha, J, residual);
 #ifdef TFMPC_BOX_PROBE
+                cyc_rollouts += __builtin_amdgcn_s_memtime() - tr0;
                 ++n_roll; if (repeats > 0) ++n_roll_rep;
 #endif
                 const float delta_J = -alpha * (r.dV1 + alpha * r.dV2);     // :339
@@ -647,7 +711,11 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
         a.iterations[b] = iteration;
         a.status[b] = status;
 #ifdef TFMPC_BOX_PROBE
-        if (g_box_counts) { int *o = g_box_counts + (size_t)b * 4; o[0] = n_sweeps; o[1] = n_sweeps_rep; o[2] = n_roll; o[3] = n_roll_rep; }
+        if (g_box_counts) {
+            int *o = g_box_counts + (size_t)b * 12;
+            o[0] = n_sweeps; o[1] = n_sweeps_rep; o[2] = n_roll; o[3] = n_roll_rep; o[4] = n_failed; o[5] = steps_failed; o[6] = steps_ok; o[7] = qp_iterations;
+            o[8] = (int)(cyc_qp >> 10); o[9] = (int)(cyc_sweeps >> 10); o[10] = (int)(cyc_rollouts >> 10); o[11] = armijo_trials;
+        }
 #endif
     }
 }

@@ -17,7 +17,7 @@ u0 = torch.zeros(B, 50, 8, 1, device="cuda")
 x0 = x0[..., None].astype(np.float32)
 lib = _hip.load()
 lib.tfmpc_debug_box_counts.argtypes = [ctypes.c_void_p]
-buf = torch.zeros((B, 4), dtype=torch.int32, device="cuda")
+buf = torch.zeros((B, 12), dtype=torch.int32, device="cuda")
 assert lib.tfmpc_debug_box_counts(buf.data_ptr()) == 0
 out = s.solve_device(x0, 50, u_init=u0); torch.cuda.synchronize()
 c = buf.cpu().numpy().astype(np.int64)
@@ -29,4 +29,11 @@ print("sweeps: total", c[:, 0].sum(), "of which repeats", c[:, 1].sum(), "| roll
 for name, sel in (("top 64 by work", order[:64]), ("top 1 %", order[:B // 100]), ("top 10 %", order[:B // 10]), ("all", order)):
     print(f"{name:15s}: sweeps per instance {c[sel, 0].mean():8.1f} (repeats {c[sel, 1].mean():8.1f}), rollouts {c[sel, 2].mean():8.1f} (repeats {c[sel, 3].mean():8.1f}), "
           f"iterations {it[sel].mean():6.1f}, capped {int(((st[sel] & 16) != 0).sum())}")
+for name, sel in (("top 1 %", order[:B // 100]), ("top 10 %", order[:B // 10]), ("all", order)):
+    print(f"{name:15s}: failed probes per instance {c[sel, 4].mean():8.1f} running {c[sel, 5].sum() / max(c[sel, 4].sum(), 1):5.1f} of 50 steps each; "
+          f"successful sweeps {(c[sel, 0] - c[sel, 4]).mean():8.1f}; time steps in failed probes {c[sel, 5].sum() / max(c[sel, 5].sum() + c[sel, 6].sum(), 1):.2f} of all sweep steps")
+print("box-QP iterations per sweep step:", c[:, 7].sum() / (c[:, 5].sum() + c[:, 6].sum()), "| top 1 %:", c[order[:B // 100], 7].sum() / (c[order[:B // 100], 5].sum() + c[order[:B // 100], 6].sum()))
+steps = c[:, 5].sum() + c[:, 6].sum()
+print(f"cycles (s_memtime ticks x 1024): box-QP {c[:, 8].sum()}, whole sweeps {c[:, 9].sum()}, rollouts {c[:, 10].sum()} | per sweep step: {1024 * c[:, 9].sum() / steps:.0f} ticks, of which box-QP {1024 * c[:, 8].sum() / steps:.0f}; per rollout {1024 * c[:, 10].sum() / c[:, 2].sum():.0f}")
+print("Armijo trials per box-QP iteration:", c[:, 11].sum() / c[:, 7].sum(), "| per sweep step:", c[:, 11].sum() / steps)
 print("work quantiles (sweep equivalents): p50", np.quantile(work, 0.5), "p90", np.quantile(work, 0.9), "p99", np.quantile(work, 0.99), "p99.9", np.quantile(work, 0.999), "max", work.max())
