@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
     // TFMPC_ST_QP_MAXITER, or -1: a factorisation failed (ilqr.py:305 raises mu).
 #ifdef TFMPC_BOX_PROBE
     int qp_iterations = 0, armijo_trials = 0;
-    unsigned long long cyc_qp = 0, cyc_sweeps = 0, cyc_rollouts = 0;
+    unsigned long long cyc_qp = 0, cyc_sweeps = 0, cyc_rollouts = 0, cyc_ldlt = 0, cyc_armijo = 0, cyc_head = 0;
 #endif
     float step_round0 = 1.0f;            // 0.6^(lane >> 3), formed by repeated products like the sequential backtracking loop's
     for (int e = 0; e < (lane >> 3); ++e) step_round0 *= 0.6f;
@@ -303,6 +303,9 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
             ++qp_iterations;
 #endif
             if (it > 0 && (old_value - value) < rtol * fabsf(old_value)) return 0;                      // :27-29
+#ifdef TFMPC_BOX_PROBE
+            const unsigned long long th0 = __builtin_amdgcn_s_memtime();
+#endif
             old_value = value;
             float g = q_r;                                                                               // :34
 #pragma unroll
@@ -330,7 +333,15 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
             }
             float X[8];
             int mpb = 0x3f800000;
+#ifdef TFMPC_BOX_PROBE
+            const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+            cyc_head += tl0 - th0;
+#endif
             ldlt8_solve_neg(M2, X, mpb);
+#ifdef TFMPC_BOX_PROBE
+            asm volatile("" : "+v"(X[0]), "+v"(X[7]));
+            cyc_ldlt += __builtin_amdgcn_s_memtime() - tl0;
+#endif
             if (mpb <= 0) return -1;                            // H_ff not positive definite
 #pragma unroll
             for (int e = 0; e < 8; ++e) Kcol[e] = X[e];         // lanes < 16: K[.][c32] of this free set
@@ -356,6 +367,9 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
             // trial's numbers are the sequential loop's, bit for bit -- and the first group in trial order that passes (or is
             // forced by min_step) wins.  Its point goes to every group (ds_bpermute) and becomes the wave-uniform iterate.
             float xc = x_r, vc = value, stepg = step_round0;
+#ifdef TFMPC_BOX_PROBE
+            const unsigned long long ta0 = __builtin_amdgcn_s_memtime();
+#endif
             for (;;) {
 #ifdef TFMPC_BOX_PROBE
                 ++armijo_trials;
@@ -384,6 +398,10 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
                 for (int e = 0; e < 8; ++e) stepg *= step_dec;                // the next eight trials
             }
             bcast(xc);
+#ifdef TFMPC_BOX_PROBE
+            asm volatile("" : "+v"(xc));
+            cyc_armijo += __builtin_amdgcn_s_memtime() - ta0;
+#endif
             x_r = xc;                                                                                    // :98-99 (xs == x already)
             value = vc;
         }
@@ -712,9 +730,10 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
         a.status[b] = status;
 #ifdef TFMPC_BOX_PROBE
         if (g_box_counts) {
-            int *o = g_box_counts + (size_t)b * 12;
+            int *o = g_box_counts + (size_t)b * 16;
             o[0] = n_sweeps; o[1] = n_sweeps_rep; o[2] = n_roll; o[3] = n_roll_rep; o[4] = n_failed; o[5] = steps_failed; o[6] = steps_ok; o[7] = qp_iterations;
             o[8] = (int)(cyc_qp >> 10); o[9] = (int)(cyc_sweeps >> 10); o[10] = (int)(cyc_rollouts >> 10); o[11] = armijo_trials;
+            o[12] = (int)(cyc_ldlt >> 10); o[13] = (int)(cyc_armijo >> 10); o[14] = (int)(cyc_head >> 10); o[15] = 0;
         }
 #endif
     }

@@ -17,7 +17,7 @@ u0 = torch.zeros(B, 50, 8, 1, device="cuda")
 x0 = x0[..., None].astype(np.float32)
 lib = _hip.load()
 lib.tfmpc_debug_box_counts.argtypes = [ctypes.c_void_p]
-buf = torch.zeros((B, 12), dtype=torch.int32, device="cuda")
+buf = torch.zeros((B, 16), dtype=torch.int32, device="cuda")
 assert lib.tfmpc_debug_box_counts(buf.data_ptr()) == 0
 out = s.solve_device(x0, 50, u_init=u0); torch.cuda.synchronize()
 c = buf.cpu().numpy().astype(np.int64)
@@ -36,4 +36,6 @@ print("box-QP iterations per sweep step:", c[:, 7].sum() / (c[:, 5].sum() + c[:,
 steps = c[:, 5].sum() + c[:, 6].sum()
 print(f"cycles (s_memtime ticks x 1024): box-QP {c[:, 8].sum()}, whole sweeps {c[:, 9].sum()}, rollouts {c[:, 10].sum()} | per sweep step: {1024 * c[:, 9].sum() / steps:.0f} ticks, of which box-QP {1024 * c[:, 8].sum() / steps:.0f}; per rollout {1024 * c[:, 10].sum() / c[:, 2].sum():.0f}")
 print("Armijo trials per box-QP iteration:", c[:, 11].sum() / c[:, 7].sum(), "| per sweep step:", c[:, 11].sum() / steps)
+print(f"inside the box-QP, ticks per projected-Newton iteration: gradient / clamp test / system set-up {1024 * c[:, 14].sum() / c[:, 7].sum():.0f}, LDL^T {1024 * c[:, 12].sum() / c[:, 7].sum():.0f}, "
+      f"direction + backtracking + broadcast {1024 * c[:, 13].sum() / c[:, 7].sum():.0f} (of {1024 * c[:, 8].sum() / c[:, 7].sum():.0f})")
 print("work quantiles (sweep equivalents): p50", np.quantile(work, 0.5), "p90", np.quantile(work, 0.9), "p99", np.quantile(work, 0.99), "p99.9", np.quantile(work, 0.999), "max", work.max())
