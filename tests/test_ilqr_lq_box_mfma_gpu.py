@@ -179,3 +179,23 @@ def test_full_size_bounded_headline_batch():
     assert float(rel.max()) < 2e-5
     print(f"\nbounded headline batch: mean iterations {float((out['iterations'].double() + 1).mean()):.2f}, "
           f"max {int(out['iterations'].max()) + 1}, NOT_PD retries on {int(((out['status'] & _hip.ST_NOT_PD) != 0).sum())} instances")
+
+
+def test_heavy_first_block_order_changes_no_result():
+    """Above 4 096 instances the launcher probes the regularisation level every instance's FIRST backward pass ends on, sorts the
+    blocks by it (counting sort on the device) and starts the instances that will probe most first; instances are independent, so
+    every output must equal the unsorted launch's (TFMPC_ILQR_RETRY=unsorted) bit for bit -- the permutation is a valid one."""
+    B, n, m, T, bound = 5003, 16, 8, 50, 0.5
+    F, f, C, c, x0 = _problem(B, n, m, seed=77)
+    solver = iLQR(LQEnv(F, f, C, c, low=-bound, high=bound), max_iterations=20)
+    x0d = torch.as_tensor(x0[..., None], device="cuda")
+    u0 = torch.zeros(B, T, m, 1, device="cuda")
+    outs = {}
+    for mode in (None, "unsorted"):
+        with _hip.option("TFMPC_ILQR_RETRY", mode):
+            o = solver.solve_device(x0d, T, u_init=u0)
+            torch.cuda.synchronize()
+            outs[mode] = {k: v.clone() for k, v in o.items() if torch.is_tensor(v) and k != "workspace"}
+    for key in ("states", "actions", "costs", "iterations", "status"):
+        assert torch.equal(outs[None][key], outs["unsorted"][key]), key
+    assert int(((outs[None]["status"] & _hip.ST_NOT_PD) != 0).sum()) > 0          # some instances did probe levels > 0

@@ -98,11 +98,13 @@ struct StepResult { float J, dV1, dV2, g_norm; bool failed; int flags; };
 __device__ int *g_box_counts = nullptr;
 #endif
 
-template <bool BRACKET>
+// MODE 1 (first-pass probe): the solve up to the regularisation level its FIRST backward pass ends on, written to the first B
+// ints of the (otherwise unused) wsq slab -- the launcher's proxy for how long an instance will run (see ilqr_lq_box_mfma_launch).
+template <bool BRACKET, int MODE = 0>
 __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = blockIdx.x;
+    const int b = (MODE == 0 && a.order) ? a.order[blockIdx.x] : blockIdx.x;
     const int lane = threadIdx.x;
     const int i = lane & 15, q = lane >> 4;
     const int r8 = lane & 7;                       // QP: the row this lane owns
@@ -607,6 +609,7 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
     int r_hint = 0;                     // the bump level the last backward pass succeeded on (see the search below)
     bool converged = false, give_up = false;
 #ifdef TFMPC_BOX_PROBE
+    int first_level = -1;
     int n_sweeps = 0, n_sweeps_rep = 0, n_roll = 0, n_roll_rep = 0, repeats = 0, n_failed = 0, steps_failed = 0, steps_ok = 0;
 #endif
     for (iteration = 0; iteration < cfg.max_iterations; ++iteration) {      // :227
@@ -671,6 +674,13 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
                     probe = hi_ok - 1;                                      // less regularisation than last time: down
                 }
             }
+#ifdef TFMPC_BOX_PROBE
+            if (first_level < 0) first_level = level;
+#endif
+            if constexpr (MODE == 1) {
+                if (lane == 0) reinterpret_cast<int32_t *>(a.wsq)[b] = give_up ? 41 : level;
+                return;
+            }
             if (level > 0) status |= TFMPC_ST_NOT_PD;
             r_hint = give_up ? 0 : level;
             if (give_up) break;
@@ -733,7 +743,7 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
             int *o = g_box_counts + (size_t)b * 16;
             o[0] = n_sweeps; o[1] = n_sweeps_rep; o[2] = n_roll; o[3] = n_roll_rep; o[4] = n_failed; o[5] = steps_failed; o[6] = steps_ok; o[7] = qp_iterations;
             o[8] = (int)(cyc_qp >> 10); o[9] = (int)(cyc_sweeps >> 10); o[10] = (int)(cyc_rollouts >> 10); o[11] = armijo_trials;
-            o[12] = (int)(cyc_ldlt >> 10); o[13] = (int)(cyc_armijo >> 10); o[14] = (int)(cyc_head >> 10); o[15] = 0;
+            o[12] = (int)(cyc_ldlt >> 10); o[13] = (int)(cyc_armijo >> 10); o[14] = (int)(cyc_head >> 10); o[15] = first_level;
         }
 #endif
     }
@@ -761,11 +771,44 @@ bool ilqr_lq_box_mfma_supported(const TfmpcEnv &env, int T)
            T >= 1 && box_lds_bytes(T) <= 48 * 1024;
 }
 
+namespace {
+// Block order: instances whose first backward pass needs many regularisation levels first.  The launch used to end with the
+// last-started of ~650 instances (of 65 536) that need ~1 000 dependent sweeps, 0.33 s each, on top of 0.43 s of chip time for the
+// whole batch; those instances all end their FIRST backward pass on level 8 .. 11 (tools/probes/box_lifetime.py), which a probe
+// launch finds for ~5 % of the work.  A counting sort by that level (descending; one workgroup) gives the block -> instance table.
+// Results do not depend on the order (instances are independent): bit-identical to the unsorted launch.
+__global__ __launch_bounds__(1024) void box_order_kernel(const int32_t *level, int32_t *order, int B)
+{
+    __shared__ int hist[64], base[64];
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += 1024) atomicAdd(&hist[min(max(level[b], 0), 63)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int at = 0;
+        for (int l = 63; l >= 0; --l) { base[l] = at; at += hist[l]; }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += 1024) order[atomicAdd(&base[min(max(level[b], 0), 63)], 1)] = b;
+}
+
+}  // namespace
+
 int ilqr_lq_box_mfma_launch(const IlqrLqArgs &a, hipStream_t stream)
 {
     const size_t lds = box_lds_bytes(a.T);
-    if (option_is(kOptIlqrRetry, "bracket")) hipLaunchKernelGGL(ilqr_lq_box_mfma_kernel<true>, dim3(a.B), dim3(kWave), lds, stream, a);
-    else hipLaunchKernelGGL(ilqr_lq_box_mfma_kernel<false>, dim3(a.B), dim3(kWave), lds, stream, a);
+    const bool bracket = option_is(kOptIlqrRetry, "bracket");
+    IlqrLqArgs run = a;
+    run.order = nullptr;
+    // more instances than resident waves (2 per SIMD x 1 024 SIMDs), and room for two ints per instance in the wsq slab
+    if (a.B > 4096 && (size_t)a.T * a.env.m >= 2 && a.wsq && !option_is(kOptIlqrRetry, "unsorted") && !bracket) {
+        int32_t *level = reinterpret_cast<int32_t *>(a.wsq), *order = level + a.B;
+        hipLaunchKernelGGL((ilqr_lq_box_mfma_kernel<false, 1>), dim3(a.B), dim3(kWave), lds, stream, a);
+        hipLaunchKernelGGL(box_order_kernel, dim3(1), dim3(1024), 0, stream, level, order, a.B);
+        run.order = order;
+    }
+    if (bracket) hipLaunchKernelGGL((ilqr_lq_box_mfma_kernel<true, 0>), dim3(a.B), dim3(kWave), lds, stream, run);
+    else hipLaunchKernelGGL((ilqr_lq_box_mfma_kernel<false, 0>), dim3(a.B), dim3(kWave), lds, stream, run);
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
 }
 

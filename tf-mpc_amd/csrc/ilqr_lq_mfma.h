@@ -23,6 +23,7 @@ struct IlqrLqArgs {
     int32_t *iterations, *status;
     float *wsK, *wsk, *wsq;      // gains K[T][m][n], k[T][m] and Q_u[T][m] scratch (HBM)
     float *wsx, *wsu, *wsc;      // candidate trajectory x[T+1][n], u[T][m], costs[T+1] (ilqr_lq_mfma32.hip only)
+    const int32_t *order;        // ilqr_lq_box_mfma.hip: block -> instance (heavy instances first), or null
 };
 
 // Control-limited twin (ilqr_lq_box_mfma.hip): bounded actions or any finite bound; the whole state machine

@@ -38,4 +38,20 @@ print(f"cycles (s_memtime ticks x 1024): box-QP {c[:, 8].sum()}, whole sweeps {c
 print("Armijo trials per box-QP iteration:", c[:, 11].sum() / c[:, 7].sum(), "| per sweep step:", c[:, 11].sum() / steps)
 print(f"inside the box-QP, ticks per projected-Newton iteration: gradient / clamp test / system set-up {1024 * c[:, 14].sum() / c[:, 7].sum():.0f}, LDL^T {1024 * c[:, 12].sum() / c[:, 7].sum():.0f}, "
       f"direction + backtracking + broadcast {1024 * c[:, 13].sum() / c[:, 7].sum():.0f} (of {1024 * c[:, 8].sum() / c[:, 7].sum():.0f})")
+# list scheduling on 2 048 wave slots: the launch time a block order gives (work = this instance's ticks in sweeps + rollouts)
+import heapq
+ticks = (c[:, 9] + c[:, 10]).astype(np.float64) * 1024
+def makespan(order_):
+    slots = [0.0] * 2048
+    heapq.heapify(slots)
+    end = 0.0
+    for b in order_:
+        t0 = heapq.heappop(slots); t1 = t0 + ticks[b]; end = max(end, t1); heapq.heappush(slots, t1)
+    return end
+first = c[:, 15]
+print("first-pass regularisation level histogram:", np.bincount(np.clip(first, 0, 41))[:16].tolist())
+print("top 1 % by work: first-pass level quantiles", np.quantile(first[order[:B // 100]], [0, 0.1, 0.5, 0.9, 1.0]).tolist())
+base = makespan(range(B))
+print(f"simulated launch (ticks): index order {base:.3e}; sorted by first-pass level (descending) {makespan(np.argsort(-first, kind='stable')):.3e}; "
+      f"sorted by true work {makespan(order):.3e}; work / slots {ticks.sum() / 2048:.3e}; heaviest instance {ticks.max():.3e}")
 print("work quantiles (sweep equivalents): p50", np.quantile(work, 0.5), "p90", np.quantile(work, 0.9), "p99", np.quantile(work, 0.99), "p99.9", np.quantile(work, 0.999), "max", work.max())
