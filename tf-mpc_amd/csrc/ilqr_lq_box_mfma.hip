@@ -279,6 +279,7 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
     int qp_iterations = 0, armijo_trials = 0;
     unsigned long long cyc_qp = 0, cyc_sweeps = 0, cyc_rollouts = 0, cyc_ldlt = 0, cyc_armijo = 0, cyc_head = 0;
 #endif
+    const bool qp_col_a = c32 < N, qp_col_h = c32 >= N && c32 < N + M, qp_col_g = c32 == N + M;     // Q~_ux | H | g~ columns of the QP system
     float step_round0 = 1.0f;            // 0.6^(lane >> 3), formed by repeated products like the sequential backtracking loop's
     for (int e = 0; e < (lane >> 3); ++e) step_round0 *= 0.6f;
     auto boxqp8 = [&](const float (&Hrow)[8], const float (&Mreg)[8], float q_r, float lo_r, float hi_r, float &x_r,
@@ -322,16 +323,17 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
 #pragma unroll
             for (int j = 0; j < 8; ++j) gcs[j] = readlane(gc, j);
             // [Q~_ux,f | H_ff | g~_f] with identity rows / columns on the clamped set -> LDL^T (:40-51, :66-72, ilqr.py:375-385)
+            // (written as selects on per-lane masks: as an if / else-if chain on the lane's column kind the compiler emitted ~25
+            // exec-mask instructions per row, a third of the iteration's instruction stream)
             f32x2 M2[4];
+            const bool col_free = qp_col_h && ((fmask >> (c32 - N)) & 1u);         // H columns: is this lane's variable free?
+            const bool lane_keep = qp_col_a || qp_col_g || col_free;               // row e of this column survives if row e is free
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const bool fe = (fmask >> e) & 1u;
-                float v;
-                if (c32 < N) v = fe ? Mreg[e] : 0.0f;
-                else if (c32 < N + M) v = (fe && ((fmask >> (c32 - N)) & 1u)) ? Mreg[e] : ((e == c32 - N) ? 1.0f : 0.0f);
-                else if (c32 == N + M) v = fe ? gcs[e] : 0.0f;
-                else v = 0.0f;
-                M2[e >> 1][e & 1] = v;
+                const bool fe = (fmask >> e) & 1u;                                  // (wave-uniform)
+                const float base = qp_col_g ? gcs[e] : Mreg[e];
+                const float ident = (qp_col_h && c32 - N == e) ? 1.0f : 0.0f;      // identity rows / columns of the clamped set
+                M2[e >> 1][e & 1] = (fe && lane_keep) ? base : ident;
             }
             float X[8];
             int mpb = 0x3f800000;
