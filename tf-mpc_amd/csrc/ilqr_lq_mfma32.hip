@@ -196,6 +196,19 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_mfma32_kernel(IlqrLqArgs a)
         }
         // inputs of step t for this lane: K[ka][8 jc ..], k[ka], x_hat[8 jc ..], u_hat[ka]
         auto load_step = [&](int t, float (&Kv)[8], float (&xv)[8], float &kv, float &uv) {
+            if (n == N && m == M && ((reinterpret_cast<uintptr_t>(xh) | reinterpret_cast<uintptr_t>(Kg)) & 15u) == 0) {
+                // the literal shape (BASELINE configs[4]), 16-byte aligned trajectories: no bounds to test, 16-byte loads
+                uv = uh[(size_t)t * M + ka];
+                if (search) {
+                    const f32x4 *Kp = reinterpret_cast<const f32x4 *>(Kg + (size_t)t * (M * N) + ka * N + 8 * jc);
+                    const f32x4 *xp = reinterpret_cast<const f32x4 *>(xh + (size_t)t * N + 8 * jc);
+                    const f32x4 K0 = Kp[0], K1 = Kp[1], x0v = xp[0], x1v = xp[1];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { Kv[j] = K0[j]; Kv[4 + j] = K1[j]; xv[j] = x0v[j]; xv[4 + j] = x1v[j]; }
+                    kv = kg[(size_t)t * M + ka];
+                }
+                return;
+            }
             const bool row = ka < m;
             uv = row ? uh[(size_t)t * m + ka] : 0.0f;
             if (search) {
@@ -391,7 +404,9 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_mfma32_kernel(IlqrLqArgs a)
                 for (int e = 0; e < M; ++e) {
                     p1 = fmaf(Mr[e], quc[e], p1);
                     const float uh = e < m ? uhat[(size_t)t * m + e] : 0.0f;
-                    gm = fmaxf(gm, e < m ? fabsf(Mr[e]) / (fabsf(uh) + 1.0f) : 0.0f);
+                    // (hardware reciprocal, 1 ulp, instead of an IEEE division -- sixteen per step were ~130 instructions: g_norm is
+                    // only ever compared with atol; the costate kernels do the same)
+                    gm = fmaxf(gm, e < m ? fabsf(Mr[e]) * __builtin_amdgcn_rcpf(fabsf(uh) + 1.0f) : 0.0f);
                 }
                 dV1 += readlane(p1, N + M);
                 gsum += readlane(gm, N + M);
