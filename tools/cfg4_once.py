@@ -10,7 +10,10 @@ solver = iLQR(Navigation.load(problems.NAV_CONFIG))
 x0 = np.random.default_rng(4).uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
 u0 = solver.random_actions(50, B, seed=4)
 out = solver.solve_device(x0, 50, u_init=u0)
-for _ in range(3):
-    out = solver.solve_device(x0, 50, u_init=u0, workspace=out["workspace"])
+import time
 torch.cuda.synchronize()
-print("iterations", float((out["iterations"].double() + 1).sum()))
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter(); out = solver.solve_device(x0, 50, u_init=u0, workspace=out["workspace"]); torch.cuda.synchronize()
+    ts.append((time.perf_counter() - t0) * 1e3)
+print("iterations", float((out["iterations"].double() + 1).sum()), "| ms per batch:", " ".join(f"{t:.2f}" for t in ts))
