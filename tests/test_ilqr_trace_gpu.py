@@ -162,3 +162,16 @@ def test_wave_kernel_trace_on_the_reference_hvac6_config():
         _check("hvac", cfg, env, x0, u0, T, 10, min_full=0.3, n64=6)
     finally:
         _hip.set_option("TFMPC_ILQR_KERNEL", None)
+
+
+def test_default_kernel_trace_on_the_reference_hvac6_config():
+    """The reference's own hvac6 config on the kernel a user gets by default: the 16-per-wave costate kernel, two instances per
+    matrix-core column, groups of eight waves at this batch size (one step size per wave, the stored rollout in segments) --
+    whole decision traces against the free-running fp32 restatement, T = 100 as in the bench line."""
+    cfg = dict(problems.HVAC6_CONFIG)
+    n, T, B = 6, 100, 32
+    env = HVAC.load(dict(cfg))
+    rng = np.random.default_rng(21)
+    x0 = rng.uniform(8.0, 25.0, size=(B, n, 1)).astype(np.float32)
+    u0 = iLQR(env).random_actions(T, B, seed=7).cpu().numpy().astype(np.float32)
+    _check("hvac", cfg, env, x0, u0, T, 12, min_full=0.8, n64=6)       # (measured: 32 of 32 whole traces, 381 passes)
