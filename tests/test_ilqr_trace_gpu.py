@@ -175,3 +175,28 @@ def test_default_kernel_trace_on_the_reference_hvac6_config():
     x0 = rng.uniform(8.0, 25.0, size=(B, n, 1)).astype(np.float32)
     u0 = iLQR(env).random_actions(T, B, seed=7).cpu().numpy().astype(np.float32)
     _check("hvac", cfg, env, x0, u0, T, 12, min_full=0.8, n64=6)       # (measured: 32 of 32 whole traces, 381 passes)
+
+
+def test_default_kernel_first_pass_on_the_reference_res4_config():
+    """The reference's own res4 config on the default kernel (four instances per matrix-core column, eight-wave groups): the first
+    pass starts from the same trajectory as the restatement's, so J_hat and the gradient norm agree to rounding; the accepted step
+    size depends on bang-bang selector ties and is compared by count."""
+    cfg = dict(problems.RES4_CONFIG)
+    n, T, B = 4, 100, 48
+    env = Reservoir.load(dict(cfg))
+    rng = np.random.default_rng(22)
+    x0 = (np.array(problems.RES4_X0, dtype=np.float32).reshape(1, n, 1) * rng.uniform(0.8, 1.2, size=(B, n, 1))).astype(np.float32)
+    u0 = iLQR(env).random_actions(T, B, seed=8).cpu().numpy().astype(np.float32)
+    out, plain = _device(env, x0, u0, T, 3)
+    for key in ("states", "actions", "costs", "iterations"):
+        assert torch.equal(out[key], plain[key]), key
+    dev = trace_records(out["trace"], out["trace_len"])
+    ref32 = trace_oracle.run_many("reservoir", cfg, x0, u0, T, "float32", 3)
+    first = 0
+    for b in range(B):
+        d, r = dev[b][0], ref32[b][0][0]
+        # (one selector bit that a rounding-level tie flips in one of the 100 steps moves the mean of the 4-action maxima by ~1 %)
+        assert abs(d["J_hat"] - r["J_hat"]) <= 2e-4 * abs(r["J_hat"]) and abs(d["g_norm"] - r["g_norm"]) <= 3e-2 * r["g_norm"]
+        first += int(d["alpha_index"] == r["alpha_index"])
+    print(f"res4: first accepted step size equal on {first} of {B} instances")
+    assert first >= B // 2, first
