@@ -2,13 +2,17 @@
 """bench.py -- headline benchmark of the batched LQR/iLQR hot path on MI355X.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
-random LQR, state_dim=16, action_dim=8, horizon=50, batch=65 536 independent
-instances PER GPU (weak scaling), fp32.  One "step" = one pass of the hot path over
-the batch = 65 536 LQR solves (Riccati backward sweep + closed-loop rollout) in one
-kernel launch; for an LQR problem one solve is one iLQR iteration.
-Inputs are resident in HBM before the timed region.
+random LQR, state_dim=16, action_dim=8, horizon=50, fp32, batch=65 536 independent
+instances.  `--scaling strong` (the default; BASELINE configs[2] literally: "batch=65 536,
+1->8 GPUs sharded"): the GLOBAL batch is 65 536, block-sharded over the N ranks
+(tfmpc.parallel.shard_bounds), so at N = 8 a GPU solves 8 192 instances per step.
+`--scaling weak`: 65 536 instances PER GPU.  At N = 1 the two are the same run.  One
+"step" = one pass of the hot path over the batch = one kernel launch per rank (Riccati
+backward sweep + closed-loop rollout of every instance of its shard); for an LQR problem
+one solve is one iLQR iteration.  Inputs are resident in HBM before the
+timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 `--gpus N` with N > 1 and no launcher (WORLD_SIZE unset) starts the N ranks itself: a
@@ -134,19 +138,11 @@ def ilqr_api_rate(n, m, T, B, reps=5):
     step and the line search (mean ~2 iterations).  Iterations counted = reference loop index + 1.
     Roofline: algorithmic flop = backward passes x T x 45.0 kflop + rollouts x T x 2.2 kflop with
     backward passes = iterations and rollouts >= iterations - 1 (a converged instance ends on a backward pass)."""
-    import problems
+    import workloads
     from tfmpc import _hip
-    from tfmpc.envs.lq import LQEnv
-    from tfmpc.solvers.ilqr import iLQR
-    from tfmpc.solvers.lqr import LQR
-    F, f, C, c, x0 = problems.make_lqr_batch_spd(B, n, m, seed=4321)
-    F = 0.25 * F
-    x0 = torch.as_tensor(x0[..., None].astype(np.float32), device="cuda")
-    opt = LQR(F, f, C, c).solve_device(x0, T)["actions"]
-    gen = torch.Generator(device="cuda").manual_seed(7)
-    u0 = (opt + 0.05 * opt.abs().amax(dim=(1, 2, 3), keepdim=True) * torch.randn(opt.shape, device="cuda", generator=gen)).contiguous()
 
-    def run(solver, reps_):
+    def run(solver, w, reps_):
+        x0, u0 = w["x0"], w["u0"]
         out = solver.solve_device(x0, T, u_init=u0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -155,27 +151,33 @@ def ilqr_api_rate(n, m, T, B, reps=5):
         torch.cuda.synchronize()
         return out, (time.perf_counter() - t0) / reps_
 
-    out, dt = run(iLQR(LQEnv(F, f, C, c)), reps)
-    its = float((out["iterations"].double() + 1).sum())
-    flop = its * T * 45.0e3 + max(its - B, 0.0) * T * 2.2e3
-    tf = flop / dt / 1e12
-    res = {"iterations_per_s": its / dt, "ms_per_batch": dt * 1e3, "mean_iterations": its / B,
-           "flagged_instances": int((out["status"] != 0).sum()),
-           "workload": f"iLQR.solve on LQEnv(0.25 F, f, C, c) of make_lqr's distribution, n={n} m={m} T={T} B={B}, start = LQR-optimal actions + 5 % noise",
-           "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
-                        "algorithmic_flop": flop, "traffic": pmc_traffic("ilqr_lq_mfma_kernel", 65536, B),
-                        "kernel": "ilqr_lq_mfma_kernel (profiles/r03_ilqr_api_kernel_stats.csv: tools/ilqr_api_once.py under rocprofv3)"}}
+    def api_line(w):
+        out, dt = run(workloads.solver_of(w), w, reps)
+        its = float((out["iterations"].double() + 1).sum())
+        flop = its * T * 45.0e3 + max(its - B, 0.0) * T * 2.2e3
+        tf = flop / dt / 1e12
+        return {"iterations_per_s": its / dt, "ms_per_batch": dt * 1e3, "mean_iterations": its / B,
+                "flagged_instances": int((out["status"] != 0).sum()), "workload": w["text"], "workload_version": w["version"],
+                "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
+                             "algorithmic_flop": flop}}
+
+    # the workloads are defined in tests/workloads.py, the module the decision-trace parity tests draw them from
+    # (tests/test_ilqr_lq_trace_gpu.py); `workload_version` says which definition a number belongs to
+    res = api_line(workloads.ilqr_api_warm(B, n, m, T))
+    res["roofline"]["traffic"] = pmc_traffic("ilqr_lq_mfma_kernel", 65536, B)
+    res["roofline"]["kernel"] = "ilqr_lq_mfma_kernel (profiles/r04_ilqr_api_kernel_stats.csv: tools/ilqr_api_once.py under rocprofv3)"
+    # the same problems from zero actions: the first rollout runs open loop through an unstable system, several step sizes are tried
+    cold = api_line(workloads.ilqr_api_cold(B, n, m, T))
+    cold["roofline"].update(note="rollouts counted as iterations - B: a lower bound here (the line search backtracks)", traffic=None)
+    res["cold_start"] = cold
     # CONTROL LIMITS: box-QP at every backward step, regularisation loop in the kernel.  On the well-conditioned generator
-    # (tests/problems.py:make_lqr_batch_fast, eigenvalues of C in [1, 2]; zero start actions) as in rounds 1-2: with
+    # (tests/problems.py:make_lqr_batch_fast, eigenvalues of C in [1, 2]; zero start actions) as in rounds 1-3: with
     # make_spd_matrix's spectrum and a +-0.5 box three quarters of the instances exhaust the regularisation attempts (the
     # reference would loop on them without bound, ilqr.py:238-270) -- a statement about those problems, not a benchmark.
-    Fw, fw, Cw, cw, x0w = problems.make_lqr_batch_fast(B, n, m, seed=4321)
-    x0 = torch.as_tensor(x0w[..., None].astype(np.float32), device="cuda")
-    u0 = torch.zeros(B, T, m, 1, device="cuda")
-    F, f, C, c = 0.25 * Fw, fw, Cw, cw
+    wl = workloads.control_limited(B, n, m, T)
 
     def limited(tag):
-        out_, dt_ = run(iLQR(LQEnv(F, f, C, c, low=-0.5, high=0.5)), 1)
+        out_, dt_ = run(workloads.solver_of(wl), wl, 1)
         its_ = float((out_["iterations"].double() + 1).sum())
         st, it = out_["status"], (out_["iterations"] + 1).float()
         return {"ms_per_batch": dt_ * 1e3, "solves_per_s": B / dt_, "iterations_per_s": its_ / dt_, "mean_iterations": its_ / B,
@@ -184,7 +186,8 @@ def ilqr_api_rate(n, m, T, B, reps=5):
                 "instances_at_attempt_cap": int(((st & 16) != 0).sum()), "regularisation_search": tag}
 
     res["control_limited"] = limited("linear probe 0, 1, 2, ... (ilqr.py:285-315; the default)")
-    res["control_limited"]["workload"] = f"LQEnv(0.25 F, f, C, c) of the well-conditioned generator, zero start, actions in [-0.5, 0.5] (ilqr.py:136-138,364-387: box-QP at every step), B={B}"
+    res["control_limited"]["workload"] = wl["text"]
+    res["control_limited"]["workload_version"] = wl["version"]
     res["control_limited"]["kernel"] = "ilqr_lq_box_mfma_kernel; round 1: wave kernel, 2.3 k solves/s at B=8192"
     with _hip.option("TFMPC_ILQR_RETRY", "bracket"):
         res["control_limited"]["bracket_search_variant"] = limited(
@@ -340,10 +343,12 @@ def other_config_rates():
                                                          pmc=(kernel_tag, 16384 * 12))
     # configs[4] at its literal dims (n = 32, m = 16, T = 100, B = 32 768) as iLQR on the generalised LQ env
     n, m, T, B = 32, 16, 100, 32768
-    F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=6)
-    solver = iLQR(LQEnv(F * (0.9 / np.sqrt(n)), f, C, c))
-    x0d = torch.as_tensor(x0[..., None].astype(np.float32), device="cuda")
-    line = ilqr_line(solver, x0d, T, torch.zeros(B, T, m, 1, device="cuda"), 2)
+    import workloads
+    wl = workloads.literal_dims(B, n, m, T)
+    solver = workloads.solver_of(wl)
+    x0d = wl["x0"]
+    line = ilqr_line(solver, x0d, T, wl["u0"], 2)
+    line["workload"], line["workload_version"] = wl["text"], wl["version"]
     # algorithmic flop (SURVEY.md 8d formulas at n = 32, m = 16): backward 352.6 kflop per step, rollout 8.8 kflop per step
     its = line["iterations_per_s"] * line["ms_per_batch"] * 1e-3
     bw_step = 4 * n ** 3 + 4 * m * n * n + 2 * m * m * n + 2 * n * n + 2 * m * n + m ** 3 / 3.0 + 2 * m * m * (n + 1) \
@@ -427,7 +432,10 @@ def dry_run_cpu(args):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from tfmpc.parallel import gather_trajectories
     from tfmpc.parallel import shard_bounds
-    n, m, T, B_total = 4, 2, 5, 64 * world + 1   # uneven block split on purpose: the first rank gets one instance more
+    # strong: a FIXED global batch split N ways; weak: a fixed batch per rank.  Uneven block splits on purpose
+    # (strong: 129 over 2 ranks = 65 + 64; weak: 64 per rank + 1: the first rank gets one instance more)
+    n, m, T = 4, 2, 5
+    B_total = 129 if args.scaling == "strong" else 64 * world + 1
     lo_, hi_ = shard_bounds(B_total, world, rank)
     B = hi_ - lo_
 
@@ -455,7 +463,7 @@ def dry_run_cpu(args):
     if rank == 0:
         line = {"metric": "DRY RUN (no GPU work)", "value": float(total.item()) * args.steps / elapsed, "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "valid": False,
-                "total_instances": int(total.item())}
+                "scaling": args.scaling, "total_instances": int(total.item())}
         if gathered is not None:
             line["gathered_states_shape"] = list(gathered[0].shape)
             line["gathered_rank_of_last_instance"] = float(gathered[0][-1, 0, 0, 0])
@@ -528,7 +536,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH, help="instances per GPU (default = BASELINE config)")
+    ap.add_argument("--batch", type=int, default=BATCH,
+                    help="instances: the GLOBAL batch with --scaling strong, per GPU with --scaling weak (default = BASELINE config)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong (default; BASELINE configs[2]: batch=65 536 sharded over 1->8 GPUs): --batch is the global batch, "
+                         "block-sharded over the ranks; weak: --batch instances on every GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary iLQR-API measurement (profiling runs)")
     ap.add_argument("--extras-only", action="store_true",
@@ -573,8 +585,16 @@ def main():
     from tfmpc.solvers.lqr import LQR
     import problems
 
-    n, m, T, B = N_STATE, N_ACTION, HORIZON, args.batch
-    # each rank owns its own contiguous shard of the global batch (weak scaling)
+    from tfmpc.parallel import shard_bounds
+    n, m, T = N_STATE, N_ACTION, HORIZON
+    # each rank owns its own contiguous shard of the global batch: strong = the block split of --batch instances over the
+    # ranks (sizes differ by at most one), weak = --batch instances on every rank.  The shard is drawn on its rank
+    # (seed 1234 + rank); at N = 1 both modes are the same 65 536 problems.
+    B_global = args.batch if args.scaling == "strong" else args.batch * world
+    lo_, hi_ = shard_bounds(B_global, world, rank)
+    B = hi_ - lo_
+    if B_global < world:               # (every rank sees this: nobody is left waiting in a collective)
+        raise SystemExit(f"bench.py: --batch {args.batch} leaves a rank of {world} without an instance")
     F, f, C, c, x0 = problems.make_lqr_batch_spd(B, n, m, seed=1234 + rank)
     lqr = LQR(F, f, C, c)
     x0_dev = lqr._prep_x0(x0)
@@ -617,7 +637,10 @@ def main():
         out = step()
     # the receive buffers of the final gather are allocated up front (rank 0), where running out of memory fails the job
     # at start-up; the gather itself is then ONE collective and nothing else (sizes follow from the block split)
-    recv = gather_buffers(out["states"], out["actions"], out["costs"], total=B * world) if use_dist else None
+    if use_dist:
+        from tfmpc.parallel import check_shard_sizes
+        check_shard_sizes(B, B_global)           # start-up agreement on the shard sizes (fails on every rank or none)
+    recv = gather_buffers(out["states"], out["actions"], out["costs"], total=B_global) if use_dist else None
     fence()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
@@ -637,7 +660,7 @@ def main():
         fence()
         g0 = time.perf_counter()
         try:
-            gathered = gather_trajectories(out["states"], out["actions"], out["costs"], total=B * world, recv=recv)
+            gathered = gather_trajectories(out["states"], out["actions"], out["costs"], total=B_global, recv=recv)
         except RuntimeError as exc:
             gather_error = repr(exc)
         fence()
@@ -652,22 +675,25 @@ def main():
         kernel_ms = float(kmax.item())
 
     if rank == 0:
-        total_solves = B * world * args.steps
+        total_solves = B_global * args.steps
         value = total_solves / elapsed
+        # roofline of the dominant kernel on the slowest rank's clock: rank 0 holds a largest shard of the block split
         traffic, traffic_source = measured_traffic(kernel, B)
         flops = lqr_flops_per_solve(n, m, T) * B
         achieved = flops / (kernel_ms * 1e-3) / 1e12
         line = {
             "metric": "iLQR iterations/sec (batch x horizon) at n=16,m=8,T=50",
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"random LQR n=16 m=8 horizon=50, batch={B} per GPU (BASELINE configs[2]); "
-                                   "one LQR solve = one iLQR iteration",
+            "config": {"workload": (f"random LQR n=16 m=8 horizon=50, global batch={B_global} block-sharded over {world} GPU(s) "
+                                    "(BASELINE configs[2]); " if args.scaling == "strong" else
+                                    f"random LQR n=16 m=8 horizon=50, batch={B} per GPU (BASELINE configs[2] on every GPU); ")
+                                   + "one LQR solve = one iLQR iteration",
                        "generator": "tests/problems.py:make_lqr_batch_spd = the reference's make_lqr (tfmpc/envs/__init__.py:9-18) "
                                     "vectorised: F, f, c ~ N(0,1), C by sklearn make_spd_matrix's formula (eigenvalues ~1e-3 .. n+m)",
                        "state_dim": n, "action_dim": m, "horizon": T, "batch_per_gpu": B,
-                       "global_batch": B * world, "parallelism": f"batch-sharded x{world}, one gather at the end",
+                       "global_batch": B_global, "parallelism": f"batch-sharded x{world}, one gather at the end",
                        "kernel": kernel},
             "timestep_iterations_per_s": value * T,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
@@ -699,7 +725,7 @@ def main():
                               "backend": dist.get_backend(), "world_size": world,
                               "ms": gather_ms, "bytes_per_rank": per_rank, "bytes_total": per_rank * world,
                               "GB_per_s_into_rank0": per_rank * (world - 1) / (gather_ms * 1e-3) / 1e9,
-                              "checked": bool(gathered is not None and torch.equal(gathered[0][-B:], out["states"]))
+                              "checked": bool(gathered is not None and torch.equal(gathered[0][:B], out["states"]))
                               if world == 1 else None}
         if gather_error is not None:
             line["gather_error"] = gather_error

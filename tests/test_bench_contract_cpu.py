@@ -40,6 +40,19 @@ def test_two_rank_dry_run_aggregates_over_ranks():
     assert line["ms_per_step"] >= 3.5                                          # the slower rank (4 ms sleeps) sets the time
 
 
+def test_strong_and_weak_scaling_modes_shard_differently():
+    """--scaling strong (the default: BASELINE configs[2], a fixed global batch block-sharded over the ranks) against
+    --scaling weak (a fixed batch per rank), three ranks: the dry run's global batch is 129 = 43 + 43 + 43 (strong) or
+    64 x 3 + 1 = 193 = 65 + 64 + 64 (weak); the line says which mode it ran."""
+    def run(mode):
+        return _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                     "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                     "bench.py", "--gpus", "3", "--dry-run-cpu", "--steps", "2", "--warmup", "1"] + (["--scaling", mode] if mode else []))
+    strong, weak = run(None), run("weak")
+    assert strong["scaling"] == "strong" and strong["total_instances"] == 129 and strong["gathered_states_shape"][0] == 129
+    assert weak["scaling"] == "weak" and weak["total_instances"] == 193 and weak["gathered_states_shape"][0] == 193
+
+
 def test_gpus_flag_alone_starts_the_ranks_itself():
     """`python bench.py --gpus 2` with NO launcher (the form the driver uses for N = 1) must not silently run one
     rank: bench.py starts the two ranks as a torch.distributed.run child process and rank 0 prints the line."""

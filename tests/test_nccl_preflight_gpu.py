@@ -33,6 +33,7 @@ def test_bench_through_the_launcher_and_rccl_with_one_rank():
     assert res.returncode == 0, res.stderr[-2000:]
     line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["status_flagged_instances"] == 0
+    assert line["scaling"] == "strong" and line["config"]["global_batch"] == 4096 and line["config"]["batch_per_gpu"] == 4096
     g = line["gather"]
     assert g["backend"] == "nccl" and g["world_size"] == 1
     assert g["checked"] is True                                  # what rank 0 gathered IS its own shard, bit for bit

@@ -63,6 +63,12 @@ def _worker(rank, world, port, B, n, m, T, out_path, with_total=False):
             with _CountingCollectives() as counted:
                 res = parallel.gather_trajectories(*shards, total=B, recv=recv)
             assert counted.calls == ["gather"], counted.calls          # ONE collective, nothing else
+            parallel.check_shard_sizes(mine.shape[0], B)                # start-up agreement: passes on both ranks
+            try:                                                       # ... and fails on BOTH when one rank's shard is wrong
+                parallel.check_shard_sizes(mine.shape[0] + (1 if rank == 1 else 0), B)
+                raise AssertionError("a wrong shard on rank 1 went unnoticed on rank %d" % rank)
+            except ValueError:
+                pass
             try:                                                       # a shard of the wrong size is refused BEFORE any collective
                 with _CountingCollectives() as counted:
                     parallel.gather_trajectories(*_fake_solve(torch.cat([mine, x0[:1]]), T, m), total=B)

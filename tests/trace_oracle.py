@@ -20,6 +20,84 @@ for _p in (ROOT, os.path.join(ROOT, "tf-mpc_amd"), os.path.join(ROOT, "tests")):
 
 ATOL_MARGIN = 1e-3     # relative margin under which an atol comparison counts as a near-tie
 COST_MARGIN = 3e-5     # ... and a cost comparison |J_hat - J| / |J_hat| (an fp32 cost sum carries ~1e-6)
+QP_MARGIN = 1e-4       # ... and the box-QP's clamp test: |gradient entry| of a coordinate on its bound / max |gradient entry|
+PIVOT_MARGIN = 1e-4    # ... and a Cholesky factorisation: smallest pivot relative to its own diagonal entry (or, when it fails, the
+                       #     most negative eigenvalue of the unit-diagonal scaling) -- "positive definite or not" is a decision too (ilqr.py:305)
+
+
+class _PivotLog:
+    """While installed, every ``np.linalg.cholesky`` call of the restatement (ilqr_ref._cholesky, boxqp_ref) leaves how far
+    its matrix was from the other outcome: success -> min_i pivot_i / A_ii, failure -> |lambda_min| of the unit-diagonal scaling."""
+
+    def __init__(self):
+        self.values, self.kept, self.failures, self.qp_values = [], [], 0, []
+        self._orig = None
+
+    def __enter__(self):
+        self._orig = np.linalg.cholesky
+        last = [np.inf]                      # clamp-test margin of the box-QP call in progress
+
+        def logged(A):
+            A = np.asarray(A)
+            if not A.size:
+                return self._orig(A)
+            # scale-free measures: pivot i relative to its own diagonal entry (1 = nothing subtracted, -> 0 = cancelled away);
+            # for a failure the most negative eigenvalue of the matrix scaled to unit diagonal
+            diag = np.diagonal(A).astype(np.float64)
+            try:
+                L = self._orig(A)
+            except np.linalg.LinAlgError:
+                lam = 1.0
+                if np.all(np.isfinite(A)) and np.all(diag > 0):
+                    d = 1.0 / np.sqrt(diag)
+                    lam = abs(float(np.min(np.linalg.eigvalsh(0.5 * (A + A.T).astype(np.float64) * d[:, None] * d[None, :]))))
+                # a probe (one regularisation level) that fails is discarded whole (ilqr.py:305-309): of its factorisations only
+                # the failing one is a decision of the pass -- the marginal pivots it met on its way fed numbers nobody uses
+                self.values = [lam]
+                self.kept, self.values = self.kept + self.values, []
+                self.qp_values, last[0] = [], np.inf        # ... and so did its clamp tests
+                self.failures += 1
+                raise
+            self.values.append(float(np.min(np.diagonal(L).astype(np.float64) ** 2 / diag)))
+            return L
+
+        np.linalg.cholesky = logged
+        # the box-QP's clamp test (optimization.py:121-127) is a decision too: a coordinate on its bound is clamped by the SIGN
+        # of its gradient entry; how far that entry is from zero, relative to the largest one.  Only the LAST evaluation of a
+        # QP call counts: it yields the free set the controller is built from (ilqr.py:375-385: clamped rows of K are zero);
+        # the iterates before it converge to the same minimiser of a strictly convex problem whichever way a test fell.
+        from oracle import boxqp_ref
+        self._indices, self._qp = boxqp_ref.get_qp_indices, boxqp_ref.projected_newton_qp
+
+        def logged_indices(g, low, high, x, eps=1e-6):
+            at_bound = np.logical_or(np.abs(x - low) < eps, np.abs(high - x) < eps)
+            last[0] = np.inf
+            if np.any(at_bound):
+                last[0] = float(np.min(np.abs(g[at_bound]))) / max(float(np.max(np.abs(g))), 1e-30)
+            return self._indices(g, low, high, x, eps=eps)
+
+        def logged_qp(*args, **kwargs):
+            last[0] = np.inf
+            try:
+                return self._qp(*args, **kwargs)
+            finally:
+                self.qp_values.append(last[0])
+
+        boxqp_ref.get_qp_indices = logged_indices
+        boxqp_ref.projected_newton_qp = logged_qp
+        return self
+
+    def __exit__(self, *exc):
+        from oracle import boxqp_ref
+        np.linalg.cholesky = self._orig
+        boxqp_ref.get_qp_indices = self._indices
+        boxqp_ref.projected_newton_qp = self._qp
+
+    def take(self):
+        both = self.kept + self.values
+        v, f, q = (min(both) if both else np.inf), self.failures, (min(self.qp_values) if self.qp_values else np.inf)
+        self.values, self.kept, self.failures, self.qp_values = [], [], 0, []
+        return v, f, q
 
 
 def make_env(kind, cfg, dtype):
@@ -31,11 +109,19 @@ def make_env(kind, cfg, dtype):
         return envs_ref.HVAC(**cfg, dtype=dtype)
     if kind == "reservoir":
         return envs_ref.Reservoir(**cfg, dtype=dtype)
+    if kind == "lq":           # cfg: F[n,n+m], f[n], C, c, low, high (scalars or None) -- tests/workloads.py:instance_cfg
+        return envs_ref.LQEnv(cfg["F"], cfg["f"], cfg["C"], cfg["c"], low=cfg.get("low"), high=cfg.get("high"), dtype=dtype)
     raise ValueError(kind)
 
 
-def solve_with_margins(o, x0, T, u_init):
-    """-> (records, states[T+1,n], actions[T,m], costs[T+1], iteration)."""
+def solve_with_margins(o, x0, T, u_init, max_attempts=64):
+    """-> (records, states[T+1,n], actions[T,m], costs[T+1], iteration).  ``max_attempts``: the product's cap on rejected
+    passes per solve (the reference loops without bound, ilqr.py:238); a solve that reaches it ends there, as on the device."""
+    with _PivotLog() as pivots:
+        return _solve_with_margins(o, x0, T, u_init, max_attempts, pivots)
+
+
+def _solve_with_margins(o, x0, T, u_init, max_attempts, pivots):
     dt = o.dtype
     mu, delta = 0.0, 1.0
     x_hat, u_hat, c_hat = o.start(x0, T, u_init=u_init)
@@ -47,11 +133,13 @@ def solve_with_margins(o, x0, T, u_init):
         models = o.derivatives(x_hat, u_hat)
         converged = False
         while True:
+            pivots.take()
             K, k, J_hat, dV1, dV2 = o._backward(T, u_hat, *models, mu, delta)
+            pivot, failures, qp_sign = pivots.take()                       # over every factorisation / clamp test of the pass, failed probes included
             g_norm = np.mean(np.max(np.abs(k) / (np.abs(u_hat) + dt(1.0)), axis=1), axis=0)[0]
             rec = dict(iteration=iteration, mu=float(mu), delta=float(delta), J_hat=float(J_hat), g_norm=float(g_norm),
-                       alpha_index=None, accepted=None, residual=None, J=None,
-                       margin=abs(float(g_norm) - o.atol) / o.atol / ATOL_MARGIN)
+                       alpha_index=None, accepted=None, residual=None, J=None, cholesky_failures=failures,
+                       margin=min(abs(float(g_norm) - o.atol) / o.atol / ATOL_MARGIN, pivot / PIVOT_MARGIN, qp_sign / QP_MARGIN))
             records.append(rec)
             if g_norm < o.atol:
                 converged = True
@@ -68,6 +156,12 @@ def solve_with_margins(o, x0, T, u_init):
                     accept = True
                     break
             rec.update(alpha_index=step, accepted=bool(accept), residual=float(residual), J=float(J))
+            # forward-error bound of the residual as the reference computes it (ilqr.py:193-194,206): delta_u = alpha k + K (x - x_hat)
+            # is a sum of n + 1 products, so an fp32 evaluation is uncertain by ~(n + 1) 2^-24 (|alpha k| + |K| |x - x_hat|) -- large
+            # where an open-loop nominal trajectory has run far from the candidate and the two terms cancel
+            dx = np.abs(np.asarray(x[:-1], dtype=np.float64) - np.asarray(x_hat[:-1], dtype=np.float64))
+            mag = np.abs(float(a) * np.asarray(k, dtype=np.float64)) + np.abs(np.asarray(K, dtype=np.float64)) @ dx
+            rec["residual_noise"] = float((K.shape[2] + 1) * 2.0 ** -24 * mag.max())
             rec["margin"] = min(rec["margin"], abs(float(residual) - o.atol) / o.atol / ATOL_MARGIN)
             if residual < o.atol:
                 converged = True
@@ -81,7 +175,7 @@ def solve_with_margins(o, x0, T, u_init):
             delta = max(o.delta_0, delta * o.delta_0)
             mu = max(o.mu_min, mu * delta)
             attempts += 1
-            if attempts >= 64 or not np.isfinite(mu) or mu > 1e30:
+            if attempts >= max_attempts or not np.isfinite(mu) or mu > 1e30:
                 return records, x_hat[..., 0], u_hat[..., 0], c_hat, iteration
         if converged:
             break
@@ -93,17 +187,29 @@ def _job(args):
     import torch
     torch.set_num_threads(1)                 # one core per worker: the steps are tiny
     from oracle import ilqr_ref
-    dtype = np.float32 if dtype_name == "float32" else np.float64
+    dtype = np.float64 if dtype_name == "float64" else np.float32
+    if dtype_name == "float32p":             # the fp32 restatement on inputs moved by ~1 ulp: how much rounding alone moves a trace
+        rng = np.random.default_rng(12345)
+        jig = lambda a: a if a is None or np.isscalar(a) else (np.asarray(a, dtype=np.float32) * (1 + 2.0 ** -23 * rng.uniform(-1, 1, size=np.shape(a)))).astype(np.float32)
+        x0, u0 = jig(x0), jig(u0)
+        if kind == "lq":
+            cfg = {k: jig(v) for k, v in cfg.items()}
     o = ilqr_ref.ILQRRef(make_env(kind, cfg, dtype), dtype=dtype, max_iterations=max_iterations)
-    recs, xs, us, cs, it = solve_with_margins(o, np.asarray(x0, dtype=dtype), T, np.asarray(u0, dtype=dtype))
+    try:
+        recs, xs, us, cs, it = solve_with_margins(o, np.asarray(x0, dtype=dtype), T, np.asarray(u0, dtype=dtype))
+    except ilqr_ref.CholeskyFailure:         # no regularisation level factorises (the restatement raises past mu = 1e30)
+        return None
     return recs, np.asarray(xs, dtype=np.float64), np.asarray(us, dtype=np.float64), np.asarray(cs, dtype=np.float64).reshape(-1), int(it)
 
 
 def run_many(kind, cfg, x0, u0, T, dtype_name, max_iterations, workers=None):
-    """x0[B,n,1], u0[B,T,m,1] -> list of _job results, computed in spawned worker processes."""
+    """x0[B,n,1], u0[B,T,m,1] -> list of _job results, computed in spawned worker processes.  ``cfg``: one env config, or a list
+    (one per instance); ``dtype_name``: "float32" | "float64" | "float32p" (fp32 on inputs perturbed by ~1 ulp), or a list."""
     import concurrent.futures
     import multiprocessing
-    jobs = [(kind, cfg, x0[b], u0[b], T, dtype_name, max_iterations) for b in range(len(x0))]
+    per_instance = isinstance(cfg, (list, tuple))            # one env per instance (LQ problems) or one shared by the batch
+    names = dtype_name if isinstance(dtype_name, (list, tuple)) else [dtype_name] * len(x0)
+    jobs = [(kind, cfg[b] if per_instance else cfg, x0[b], u0[b], T, names[b], max_iterations) for b in range(len(x0))]
     # at most FOUR workers: the restatement's envs import torch, which opens the GPU device in every process that loads
     # it, and a GPU box allows six processes on its card at once (this one included)
     workers = workers or max(1, min(len(jobs), (os.cpu_count() or 2) - 1, 4))

@@ -1,0 +1,76 @@
+"""The secondary iLQR workloads of ``bench.py`` (``extra.ilqr_api`` and friends), defined ONCE so that the bench line and the
+decision-trace parity tests (tests/test_ilqr_lq_trace_gpu.py) run the very same problems.  Needs the GPU (start actions of
+the warm-start workload come from ``LQR.solve`` on the device and a device-side noise generator); all returned arrays
+are numpy float64 / float32 on the host plus the device tensors a solver call takes.
+
+Every workload carries a ``version`` tag that ``bench.py`` prints with its numbers: a number is comparable across
+rounds only under the same tag (the definitions changed in round 3 without one)."""
+
+import numpy as np
+import torch
+
+import problems
+
+N, M, T = 16, 8, 50
+
+
+def ilqr_api_warm(B, n=N, m=M, horizon=T):
+    """``iLQR.solve`` on ``LQEnv(0.25 F, f, C, c)`` of the reference's ``make_lqr`` distribution
+    (tests/problems.py:make_lqr_batch_spd), start = the LQR-optimal open-loop actions + 5 % noise (an MPC re-solve;
+    ~2 iterations, the first step size accepted).  Round 3's definition, unchanged."""
+    from tfmpc.solvers.lqr import LQR
+    F, f, C, c, x0 = problems.make_lqr_batch_spd(B, n, m, seed=4321)
+    F = 0.25 * F
+    x0d = torch.as_tensor(x0[..., None].astype(np.float32), device="cuda")
+    opt = LQR(F, f, C, c).solve_device(x0d, horizon)["actions"]
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    u0 = (opt + 0.05 * opt.abs().amax(dim=(1, 2, 3), keepdim=True) * torch.randn(opt.shape, device="cuda", generator=gen)).contiguous()
+    return dict(version="ilqr_api/warm-r3", F=F, f=f, C=C, c=c, x0=x0d, u0=u0, low=None, high=None, T=horizon,
+                text=f"iLQR.solve on LQEnv(0.25 F, f, C, c) of make_lqr's distribution, n={n} m={m} T={horizon} B={B}, "
+                     "start = LQR-optimal actions + 5 % noise")
+
+
+def ilqr_api_cold(B, n=N, m=M, horizon=T):
+    """The same problems from a COLD start: zero actions (the line search has to backtrack on part of the batch and the
+    solve takes more iterations than from the warm start)."""
+    F, f, C, c, x0 = problems.make_lqr_batch_spd(B, n, m, seed=4321)
+    F = 0.25 * F
+    x0d = torch.as_tensor(x0[..., None].astype(np.float32), device="cuda")
+    u0 = torch.zeros(B, horizon, m, 1, device="cuda")
+    return dict(version="ilqr_api/cold-r4", F=F, f=f, C=C, c=c, x0=x0d, u0=u0, low=None, high=None, T=horizon,
+                text=f"the same LQEnv problems, n={n} m={m} T={horizon} B={B}, start = zero actions")
+
+
+def control_limited(B, n=N, m=M, horizon=T, bound=0.5):
+    """``LQEnv(0.25 F, f, C, c)`` of the well-conditioned generator (tests/problems.py:make_lqr_batch_fast, eigenvalues of
+    C in [1, 2]), zero start, actions in [-bound, bound]: the box-QP at every backward step (ilqr.py:136-138, 364-387).
+    Round 3's definition, unchanged (rounds 1-2 used the same generator)."""
+    F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=4321)
+    F = 0.25 * F
+    x0d = torch.as_tensor(x0[..., None].astype(np.float32), device="cuda")
+    u0 = torch.zeros(B, horizon, m, 1, device="cuda")
+    return dict(version="control_limited/fast-r3", F=F, f=f, C=C, c=c, x0=x0d, u0=u0, low=-bound, high=bound, T=horizon,
+                text=f"LQEnv(0.25 F, f, C, c) of the well-conditioned generator, zero start, actions in [{-bound}, {bound}] "
+                     f"(ilqr.py:136-138,364-387: box-QP at every step), B={B}")
+
+
+def literal_dims(B, n=32, m=16, horizon=100):
+    """BASELINE configs[4] at its literal dims as iLQR on the LQ env: well-conditioned generator, F scaled to
+    spectral radius ~0.9, zero start."""
+    F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=6)
+    F = F * (0.9 / np.sqrt(n))
+    x0d = torch.as_tensor(x0[..., None].astype(np.float32), device="cuda")
+    u0 = torch.zeros(B, horizon, m, 1, device="cuda")
+    return dict(version="literal_dims/fast-r2", F=F, f=f, C=C, c=c, x0=x0d, u0=u0, low=None, high=None, T=horizon,
+                text=f"iLQR.solve on LQEnv(0.9/sqrt(n) F, f, C, c), n={n} m={m} T={horizon} B={B}, zero start")
+
+
+def solver_of(w, **kwargs):
+    from tfmpc.envs.lq import LQEnv
+    from tfmpc.solvers.ilqr import iLQR
+    return iLQR(LQEnv(w["F"], w["f"], w["C"], w["c"], low=w["low"], high=w["high"]), **kwargs)
+
+
+def instance_cfg(w, b, u0_host=None):
+    """One instance of a workload as the per-instance config ``tests/trace_oracle.py`` takes (kind ``"lq"``)."""
+    return dict(F=w["F"][b], f=w["f"][b], C=w["C"][b], c=w["c"][b], low=w["low"], high=w["high"])

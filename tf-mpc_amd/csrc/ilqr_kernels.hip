@@ -545,22 +545,26 @@ int tfmpc_ilqr_solve_trace_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, 
     {
         // LQ env on the matrix cores (ilqr_lq_mfma.hip); instances it cannot finish (mu > 0 needed)
         // come back flagged and are re-solved from scratch by the wave kernel right behind it
-        // (the matrix-core LQ kernels record no decision trace: a traced solve goes to the wave kernel)
-        const bool forced_wave = option_is(kOptIlqrKernel, "wave") || traced;
+        // (a traced solve stays on these kernels: each records the same row per pass as the wave kernel, and the
+        // second-chance launch rewrites the rows of the instances it re-solves)
+        const bool forced_wave = option_is(kOptIlqrKernel, "wave");
         if (!forced_wave && !cfg->storage_bf16 && ilqr_lq_box_mfma_supported(*env, T)) {
             // control-limited LQ problems: box-QP in registers, the complete solve loop in one kernel
             IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk, a.wsu};
+            la.trace = tr;
             return ilqr_lq_box_mfma_launch(la, st);
         }
         if (!forced_wave && !cfg->storage_bf16 && ilqr_lq_mfma32_supported(*env, T)) {
             // BASELINE configs[4]'s literal dims (n <= 32, m <= 16): 2 x 2 tiles, trajectories in HBM; second chance as below
             IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk, a.wsu,
                           a.wsx, a.wsu, a.wsc};
+            la.trace = tr;
             if ((rc = ilqr_lq_mfma32_launch(la, st)) != TFMPC_OK) return rc;
             a.only_flagged = 1;
         }
         if (!forced_wave && !cfg->storage_bf16 && ilqr_lq_mfma_supported(*env, T)) {
             IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk, a.wsu};
+            la.trace = tr;
             if ((rc = ilqr_lq_mfma_launch(la, st)) != TFMPC_OK) return rc;
             a.only_flagged = 1;
         }

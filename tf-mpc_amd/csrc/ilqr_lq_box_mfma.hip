@@ -686,13 +686,24 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
             if (level > 0) status |= TFMPC_ST_NOT_PD;
             r_hint = give_up ? 0 : level;
             if (give_up) break;
-            if (r.g_norm < cfg.atol) { converged = true; break; }           // :243-248
+            // decision trace (what ilqr.py:243-279 logs per pass; rows == nullptr: none).  Row = passes made so far = iteration +
+            // rejected passes; mu / delta are the solve-level values (the local bump of a failed factorisation is not logged, Q2)
+            if (r.g_norm < cfg.atol) {                                      // :243-248
+                if (a.trace.rows) {
+                    const float J_conv = sum_costs(cnom);
+                    if (lane == 0) trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, J_conv, r.g_norm, -1, 0.0f, 0.0f, -1, -1.0f);
+                }
+                converged = true;
+                break;
+            }
             const float J_hat = sum_costs(cnom);                            // :104,164
             bool accept = false;
-            float residual = 0.0f;
+            float residual = 0.0f, J_last = 0.0f;
+            int ai_last = -1;
             for (int ai = 0; ai < cfg.n_alphas; ++ai) {                     // _forward :317-355
                 const float alpha = cfg.alphas[ai];
                 float J;
+                ai_last = ai;
 #ifdef TFMPC_BOX_PROBE
                 const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -701,12 +712,16 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a
                 cyc_rollouts += __builtin_amdgcn_s_memtime() - tr0;
                 ++n_roll; if (repeats > 0) ++n_roll_rep;
 #endif
+                J_last = J;
                 const float delta_J = -alpha * (r.dV1 + alpha * r.dV2);     // :339
                 const float dcost = J_hat - J;
                 const float z = (delta_J > 0.0f) ? dcost / delta_J : sgn(dcost);   // :342-346
                 if (z >= cfg.c1) { accept = true; break; }                  // :351-353
             }
             const bool small_step = residual < cfg.atol;                   // :253-257 (taken even if rejected)
+            if (lane == 0)
+                trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, J_hat, r.g_norm, ai_last,
+                            ai_last >= 0 ? cfg.alphas[ai_last] : 0.0f, J_last, accept ? 1 : 0, residual);
             if (small_step || accept) {
                 float *tz = nom; nom = cand; cand = tz;
                 float *tcst = cnom; cnom = ccand; ccand = tcst;

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "../../include/tfmpc_hip.h"
+#include "ilqr_trace.h"
 
 namespace tfmpc {
 
@@ -24,6 +25,7 @@ struct IlqrLqArgs {
     float *wsK, *wsk, *wsq;      // gains K[T][m][n], k[T][m] and Q_u[T][m] scratch (HBM)
     float *wsx, *wsu, *wsc;      // candidate trajectory x[T+1][n], u[T][m], costs[T+1] (ilqr_lq_mfma32.hip only)
     const int32_t *order;        // ilqr_lq_box_mfma.hip: block -> instance (heavy instances first), or null
+    TraceArgs trace;             // optional decision trace (ilqr_trace.h): one row per backward pass + line search; rows == nullptr: none
 };
 
 // Control-limited twin (ilqr_lq_box_mfma.hip): bounded actions or any finite bound; the whole state machine

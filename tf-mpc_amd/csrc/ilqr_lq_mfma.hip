@@ -201,6 +201,7 @@ __global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
 
     int status = 0, iteration = 0;
     bool converged = false, retry = false;
+    float delta = 1.0f;                                                // :216 (mu stays 0 in this kernel; delta is only logged)
     for (iteration = 0; iteration < cfg.max_iterations; ++iteration) {
         // ---- derivatives (ilqr.py:234): l_z(t) for the whole nominal trajectory -------------
         float *Lz = cand;
@@ -309,13 +310,21 @@ __global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
             g_norm = T > 0 ? wave_sum(gs) / (float)T : 0.0f;
         }
         const float dV2 = -0.5f * dV1;
-        if (g_norm < cfg.atol) { converged = true; break; }        // :243-248
+        // decision trace (ilqr.py:243-279 logs these per pass): every pass of this kernel runs at mu = 0, so the row index
+        // is the iteration; an instance handed to the wave kernel (retry) has its rows rewritten by that kernel
+        if (g_norm < cfg.atol) {                                   // :243-248
+            if (lane == 0) trace_write(a.trace, b, iteration, iteration, 0.0f, delta, J_hat, g_norm, -1, 0.0f, 0.0f, -1, -1.0f);
+            converged = true;
+            break;
+        }
 
         // ---- forward / line search (ilqr.py:317-355, :174-212) -----------------------------------
         bool accept = false;
-        float residual = 0.0f;
+        float residual = 0.0f, J_last = 0.0f;
+        int ai_last = -1;
         for (int ai = 0; ai < cfg.n_alphas; ++ai) {
             const float alpha = cfg.alphas[ai];
+            ai_last = ai;
             if (lane < N) cand[lane] = nom[lane];
             if (lane < M) cand[T * kZld + N + lane] = 0.0f;
             float rmax = 0.0f;
@@ -362,19 +371,23 @@ __global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
             cz_pass(cand, Tp, ccand, false);
             __syncthreads();
             const float J = sum_costs(ccand);
+            J_last = J;
             const float delta_J = -alpha * (dV1 + alpha * dV2);                    // :339
             const float dcost = J_hat - J;
             const float z = (delta_J > 0.0f) ? dcost / delta_J : sgn(dcost);       // :342-346
             if (z >= cfg.c1) { accept = true; break; }                             // :351-353
         }
         const bool small_step = residual < cfg.atol;                              // :253-257
+        if (lane == 0)
+            trace_write(a.trace, b, iteration, iteration, 0.0f, delta, J_hat, g_norm, ai_last,
+                        ai_last >= 0 ? cfg.alphas[ai_last] : 0.0f, J_last, accept ? 1 : 0, residual);
         if (small_step || accept) {                                                // swap nominal <-> candidate
             float *tz = nom; nom = cand; cand = tz;
             float *tcst = cnom; cnom = ccand; ccand = tcst;
         }
         if (small_step) { converged = true; break; }
         if (!accept) { retry = true; break; }                                      // would raise mu (:267-270)
-        // accepted with mu = 0: delta shrinks, mu stays 0 (:259-266)
+        delta = fminf(1.0f / cfg.delta_0, delta / cfg.delta_0);                    // accepted with mu = 0: delta shrinks, mu stays 0 (:259-266)
     }
     if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
     (void)converged;

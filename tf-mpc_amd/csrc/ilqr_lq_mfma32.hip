@@ -279,6 +279,7 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_mfma32_kernel(IlqrLqArgs a)
 
     int status = 0, iteration = 0;
     bool converged = false, retry = false;
+    float delta = 1.0f;                                                // :216 (mu stays 0 in this kernel; delta is only logged)
     for (iteration = 0; iteration < cfg.max_iterations; ++iteration) {
         float *const xhat = xb[flip], *const uhat = ub[flip];
         float *const xc = xb[flip ^ 1], *const uc = ub[flip ^ 1], *const cc = cb[flip ^ 1];
@@ -468,13 +469,21 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_mfma32_kernel(IlqrLqArgs a)
         if (min_pivot_bits <= 0) { status |= TFMPC_ST_NOT_PD; retry = true; break; }   // needs mu > 0
         const float dV2 = -0.5f * dV1;                                                 // :167 at mu = 0
         const float g_norm = T > 0 ? gsum / (float)T : 0.0f;
-        if (g_norm < cfg.atol) { converged = true; break; }                            // :243-248
+        // decision trace (what ilqr.py:243-279 logs per pass): mu = 0 in every pass of this kernel, so row = iteration; an
+        // instance handed to the wave kernel (retry) has its rows rewritten by that kernel
+        if (g_norm < cfg.atol) {                                                       // :243-248
+            if (lane == 0) trace_write(a.trace, b, iteration, iteration, 0.0f, delta, J_hat, g_norm, -1, 0.0f, 0.0f, -1, -1.0f);
+            converged = true;
+            break;
+        }
 
         // ---- forward / line search (ilqr.py:317-355) -------------------------------------------------------------------
         bool accept = false;
         float residual = 0.0f, J = 0.0f;
+        int ai_last = -1;
         for (int ai = 0; ai < cfg.n_alphas; ++ai) {
             const float alpha = cfg.alphas[ai];
+            ai_last = ai;
             rollout(true, alpha, xhat, uhat, xc, uc, residual);
             J = cz_pass(xc, uc, false, nullptr, nullptr, cc);
             const float delta_J = -alpha * (dV1 + alpha * dV2);                    // :339
@@ -483,9 +492,13 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_mfma32_kernel(IlqrLqArgs a)
             if (z >= cfg.c1) { accept = true; break; }                             // :351-353
         }
         const bool small_step = residual < cfg.atol;                              // :253-257
+        if (lane == 0)
+            trace_write(a.trace, b, iteration, iteration, 0.0f, delta, J_hat, g_norm, ai_last,
+                        ai_last >= 0 ? cfg.alphas[ai_last] : 0.0f, J, accept ? 1 : 0, residual);
         if (small_step || accept) { flip ^= 1; J_hat = J; }                        // the candidate becomes the nominal
         if (small_step) { converged = true; break; }
         if (!accept) { retry = true; break; }                                      // would raise mu (:267-270)
+        delta = fminf(1.0f / cfg.delta_0, delta / cfg.delta_0);                    // :259-266 at mu = 0
     }
     if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
     (void)converged;

@@ -22,6 +22,23 @@ def shard(tensor, world_size=None, rank=None):
     return tensor[lo:hi]
 
 
+def check_shard_sizes(b, total, group=None):
+    """Start-up agreement (NOT part of the data path): every rank checks that the ``b`` instances it holds are what the
+    block split of ``total`` gives it, and the ranks all_reduce a 4-byte flag, so a wrong shard raises ``ValueError`` on
+    EVERY rank.  ``gather_trajectories(total=...)`` itself stays one collective: there a wrong shard raises on its own rank
+    only, before anything is sent, and the other ranks would wait inside the gather -- call this once when the job starts."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_bounds(total, world, rank)
+    ok = torch.tensor([1 if int(b) == hi - lo else 0], dtype=torch.int32,
+                      device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 0:
+        raise ValueError(f"check_shard_sizes: at least one rank holds a shard that is not the block split of {total} "
+                         f"(this rank: {int(b)} instances, the split gives it {hi - lo})")
+
+
 def gather_buffers(states, actions, costs, total, dst=0, group=None):
     """The receive buffers of ``gather_trajectories(..., total=total)`` on rank ``dst`` (``None`` elsewhere): allocate
     them when the job starts, where running out of memory is an ordinary start-up error, instead of in front of the
@@ -45,7 +62,8 @@ def gather_trajectories(states, actions, costs, dst=0, group=None, total=None, r
     then knows every shard's size, and the ONLY communication is one ``dist.gather`` of the packed rows (padded to
     the largest shard, which is at most one row more than the smallest) -- SURVEY.md 8(e)'s single RCCL gather.
     ``recv`` = buffers from ``gather_buffers`` (else they are allocated here; an allocation failure then raises on
-    that rank only).
+    that rank only).  A shard whose size is not the block split's raises ``ValueError`` on ITS rank before anything is
+    sent -- the other ranks would then wait in the gather: ``check_shard_sizes`` at start-up makes that error collective.
 
     Without ``total`` the shards may be of any sizes: an 8-byte ``all_gather`` of the sizes and a 4-byte
     ``all_reduce`` by which the ranks agree that every buffer could be allocated precede the gather, so that an
