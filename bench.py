@@ -520,6 +520,15 @@ def extras_only(args):
         extra["ilqr_api"] = ilqr_api_rate(n, m, T, B)
         extra["other_configs"] = other_config_rates()
         try:
+            # BASELINE configs[4] "fp32 vs bf16 tolerance sweep": three numbers of the table tests/test_bf16_storage_sweep_gpu.py
+            # asserts on (full table: profiles/r04_bf16_storage_sweep.json), measured here on a smaller batch
+            import bf16_sweep
+            extra["bf16_storage_sweep"] = dict(bf16_sweep.headline(bf16_sweep.sweep(B=256, n_oracle=2, kinds=("hvac",))),
+                                               note="iLQR on HVAC n=m=32 T=100, 16-bit trajectory containers vs fp32 ones, against the fp64 "
+                                                    "restatement (2 instances) / over 256 instances")
+        except Exception as exc:                              # noqa: BLE001
+            extra["bf16_storage_sweep"] = {"error": repr(exc)}
+        try:
             extra["torchenv_generic_env"] = torchenv_rate()
         except Exception as exc:                              # noqa: BLE001
             extra["torchenv_generic_env"] = {"error": repr(exc)}

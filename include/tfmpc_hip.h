@@ -49,7 +49,9 @@ int tfmpc_version(void);
  * Reservoir kernel; default: the form that brings the launch to about two waves per SIMD) and TFMPC_ILQR_RETRY (bracket: the control-limited LQ kernel looks for the regularisation level
  * of a failed factorisation around the level of its previous pass instead of probing 0, 1, 2, ... as ilqr.py:285-315
  * does -- another regularisation path on ~0.5 % of the instances; unsorted: that kernel launches its blocks in instance order instead of
- * starting the instances whose first backward pass probes most levels first -- same results, for A/B timing) are read ONCE per process, at the first use of the library; afterwards only
+ * starting the instances whose first backward pass probes most levels first -- same results, for A/B timing) and TFMPC_COSTATE_COUPLING
+ * (dense: the 16-per-wave Reservoir kernel multiplies by its `downstream` matrix also when that matrix is a shift -- a chain of
+ * reservoirs, every config the reference holds -- instead of moving rows; same bits, for A/B timing and tests) are read ONCE per process, at the first use of the library; afterwards only
  * this call changes them (value NULL or "" = back to the dispatcher's own choice).  Returns TFMPC_ERR_ARG
  * for an unknown name.  Process-wide; not meant to be flipped while other threads launch. */
 int tfmpc_set_option(const char *name, const char *value);

@@ -228,3 +228,48 @@ def test_every_group_form_returns_the_same_bits(force_kernel, kind, n, T, B):
     if kind == "hvac":
         c1, c2 = outs["1"]["costs"].sum(dim=1), outs["2"]["costs"].sum(dim=1)
         assert int(((c1 - c2).abs() > 1e-4 * c1.abs()).sum()) <= max(1, B // 10)
+
+
+@pytest.mark.parametrize("n,T,B", [(32, 100, 64), (20, 40, 33), (17, 12, 5), (31, 25, 16)])
+def test_shift_coupling_is_the_matrix_product_bit_for_bit(force_kernel, n, T, B):
+    """Round 4: the `downstream` matrix of a chain of reservoirs (every config the reference holds:
+    /root/reference/tests/conftest.py:70-75, tfmpc/envs/reservoir/res4.config.json:13-18) is a shift, and the two-tile kernel moves
+    rows instead of multiplying (ilqr_adjoint_mfma.hip:shift_apply).  TFMPC_COSTATE_COUPLING=dense keeps the products: every output
+    and the decision trace must be the same bits, also for n < 32 (the padding row below the last reservoir must stay 0)."""
+    env, x0 = _env("reservoir", n, B, n)
+    solver = iLQR(env, max_iterations=8)
+    u0 = solver.random_actions(T, B, seed=n)
+    force_kernel("costate_mfma")
+    out = {}
+    for mode in (None, "dense"):
+        with _hip.option("TFMPC_COSTATE_COUPLING", mode):
+            o = solver.solve_device(x0, T, u_init=u0, trace_rows=24)
+            torch.cuda.synchronize()
+            out[mode] = {k: v.clone() for k, v in o.items() if torch.is_tensor(v) and k != "workspace"}
+    for key in ("iterations", "status", "states", "actions", "costs", "trace_len"):
+        assert torch.equal(out[None][key], out["dense"][key]), key
+    assert torch.equal(torch.nan_to_num(out[None]["trace"]), torch.nan_to_num(out["dense"]["trace"]))
+    assert int(out[None]["iterations"].max()) >= 2 and bool(torch.isfinite(out[None]["costs"]).all())
+
+
+@pytest.mark.parametrize("n", [32, 22])
+def test_a_downstream_matrix_that_is_no_chain_keeps_the_products(force_kernel, n):
+    """Two separate chains (the link 5 -> 6 removed) are no shift of the whole state: the kernel must notice and multiply -- and with
+    one nonzero per row it stays bit-identical to the wave kernel, as before.  (A tree, two reservoirs feeding one, has rows of two
+    terms that the matrix cores add in another order than the wave kernel: fp32 tolerance there, as for dense couplings.)"""
+    T, B = 30, 20
+    cfg = dict(problems.reservoir_config(n, seed=n))
+    D = np.array(cfg["downstream"])
+    D[5, 6] = 0.0
+    cfg["downstream"] = D.tolist()
+    env = Reservoir.load(cfg)
+    x0 = np.random.default_rng(n).uniform(20.0, 90.0, size=(B, n, 1)).astype(np.float32)
+    solver = iLQR(env, max_iterations=5)
+    u0 = solver.random_actions(T, B, seed=n)
+    out = _both(force_kernel, solver, x0, T, u0)
+    for key in ("iterations", "status", "states", "actions", "costs"):
+        assert torch.equal(out["costate_mfma"][key], out["wave"][key]), key
+    # ... and it is NOT what the unbroken chain gives (the removed link matters)
+    chain = iLQR(Reservoir.load(dict(problems.reservoir_config(n, seed=n))), max_iterations=5)
+    force_kernel("costate_mfma")
+    assert not torch.equal(chain.solve_device(x0, T, u_init=u0)["states"], out["costate_mfma"]["states"])

@@ -18,6 +18,7 @@ struct AdjointSolveArgs {
     float *wsk, *wsx, *wsu, *wsc;        // gains k[T][m], candidate x[T+1][n], u[T][m], costs[T+1]
     void *wave_ws;                       // 16-per-wave kernel: its wave-major trajectory buffers (ilqr_adjoint_mfma_workspace_bytes)
     TraceArgs trace;                     // 16-per-wave kernel only: the optional decision trace
+    int dense_coupling;                  // 16-per-wave kernel: 1 = multiply by the coupling matrix even when it is a shift (A/B runs, tests)
 };
 
 bool ilqr_adjoint_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg);

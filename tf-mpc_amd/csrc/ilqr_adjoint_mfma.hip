@@ -359,8 +359,12 @@ template <int NT, bool SPARE_REGISTERS> struct MatOp;
 template <bool S> struct MatOp<1, S> { float a[1][1][4]; };
 // all three parts of M resident (HVAC: 24 registers)
 template <> struct MatOp<2, false> { u32x4 h[2], m[2], l[2]; };
-// only the leading part resident; the other two parts live in LDS and are read when M is not bf16-exact (Reservoir: 8 registers)
-template <> struct MatOp<2, true> { u32x4 h[2]; const u32x4 *rest; bool exact; };
+// only the leading part resident; the other two parts live in LDS and are read when M is not bf16-exact (Reservoir: 8 registers).
+// `shift` (round 4): M is a SHIFT -- M[R][C] = 1 exactly where C == R + shift (shift = -1 | +1, rows and columns < n), 0 elsewhere:
+// the transpose of / the off-diagonal part of the `downstream` matrix of a chain of reservoirs, which is what every config
+// the reference holds is (/root/reference/tests/conftest.py:70-75 `linear_topology`, tfmpc/envs/reservoir/res4.config.json:13-18).
+// Then M Z is a move of Z by one row: no product at all (mat_apply below).  shift == 0: any other matrix, the products above.
+template <> struct MatOp<2, true> { u32x4 h[2]; const u32x4 *rest; bool exact; int shift; int leak_mask; };
 
 struct ZParts { u32x4 h, m, l; };
 __device__ __forceinline__ ZParts split_rows(const float (&z)[8])
@@ -397,8 +401,43 @@ __device__ __forceinline__ void mat_apply(const MatOp<2, false> &A, const float 
 #pragma unroll
     for (int a = 0; a < 2; ++a) { acc[4 * a] = c[a][0]; acc[4 * a + 1] = c[a][1]; acc[4 * a + 2] = c[a][2]; acc[4 * a + 3] = c[a][3]; }
 }
+// acc += M z for a shift matrix: row R of the result is z[R + shift].  A lane holds rows 16 b + 4 q + r in z[4 b + r], so three of
+// the four rows of a tile move between the lane's own registers and the fourth comes from the neighbouring lane quarter
+// (ds_bpermute: a rotation of the wave by 16 lanes; quarter 0 / 3 wraps into the other tile, the matrix edge gets 0).  The value
+// is z itself -- what the matrix-core product (0 + Zh) + Zm + Zl returned bit for bit -- so results do not change; it replaces
+// the 3-part split of eight rows (44 vector instructions) and six v_mfma_f32_16x16x32_bf16 per chain-step by 2 ds_bpermute
+// + 2 selects (+ 8 adds that keep `acc + z`'s treatment of -0).  `leak_mask`: for n < 32 the row R == n of a forward shift
+// would receive z[n - 1]; it is a padding row and must stay 0.
+__device__ __forceinline__ void shift_apply(int shift, int leak_mask, const float (&z)[8], float (&acc)[8])
+{
+    const int lane = lane_id(), q = lane >> 4;
+    float o[8];
+    if (shift < 0) {                                                          // wave-uniform: o[R] = z[R - 1]
+        const int src = ((lane - 16) & 63) << 2;
+        const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, z[3])));
+        const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, z[7])));
+        o[0] = (q == 0) ? 0.0f : t0;  o[1] = z[0]; o[2] = z[1]; o[3] = z[2];
+        o[4] = (q == 0) ? t0 : t1;    o[5] = z[4]; o[6] = z[5]; o[7] = z[6];
+        if (leak_mask) {                                                      // wave-uniform (n < 32)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = ((leak_mask >> e) & 1) ? 0.0f : o[e];
+        }
+    } else {                                                                  // o[R] = z[R + 1]
+        const int src = ((lane + 16) & 63) << 2;
+        const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, z[0])));
+        const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, z[4])));
+        o[0] = z[1]; o[1] = z[2]; o[2] = z[3]; o[3] = (q == 3) ? t1 : t0;
+        o[4] = z[5]; o[5] = z[6]; o[6] = z[7]; o[7] = (q == 3) ? 0.0f : t1;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += o[e];
+}
 __device__ __forceinline__ void mat_apply(const MatOp<2, true> &A, const float (&z)[8], float (&acc)[8])
 {
+    if (A.shift != 0) {                                                        // wave-uniform
+        shift_apply(A.shift, A.leak_mask, z, acc);
+        return;
+    }
     const ZParts Z = split_rows(z);
     f32x4 c[2];
 #pragma unroll
@@ -422,6 +461,10 @@ __device__ __forceinline__ void mat_apply(const MatOp<2, true> &A, const float (
 #pragma unroll
     for (int a = 0; a < 2; ++a) { acc[4 * a] = c[a][0]; acc[4 * a + 1] = c[a][1]; acc[4 * a + 2] = c[a][2]; acc[4 * a + 3] = c[a][3]; }
 }
+
+// TFMPC_COSTATE_COUPLING=dense (AdjointSolveArgs::dense_coupling): keep the products also for a shift matrix
+template <int NT, bool S> __device__ __forceinline__ void force_dense(MatOp<NT, S> &, bool) {}
+__device__ __forceinline__ void force_dense(MatOp<2, true> &A, bool dense) { if (dense) A.shift = 0; }
 
 // A copy of a lane-dependent index the optimiser cannot see through: what is computed from it inside a loop stays
 // inside (hoisted out, the 16 operand addresses of each phase would stay live across the whole solve).
@@ -492,6 +535,27 @@ __device__ __forceinline__ void load_operand(int n, int i, int q, F el, MatOp<2,
     wave_sync();
     A.rest = rest;
     A.exact = __all(exact);
+    // is M a shift?  Every lane tests the 16 entries it holds of each output tile against both candidates.
+    bool down = true, up = true;                 // M[R][C] == (C == R - 1) / (C == R + 1) on the n x n block
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int R = 16 * a + i, C = 16 * b + 4 * q + r;
+                const float v = (R < n && C < n) ? el(R, C) : 0.0f;
+                down = down && v == ((R < n && C < n && C == R - 1) ? 1.0f : 0.0f);
+                up = up && v == ((R < n && C < n && C == R + 1) ? 1.0f : 0.0f);
+            }
+    A.shift = __all(down) ? -1 : (__all(up) ? 1 : 0);
+    A.leak_mask = 0;
+    if (A.shift < 0 && n < 32) {
+        int mask = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mask |= (16 * (e >> 2) + 4 * q + (e & 3) == n) ? (1 << e) : 0;
+        A.leak_mask = __any(mask != 0) ? (mask | 0x100) : 0;          // bit 8: "some lane has a leak row" keeps the test wave-uniform
+    }
 }
 
 // Per-row parameter vectors that a step uses ONCE live in LDS ([slot][32] floats, rows >= n padded), not in registers:
@@ -1009,6 +1073,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
         typename EnvM<KIND, NT, (NW > 1)>::Operand A;
         env.fence();
         env.template load_forward<PK>(genv, opaque(j), opaque(q), A, op_rest);
+        force_dense(A, a.dense_coupling != 0);
         constexpr bool RING = SEARCH && kLdsRing;           // wave-major fp32 inputs: the LDS-DMA ring; else a register ring
         constexpr int kSlots = RING ? 1 : kAheadRoll, kLoads = NT + 1;      // kLoads: DMA instructions per step
         float x[NA][NV], ur[kSlots][NV], J[NA];
@@ -1232,6 +1297,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
             typename EnvM<KIND, NT, (NW > 1)>::Operand A;
             env.fence();
             env.template load_backward<PK>(genv, opaque(j), opaque(q), A, op_rest);
+            force_dense(A, a.dense_coupling != 0);
             constexpr bool RING = kLdsRing;
             constexpr int kSlots = RING ? 1 : kAhead, kLoads = 2 * NT + 1;
             float vx[NV], xT[NV], p1[NV], ka[NV], xr[kSlots][NV], ur[kSlots][NV], lr[kSlots];

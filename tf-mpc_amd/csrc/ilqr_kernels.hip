@@ -573,7 +573,8 @@ int tfmpc_ilqr_solve_trace_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, 
         // HVAC / Reservoir at n <= 32: register-resident costate kernel (ilqr_adjoint.hip),
         // bit-identical to the generic wave kernel below (TFMPC_ILQR_KERNEL=wave selects that one)
         const bool forced_wave = option_is(kOptIlqrKernel, "wave");
-        const AdjointSolveArgs aa{B, T, x0, u_init, states, actions, costs, iterations, status, a.wsk, a.wsx, a.wsu, a.wsc, after_lane, tr};
+        const AdjointSolveArgs aa{B, T, x0, u_init, states, actions, costs, iterations, status, a.wsk, a.wsx, a.wsu, a.wsc, after_lane, tr,
+                                  option_is(kOptCostateCoupling, "dense") ? 1 : 0};
         // a batch that shares one env: 16 instances per wave with the coupling-matrix products on the matrix
         // cores (ilqr_adjoint_mfma.hip); TFMPC_ILQR_KERNEL=costate_mfma forces it, lean / lean1 the kernels above.
         // storage_bf16: that kernel keeps its trajectories in REAL 16-bit containers (the wave kernel below emulates
