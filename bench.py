@@ -287,39 +287,17 @@ def other_config_rates():
     res["cfg4_navigation_ilqr"]["note"] = ("one launch lasts as long as its slowest instance (median 8 iterations, p99 20, max 87: "
                                            "profiles/r02_cfg4_iteration_histogram.json); several batches in flight fill the chip; round 3: "
                                            "closed-form two-variable box-QP, hardware sqrt / exp2 / rcp in the env")
-    # The FIRST eight streams a process creates run this loop 40 % slower than any later eight (5.9 vs 4.2 ms per batch on
-    # the same box, whatever precedes them: fresh or reused memory, idle or busy GPU -- tools/probes/repro_cfg4_bench2.py;
-    # with GPU_MAX_HW_QUEUES=8: 4.9 vs 3.9): an artefact of how ROCm binds streams to hardware queues, not of the solver.
-    # A service that keeps batches in flight owns a long-lived stream pool, so the pool measured here is created after a
-    # throw-away one.
-    primer = [torch.cuda.Stream() for _ in range(8)]
-    for st in primer:
-        with torch.cuda.stream(st):
-            torch.zeros(16, device="cuda").add_(1)
-    torch.cuda.synchronize()
-    del primer
-    streams = [torch.cuda.Stream() for _ in range(8)]
-    data = [(torch.as_tensor(np.random.default_rng(100 + i).uniform(0, 10, size=(Bn, 2, 1)).astype(np.float32), device="cuda"),
-             solver.random_actions(50, Bn, seed=100 + i)) for i in range(8)]
-    ws, outs = [None] * 8, [None] * 8
-    # steady state: one untimed round of 8 batches (allocates the workspaces), then 48 timed batches -- the slowest
-    # instance's tail (13 ms) is paid once at the end
-    warm_reps, timed_reps = 1, 6
-    for rep in range(warm_reps + timed_reps):
-        if rep == warm_reps:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        for i, st in enumerate(streams):
-            with torch.cuda.stream(st):
-                outs[i] = solver.solve_device(data[i][0], 50, u_init=data[i][1], workspace=ws[i])
-                ws[i] = outs[i]["workspace"]
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    its = sum(float((o["iterations"].double() + 1).sum()) for o in outs) * timed_reps
-    res["cfg4_navigation_ilqr"]["sustained_8_batches_in_flight"] = {
-        "ms_per_batch": dt / (8 * timed_reps) * 1e3, "iterations_per_s": its / dt, "batches_timed": 8 * timed_reps,
-        "roofline": roofline_hbm(1820 * its, dt, None)}
-    del ws, outs, data
+    # Sustained rate: ONE launch of 8 x 16 384 instances.  The group kernel is persistent since round 4 (ilqr_lane.hip: the grid is
+    # what the chip holds at once, a group whose instance has finished takes the next one from an atomic queue), so the rate that
+    # round 3 needed eight batches in flight on eight host streams (and a throw-away stream pool) for comes out of a single launch.
+    x8 = torch.as_tensor(np.concatenate([np.random.default_rng(100 + i).uniform(0, 10, size=(Bn, 2, 1)) for i in range(8)]).astype(np.float32),
+                         device="cuda")
+    u8 = torch.cat([solver.random_actions(50, Bn, seed=100 + i) for i in range(8)])
+    big = ilqr_line(solver, x8, 50, u8, 3, alg_bytes=1820)
+    res["cfg4_navigation_ilqr"]["one_launch_of_8x16384_instances"] = big
+    res["cfg4_navigation_ilqr"]["one_launch_of_8x16384_instances"]["note"] = (
+        "persistent lane groups + instance queue; round 3: 8 streams x 16 384 = 51.1 M it/s (profiles/r03_cfg4_sustained.json)")
+    del x8, u8
     # cfg5: n = m = 32, T = 100 -> read x, u 25.7 KB + write x, u, c 26.1 KB = 51.8 KB per iteration
     for kind, kernel_tag in (("hvac", "ilqr_adjoint_mfma_kernel<3, 2"), ("reservoir", "ilqr_adjoint_mfma_kernel<4, 2")):     # two-tile instantiations
         n, T, B = 32, 100, 32768

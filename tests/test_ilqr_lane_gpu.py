@@ -137,6 +137,31 @@ def test_four_groups_per_wave_equal_the_per_lane_kernel(force_kernel, kind, T):
         assert torch.equal(out[None][key], out["lane1"][key]), key
 
 
+def test_instance_queue_of_the_persistent_groups(force_kernel):
+    """Round 4: the group kernel's grid is what the chip holds at once (~3 840 wavefronts = 15 360 groups) and a group whose
+    instance has finished takes the next one from an atomic queue.  20 011 instances are more than one round of groups: every
+    instance must come out exactly as the one-lane-per-instance kernel computes it (bit for bit, iterations and status included),
+    whichever group picked it up and whatever its neighbours in the wave were doing; and a second launch on the same workspace
+    (the queue counter is reset by the launcher) returns the same."""
+    rng = np.random.default_rng(44)
+    B, T = 20011, 50
+    solver = iLQR(Navigation.load(problems.NAV_CONFIG))
+    x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
+    u0 = solver.random_actions(T, B, seed=9)
+    force_kernel("lane1")
+    ref = solver.solve_device(x0, T, u_init=u0)
+    force_kernel(None)
+    out = solver.solve_device(x0, T, u_init=u0)
+    torch.cuda.synchronize()
+    first = {k: out[k].clone() for k in ("iterations", "status", "states", "actions", "costs")}
+    again = solver.solve_device(x0, T, u_init=u0, workspace=out["workspace"])
+    torch.cuda.synchronize()
+    for key in ("iterations", "status", "states", "actions", "costs"):
+        assert torch.equal(first[key], ref[key]), key
+        assert torch.equal(again[key], ref[key]), key
+    assert int(ref["iterations"].max()) >= 30 and int(ref["iterations"].min()) <= 3     # the spread the queue exists for
+
+
 def test_two_variable_boxqp_closed_form_against_the_restatement():
     """The lane kernels' box-QP for two actions (closed form over the nine candidate active sets, iteration as fall-back;
     reached through tfmpc_boxqp_f32 at m = 2) against oracle/boxqp_ref.py (optimization.py:6-101 restated) on 4 000 random

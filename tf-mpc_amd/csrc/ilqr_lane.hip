@@ -8,6 +8,7 @@
 // ([slot][lane], bank-conflict free) when the horizon fits (T <= 62), else in HBM slabs.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -441,6 +442,7 @@ struct SolveArgsLane {
     int32_t *iterations, *status;
     float *wsK, *wsk, *wsx, *wsu, *wsc;
     float *scratch;          // group kernel only: one block of candidate trajectories per wavefront
+    int *queue;              // group kernel only: the next instance nobody has taken yet (zeroed by the launcher)
     TraceArgs trace;         // group kernel only: the optional decision trace
 };
 
@@ -853,6 +855,16 @@ struct ScratchSink {
     __device__ void c(int t, float v) const { if (live) col[(T * N + T * M + t) * 64] = v; }
 };
 
+// Round 4: PERSISTENT groups with an instance QUEUE.  A launch used to give every group exactly one instance, so a wave lasted as
+// long as the slowest of its four instances (cfg4: median 8 iterations, p99 20, max 87) and a batch as long as its slowest wave;
+// the sustained rate needed eight batches in flight on eight host streams.  Now the grid is what the chip holds at once and a
+// group whose instance has finished takes the next one from an atomic counter (`a.queue`, zeroed by the launcher): ONE launch of
+// any number of instances keeps every group busy until the queue is empty.  For that the solve is a flat state machine -- one
+// trip of the loop below = (take an instance and roll out its start) | (one backward pass + line search of the group's
+// instance) -- because lanes that leave a NESTED loop early wait at its exit for the rest of the wave: with the reference's loop
+// nest (ilqr.py:227, :238) a finished group would have waited for its neighbours anyway, and a group whose step was accepted
+// waited for a neighbour's rejected passes.  Every instance still runs exactly the reference's sequence of passes with the same
+// arithmetic: outputs are bit-identical to the one-instance-per-group launch (tested against the per-lane kernel as before).
 template <int KIND, int N, int M, int GROUPS>
 __global__ __launch_bounds__(64, 4) void ilqr_group_solve_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, SolveArgsLane a)
 {
@@ -877,68 +889,88 @@ __global__ __launch_bounds__(64, 4) void ilqr_group_solve_kernel(TfmpcEnv genv, 
     const ScratchSink<N, M> sink{scratch + threadIdx.x, T, true};
     Store st{lane_lds + grp, T};
 
-    const int b = blockIdx.x * GROUPS + grp;
-    if (b < a.B) {                                  // whole group leaves together
-        LaneEnv<KIND, N, M> env;
-        env.load(genv, b);
-        float *xout = a.states + (size_t)b * (T + 1) * N, *uout = a.actions + (size_t)b * T * M,
-              *chat = a.costs + (size_t)b * (T + 1);
-        float mu = 0.0f, delta = 1.0f;
-        int status = 0, attempts = 0, iteration = 0;
-        {   // start (ilqr.py:218), redundantly on every lane of the group
-            float x[N], xn[N], u[M];
-#pragma unroll
-            for (int i = 0; i < N; ++i) { x[i] = a.x0[(size_t)b * N + i]; st.set_x(0, i, x[i]); }
-            for (int t = 0; t < T; ++t) {
-#pragma unroll
-                for (int i = 0; i < M; ++i) { u[i] = a.u_init[((size_t)b * T + t) * M + i]; st.set_u(t, i, u[i]); }
-                const float c = env.cost(x, u);
-                if (leader) chat[t] = c;
-                env.transition(x, u, xn);
-#pragma unroll
-                for (int i = 0; i < N; ++i) { x[i] = xn[i]; st.set_x(t + 1, i, xn[i]); }
-            }
-            const float fc = env.final_cost(x);
-            if (leader) chat[T] = fc;
-        }
+    // ---- per-group state of the machine --------------------------------------------------------------------------------
+    LaneEnv<KIND, N, M> env;
+    int b = 0;
+    bool have = false, exhausted = false, need_pre = false;
+    float mu = 0.0f, delta = 1.0f;
+    int status = 0, attempts = 0, iteration = 0;
 #ifdef TFMPC_PHASE_PROBE
-        LaneProbe pr{};
+    LaneProbe pr{};
 #endif
-        bool converged = false, give_up = false;
-        for (; iteration < cfg.max_iterations; ++iteration) {
-            if constexpr (PRE > 0) {
-                // x-only part of the linearisation of every timestep, one timestep per lane (the nominal trajectory is
-                // fixed until a candidate is adopted, also across the regularisation retries below)
-                TFMPC_PROBE_START();
-                for (int t = gl; t < T; t += G) {
-                    float x[N], pre[PRE];
+    for (;;) {
+        if (!have && !exhausted) {
+            // ---- take the next instance (the leader asks, the group hears) and roll out its start (ilqr.py:218) --------
+            int next = 0;
+            if (leader) next = atomicAdd(a.queue, 1);
+            next = __shfl(next, grp * G, 64);
+            if (next >= a.B) {
+                exhausted = true;
+            } else {
+                b = next;
+                have = true;
+                env.load(genv, b);
+                mu = 0.0f; delta = 1.0f;                                         // :215-216
+                status = 0; attempts = 0; iteration = 0;
+                need_pre = true;
+                float *chat0 = a.costs + (size_t)b * (T + 1);
+                float x[N], xn[N], u[M];
 #pragma unroll
-                    for (int i = 0; i < N; ++i) x[i] = st.x(t, i);
-                    env.prelinearize(x, pre);
+                for (int i = 0; i < N; ++i) { x[i] = a.x0[(size_t)b * N + i]; st.set_x(0, i, x[i]); }
+                for (int t = 0; t < T; ++t) {
 #pragma unroll
-                    for (int j = 0; j < PRE; ++j) st.set_pre(t, j, pre[j]);
+                    for (int i = 0; i < M; ++i) { u[i] = a.u_init[((size_t)b * T + t) * M + i]; st.set_u(t, i, u[i]); }
+                    const float c = env.cost(x, u);
+                    if (leader) chat0[t] = c;
+                    env.transition(x, u, xn);
+#pragma unroll
+                    for (int i = 0; i < N; ++i) { x[i] = xn[i]; st.set_x(t + 1, i, xn[i]); }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                TFMPC_PROBE(7);
+                const float fc = env.final_cost(x);
+                if (leader) chat0[T] = fc;
             }
-            for (;;) {
-                float mu_l = mu, delta_l = delta;
-                LaneBackward r;
-                for (int retry = 0;; ++retry) {                                  // :285-315
-                    r = backward_lane<KIND, N, M, Store, true>(env, T, mu_l, bounded, low, high, st TFMPC_PROBE_PASS);
-                    status |= r.flags;
-                    if (!r.failed) break;
-                    status |= TFMPC_ST_NOT_PD;
-                    delta_l = fmaxf(cfg.delta_0, delta_l * cfg.delta_0);
-                    mu_l = fmaxf(cfg.mu_min, mu_l * delta_l);
-                    if (retry >= 40) { give_up = true; break; }
+        }
+        if (!__any(have)) break;                    // every group of the wave has found the queue empty
+        if (have) {
+            float *xout = a.states + (size_t)b * (T + 1) * N, *uout = a.actions + (size_t)b * T * M,
+                  *chat = a.costs + (size_t)b * (T + 1);
+            bool finished = false, give_up = false;
+            if constexpr (PRE > 0) {
+                if (need_pre) {
+                    // x-only part of the linearisation of every timestep, one timestep per lane (the nominal trajectory is
+                    // fixed until a candidate is adopted, also across the regularisation retries)
+                    TFMPC_PROBE_START();
+                    for (int t = gl; t < T; t += G) {
+                        float x[N], pre[PRE];
+#pragma unroll
+                        for (int i = 0; i < N; ++i) x[i] = st.x(t, i);
+                        env.prelinearize(x, pre);
+#pragma unroll
+                        for (int j = 0; j < PRE; ++j) st.set_pre(t, j, pre[j]);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    TFMPC_PROBE(7);
                 }
-                if (give_up) break;
-                if (r.g_norm < cfg.atol) {                                       // :243-248
-                    if (leader) trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, r.J, r.g_norm, -1, 0.0f, 0.0f, -1, -1.0f);
-                    converged = true;
-                    break;
-                }
+            }
+            need_pre = false;
+            // ---- one pass through the body of ilqr.py:238-270 ------------------------------------------------------------
+            float mu_l = mu, delta_l = delta;
+            LaneBackward r;
+            for (int retry = 0;; ++retry) {                                      // :285-315
+                r = backward_lane<KIND, N, M, Store, true>(env, T, mu_l, bounded, low, high, st TFMPC_PROBE_PASS);
+                status |= r.flags;
+                if (!r.failed) break;
+                status |= TFMPC_ST_NOT_PD;
+                delta_l = fmaxf(cfg.delta_0, delta_l * cfg.delta_0);
+                mu_l = fmaxf(cfg.mu_min, mu_l * delta_l);
+                if (retry >= 40) { give_up = true; break; }
+            }
+            if (give_up) {
+                finished = true;
+            } else if (r.g_norm < cfg.atol) {                                    // :243-248
+                if (leader) trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, r.J, r.g_norm, -1, 0.0f, 0.0f, -1, -1.0f);
+                finished = true;
+            } else {
                 // all step sizes at once, one per lane (ilqr.py:322-353), candidates into the scratch columns
                 float J, residual;
                 TFMPC_PROBE_START();
@@ -971,32 +1003,36 @@ __global__ __launch_bounds__(64, 4) void ilqr_group_solve_kernel(TfmpcEnv genv, 
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     TFMPC_PROBE(6);
                 }
-                if (small_step) { converged = true; break; }
-                if (accept) {                                                    // :259-266
+                if (small_step) {
+                    finished = true;
+                } else if (accept) {                                             // :259-266: the next iteration of :227
                     delta = fminf(1.0f / cfg.delta_0, delta / cfg.delta_0);
                     mu = (mu * delta > cfg.mu_min) ? mu * delta : 0.0f;
-                    break;
+                    need_pre = true;
+                    if (++iteration >= cfg.max_iterations) { iteration = cfg.max_iterations - 1; finished = true; }   // python's loop variable after exhaustion
+                } else {
+                    delta = fmaxf(cfg.delta_0, delta * cfg.delta_0);             // :267-270: once more from :238
+                    mu = fmaxf(cfg.mu_min, mu * delta);
+                    if (++attempts >= cfg.max_attempts || !(mu < 1e30f)) { give_up = true; finished = true; }
                 }
-                delta = fmaxf(cfg.delta_0, delta * cfg.delta_0);                 // :267-270
-                mu = fmaxf(cfg.mu_min, mu * delta);
-                if (++attempts >= cfg.max_attempts || !(mu < 1e30f)) { give_up = true; break; }
             }
-            if (converged || give_up) break;
-        }
-        if (give_up) status |= TFMPC_ST_MAX_ATTEMPTS;
-        if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
-        for (int idx = gl; idx < (T + 1) * N; idx += G) xout[idx] = st.at(idx);
-        for (int idx = gl; idx < T * M; idx += G) uout[idx] = st.at(st.uoff() + idx);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // chat[T] may have been written by another lane
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (leader) {
-            const float cT = chat[T];
-            if (!(cT == cT)) status |= TFMPC_ST_NAN;
-            a.iterations[b] = iteration;
-            a.status[b] = status;
+            if (finished) {
+                if (give_up) status |= TFMPC_ST_MAX_ATTEMPTS;
+                for (int idx = gl; idx < (T + 1) * N; idx += G) xout[idx] = st.at(idx);
+                for (int idx = gl; idx < T * M; idx += G) uout[idx] = st.at(st.uoff() + idx);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // chat[T] may have been written by another lane
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (leader) {
+                    const float cT = chat[T];
+                    if (!(cT == cT)) status |= TFMPC_ST_NAN;
+                    a.iterations[b] = iteration;
+                    a.status[b] = status;
 #ifdef TFMPC_PHASE_PROBE
-            for (int i = 0; i < 8; ++i) chat[i] = (float)pr.acc[i];
+                    for (int i = 0; i < 8; ++i) chat[i] = (float)pr.acc[i];
 #endif
+                }
+                have = false;
+            }
         }
     }
 }
@@ -1044,13 +1080,25 @@ bool ilqr_lane_supported(const TfmpcEnv &env)
     return false;
 }
 
+constexpr size_t kQueueBytes = 256;
 // Workspace of the group kernel beyond the five slabs every solve kernel gets: one scratch block per wavefront
 // (candidate trajectories of the line search, ScratchSink).
 size_t ilqr_lane_extra_workspace_bytes(int B, int n, int m, int T)
 {
     if (n != 2 || m != 2 || B <= 0) return 0;
     const size_t blocks = B <= kOneGroupMaxBatch ? (size_t)B : ((size_t)B + 3) / 4;
-    return blocks * (size_t)ScratchSink<2, 2>::rows(T) * 64 * sizeof(float) + 256;
+    return blocks * (size_t)ScratchSink<2, 2>::rows(T) * 64 * sizeof(float) + 256 + kQueueBytes;      // + the instance queue's counter
+}
+
+// Wavefronts of the group kernel the chip holds at once (what a persistent grid is sized by), per variant; asked once per process.
+template <class Kern>
+static int resident_blocks(Kern kern, size_t lds)
+{
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), 64, lds) != hipSuccess || per_cu < 1) per_cu = 8;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return per_cu * 256;
+    return per_cu * prop.multiProcessorCount;
 }
 
 template <int KIND>
@@ -1060,10 +1108,16 @@ static int group_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const S
     const int B = a.B, T = a.T;
     const dim3 block(64);
     const size_t lds1 = GroupStore<2, 2, 1, PRE>::bytes(T), lds4 = GroupStore<2, 2, 4, PRE>::bytes(T);
-    if (B <= kOneGroupMaxBatch)      // the chip has room for a wavefront per instance: no divergence between groups
+    if (hipMemsetAsync(a.queue, 0, sizeof(int), stream) != hipSuccess) return TFMPC_ERR_LAUNCH;
+    if (B <= kOneGroupMaxBatch) {    // the chip has room for a wavefront per instance: no divergence between groups
         hipLaunchKernelGGL((ilqr_group_solve_kernel<KIND, 2, 2, 1>), dim3(B), block, lds1, stream, env, cfg, a);
-    else
-        hipLaunchKernelGGL((ilqr_group_solve_kernel<KIND, 2, 2, 4>), dim3((B + 3) / 4), block, lds4, stream, env, cfg, a);
+    } else {
+        // persistent grid: as many wavefronts as are resident at once (or fewer, if the batch is smaller); the groups
+        // pull instances from the queue until it is empty
+        static const int resident = resident_blocks(ilqr_group_solve_kernel<KIND, 2, 2, 4>, lds4);
+        const int blocks = std::min((B + 3) / 4, resident);
+        hipLaunchKernelGGL((ilqr_group_solve_kernel<KIND, 2, 2, 4>), dim3(blocks), block, lds4, stream, env, cfg, a);
+    }
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
 }
 
@@ -1078,7 +1132,9 @@ int ilqr_lane_solve_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, int 
         const bool per_lane = option_is(kOptIlqrKernel, "lane1") && !trace.rows;      // (only the group kernel records a trace)
         const size_t glds = GroupStore<2, 2, 4, 3>::bytes(T);
         if (!per_lane && glds <= 64 * 1024) {
-            a.scratch = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(extra) + 255) & ~(uintptr_t)255);
+            // [queue counter: 256 bytes][scratch blocks]
+            a.queue = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(extra) + 255) & ~(uintptr_t)255);
+            a.scratch = reinterpret_cast<float *>(reinterpret_cast<char *>(a.queue) + kQueueBytes);
             if (env.kind == TFMPC_ENV_NAVLQR) return group_launch<TFMPC_ENV_NAVLQR>(env, cfg, a, stream);
             if (env.kind == TFMPC_ENV_NAVIGATION) return group_launch<TFMPC_ENV_NAVIGATION>(env, cfg, a, stream);
             return TFMPC_ERR_UNSUPPORTED;
