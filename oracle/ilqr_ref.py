@@ -46,6 +46,7 @@ class ILQRRef:
         self.c1 = kwargs.get("c1", 0.0)
         self.alpha_min = kwargs.get("alpha_min", 1e-3)
         self.trace = []            # per backward attempt: dict(iteration, mu, alpha, accepted, ...)
+        self.on_bang_bang = None   # optional callback(t, Q_u, |l_u| + |f_u|^T |V_x|) where the bang-bang controller of ilqr.py:140-141 is taken
 
     @property
     def low(self):
@@ -127,6 +128,8 @@ class ILQRRef:
                 else:
                     K_t = np.zeros((m, n), dtype=dt)
                     k_t = np.where(Q_u >= 0.0, low - actions[t], high - actions[t])
+                    if self.on_bang_bang is not None:          # test hook: the selector's operand and the size of the terms it is
+                        self.on_bang_bang(t, Q_u, np.abs(l_u) + np.abs(f_u).T @ np.abs(V_x))     # the sum of (tests/trace_oracle.py)
             else:
                 K_t, k_t = self._get_unconstrained_controller(Q_uu_reg, Q_ux_reg, Q_u)
 

@@ -217,12 +217,27 @@ def test_fused_solve_matches_golden_and_host_driven_loop(golden, case):
             case[0], lambda: envs_ref.Navigation(problems.NAV_CONFIG["goal"], problems.NAV_CONFIG["deceleration"]["center"],
                                                  problems.NAV_CONFIG["deceleration"]["decay"], problems.NAV_CONFIG["low"],
                                                  problems.NAV_CONFIG["high"], dtype=np.float32))()
+        # Round 4: a decision-trace check instead of round 1's "within 1 % / 3 % of the cost, iterations within a third".  The device
+        # trace (iLQR.solve(trace=True)) must equal the free-running fp32 restatement's pass by pass up to the restatement's first
+        # near-tie (tests/trace_oracle.py: atol / cost comparisons and the bang-bang selector); with no near-tie at all the
+        # iteration count is the restatement's and the cost agrees to fp32 accuracy, otherwise either side is right from the
+        # tie on and the two converged costs may differ by what the restatements differ by among themselves (res4: 1.8 %).
+        import trace_oracle
+        from test_ilqr_trace_gpu import _compare
+        from tfmpc.solvers.ilqr import trace_records
         o32 = ilqr_ref.ILQRRef(oenv, dtype=np.float32)
-        _, _, c32, it32 = o32.solve(x0, T, u_init=u0)
+        records, _, _, c32, it32 = trace_oracle.solve_with_margins(o32, x0.astype(np.float32), T, u0.astype(np.float32))
+        traj_t, it_t = solver.solve(x0, T, show_progress=False, u_init=u0, trace=True)
+        assert it_t == iteration and np.array_equal(traj_t.costs, traj.costs)
+        agreed, verdict = _compare(solver.last_trace[0], records)
+        assert not verdict.startswith("mismatch"), verdict
         total64 = G("sol_costs").sum()
-        assert abs(traj.total_cost - c32.sum()) <= 1e-2 * abs(c32.sum())
-        assert abs(traj.total_cost - total64) <= 3e-2 * abs(total64)
-        assert abs(iteration - it32) <= max(3, it32 // 3)
+        if verdict == "full":
+            assert iteration == it32 and abs(traj.total_cost - c32.sum()) <= 1e-4 * abs(c32.sum())
+        else:
+            if case[0] != "res4":                                      # (Reservoir: a selector operand cancels exactly in every first pass,
+                assert agreed >= 1, (agreed, verdict)                  #  tests/test_ilqr_trace_gpu.py) -- elsewhere the first pass is tie-free
+            assert abs(traj.total_cost - c32.sum()) <= 3e-2 * abs(c32.sum()) and abs(traj.total_cost - total64) <= 3e-2 * abs(total64)
     else:
         assert iteration == int(G("sol_iteration"))
         _close(traj.states, G("sol_states"), 1e-3, f"{case[0]}.sol.states")

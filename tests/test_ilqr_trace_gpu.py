@@ -62,7 +62,7 @@ def _device(env, x0, u0, T, max_iterations, rows=160, **kw):
     return out, plain
 
 
-def _check(kind, cfg, env, x0, u0, T, max_iterations, min_full, n64, same_kernel_untraced=True):
+def _check(kind, cfg, env, x0, u0, T, max_iterations, min_full, n64, same_kernel_untraced=True, min_passes=0.6):
     out, plain = _device(env, x0, u0, T, max_iterations)
     if same_kernel_untraced:                     # the trace is a by-product: the traced and the plain launch agree bit for bit
         for key in ("states", "actions", "costs", "iterations", "status"):
@@ -78,7 +78,7 @@ def _check(kind, cfg, env, x0, u0, T, max_iterations, min_full, n64, same_kernel
     print(f"{kind}: {len(full)} of {len(x0)} whole traces agree, {passes} passes compared in all, "
           f"{sum(1 for n, v in verdicts if v == 'tie')} instances end at a near-tie")
     assert len(full) >= min_full * len(x0), (len(full), len(x0))
-    assert passes >= 0.6 * sum(len(r[0]) for r in ref32), passes           # most passes lie before an instance's first near-tie
+    assert passes >= min_passes * sum(len(r[0]) for r in ref32), passes    # most passes lie before an instance's first near-tie
     for b in full:                               # same decisions all the way: same iteration count
         assert its[b] == ref32[b][4], (b, its[b], ref32[b][4])
     # final trajectories inside the fp32 budget where the fp64 restatement takes the same decisions too
@@ -147,6 +147,13 @@ def test_reservoir_cfg5_traces_up_to_the_first_tie():
         assert abs(d["J_hat"] - r["J_hat"]) <= 2e-4 * abs(r["J_hat"]) and abs(d["g_norm"] - r["g_norm"]) <= 5e-3 * r["g_norm"]
         first += int(d["alpha_index"] == r["alpha_index"])
     assert first >= B // 2, first
+    # Round 4: the restatement now reports the selector's margin (tests/trace_oracle.py: the smallest nonzero |Q_u,i| of a step
+    # relative to the step's largest).  At n = 32 EVERY pass of EVERY instance has a selector operand at rounding level
+    # (Q_u,i = x_i (V_x,i+1 - V_x,i) with equal cost gradients on neighbouring reservoirs): there is no tie-free pass to compare
+    # beyond the numbers above -- which is why this test counts instead of comparing traces.  (res4, below, has tie-free passes.)
+    tie_free = sum(1 for b in range(B) for r in ref32[b][0] if r["selector_margin"] >= 1.0)
+    print(f"Reservoir n = 32: {tie_free} of {sum(len(ref32[b][0]) for b in range(B))} passes of the restatement are free of selector ties")
+    assert tie_free <= 2
 
 
 def test_wave_kernel_trace_on_the_reference_hvac6_config():
@@ -180,7 +187,13 @@ def test_default_kernel_trace_on_the_reference_hvac6_config():
 def test_default_kernel_first_pass_on_the_reference_res4_config():
     """The reference's own res4 config on the default kernel (four instances per matrix-core column, eight-wave groups): the first
     pass starts from the same trajectory as the restatement's, so J_hat and the gradient norm agree to rounding; the accepted step
-    size depends on bang-bang selector ties and is compared by count."""
+    size depends on bang-bang selector ties and is compared by count.  Round 4: the restatement reports the selector's margin
+    (tests/trace_oracle.py; |Q_u,i| relative to the terms it is the sum of, ilqr.py:136-141) -- and on this env EVERY first pass has
+    an entry that cancels exactly, Q_u,i = x_i (V_x,i+1 - V_x,i) with V_x,i+1 == V_x,i (numpy adds the two rounded products to an
+    exact 0 and takes `low - u`; a program that fuses one multiply-add, as this kernel and any FMA build of Eigen do, is left with
+    the rounding error of the other product, of either sign).  So there is no tie-free pass to compare traces on; what holds the
+    Reservoir kernels to the restatement is the teacher-forced comparison of tests/test_ilqr_costate_mfma_oracle_gpu.py (the
+    restatement's forward pass driven with the DEVICE's selector bits and step size must reproduce the device's trajectory)."""
     cfg = dict(problems.RES4_CONFIG)
     n, T, B = 4, 100, 48
     env = Reservoir.load(dict(cfg))
@@ -200,3 +213,6 @@ def test_default_kernel_first_pass_on_the_reference_res4_config():
         first += int(d["alpha_index"] == r["alpha_index"])
     print(f"res4: first accepted step size equal on {first} of {B} instances")
     assert first >= B // 2, first
+    tie_free = sum(1 for b in range(B) if ref32[b][0][0]["selector_margin"] >= 1.0)
+    print(f"res4: {tie_free} of {B} first passes of the restatement are free of selector ties")
+    assert tie_free <= B // 8

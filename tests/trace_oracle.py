@@ -20,6 +20,11 @@ for _p in (ROOT, os.path.join(ROOT, "tf-mpc_amd"), os.path.join(ROOT, "tests")):
 
 ATOL_MARGIN = 1e-3     # relative margin under which an atol comparison counts as a near-tie
 COST_MARGIN = 3e-5     # ... and a cost comparison |J_hat - J| / |J_hat| (an fp32 cost sum carries ~1e-6)
+SELECTOR_MARGIN = 3e-7 # (per time step of the horizon: the costate V_x it is formed from has gone through T - t steps of the recursion, each adding a
+                       #     rounding error of its own size) ... and the bang-bang controller's selector (ilqr.py:140-141: k_i = Q_u,i >= 0 ? low - u : high - u): the smallest
+                       #     |Q_u,i| relative to the terms it is the sum of, |l_u,i| + (|f_u|^T |V_x|)_i (an exact 0 -- e.g. under
+                       #     V_x = 0 -- is 0 in every program; Reservoir's Q_u,i = x_i (V_x,i+1 - V_x,i) cancels to rounding level
+                       #     somewhere in most sweeps: equal cost gradients on neighbouring reservoirs)
 QP_MARGIN = 1e-4       # ... and the box-QP's clamp test: |gradient entry| of a coordinate on its bound / max |gradient entry|
 PIVOT_MARGIN = 1e-4    # ... and a Cholesky factorisation: smallest pivot relative to its own diagonal entry (or, when it fails, the
                        #     most negative eigenvalue of the unit-diagonal scaling) -- "positive definite or not" is a decision too (ilqr.py:305)
@@ -123,6 +128,16 @@ def solve_with_margins(o, x0, T, u_init, max_attempts=64):
 
 def _solve_with_margins(o, x0, T, u_init, max_attempts, pivots):
     dt = o.dtype
+    selector = [np.inf]
+
+    def on_bang_bang(t, Q_u, terms):
+        q = np.abs(np.asarray(Q_u, dtype=np.float64)).reshape(-1)
+        scale = np.asarray(terms, dtype=np.float64).reshape(-1)
+        nz = scale > 0          # (an entry whose TERMS are all zero -- e.g. under V_x = 0 -- is an exact 0 in every program; an entry that
+        if np.any(nz):          # cancels to exactly 0 here, V_x,i+1 == V_x,i, is +-rounding in a program that fuses one multiply-add)
+            selector[0] = min(selector[0], float(np.min(q[nz] / scale[nz])))
+
+    o.on_bang_bang = on_bang_bang
     mu, delta = 0.0, 1.0
     x_hat, u_hat, c_hat = o.start(x0, T, u_init=u_init)
     records = []
@@ -134,12 +149,15 @@ def _solve_with_margins(o, x0, T, u_init, max_attempts, pivots):
         converged = False
         while True:
             pivots.take()
+            selector[0] = np.inf
             K, k, J_hat, dV1, dV2 = o._backward(T, u_hat, *models, mu, delta)
             pivot, failures, qp_sign = pivots.take()                       # over every factorisation / clamp test of the pass, failed probes included
             g_norm = np.mean(np.max(np.abs(k) / (np.abs(u_hat) + dt(1.0)), axis=1), axis=0)[0]
             rec = dict(iteration=iteration, mu=float(mu), delta=float(delta), J_hat=float(J_hat), g_norm=float(g_norm),
                        alpha_index=None, accepted=None, residual=None, J=None, cholesky_failures=failures,
-                       margin=min(abs(float(g_norm) - o.atol) / o.atol / ATOL_MARGIN, pivot / PIVOT_MARGIN, qp_sign / QP_MARGIN))
+                       selector_margin=selector[0] / (SELECTOR_MARGIN * max(T, 1)),
+                       margin=min(abs(float(g_norm) - o.atol) / o.atol / ATOL_MARGIN, pivot / PIVOT_MARGIN, qp_sign / QP_MARGIN,
+                                  selector[0] / (SELECTOR_MARGIN * max(T, 1))))
             records.append(rec)
             if g_norm < o.atol:
                 converged = True

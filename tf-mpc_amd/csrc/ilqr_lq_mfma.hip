@@ -54,7 +54,12 @@ constexpr int kZld = 26;
 
 __device__ __forceinline__ float sgn(float y) { return (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f); }
 
-__global__ __launch_bounds__(kWave) void ilqr_lq_mfma_kernel(IlqrLqArgs a)
+#ifdef TFMPC_LQ_EU        // A/B builds: ask the compiler for that many waves per SIMD (register budget 512 / TFMPC_LQ_EU)
+#define TFMPC_LQ_OCCUPANCY __attribute__((amdgpu_waves_per_eu(TFMPC_LQ_EU, TFMPC_LQ_EU)))
+#else
+#define TFMPC_LQ_OCCUPANCY
+#endif
+__global__ __launch_bounds__(kWave) TFMPC_LQ_OCCUPANCY void ilqr_lq_mfma_kernel(IlqrLqArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x;
