@@ -253,3 +253,79 @@ def test_an_env_that_cannot_be_captured_runs_eagerly():
             assert solver._graphed["rollouts"].eager
     for key in ("states", "actions", "costs", "iterations"):
         assert torch.equal(outs[False][key], outs[True][key]), key
+
+
+def test_rebinding_what_the_env_functions_close_over_drops_the_captured_graphs():
+    """a captured hipGraph has baked in the ADDRESS of every tensor (and the value of every Python scalar) the env's
+    functions close over.  Rebinding one of them between two solves of the same shape must not replay the stale graph: `solve`
+    compares a signature of the closures (tensor identity + address, scalars by value, the bounds by value) and captures again."""
+    def make():
+        goal = torch.tensor([8.0, 9.0], device="cuda")
+        weight = 0.1
+
+        def cost(x, u):
+            return ((x - goal) ** 2).sum() + weight * (u ** 2).sum()
+
+        def final(x):
+            return ((x - goal) ** 2).sum()
+
+        def rebind(new_goal, new_weight):
+            nonlocal goal, weight
+            goal, weight = new_goal, new_weight
+        return TorchEnv(lambda x, u: x + u, cost, final, 2, 2), rebind
+
+    env, rebind = make()
+    B, T = 9, 8
+    x0 = np.random.default_rng(5).uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
+    solver = iLQR(env, max_iterations=4)                   # graphs=True is the default
+    u0 = solver.random_actions(T, B, seed=1)
+    first = {k: v.clone() for k, v in solver.solve_device(x0, T, u_init=u0).items() if torch.is_tensor(v)}
+    assert not any(g.eager for g in solver._graphed.values()) and len(solver._graphed) == 2
+    captured = dict(solver._graphed)
+    again = solver.solve_device(x0, T, u_init=u0)          # nothing changed: the same graphs replay
+    assert all(solver._graphed[k] is captured[k] for k in captured) and torch.equal(again["states"], first["states"])
+    rebind(torch.tensor([-3.0, 2.0], device="cuda"), 0.5)  # a NEW tensor and another scalar behind the same function objects
+    second = solver.solve_device(x0, T, u_init=u0)
+    assert all(solver._graphed[k] is not captured[k] for k in captured)          # captured again
+    eager = iLQR(env, max_iterations=4, graphs=False).solve_device(x0, T, u_init=u0)
+    for key in ("states", "actions", "costs", "iterations"):
+        assert torch.equal(second[key], eager[key]), key
+    assert not torch.equal(second["states"], first["states"])
+    # an in-place update keeps the address: the replay sees it, no new capture is needed
+    captured = dict(solver._graphed)
+    env._l.__closure__                                          # (the cells are what the signature reads)
+    for cell in env._l.__closure__:
+        if isinstance(cell.cell_contents, torch.Tensor):
+            cell.cell_contents.copy_(torch.tensor([1.0, 1.0], device="cuda"))
+    third = solver.solve_device(x0, T, u_init=u0)
+    assert all(solver._graphed[k] is captured[k] for k in captured)
+    eager = iLQR(env, max_iterations=4, graphs=False).solve_device(x0, T, u_init=u0)
+    assert torch.equal(third["states"], eager["states"])
+    # new bounds on the same env object: the cached device copies go with the graphs
+    env.action_space.low[:] = -0.25
+    env.action_space.high[:] = 0.25
+    fourth = solver.solve_device(x0, T, u_init=u0)
+    assert float(fourth["actions"].abs().max()) <= 0.25 + 1e-6
+
+
+def test_decision_trace_of_the_generic_env_path():
+    """`iLQR.solve(trace=True)` on a TorchEnv (it raised KeyError): the host-driven loop records the same row per pass
+    as the fused kernels -- compared with the built-in NavigationLQR's device trace on the same problems (same decisions, numbers
+    to fp32 accuracy)."""
+    from tfmpc.solvers.ilqr import trace_records
+    goal, beta, B, T = [[5.5], [-9.0]], 5.0, 10, 10
+    sb, sg = iLQR(NavigationLQR(goal, beta, -1.0, 1.0)), iLQR(_navlqr_torch(goal, beta, -1.0, 1.0))
+    x0 = np.random.default_rng(2).normal(size=(B, 2, 1)).astype(np.float32)
+    u0 = sb.random_actions(T, B, seed=4)
+    ob = sb.solve_device(x0, T, u_init=u0, trace_rows=40)
+    og = sg.solve_device(x0, T, u_init=u0, trace_rows=40)
+    assert torch.equal(ob["trace_len"], og["trace_len"]) and torch.equal(ob["iterations"], og["iterations"])
+    for rb, rg in zip(trace_records(ob["trace"], ob["trace_len"]), trace_records(og["trace"], og["trace_len"])):
+        assert len(rb) == len(rg) >= 1
+        for a, c in zip(rb, rg):
+            assert (a["iteration"], a["alpha_index"], a["accepted"]) == (c["iteration"], c["alpha_index"], c["accepted"])
+            for key in ("mu", "delta", "J_hat", "g_norm", "J", "residual"):
+                if a[key] is not None:
+                    assert abs(a[key] - c[key]) <= 1e-3 * max(abs(a[key]), 1e-3), (key, a[key], c[key])
+    traj, it = sg.solve(x0[0], T, show_progress=False, u_init=u0[0], trace=True)          # the call that used to raise
+    assert len(sg.last_trace[0]) >= it + 1

@@ -88,9 +88,12 @@ class _Graphed:
         if key != self.key:
             try:
                 self._capture(args, key)
-            except Exception:
+            except RuntimeError as exc:          # what a failed capture raises (an unsupported operation or a synchronisation inside)
+                import warnings
                 torch.cuda.synchronize()
                 self.eager, self.graph = True, None
+                warnings.warn(f"tfmpc: this block cannot be captured as a hipGraph and runs eagerly from now on ({exc!s:.200})",
+                              RuntimeWarning, stacklevel=2)
                 return self.fn(*args)
         for dst, src in zip(self.inputs, args):
             dst.copy_(src)
@@ -359,7 +362,7 @@ class iLQR:
         if ub and not batched:
             x0, batched, B = x0.expand(u.shape[0], n).contiguous(), True, u.shape[0]
         if self._generic_env:
-            return self._solve_host_driven(x0, u.expand(B, T, m).contiguous(), batched)
+            return self._solve_host_driven(x0, u.expand(B, T, m).contiguous(), batched, trace_rows=int(trace_rows))
         eb = self.env.env_batch_size()
         if eb is not None:
             if batched and eb != B:
@@ -484,6 +487,53 @@ class iLQR:
         J = co.sum(dim=1)
         return (st, ac, co, J, res) if batched else (st[0], ac[0], co[0], J[0], res[0])
 
+    # A captured graph has baked in every tensor ADDRESS and every Python scalar the env's functions read (their closures),
+    # and the bounds copied to the device by `_bound`.  Tensors updated IN PLACE keep their address and are seen by a replay;
+    # anything REBOUND (a new goal tensor, another scalar, another `action_space`) is not.  `_graph_signature` is what the
+    # captures depend on as far as it can be seen from outside: the three function objects, the cells of their closures
+    # (tensors by identity and address, numbers / strings by value), the bounds by value.  `solve` compares it before every
+    # solve and drops the captures when it has changed; state reached through globals or attributes of objects in the closure
+    # cannot be seen -- call `invalidate_graphs()` after changing such state (or construct the solver with graphs=False).
+    def _graph_signature(self):
+        def cell_sig(fn):
+            sig = [id(fn), id(getattr(fn, "__code__", None))]
+            for cell in (getattr(fn, "__closure__", None) or ()):
+                try:
+                    v = cell.cell_contents
+                except ValueError:                       # an empty cell
+                    sig.append(None)
+                    continue
+                if isinstance(v, torch.Tensor):
+                    sig.append((id(v), v.data_ptr(), tuple(v.shape), v.dtype))
+                elif isinstance(v, (int, float, bool, str, bytes, type(None))):
+                    sig.append(v)
+                elif isinstance(v, np.ndarray):
+                    sig.append((id(v), v.shape, v.tobytes() if v.size <= 4096 else None))
+                else:
+                    sig.append(id(v))
+            return tuple(sig)
+        env = self.env
+        space = env.action_space
+        return (tuple(cell_sig(getattr(env, name, None)) for name in ("_f", "_l", "_lf")), id(space),
+                np.asarray(space.low, dtype=np.float32).tobytes(), np.asarray(space.high, dtype=np.float32).tobytes())
+
+    def invalidate_graphs(self):
+        """Drop the captured hipGraphs of the generic-env path (and the cached device copies of the bounds): the next solve
+        captures again.  Called by ``solve`` / ``solve_device`` themselves when the env's functions, the tensors or scalars in
+        their closures, or the action bounds have been REBOUND since the capture; call it yourself after changing state the
+        functions reach in any other way (globals, attributes of captured objects)."""
+        self._graphed = {}
+        self.__dict__.pop("_bounds", None)
+        self._graph_sig = None
+
+    def _check_graphs(self):
+        if not self.graphs or not self._generic_env:
+            return
+        sig = self._graph_signature()
+        if getattr(self, "_graph_sig", None) != sig:
+            self.invalidate_graphs()
+            self._graph_sig = sig
+
     def _rollouts_graphed(self, xh, uh, K, k, alphas):
         if not self.graphs:
             return self._line_search_rollouts(xh, uh, K, k, alphas)
@@ -502,9 +552,14 @@ class iLQR:
         nt, nc = len(TransitionApprox._fields), len(CostApprox._fields)
         return TransitionApprox(*out[:nt]), CostApprox(*out[nt:nt + nc]), FinalCostApprox(*out[nt + nc:])
 
-    def _solve_host_driven(self, x0, u, batched):
+    def _solve_host_driven(self, x0, u, batched, trace_rows=0):
+        self._check_graphs()
         dev = self.device
         B, T, m = u.shape
+        trace = trace_len = None
+        if trace_rows > 0:                              # the same rows as tfmpc_ilqr_solve_trace_f32 writes (one per pass, TRACE_COLUMNS)
+            trace = torch.full((B, trace_rows, _hip.TRACE_COLS), float("nan"), dtype=torch.float32, device=dev)
+            trace_len = torch.zeros((B,), dtype=torch.int32, device=dev)
         alphas = torch.as_tensor(self._alphas(), dtype=torch.float32, device=dev)
         A = alphas.numel()
         xh, ch = self._rollout_torch(x0, u)
@@ -562,6 +617,16 @@ class iLQR:
                 accepted = ok.any(dim=1)
                 chosen = torch.where(accepted, ok.float().argmax(dim=1), torch.full_like(ar, A - 1))
                 small = res[ar, chosen] < self.atol                                      # :253-257
+                if trace is not None:                   # mu / delta as handed to this pass, before the schedule below moves them
+                    row = (iterations + attempts).long()
+                    searched = ls.float()
+                    vals = torch.stack([iterations.float(), mu, delta, J_hat, g_norm,
+                                        torch.where(ls, chosen.float(), torch.full_like(mu, -1.0)), searched * alphas[chosen],
+                                        searched * J[ar, chosen], torch.where(ls, accepted.float(), torch.full_like(mu, -1.0)),
+                                        torch.where(ls, res[ar, chosen], torch.full_like(mu, -1.0))], dim=1)
+                    put = pending & (row < trace_rows)
+                    trace[ar[put], row[put]] = vals[put]
+                    trace_len = torch.where(pending, (row + 1).int(), trace_len)
                 take = ls & (small | accepted)
                 xh = torch.where(take[:, None, None], xs[ar, chosen], xh)
                 uh = torch.where(take[:, None, None], us[ar, chosen], uh)
@@ -580,5 +645,8 @@ class iLQR:
             active = active & ~converged
         status[~torch.isfinite(ch[:, -1])] |= _hip.ST_NAN
         self.last_status = status
-        return dict(states=xh.unsqueeze(-1), actions=uh.unsqueeze(-1), costs=ch, iterations=iterations, status=status,
-                    batched=batched, workspace=None)
+        out = dict(states=xh.unsqueeze(-1), actions=uh.unsqueeze(-1), costs=ch, iterations=iterations, status=status,
+                   batched=batched, workspace=None)
+        if trace is not None:
+            out.update(trace=trace, trace_len=trace_len)
+        return out
