@@ -60,6 +60,11 @@ int tfmpc_get_option(const char *name, char *buf, int len);
 /* Name of the kernel variant the dispatcher would pick for an LQR shape
  * ("generic_wave", "mfma_16x8", ...).  Host-only; never touches the GPU. */
 const char *tfmpc_lqr_kernel_name(int n, int m, int T);
+/* Name of the kernel family the calling thread's LAST tfmpc_ilqr_solve_f32 / tfmpc_ilqr_solve_trace_f32 was dispatched to ("" before
+ * the first).  A traced solve records its rows in the kernel that solves it; on HVAC / Reservoir and on the per-lane kernel of the
+ * tiny 2-D envs that can be another kernel than the untraced solve takes (the LQ env's matrix-core kernels record their own trace
+ * since round 4), which is what this call lets a caller report next to the trace (the CLI's -v writes it into trace.log). */
+const char *tfmpc_ilqr_last_kernel_name(void);
 
 /* ---------------------------------------------------------------- LQR --------
  * Problem (tfmpc/solvers/lqr.py:18-57): x' = F [x;u] + f, stage cost

@@ -71,6 +71,8 @@ def test_ilqr_offline_batch_of_samples_and_online(tmp_path):
     result = CliRunner().invoke(tfmpc_cli.cli, ["ilqr", env, "-hr", "20", "--logdir", str(logdir), "--seed", "3", "-v"])
     assert result.exit_code == 0, result.output                                               # -v: ilqr.py:41-43 trace.log
     log = (logdir / "trace.log").read_text().splitlines()
+    assert log[0].startswith("[KERNEL] lane_group")                                          # which kernel recorded the trace (round 4)
+    log = log[1:]
     assert log[0] == "[SOLVE] >>>>>>> Iteration = 0 <<<<<<<" and log[1].startswith("[BACKWARD] mu = ")
     assert any(line.startswith("[FORWARD] num_iter = ") for line in log) and any("g_norm" in line for line in log)
     assert np.allclose(pd.read_csv(logdir / "data.csv", index_col="Timestep").to_numpy(), df.to_numpy())   # tracing changes nothing

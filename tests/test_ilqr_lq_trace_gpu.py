@@ -241,6 +241,7 @@ def test_solve_trace_true_on_an_lq_env_stays_on_the_matrix_core_kernel():
     records = solver.last_trace[0]
     assert it == it_t and np.array_equal(traj.states, traj_t.states) and np.array_equal(traj.costs, traj_t.costs)
     assert len(records) == it + 1 and records[0]["mu"] == 0.0 and records[0]["delta"] == 1.0
+    assert solver.last_kernel.startswith("lq_mfma (matrix cores)")            # tfmpc_ilqr_last_kernel_name: traced or not
     with _hip.option("TFMPC_ILQR_KERNEL", "wave"):
         traj_w, it_w = solver.solve(x0, w["T"], show_progress=False, u_init=u0)
     assert it_w == it and not np.array_equal(traj_w.states, traj.states)     # another program: other rounding

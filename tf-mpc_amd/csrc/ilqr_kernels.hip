@@ -493,6 +493,12 @@ size_t tfmpc_ilqr_workspace_bytes(int B, int n, int m, int T)
     return IlqrWsLayout(B, n, m, T).total;
 }
 
+// which kernel family the last tfmpc_ilqr_solve[_trace]_f32 of this thread went to (a traced solve of HVAC / Reservoir, or of a
+// tiny 2-D env forced onto the per-lane kernel, takes a kernel that records a trace: the caller can see which one solved it)
+static thread_local const char *g_last_ilqr_kernel = "";
+
+const char *tfmpc_ilqr_last_kernel_name(void) { return g_last_ilqr_kernel; }
+
 int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B, int T, const float *x0,
                          const float *u_init, float *states, float *actions, float *costs, int32_t *iterations,
                          int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
@@ -537,10 +543,12 @@ int tfmpc_ilqr_solve_trace_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, 
         // size -- also for one instance it has the shorter critical path (Navigation, T = 50, B = 1: 2.3 ms against
         // 7.2 ms for the wave kernel; tools/small_batch_lane_vs_wave.py).  TFMPC_ILQR_KERNEL=lane|lane1|wave forces.
         const bool forced_wave = option_is(kOptIlqrKernel, "wave");
-        if (ilqr_lane_supported(*env) && !forced_wave && !cfg->storage_bf16 && (!traced || ilqr_lane_group_fits(T)))
+        if (ilqr_lane_supported(*env) && !forced_wave && !cfg->storage_bf16 && (!traced || ilqr_lane_group_fits(T))) {
+            g_last_ilqr_kernel = (option_is(kOptIlqrKernel, "lane1") && !traced) ? "lane (one lane per instance)" : "lane_group (16 lanes per instance, instance queue)";
             return ilqr_lane_solve_launch(*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status,
                                           a.wsK, a.wsk, a.wsx, a.wsu, a.wsc,
                                           after_slabs, tr, st);
+        }
     }
     {
         // LQ env on the matrix cores (ilqr_lq_mfma.hip); instances it cannot finish (mu > 0 needed)
@@ -552,6 +560,7 @@ int tfmpc_ilqr_solve_trace_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, 
             // control-limited LQ problems: box-QP in registers, the complete solve loop in one kernel
             IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk, a.wsu};
             la.trace = tr;
+            g_last_ilqr_kernel = "lq_box_mfma (matrix cores, control-limited)";
             return ilqr_lq_box_mfma_launch(la, st);
         }
         if (!forced_wave && !cfg->storage_bf16 && ilqr_lq_mfma32_supported(*env, T)) {
@@ -561,12 +570,14 @@ int tfmpc_ilqr_solve_trace_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, 
             la.trace = tr;
             if ((rc = ilqr_lq_mfma32_launch(la, st)) != TFMPC_OK) return rc;
             a.only_flagged = 1;
+            g_last_ilqr_kernel = "lq_mfma32 (matrix cores, 2 x 2 tiles) + wave kernel for flagged instances";
         }
         if (!forced_wave && !cfg->storage_bf16 && ilqr_lq_mfma_supported(*env, T)) {
             IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk, a.wsu};
             la.trace = tr;
             if ((rc = ilqr_lq_mfma_launch(la, st)) != TFMPC_OK) return rc;
             a.only_flagged = 1;
+            g_last_ilqr_kernel = "lq_mfma (matrix cores) + wave kernel for flagged instances";
         }
     }
     {
@@ -584,10 +595,17 @@ int tfmpc_ilqr_solve_trace_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, 
         if (!forced_wave && !forced_lean && ilqr_adjoint_mfma_supported(*env, *cfg) &&
             (forced_mfma || cfg->storage_bf16 || traced ||
              B >= ((n > 16 && env->kind != TFMPC_ENV_RESERVOIR) ? kCostateMfmaMinBatchLarge : kCostateMfmaMinBatchSmall)))
+        {
+            g_last_ilqr_kernel = "costate_mfma (16 instances per wave)";
             return ilqr_adjoint_mfma_launch(*env, *cfg, aa, st);
-        if (!forced_wave && !traced && ilqr_adjoint_supported(*env, *cfg)) return ilqr_adjoint_launch(*env, *cfg, aa, st);
+        }
+        if (!forced_wave && !traced && ilqr_adjoint_supported(*env, *cfg)) {
+            g_last_ilqr_kernel = "costate (register-resident, one instance per wave)";
+            return ilqr_adjoint_launch(*env, *cfg, aa, st);
+        }
     }
     const size_t smem = ilqr_solve_smem_bytes(env->kind, n, m, env->n_zones);
+    if (!a.only_flagged) g_last_ilqr_kernel = "wave (one instance per wave, any env)";
     if (env->kind == TFMPC_ENV_LQ && n >= kBlockedFrom) {      // the only dense env that comes in large shapes
         auto kern = ilqr_solve_kernel<TFMPC_ENV_LQ, true>;
         if ((rc = prep(kern, smem)) != TFMPC_OK) return rc;

@@ -107,7 +107,9 @@ def navlin(initial_state, goal, beta, horizon, debug, verbose):
               "(build addition).")
 @click.option("--warm-start", is_flag=True, help="Online mode: start each re-solve from the shifted previous plan "
               "(build addition; the reference cold-starts).")
-@click.option("--verbose", "-v", count=True, help="Verbosity level flag.")
+@click.option("--verbose", "-v", count=True,
+              help="Verbosity level flag. -v also writes <logdir>/trace.log from the decision trace of the solve; its first line names the "
+                   "kernel that recorded it (HVAC / Reservoir: a traced solve may run on another kernel family than an untraced one).")
 def ilqr(env, online, horizon, atol, max_iterations, logdir, num_samples, num_workers, seed, warm_start, verbose):
     """Run iLQR for a given environment and horizon.
 
@@ -140,6 +142,9 @@ def ilqr(env, online, horizon, atol, max_iterations, logdir, num_samples, num_wo
         trajectory, _ = solver.solve(x0, horizon, seed=seed, trace=verbose >= 1, show_progress=num_samples <= 1)
         if verbose >= 1:
             with open(os.path.join(logdir, "trace.log"), "w") as file:
+                # (the trace is recorded by the kernel that solves; for HVAC / Reservoir that can be another kernel family -- other
+                # rounding, possibly other line-search decisions -- than the run without -v takes: say which one this was)
+                file.write(f"[KERNEL] {getattr(solver, 'last_kernel', 'host-driven loop (generic env)')}\n")
                 for b, records in enumerate(solver.last_trace):
                     if len(solver.last_trace) > 1:
                         file.write(f"[SAMPLE] {b}\n")

@@ -390,6 +390,7 @@ class iLQR:
                                             _hip.ptr(workspace), workspace.numel() * workspace.element_size(), _hip.stream())
         _hip.check(rc, "tfmpc_ilqr_solve_trace_f32")
         self.last_status = status
+        self.last_kernel = lib.tfmpc_ilqr_last_kernel_name().decode()      # which kernel family solved it (a traced solve can take another)
         out = dict(states=states.unsqueeze(-1), actions=actions.unsqueeze(-1), costs=costs, iterations=iterations,
                    status=status, batched=batched, workspace=workspace)
         if trace is not None:
