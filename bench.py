@@ -185,7 +185,17 @@ def ilqr_api_rate(n, m, T, B, reps=5):
                 "instances_with_cholesky_retries": int(((st & 2) != 0).sum()),
                 "instances_at_attempt_cap": int(((st & 16) != 0).sum()), "regularisation_search": tag}
 
+    # ... and the same problems with a stable open loop (0.18 F): every instance is one fp32 can pose (tests/workloads.py)
+    wl_run, wl = wl, workloads.control_limited_stable(B, n, m, T)
+    stable = limited("linear probe 0, 1, 2, ... (ilqr.py:285-315; the default)")
+    stable["workload"], stable["workload_version"] = wl["text"], wl["version"]
+    wl = wl_run
     res["control_limited"] = limited("linear probe 0, 1, 2, ... (ilqr.py:285-315; the default)")
+    res["control_limited"]["stable_open_loop_variant"] = stable
+    res["control_limited"]["note"] = ("8 701 instances of this batch start from an open-loop rollout of cost 1e12 .. 1e21 (0.25 F is unstable for them): "
+                                      "their Cholesky retries and 100-iteration crawls are fp32 artefacts that the fp32 restatement reproduces and "
+                                      "the fp64 one does not have (profiles/r04_box_family_oracle.json, r04_box_first_level.txt); they are most of this "
+                                      "launch's time.  `stable_open_loop_variant` is the same workload without them.")
     res["control_limited"]["workload"] = wl["text"]
     res["control_limited"]["workload_version"] = wl["version"]
     res["control_limited"]["kernel"] = "ilqr_lq_box_mfma_kernel; round 1: wave kernel, 2.3 k solves/s at B=8192"
