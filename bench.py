@@ -113,7 +113,8 @@ def pmc_traffic(kernel_substring, per_launch_units, units):
             continue
         for name, c in d.get("counters_per_launch", {}).items():
             if kernel_substring in name and "hbm_bytes_per_launch" in c:
-                key = next((k for k in KERNEL_SOURCES if k in kernel_substring or kernel_substring in k), None)
+                # the LONGEST key that matches ("mfma" alone is the headline kernel and is part of every other name)
+                key = max((k for k in KERNEL_SOURCES if k in kernel_substring or kernel_substring in k), key=len, default=None)
                 if not _summary_is_current(d, key):
                     return None
                 return c["hbm_bytes_per_launch"]["total_corrected"] * units / float(per_launch_units)
@@ -316,8 +317,29 @@ def other_config_rates():
         else:
             env, x0 = Reservoir.load(dict(problems.reservoir_config(n, seed=5))), rng.uniform(50, 75, size=(B, n, 1)).astype(np.float32)
         solver = iLQR(env, max_iterations=12)
-        res[f"cfg5_{kind}_ilqr_n32"] = ilqr_line(solver, x0, T, solver.random_actions(T, B, seed=5), 3,
-                                                 alg_bytes=4 * (2 * (T + 1) * n + 2 * T * n + (T + 1)), pmc=(kernel_tag, 32768 * 12))
+        u0c = solver.random_actions(T, B, seed=5)
+        line = ilqr_line(solver, x0, T, u0c, 3, alg_bytes=4 * (2 * (T + 1) * n + 2 * T * n + (T + 1)), pmc=(kernel_tag, 32768 * 12))
+        # The flop side (round 4): rollouts per iteration MEASURED from the decision trace of the same solve (a traced launch returns
+        # the same bits): a pass of the reference's line search makes alpha_index + 1 rollouts (ilqr.py:322-353).  Algorithmic flop
+        # per iteration, SURVEY.md 8(d) dense count: costate sweep T x 4 n^2 + rollouts x T x (4 n^2 + env), env = 20 n flop per step
+        # (element-wise transition + cost); against the fp32 peak.  Which side binds is whichever fraction is larger.
+        tr = solver.solve_device(x0, T, u_init=u0c, trace_rows=int(solver.max_iterations) + int(solver.max_attempts) + 1)
+        rows, ln = tr["trace"], tr["trace_len"]
+        valid = torch.arange(rows.shape[1], device=rows.device)[None, :] < ln[:, None]
+        searched = valid & (rows[..., 8] >= 0)
+        rollouts = float((rows[..., 5] + 1)[searched].sum())
+        passes = float(valid.sum())
+        its_c = line["iterations_per_s"] * line["ms_per_batch"] * 1e-3
+        flop = T * 4 * n * n * passes + rollouts * T * (4 * n * n + 20 * n)
+        tfl = flop / (line["ms_per_batch"] * 1e-3) / 1e12
+        line["rollouts_per_iteration_measured"] = rollouts / max(its_c, 1.0)
+        line["backward_passes_per_iteration_measured"] = passes / max(its_c, 1.0)
+        line["roofline_flop_side"] = {"bound": "mfma", "achieved": tfl, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tfl / PEAK_F32_TFLOPS,
+                                      "algorithmic_flop": flop, "algorithmic_flop_per_iteration": flop / max(its_c, 1.0),
+                                      "flop_per_algorithmic_byte": flop / max(its_c, 1.0) / (4 * (2 * (T + 1) * n + 2 * T * n + (T + 1))),
+                                      "note": "dense count of SURVEY.md 8(d) with the measured rollouts; the ridge is 157.3 TF / 8 TB/s = 19.7 flop/B"}
+        del tr, rows
+        res[f"cfg5_{kind}_ilqr_n32"] = line
     # the reference's own env configs (hvac6.config.json n = 6, res4.config.json n = 4) at a large batch
     for name, env, x0r, kernel_tag in (("hvac6", HVAC.load(dict(problems.HVAC6_CONFIG)), problems.HVAC6_X0, "ilqr_adjoint_mfma_kernel<3, 1"),
                                        ("res4", Reservoir.load(dict(problems.RES4_CONFIG)), problems.RES4_X0, "ilqr_adjoint_mfma_kernel<4, 1")):

@@ -230,12 +230,14 @@ def test_every_group_form_returns_the_same_bits(force_kernel, kind, n, T, B):
         assert int(((c1 - c2).abs() > 1e-4 * c1.abs()).sum()) <= max(1, B // 10)
 
 
-@pytest.mark.parametrize("n,T,B", [(32, 100, 64), (20, 40, 33), (17, 12, 5), (31, 25, 16)])
+@pytest.mark.parametrize("n,T,B", [(32, 100, 64), (20, 40, 33), (17, 12, 5), (31, 25, 16),
+                                   (4, 100, 48), (3, 30, 21), (8, 40, 30), (6, 25, 17), (7, 12, 9), (16, 50, 20), (12, 33, 40), (2, 9, 5)])
 def test_shift_coupling_is_the_matrix_product_bit_for_bit(force_kernel, n, T, B):
     """Round 4: the `downstream` matrix of a chain of reservoirs (every config the reference holds:
     /root/reference/tests/conftest.py:70-75, tfmpc/envs/reservoir/res4.config.json:13-18) is a shift, and the two-tile kernel moves
     rows instead of multiplying (ilqr_adjoint_mfma.hip:shift_apply).  TFMPC_COSTATE_COUPLING=dense keeps the products: every output
-    and the decision trace must be the same bits, also for n < 32 (the padding row below the last reservoir must stay 0)."""
+    and the decision trace must be the same bits, also for n < 32 (the padding row below the last reservoir must stay 0), and for the
+    one-tile kernels with 1, 2 or 4 instances per matrix-core column (n <= 16 / 8 / 4: the shift stays inside an instance's rows)."""
     env, x0 = _env("reservoir", n, B, n)
     solver = iLQR(env, max_iterations=8)
     u0 = solver.random_actions(T, B, seed=n)

@@ -356,7 +356,7 @@ __device__ __forceinline__ void stc(bf16_t *p, float v) { gst(p, narrow(v)); }
 //     dropped terms are below 2^-24 relative (the same bound as one fp32 rounding of the product): 12 MFMAs x 16 cycles.
 using bf3::u32x4;
 template <int NT, bool SPARE_REGISTERS> struct MatOp;
-template <bool S> struct MatOp<1, S> { float a[1][1][4]; };
+template <bool S> struct MatOp<1, S> { float a[1][1][4]; int shift, leak_mask, pk; };      // shift / leak_mask: see MatOp<2, true>; pk: instances per column
 // all three parts of M resident (HVAC: 24 registers)
 template <> struct MatOp<2, false> { u32x4 h[2], m[2], l[2]; };
 // only the leading part resident; the other two parts live in LDS and are read when M is not bf16-exact (Reservoir: 8 registers).
@@ -372,9 +372,40 @@ __device__ __forceinline__ ZParts split_rows(const float (&z)[8])
     const bf3::Split3 s0 = bf3::split3(f32x4{z[0], z[1], z[2], z[3]}), s1 = bf3::split3(f32x4{z[4], z[5], z[6], z[7]});
     return ZParts{u32x4{s0.h01, s0.h23, s1.h01, s1.h23}, u32x4{s0.m01, s0.m23, s1.m01, s1.m23}, u32x4{s0.l01, s0.l23, s1.l01, s1.l23}};
 }
+// One tile, PK instances per column (rows 4 q + r of a lane; an instance owns 16 / PK consecutive rows = 4 / PK lane quarters):
+// the shift of MatOp<2, true> inside every instance's rows.  Replaces four DEPENDENT v_mfma_f32_16x16x4_f32 (~130 cycles of
+// latency on the critical path of a step of the small-env kernels, which are bound by one wave's instruction latency).
+__device__ __forceinline__ void shift_apply1(int shift, int leak_mask, int pk, const float (&z)[4], float (&acc)[4])
+{
+    const int QS = 4 / pk;                           // lane quarters per instance (wave-uniform)
+    const int lane = lane_id(), q = lane >> 4;
+    float o[4];
+    if (shift < 0) {                                 // wave-uniform: o[R] = z[R - 1]
+        float t = 0.0f;
+        if (QS > 1) {
+            t = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane - 16) & 63) << 2, __builtin_bit_cast(int, z[3])));
+            t = (q % QS == 0) ? 0.0f : t;
+        }
+        o[0] = t; o[1] = z[0]; o[2] = z[1]; o[3] = z[2];
+        if (leak_mask) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ((leak_mask >> e) & 1) ? 0.0f : o[e];
+        }
+    } else {                                         // o[R] = z[R + 1]
+        float t = 0.0f;
+        if (QS > 1) {
+            t = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, __builtin_bit_cast(int, z[0])));
+            t = (q % QS == QS - 1) ? 0.0f : t;
+        }
+        o[0] = z[1]; o[1] = z[2]; o[2] = z[3]; o[3] = t;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += o[e];
+}
 template <bool S>
 __device__ __forceinline__ void mat_apply(const MatOp<1, S> &A, const float (&z)[4], float (&acc)[4])
 {
+    if (A.shift != 0) { shift_apply1(A.shift, A.leak_mask, A.pk, z, acc); return; }      // wave-uniform
     f32x4 c = {acc[0], acc[1], acc[2], acc[3]};
 #pragma unroll
     for (int r = 0; r < 4; ++r) c = __builtin_amdgcn_mfma_f32_16x16x4f32(A.a[0][0][r], z[r], c, 0, 0, 0);
@@ -463,8 +494,9 @@ __device__ __forceinline__ void mat_apply(const MatOp<2, true> &A, const float (
 }
 
 // TFMPC_COSTATE_COUPLING=dense (AdjointSolveArgs::dense_coupling): keep the products also for a shift matrix
-template <int NT, bool S> __device__ __forceinline__ void force_dense(MatOp<NT, S> &, bool) {}
+__device__ __forceinline__ void force_dense(MatOp<2, false> &, bool) {}
 __device__ __forceinline__ void force_dense(MatOp<2, true> &A, bool dense) { if (dense) A.shift = 0; }
+template <bool S> __device__ __forceinline__ void force_dense(MatOp<1, S> &A, bool dense) { if (dense) A.shift = 0; }
 
 // A copy of a lane-dependent index the optimiser cannot see through: what is computed from it inside a loop stays
 // inside (hoisted out, the 16 operand addresses of each phase would stay live across the whole solve).
@@ -491,6 +523,24 @@ __device__ __forceinline__ void load_operand(int n, int i, int q, F el, MatOp<1,
             const int Rl = R % kSub, Cl = C % kSub;
             A.a[0][0][r] = (R / kSub == C / kSub && Rl < n && Cl < n) ? el(Rl, Cl) : 0.0f;
         }
+    }
+    // is the (block-diagonal) operand a shift inside every instance's rows?  (see MatOp<2, true>)
+    bool down = true, up = true;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int R = i, C = 4 * q + r, Rl = R % kSub, Cl = C % kSub;
+        const bool in = R / kSub == C / kSub && Rl < n && Cl < n;
+        down = down && A.a[0][0][r] == ((in && Cl == Rl - 1) ? 1.0f : 0.0f);
+        up = up && A.a[0][0][r] == ((in && Cl == Rl + 1) ? 1.0f : 0.0f);
+    }
+    A.shift = __all(down) ? -1 : (__all(up) ? 1 : 0);
+    A.pk = PK;
+    A.leak_mask = 0;
+    if (A.shift < 0 && n < kSub) {
+        int mask = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mask |= ((4 * q + e) % kSub == n) ? (1 << e) : 0;
+        A.leak_mask = __any(mask != 0) ? (mask | 0x100) : 0;
     }
 }
 // two tiles: lane (i, q) holds, for output tile a, M[16 a + i][k-slots of quarter q] split into its three bf16 parts
