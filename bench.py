@@ -519,6 +519,38 @@ def collect_extras(child, timeout=900):
         return {"error": repr(exc)}
 
 
+def summarise_extras(extra):
+    """One short dict of the secondary numbers (ms per batch, M iterations/s, roofline fraction), keyed by workload."""
+    def get(d, *keys):
+        for k in keys:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+    r3 = lambda v: None if v is None else float(f"{v:.3g}")
+    oc = extra.get("other_configs", {}) if isinstance(extra, dict) else {}
+    api = extra.get("ilqr_api", {}) if isinstance(extra, dict) else {}
+    out = {"ilqr_api_warm": [r3(get(api, "ms_per_batch")), r3(get(api, "roofline", "frac"))],
+           "ilqr_api_cold": [r3(get(api, "cold_start", "ms_per_batch")), r3(get(api, "cold_start", "roofline", "frac"))],
+           "control_limited_ms": r3(get(api, "control_limited", "ms_per_batch")),
+           "control_limited_stable_ms": r3(get(api, "control_limited", "stable_open_loop_variant", "ms_per_batch")),
+           "cfg4_single_batch_ms": r3(get(oc, "cfg4_navigation_ilqr", "ms_per_batch")),
+           "cfg4_one_launch_8x16384_Mit_s": r3((get(oc, "cfg4_navigation_ilqr", "one_launch_of_8x16384_instances", "iterations_per_s") or 0) / 1e6),
+           "bf16_sweep": get(extra, "bf16_storage_sweep") if isinstance(extra, dict) and "error" not in (extra.get("bf16_storage_sweep") or {}) else None,
+           "torchenv_kit_s": r3((get(extra, "torchenv_generic_env", "iterations_per_s") or 0) / 1e3),
+           "format": "[ms per batch, roofline frac (, flop-side frac)]"}
+    for key, short in (("cfg5_hvac_ilqr_n32", "cfg5_hvac"), ("cfg5_reservoir_ilqr_n32", "cfg5_reservoir"), ("hvac6_reference_config_ilqr", "hvac6"),
+                       ("res4_reference_config_ilqr", "res4"), ("cfg5_literal_dims_ilqr_lq_n32_m16", "literal_dims"), ("lqr_n32_m16", "lqr_n32_m16")):
+        v = [r3(get(oc, key, "ms_per_batch")), r3(get(oc, key, "roofline", "frac"))]
+        if get(oc, key, "roofline_flop_side", "frac") is not None:
+            v.append(r3(get(oc, key, "roofline_flop_side", "frac")))
+        out[short] = v
+    if isinstance(out.get("bf16_sweep"), dict):
+        out["bf16_sweep"] = {k.replace("hvac_", "").replace("_state_rel_err_vs_fp64", "").replace("_total_cost_rel_diff_bf16_vs_fp32", "_cost"): r3(v)
+                             for k, v in out["bf16_sweep"].items() if isinstance(v, float)}
+    return out
+
+
 def extras_only(args):
     """Child side: secondary numbers of a single-GPU run (the iLQR-API line, the other BASELINE configs, the numpy rate)."""
     import torch                                              # (imported while waiting: importing does not touch the GPU)
@@ -752,6 +784,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(n, m, T)
         if extras_child is not None:
             line["extra"] = collect_extras(extras_child)
+            # the secondary numbers once more, compact and LAST in the line: a log that keeps only the tail of the line still shows them
+            line["extra_summary"] = summarise_extras(line["extra"])
         print(json.dumps(line), flush=True)
 
     if use_dist:
