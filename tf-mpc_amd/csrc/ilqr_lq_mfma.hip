@@ -20,6 +20,7 @@
 
 #include "ilqr_lq_mfma.h"
 #include "mfma_bf16x3.h"
+#include "options.h"
 #include "wave_ldlt8.h"
 #include "wave_ops.h"
 
@@ -50,7 +51,15 @@ constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141;
 // staging), gains K~ [32 cols][8], V_xx transpose staging [16][kVtLd]
 constexpr int kMs = 0, kKs = 256, kVt = 512, kVtLd = 20, kDyn = kVt + 16 * kVtLd;
 constexpr int kZero = kMs + 25 * 8, kQx = kMs + 28 * 8;
-constexpr int kZld = 26;
+// Floats per trajectory row z_t = [x(16) | u(8)] in LDS.  24 (round 4): the slice of a wave at T = 50 is 13.6 KB, so TWELVE waves fit the
+// CU's 160 KB -- three on every SIMD, which is what the 153 - 162 registers allow; with the padded stride 26 of rounds 1 - 3 (14.4 KB) the
+// eleventh wave was the last and one SIMD in four ran two.  Rows i and i + 8 share banks at this stride (two-way conflicts in the C Z tile
+// reads, as many as 26 had); the conflict-free stride 28 costs the CU two waves and measures the same as 26 (tools/probes/r4_api_zld.sh:
+// T = 50: 26 -> 5.01 ms, 24 -> 4.70 ms, 28 -> 5.00 ms; at T = 20, where LDS binds nothing: 2.06 / 2.06 / 2.01).  -DTFMPC_LQ_ZLD=.. for A/B builds.
+#ifndef TFMPC_LQ_ZLD
+#define TFMPC_LQ_ZLD 24
+#endif
+constexpr int kZld = TFMPC_LQ_ZLD;
 
 __device__ __forceinline__ float sgn(float y) { return (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f); }
 
@@ -59,6 +68,9 @@ __device__ __forceinline__ float sgn(float y) { return (y > 0.0f) ? 1.0f : ((y <
 #else
 #define TFMPC_LQ_OCCUPANCY
 #endif
+// EXACT: n == 16 and m == 8 (the BASELINE shape) as compile-time constants -- the padding guards of the shape-generic form fold
+// away and the gains move as 8-byte pieces (round 4; same arithmetic, same bits).
+template <bool EXACT>
 __global__ __launch_bounds__(kWave) TFMPC_LQ_OCCUPANCY void ilqr_lq_mfma_kernel(IlqrLqArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -66,12 +78,12 @@ __global__ __launch_bounds__(kWave) TFMPC_LQ_OCCUPANCY void ilqr_lq_mfma_kernel(
     const int lane = threadIdx.x;
     const int i = lane & 15, q = lane >> 4;
     const int T = a.T, Tp = T + 1;
-    const int n = a.env.n, m = a.env.m, d = n + m;
+    const int n = EXACT ? N : a.env.n, m = EXACT ? M : a.env.m, d = n + m;
     const TfmpcIlqrConfig &cfg = a.cfg;
 
     // dynamic LDS: two trajectory buffers, two cost buffers (k_t and Q_u(t) live in the HBM workspace:
     // 3.2 KB less LDS per wave at T = 50 is two more waves per CU)
-    float *bufA = lds + kDyn;                    // [(T+1)][26]
+    float *bufA = lds + kDyn;                    // [(T+1)][kZld]
     float *bufB = bufA + Tp * kZld;
     float *costA = bufB + Tp * kZld;             // [T+1]
     float *costB = costA + ((Tp + 3) & ~3);
@@ -285,8 +297,12 @@ __global__ __launch_bounds__(kWave) TFMPC_LQ_OCCUPANCY void ilqr_lq_mfma_kernel(
             vd = vacc;
             {   // gains to HBM, row-major K[t][a][j] (guarded for padded shapes)
                 const float kx = lds[kKs + (2 * jc) * 8 + ka], ky = lds[kKs + (2 * jc + 1) * 8 + ka];
-                if (ka < m && 2 * jc < n) Kg[(size_t)t * m * n + ka * n + 2 * jc] = kx;
-                if (ka < m && 2 * jc + 1 < n) Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] = ky;
+                if (EXACT) {                                   // ka * 16 + 2 jc == 2 lane: one 8-byte store per lane
+                    *reinterpret_cast<float2 *>(&Kg[(size_t)t * (M * N) + 2 * lane]) = float2{kx, ky};
+                } else {
+                    if (ka < m && 2 * jc < n) Kg[(size_t)t * m * n + ka * n + 2 * jc] = kx;
+                    if (ka < m && 2 * jc + 1 < n) Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] = ky;
+                }
                 if (lane < m) kg[(size_t)t * m + lane] = lds[kKs + 24 * 8 + lane];
             }
             __syncthreads();
@@ -336,6 +352,12 @@ __global__ __launch_bounds__(kWave) TFMPC_LQ_OCCUPANCY void ilqr_lq_mfma_kernel(
             // gains of step t for this lane, loaded one step ahead (they come back from HBM / Infinity Cache)
             const bool row = ka < m;
             auto load_gain = [&](int t, float &gx, float &gy, float &gk) {
+                if (EXACT) {
+                    const float2 g2 = *reinterpret_cast<const float2 *>(&Kg[(size_t)t * (M * N) + 2 * lane]);
+                    gx = g2.x; gy = g2.y;
+                    gk = kg[(size_t)t * M + ka];
+                    return;
+                }
                 gx = (row && 2 * jc < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc] : 0.0f;
                 gy = (row && 2 * jc + 1 < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] : 0.0f;
                 gk = row ? kg[(size_t)t * m + ka] : 0.0f;
@@ -431,7 +453,11 @@ bool ilqr_lq_mfma_supported(const TfmpcEnv &env, int T)
 int ilqr_lq_mfma_launch(const IlqrLqArgs &a, hipStream_t stream)
 {
     const size_t lds = ilqr_lq_mfma_lds_bytes(a.T);
-    hipLaunchKernelGGL(ilqr_lq_mfma_kernel, dim3(a.B), dim3(kWave), lds, stream, a);
+    // the workspace slabs are 256-byte aligned and an instance's K slab is T * 128 floats: the 8-byte pieces of the exact form are aligned
+    // (TFMPC_ILQR_KERNEL=lq_generic keeps the shape-generic form: A/B timing, tests)
+    const bool exact = a.env.n == N && a.env.m == M && (reinterpret_cast<uintptr_t>(a.wsK) & 7u) == 0 && !option_is(kOptIlqrKernel, "lq_generic");
+    if (exact) hipLaunchKernelGGL(ilqr_lq_mfma_kernel<true>, dim3(a.B), dim3(kWave), lds, stream, a);
+    else hipLaunchKernelGGL(ilqr_lq_mfma_kernel<false>, dim3(a.B), dim3(kWave), lds, stream, a);
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
 }
 
