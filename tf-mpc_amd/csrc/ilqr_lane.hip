@@ -865,8 +865,14 @@ struct ScratchSink {
 // nest (ilqr.py:227, :238) a finished group would have waited for its neighbours anyway, and a group whose step was accepted
 // waited for a neighbour's rejected passes.  Every instance still runs exactly the reference's sequence of passes with the same
 // arithmetic: outputs are bit-identical to the one-instance-per-group launch (tested against the per-lane kernel as before).
+// Waves per SIMD the register budget is sized for.  3 (round 4): the flat state machine needs 148 VGPRs; sized for 4 (128 VGPRs) it
+// spilled 19 of them inside the passes.  Measured (tools/probes/r4_cfg4_eu.sh, three alternating runs): single batch of 16 384
+// 8.7 - 9.0 -> 7.9 - 8.5 ms, one launch of 131 072 instances 20.3 - 20.8 -> 20.0 - 20.6 ms.
+#ifndef TFMPC_GROUP_LANE_EU
+#define TFMPC_GROUP_LANE_EU 3
+#endif
 template <int KIND, int N, int M, int GROUPS>
-__global__ __launch_bounds__(64, 4) void ilqr_group_solve_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, SolveArgsLane a)
+__global__ __launch_bounds__(64, TFMPC_GROUP_LANE_EU) void ilqr_group_solve_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, SolveArgsLane a)
 {
     extern __shared__ float lane_lds[];
     constexpr int G = 16;
