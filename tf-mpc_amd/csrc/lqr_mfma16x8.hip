@@ -77,7 +77,10 @@ constexpr int kKs = 256;        // [32 cols][8 rows]  K~ = -Q_uu^-1 [Q_ux | . | 
 constexpr int kZs = 512;        // rollout chunk: rows z_t = [x_t(16); u_t(8)], stride kZld (sweep: V' transpose staging)
 constexpr int kZld = 26;        // even (8-byte aligned rows), 26 n mod 32 distinct for n < 16
 constexpr int kVtLd = 20;        // V' transpose staging [16 cols][kVtLd] inside the rollout buffer
-constexpr int kTC = 52;         // timesteps per rollout chunk (T = 50 fits one chunk)
+#ifndef TFMPC_LQR_TC
+#define TFMPC_LQR_TC 52
+#endif
+constexpr int kTC = TFMPC_LQR_TC;         // timesteps per rollout chunk (T = 50 fits one chunk of 52)
 constexpr int kLdsFloats = kZs + (kTC + 1) * kZld + 6;
 
 // DPP lane exchanges inside a row of 16 lanes (no LDS traffic, folded into the VALU op)
@@ -96,8 +99,18 @@ constexpr int kDppHalfMirror = 0x141; // lane i <-> 7 - i inside each 8-lane hal
 // (the padded gains come out exactly 0).
 // OUT16: the 16-bit copies of the policy / value outputs (LqrArgs::K16 ...) are compiled into separate instantiations, so
 // that the default kernels carry none of their code
+// Register budget (round 4).  Left to itself the compiler takes 105 - 109 VGPRs for the solve kernels: FOUR waves per SIMD (512 / 112).  Sized
+// for FIVE (<= 96) the kernels without value-function outputs need 74 - 89 registers and spill nothing -- the LDS slice (7.6 KB) lets 21 waves
+// into a CU -- and the headline launch gains 2 - 4 % on every box tried (tools/probes/r4_headline_eu.sh, alternating: 1.787 -> 1.744 ms, 1.86 ->
+// 1.83 ms).  The VALUE instantiations would spill 2 - 19 registers at that budget and keep four.  -DTFMPC_LQR_EU=n forces a budget (A/B builds).
+#ifdef TFMPC_LQR_EU
+#define TFMPC_LQR_WAVES(VALUE_) TFMPC_LQR_EU
+#else
+#define TFMPC_LQR_WAVES(VALUE_) ((VALUE_) ? 4 : 5)
+#endif
+#define TFMPC_LQR_OCCUPANCY __attribute__((amdgpu_waves_per_eu(TFMPC_LQR_WAVES(VALUE), TFMPC_LQR_WAVES(VALUE))))
 template <bool BACKWARD, bool FORWARD, bool VALUE, bool EXACT, bool BF3, bool OUT16 = false>
-__global__ __launch_bounds__(kWave) void lqr_mfma16x8_kernel(LqrArgs a)
+__global__ __launch_bounds__(kWave) TFMPC_LQR_OCCUPANCY void lqr_mfma16x8_kernel(LqrArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     const int b = blockIdx.x;
