@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-4 measurements on the GPU box (copy what is to be judged into profiles/):  bash tools/profile_r04.sh <part>
 #   part a: headline PMC passes (tools/pmc_passes.sh) + iLQR API + control-limited        part b: cfg5, small envs, large tiles, cfg4
+#   part c: the kernels that changed after parts a / b were taken (headline register budget, iLQR-API exact shape + LDS stride, cfg4 register budget)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
@@ -15,6 +16,11 @@ b)
   bash tools/pmc_kernel.sh r04_cfg5 ilqr_adjoint_mfma tools/cfg5_once.py > /dev/null 2>&1; echo cfg5 done
   bash tools/pmc_kernel.sh r04_small_env ilqr_adjoint_mfma tools/small_env_once.py > /dev/null 2>&1; echo small done
   bash tools/pmc_kernel.sh r04_large_tile mfma32 tools/large_tile_once.py > /dev/null 2>&1; echo large done
+  bash tools/pmc_kernel.sh r04_cfg4 ilqr_group_solve tools/cfg4_once.py > /dev/null 2>&1; echo cfg4 done
+  ;;
+c)
+  bash tools/pmc_passes.sh r04 > gpurun_out/r04_headline_pmc.log 2>&1; echo headline done
+  bash tools/pmc_kernel.sh r04_ilqr_api ilqr_lq_mfma_kernel tools/ilqr_api_once.py > /dev/null 2>&1; echo api done
   bash tools/pmc_kernel.sh r04_cfg4 ilqr_group_solve tools/cfg4_once.py > /dev/null 2>&1; echo cfg4 done
   ;;
 esac
