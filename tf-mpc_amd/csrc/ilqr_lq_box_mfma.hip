@@ -100,8 +100,11 @@ __device__ int *g_box_counts = nullptr;
 
 // MODE 1 (first-pass probe): the solve up to the regularisation level its FIRST backward pass ends on, written to the first B
 // ints of the (otherwise unused) wsq slab -- the launcher's proxy for how long an instance will run (see ilqr_lq_box_mfma_launch).
+#ifndef TFMPC_BOX_EU                 // waves per SIMD the register budget is sized for (A/B builds)
+#define TFMPC_BOX_EU 2
+#endif
 template <bool BRACKET, int MODE = 0>
-__global__ __launch_bounds__(kWave, 2) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a)
+__global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = (MODE == 0 && a.order) ? a.order[blockIdx.x] : blockIdx.x;
