@@ -248,12 +248,12 @@ def torchenv_rate(B=1024, T=40):
 
 def other_config_rates():
     """Secondary numbers (not `value`): the other BASELINE.json configs, timed launches after a warm-up --
-    cfg2 navlin LQR (B=4096), cfg4 Navigation iLQR (B=16384: single batch AND 8 batches in flight), cfg5 HVAC / Reservoir
+    cfg2 navlin LQR (B=4096), cfg4 Navigation iLQR (B=16384: single batch, AND one launch of 8 x 16384 instances through the persistent kernel), cfg5 HVAC / Reservoir
     iLQR (n=32, T=100, B=32768, <= 12 iterations; shared env: 16 instances per wave, coupling products on the matrix
     cores), the reference's own hvac6 / res4 configs (B=16384), configs[4]'s literal dims (n=32, m=16) as iLQR on the
     LQ env, and a dense LQR beyond the headline tile (n=32, m=16, B=8192).  Inputs as in SURVEY.md 8(d).  HBM-bound
     configs carry a `roofline` block: algorithmic bytes per iteration x iterations / time against 8 TB/s,
-    `traffic` = PMC-measured HBM bytes of the same launch (profiles/r02_*_pmc.json)."""
+    `traffic` = PMC-measured HBM bytes of the same launch (the newest profiles/r*_pmc.json taken on the kernel's current sources)."""
     import problems
     from tfmpc.envs import make_lqr_linear_navigation
     from tfmpc.envs.hvac import HVAC
@@ -296,7 +296,7 @@ def other_config_rates():
     u0 = solver.random_actions(50, Bn, seed=4)
     res["cfg4_navigation_ilqr"] = ilqr_line(solver, x0, 50, u0, 2, alg_bytes=1820, pmc=("ilqr_group_solve", 142719))
     res["cfg4_navigation_ilqr"]["note"] = ("one launch lasts as long as its slowest instance (median 8 iterations, p99 20, max 87: "
-                                           "profiles/r02_cfg4_iteration_histogram.json); several batches in flight fill the chip; round 3: "
+                                           "profiles/r02_cfg4_iteration_histogram.json); a larger launch keeps the chip full (below); round 3: "
                                            "closed-form two-variable box-QP, hardware sqrt / exp2 / rcp in the env")
     # Sustained rate: ONE launch of 8 x 16 384 instances.  The group kernel is persistent since round 4 (ilqr_lane.hip: the grid is
     # what the chip holds at once, a group whose instance has finished takes the next one from an atomic queue), so the rate that
@@ -368,7 +368,7 @@ def other_config_rates():
     tf = flop / (line["ms_per_batch"] * 1e-3) / 1e12
     line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
                         "algorithmic_flop": flop,
-                        # PMC: profiles/r02_large_tile_pmc.json, taken at 8 192 instances x 2.02 iterations (tools/large_tile_once.py)
+                        # PMC: profiles/r04_large_tile_pmc.json, taken at 8 192 instances x 2.02 iterations (tools/large_tile_once.py)
                         "traffic": pmc_traffic("ilqr_lq_mfma32_kernel", 8192 * 2.02, its)}
     line["kernel"] = "ilqr_lq_mfma32_kernel (2 x 2 tiles of bf16x3, trajectories in HBM); round-2 start: wave kernel, 1 123 ms"
     res["cfg5_literal_dims_ilqr_lq_n32_m16"] = line
