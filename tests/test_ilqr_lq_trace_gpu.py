@@ -100,7 +100,7 @@ def _compare_lq(dev_rows, r32, r64, r32p, atol=5e-3):
     return n, "full"
 
 
-def _check(w, out, pick, max_iterations, min_full, min_passes=0.6, label="", traj_floor=2e-6):
+def _check(w, out, pick, max_iterations, min_full, min_passes=0.6, label="", traj_floor=2e-6, fp32_only=()):
     """Device rows of the instances `pick` against the free-running fp32 restatement; final trajectories against fp64."""
     pick = [int(b) for b in pick]
     x0 = w["x0"][pick].cpu().numpy().astype(np.float32)
@@ -109,9 +109,14 @@ def _check(w, out, pick, max_iterations, min_full, min_passes=0.6, label="", tra
     dev = trace_records(out["trace"][pick], out["trace_len"][pick])
     its = out["iterations"][pick].cpu().numpy()
     P = len(pick)
-    runs = trace_oracle.run_many("lq", cfgs * 2, np.concatenate([x0] * 2), np.concatenate([u0] * 2), w["T"],
-                                 ["float32"] * P + ["float64"] * P, max_iterations)
-    ref32, ref64 = runs[:P], runs[P:]
+    # (`fp32_only`: instances whose fp64 run is skipped -- the heavy instances of the control-limited batch cost the restatement a minute
+    # each and have a margin under 1 in their first pass anyway; their fp64 behaviour is on file, profiles/r04_box_family_oracle.json)
+    with64 = [i for i in range(P) if pick[i] not in set(int(b) for b in fp32_only)]
+    runs = trace_oracle.run_many("lq", cfgs + [cfgs[i] for i in with64], np.concatenate([x0, x0[with64]]), np.concatenate([u0, u0[with64]]), w["T"],
+                                 ["float32"] * P + ["float64"] * len(with64), max_iterations)
+    ref32, ref64 = runs[:P], [None] * P
+    for j, i in enumerate(with64):
+        ref64[i] = runs[P + j]
     assert all(r is not None for r in ref32)
     rows_of = lambda r: r[0] if r is not None else None
     verdicts = [_compare_lq(dev[i], ref32[i][0], rows_of(ref64[i]), None) for i in range(P)]
@@ -171,7 +176,7 @@ def test_ilqr_api_cold_start_traces():
 
 
 def test_control_limited_workload_traces_on_the_box_kernel():
-    """bench.py's `control_limited` workload: 256 instances -- 200 taken in order, 40 with Cholesky retries (TFMPC_ST_NOT_PD), 8 of the
+    """bench.py's `control_limited` workload: >= 256 instances -- 212 taken in order, 40 with Cholesky retries (TFMPC_ST_NOT_PD), 8 of the
     family that runs all 100 iterations with ~10 regularisation probes per pass, 8 at the attempt cap."""
     w = workloads.control_limited(65536)
     out = _solve_both(w, rows=170)
@@ -181,10 +186,12 @@ def test_control_limited_workload_traces_on_the_box_kernel():
     family = np.flatnonzero((it == 99) & ((st & _hip.ST_MAX_ATTEMPTS) == 0) & ((st & _hip.ST_NOT_PD) != 0))
     assert len(retried) >= 40 and len(family) >= 8
     light = retried[np.argsort(it[retried], kind="stable")][:40]          # retries, but few iterations: cheap for the restatement
-    pick = [int(b) for b in np.unique(np.concatenate([np.arange(200), light, family[:8], capped[:8]]))]
-    verdicts, ref32, ref64 = _check(w, out, pick, 100, min_full=0.25, min_passes=0.1, label="control-limited", traj_floor=5e-4)     # (floor: see the stable variant's test)
+    pick = [int(b) for b in np.unique(np.concatenate([np.arange(212), light, family[:8], capped[:8]]))]
+    assert len(pick) >= 256
+    verdicts, ref32, ref64 = _check(w, out, pick, 100, min_full=0.25, min_passes=0.1, label="control-limited", traj_floor=5e-4,     # (floor: see the stable variant's test)
+                                    fp32_only=list(family[:8]) + list(capped[:8]))
     pos = {int(b): i for i, b in enumerate(pick)}
-    groups = {"in order": range(200), "Cholesky retries, few iterations": light, "100-iteration family": family[:8], "attempt cap": capped[:8]}
+    groups = {"in order": range(212), "Cholesky retries, few iterations": light, "100-iteration family": family[:8], "attempt cap": capped[:8]}
     stats = {}
     for name, members in groups.items():
         idx = [pos[int(b)] for b in members]
@@ -192,9 +199,9 @@ def test_control_limited_workload_traces_on_the_box_kernel():
                        sum(any(r["cholesky_failures"] > 0 for r in ref32[i][0][:max(verdicts[i][0], 1)]) for i in idx))
         print(f"  {name}: {stats[name][0]} of {stats[name][1]} whole traces, {stats[name][2]} of {stats[name][3]} passes compared, "
               f"{stats[name][4]} instances with a Cholesky failure inside the compared passes")
-    # (measured on the round-4 kernel: in order 85 of 200 whole traces, 812 of 3 443 passes; every instance of the other three groups
+    # (measured on the round-4 kernel: in order 85 of the first 200 whole traces, 812 of 3 443 passes; every instance of the other three groups
     # has a margin under 1 in its FIRST pass)
-    assert stats["in order"][0] >= 0.3 * 200 and stats["in order"][2] >= 0.15 * stats["in order"][3], stats["in order"]
+    assert stats["in order"][0] >= 0.3 * 212 and stats["in order"][2] >= 0.15 * stats["in order"][3], stats["in order"]
     # The heavy groups: tools/box_family_oracle.py (profiles/r04_box_family_oracle.json) shows what they are -- instances whose
     # zero-action open-loop START has run away (start cost 1e12 .. 1e21 through an unstable F): fp32 has lost the problem, the
     # fp64 restatement solves it in 30-60 iterations to a cost of ~1e3, while EVERY fp32 program (this kernel and the fp32
@@ -213,10 +220,10 @@ def test_control_limited_workload_traces_on_the_box_kernel():
         dev_cost, ref_cost = float(out["costs"][pick[i]].double().sum()), float(np.sum(ref32[i][3]))
         assert abs(dev_cost - ref_cost) <= 1e-4 * abs(ref_cost), (pick[i], dev_cost, ref_cost)
     fam = [pos[int(b)] for b in family[:8]]
-    print(f"  100-iteration family: restatement iterations {[ref32[i][4] + 1 for i in fam]}, fp64 restatement iterations "
-          f"{[ref64[i][4] + 1 if ref64[i] else None for i in fam]}; whole decision sequence equal to the fp32 restatement's on "
-          f"{sum(decisions_equal(i) for i in fam)} of 8; final cost device / fp32 / fp64: "
-          f"{[(float(out['costs'][pick[i]].sum()), float(np.sum(ref32[i][3])), float(np.sum(ref64[i][3])) if ref64[i] else None) for i in fam[:3]]}")
+    print(f"  100-iteration family: fp32 restatement iterations {[ref32[i][4] + 1 for i in fam]}; whole decision sequence equal to the fp32 "
+          f"restatement's on {sum(decisions_equal(i) for i in fam)} of 8; final cost device / fp32 restatement: "
+          f"{[(float(out['costs'][pick[i]].sum()), float(np.sum(ref32[i][3]))) for i in fam[:3]]} "
+          "(the fp64 restatement solves these in 30 - 60 iterations to ~1e3: profiles/r04_box_family_oracle.json)")
 
 
 def test_control_limited_stable_workload_traces():
