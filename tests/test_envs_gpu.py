@@ -156,7 +156,7 @@ def test_reservoir_parameters_and_closed_forms():
 
 
 def test_reservoir_sine_and_cosine_over_both_paths_of_trig_h():
-    """csrc/trig.h: level / capacity <= pi/2 takes the Taylor path, anything else the fp64-reduced general path.  Drive
+    """csrc/trig.h: level / capacity <= pi/2 takes the short polynomial path (minimax since round 4), anything else the fp64-reduced general path.  Drive
     both through the env kernels (transition: sine; f_x: sine and cosine) with capacities of 1 so that the argument IS
     the state: physical levels, arguments beyond pi/2, negative and large ones, against numpy in fp64."""
     n = 4

@@ -2,8 +2,8 @@
 // (evaporation 0.5 sin(x / cap) x, tfmpc/envs/reservoir/__init__.py:85-89, and its derivative), so that all of them
 // round identically: the value depends on the argument alone, never on which kernel or lane evaluates it.
 //
-// |r| <= pi/2 -- every physical state, r = level / capacity -- takes the Taylor polynomials through r^13 (sine) and
-// r^14 (cosine) in Horner form: truncation < 1e-9, eight instructions.  Any other argument (and NaN) takes the general
+// |r| <= pi/2 -- every physical state, r = level / capacity -- takes minimax polynomials through r^9 (sine) and r^10 (cosine)
+// in Horner form: approximation error < 5e-9, six instructions (rounds 1 - 3: Taylor through r^13 / r^14, eight).  Any other argument (and NaN) takes the general
 // path: reduction in fp64 (k = rint(r 2/pi), y = r - k pi/2 with a two-part pi/2: exact to fp32 rounding for
 // |r| < 2^30; beyond that -- a reservoir a billion times over capacity -- the result is some value in [-1, 1]), the
 // Cephes single-precision minimax kernels on [-pi/4, pi/4] and the quadrant fix-up, all branch-free.  The general path
@@ -38,24 +38,25 @@ __device__ __forceinline__ void sincos_general(float r, float &s, float &c)
 
 __device__ __forceinline__ bool trig_small(float r) { return fabsf(r) <= 1.5707963f; }       // false for NaN
 
+// Round 4: MINIMAX polynomials on [0, pi/2] instead of the Taylor ones through r^13 / r^14 -- two multiply-adds fewer each at the same
+// accuracy (sine through r^9: |error| < 4.7e-9 before rounding; cosine through r^10: < 4e-10; evaluated in fp32 over 2.5 M arguments in
+// [0, pi/2] the sine is within 1.85 ulp (Taylor: 1.96) and the cosine within 7.5e-8 absolute (the same)).  Coefficients: weighted
+// minimax fit (Lawson iteration) of (sin r - r) / r^3 and (cos r - 1 + r^2 / 2) / r^4 in z = r^2.  Every kernel that evaluates the
+// Reservoir env shares these functions, so they still round identically everywhere.
 __device__ __forceinline__ float sin_small(float r)
 {
     const float z = r * r;
-    float p = fmaf(z, 1.6059044e-10f, -2.5052108e-08f);        // 1/13!, -1/11!
-    p = fmaf(p, z, 2.7557319e-06f);                            // 1/9!
-    p = fmaf(p, z, -1.9841270e-04f);                           // -1/7!
-    p = fmaf(p, z, 8.3333333e-03f);                            // 1/5!
-    p = fmaf(p, z, -1.6666667e-01f);                           // -1/3!
+    float p = fmaf(z, 2.60005346e-06f, -1.98066145e-04f);
+    p = fmaf(p, z, 8.33301728e-03f);
+    p = fmaf(p, z, -1.66666571e-01f);
     return fmaf(r * z, p, r);
 }
 __device__ __forceinline__ float cos_small(float r)
 {
     const float z = r * r;
-    float p = fmaf(z, -1.1470746e-11f, 2.0876757e-09f);        // -1/14!, 1/12!
-    p = fmaf(p, z, -2.7557319e-07f);                           // -1/10!
-    p = fmaf(p, z, 2.4801587e-05f);                            // 1/8!
-    p = fmaf(p, z, -1.3888889e-03f);                           // -1/6!
-    p = fmaf(p, z, 4.1666668e-02f);                            // 1/4!
+    float p = fmaf(z, -2.61938020e-07f, 2.47693035e-05f);
+    p = fmaf(p, z, -1.38885691e-03f);
+    p = fmaf(p, z, 4.16666558e-02f);
     return fmaf(z * z, p, fmaf(-0.5f, z, 1.0f));
 }
 
