@@ -60,14 +60,25 @@ __device__ __forceinline__ float cos_small(float r)
     return fmaf(z * z, p, fmaf(-0.5f, z, 1.0f));
 }
 
+// "do all N arguments of this lane take the short path?" as ONE comparison of their largest magnitude (v_max3_f32 with |.| operand
+// modifiers: N / 2 instructions instead of N compares and N - 1 ands).  A NaN argument is not seen by the maximum -- and need not be:
+// the short polynomials return NaN for NaN, as the general path does.
+template <int N>
+__device__ __forceinline__ bool trig_all_small(const float (&r)[N])
+{
+    float m = fabsf(r[0]);
+#pragma unroll
+    for (int e = 1; e < N; ++e) m = fmaxf(m, fabsf(r[e]));
+    return m <= 1.5707963f;
+}
+
 // s[e] = sin(r[e]) (and c[e] = cos(r[e])) for the N arguments of a lane
 template <int N>
 __device__ __forceinline__ void sin_vec(const float (&r)[N], float (&s)[N])
 {
-    bool all_small = true;
 #pragma unroll
-    for (int e = 0; e < N; ++e) { s[e] = sin_small(r[e]); all_small = all_small && trig_small(r[e]); }
-    if (__any(!all_small)) {
+    for (int e = 0; e < N; ++e) s[e] = sin_small(r[e]);
+    if (__any(!trig_all_small(r))) {
 #pragma unroll
         for (int e = 0; e < N; ++e) {
             float sg, cg;
@@ -79,10 +90,9 @@ __device__ __forceinline__ void sin_vec(const float (&r)[N], float (&s)[N])
 template <int N>
 __device__ __forceinline__ void sincos_vec(const float (&r)[N], float (&s)[N], float (&c)[N])
 {
-    bool all_small = true;
 #pragma unroll
-    for (int e = 0; e < N; ++e) { s[e] = sin_small(r[e]); c[e] = cos_small(r[e]); all_small = all_small && trig_small(r[e]); }
-    if (__any(!all_small)) {
+    for (int e = 0; e < N; ++e) { s[e] = sin_small(r[e]); c[e] = cos_small(r[e]); }
+    if (__any(!trig_all_small(r))) {
 #pragma unroll
         for (int e = 0; e < N; ++e) {
             float sg, cg;
