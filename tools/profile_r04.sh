@@ -25,3 +25,8 @@ c)
   ;;
 esac
 ls gpurun_out | grep pmc_r04
+# part d (after trig.h changed): cfg5 + small envs again
+if [ "${1:-a}" = d ]; then
+  bash tools/pmc_kernel.sh r04_cfg5 ilqr_adjoint_mfma tools/cfg5_once.py > /dev/null 2>&1; echo cfg5 done
+  bash tools/pmc_kernel.sh r04_small_env ilqr_adjoint_mfma tools/small_env_once.py > /dev/null 2>&1; echo small done
+fi
