@@ -693,15 +693,18 @@ def main():
         check_shard_sizes(B, B_global)           # start-up agreement on the shard sizes (fails on every rank or none)
     recv = gather_buffers(out["states"], out["actions"], out["costs"], total=B_global) if use_dist else None
     fence()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # ONE pair of HIP events around the K launches, on the stream the kernel is launched on: their difference / K is the
+    # kernel's average duration INCLUDING the gap to the next launch.  (Rounds 1-4 bracketed every step with its own pair:
+    # 2 K extra packets in the queue, which at the 8-GPU shard size -- 0.24 ms per launch -- showed up as 0.03 ms per step.)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for s, e in ev:
-        s.record()              # HIP events on the stream the kernel is launched on
+    ev0.record()
+    for _ in range(args.steps):
         out = step()
-        e.record()
+    ev1.record()
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if ev else float("nan")
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps if args.steps else float("nan")
 
     status_bad = int((out["status"] != 0).sum())
     # the one collective of the path: gather the result trajectories on rank 0 (outside

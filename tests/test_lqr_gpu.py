@@ -176,6 +176,34 @@ def test_mfma_kernel_on_padded_shapes(n, m):
             (key, np.median(ratios), max(ratios))
 
 
+@pytest.mark.parametrize("shape", [(16, 8), (12, 5)])
+@pytest.mark.parametrize("mfma", ["bf16x3", "f32"])
+def test_register_budget_variants_are_bit_identical(shape, mfma):
+    """TFMPC_LQR_WAVES=4|5 picks the instantiation of the headline kernel whose register allocation is sized for four or five
+    resident waves per SIMD (lqr_mfma16x8.hip, round 5: five is the rule at every shard size of a strong-scaling run).  The
+    instruction stream per wave is the same up to register allocation, so the variants and the default must agree bit for bit --
+    at the 8-GPU shard size of the headline batch (8 192 instances) for the exact shape, also on a padded shape and on the
+    split backward / forward entry points."""
+    n, m = shape
+    B, T = (8192, 50) if shape == (16, 8) else (300, 20)
+    F, f, C, c, x0 = problems.make_lqr_batch_spd(B, n, m, seed=77)
+    lqr = LQR(F, f, C, c)
+    outs = {}
+    with _hip.option("TFMPC_LQR_MFMA", mfma):
+        for eu in ("4", "5", None):
+            with _hip.option("TFMPC_LQR_WAVES", eu):
+                o = lqr.solve_device(x0, T, want_policy=True)
+                pol, _ = lqr.backward(T) if B <= 300 else (None, None)
+                torch.cuda.synchronize()
+                assert int(o["status"].abs().sum()) == 0
+                outs[eu] = [o[k].clone() for k in ("states", "actions", "costs", "K", "k")]
+                if pol is not None:
+                    outs[eu] += [pol.K.clone(), pol.k.clone()]
+    for eu in ("5", None):
+        for a, b in zip(outs["4"], outs[eu]):
+            assert torch.equal(a, b), (shape, mfma, eu)
+
+
 def test_f32_mfma_variant_agrees_with_bf16x3_default():
     """TFMPC_LQR_MFMA=f32 keeps the sweep's big products on v_mfma_f32_16x16x4_f32; the default
     evaluates them as bf16x3.  Both are fp32-accurate, so they agree like two fp32 programs."""

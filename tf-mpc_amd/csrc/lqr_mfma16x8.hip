@@ -103,13 +103,19 @@ constexpr int kDppHalfMirror = 0x141; // lane i <-> 7 - i inside each 8-lane hal
 // for FIVE (<= 96) the kernels without value-function outputs need 74 - 89 registers and spill nothing -- the LDS slice (7.6 KB) lets 21 waves
 // into a CU -- and the headline launch gains 2 - 4 % on every box tried (tools/probes/r4_headline_eu.sh, alternating: 1.787 -> 1.744 ms, 1.86 ->
 // 1.83 ms).  The VALUE instantiations would spill 2 - 19 registers at that budget and keep four.  -DTFMPC_LQR_EU=n forces a budget (A/B builds).
+// Round 5: the budget is a template parameter (EU = resident waves per SIMD the register allocation is sized for) and TFMPC_LQR_WAVES=4|5
+// picks the instantiation at run time, because round 4's verdict suspected the shard sizes of a strong-scaling run to prefer four: 8 192
+// instances (the 8-GPU shard of the headline batch) are 8 waves per SIMD = 5 + 3 at five resident, 4 + 4 at four.  Measured on every shard
+// size from 1 024 to 65 536 instances (tools/probes/r5_headline_shard_sweep.py, profiles/r05_headline_shard_sweep.json): FIVE wins at each
+// of them (8 192: 0.238 against 0.258 ms; the kernel's time is 27.2 us per wave of a SIMD + ~20 us, the rounds overlap because waves do not
+// finish together), so five stays the rule for every launch.  Same instruction stream per wave up to register allocation: bit-identical.
 #ifdef TFMPC_LQR_EU
-#define TFMPC_LQR_WAVES(VALUE_) TFMPC_LQR_EU
+#define TFMPC_LQR_WAVES(EU_) TFMPC_LQR_EU
 #else
-#define TFMPC_LQR_WAVES(VALUE_) ((VALUE_) ? 4 : 5)
+#define TFMPC_LQR_WAVES(EU_) (EU_)
 #endif
-#define TFMPC_LQR_OCCUPANCY __attribute__((amdgpu_waves_per_eu(TFMPC_LQR_WAVES(VALUE), TFMPC_LQR_WAVES(VALUE))))
-template <bool BACKWARD, bool FORWARD, bool VALUE, bool EXACT, bool BF3, bool OUT16 = false>
+#define TFMPC_LQR_OCCUPANCY __attribute__((amdgpu_waves_per_eu(TFMPC_LQR_WAVES(EU), TFMPC_LQR_WAVES(EU))))
+template <bool BACKWARD, bool FORWARD, bool VALUE, bool EXACT, bool BF3, bool OUT16 = false, int EU = 4>
 __global__ __launch_bounds__(kWave) TFMPC_LQR_OCCUPANCY void lqr_mfma16x8_kernel(LqrArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
@@ -505,17 +511,35 @@ bool use_bf16x3()
     return !option_is(kOptLqrMfma, "f32");
 }
 
-template <bool BW, bool FW, bool VAL, bool O16 = false>
-int launch(const LqrArgs &a, hipStream_t stream)
+// Register budget of a launch without value outputs: five waves per SIMD (see the note above the kernel); TFMPC_LQR_WAVES=4|5 forces
+// (A/B timing, the bit-identity test).
+int pick_eu()
+{
+    const int forced = option_int(kOptLqrWaves, 0);
+    return forced == 4 ? 4 : 5;
+}
+
+template <bool BW, bool FW, bool VAL, bool O16, int EU>
+int launch_eu(const LqrArgs &a, hipStream_t stream)
 {
     const bool exact = a.n == N && a.m == M;
     const bool bf3 = BW && use_bf16x3();
     const dim3 grid(a.B), block(kWave);
-    if (exact && bf3) hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, true, true, O16>), grid, block, 0, stream, a);
-    else if (exact) hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, true, false, O16>), grid, block, 0, stream, a);
-    else if (bf3) hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, false, true, O16>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, false, false, O16>), grid, block, 0, stream, a);
+    if (exact && bf3) hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, true, true, O16, EU>), grid, block, 0, stream, a);
+    else if (exact) hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, true, false, O16, EU>), grid, block, 0, stream, a);
+    else if (bf3) hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, false, true, O16, EU>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((lqr_mfma16x8_kernel<BW, FW, VAL, false, false, O16, EU>), grid, block, 0, stream, a);
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
+}
+
+template <bool BW, bool FW, bool VAL, bool O16 = false>
+int launch(const LqrArgs &a, hipStream_t stream)
+{
+    // the VALUE instantiations would spill at the budget for five (round 4): they keep four
+    if constexpr (!VAL) {
+        if (pick_eu() == 5) return launch_eu<BW, FW, VAL, O16, 5>(a, stream);
+    }
+    return launch_eu<BW, FW, VAL, O16, 4>(a, stream);
 }
 
 }  // namespace

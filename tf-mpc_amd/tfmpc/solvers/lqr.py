@@ -233,7 +233,8 @@ class LQR:
         out = dict(states=torch.empty((Bk, T + 1, n, 1), device=dev),
                    actions=torch.empty((Bk, T, m, 1), device=dev),
                    costs=torch.empty((Bk, T + 1, 1, 1), device=dev),
-                   status=torch.zeros((Bk,), dtype=torch.int32, device=dev))
+                   # every LQR kernel writes status[b] of every instance it is launched on: no memset kernel per call
+                   status=(torch.zeros if B == 0 else torch.empty)((Bk,), dtype=torch.int32, device=dev))
         odt = torch.bfloat16 if storage_bf16 else torch.float32
         if storage_bf16 and self._suffix != "_f32":
             raise NotImplementedError("16-bit outputs are served for symmetric C (the fast kernels and the wave kernel)")
