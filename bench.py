@@ -255,6 +255,7 @@ def other_config_rates():
     configs carry a `roofline` block: algorithmic bytes per iteration x iterations / time against 8 TB/s,
     `traffic` = PMC-measured HBM bytes of the same launch (the newest profiles/r*_pmc.json taken on the kernel's current sources)."""
     import problems
+    import workloads
     from tfmpc.envs import make_lqr_linear_navigation
     from tfmpc.envs.hvac import HVAC
     from tfmpc.envs.lq import LQEnv
@@ -312,12 +313,9 @@ def other_config_rates():
     # cfg5: n = m = 32, T = 100 -> read x, u 25.7 KB + write x, u, c 26.1 KB = 51.8 KB per iteration
     for kind, kernel_tag in (("hvac", "ilqr_adjoint_mfma_kernel<3, 2"), ("reservoir", "ilqr_adjoint_mfma_kernel<4, 2")):     # two-tile instantiations
         n, T, B = 32, 100, 32768
-        if kind == "hvac":
-            env, x0 = HVAC.load(dict(problems.hvac_config(n, seed=5))), np.full((B, n, 1), 10.0, dtype=np.float32)
-        else:
-            env, x0 = Reservoir.load(dict(problems.reservoir_config(n, seed=5))), rng.uniform(50, 75, size=(B, n, 1)).astype(np.float32)
+        w5 = workloads.cfg5(kind, B, n, T)            # the same problems tests/test_ilqr_teacher_forced_gpu.py holds against the restatement
+        env, x0, u0c = w5["env"], w5["x0"], w5["u0"]
         solver = iLQR(env, max_iterations=12)
-        u0c = solver.random_actions(T, B, seed=5)
         line = ilqr_line(solver, x0, T, u0c, 3, alg_bytes=4 * (2 * (T + 1) * n + 2 * T * n + (T + 1)), pmc=(kernel_tag, 32768 * 12))
         # The flop side (round 4): rollouts per iteration MEASURED from the decision trace of the same solve (a traced launch returns
         # the same bits): a pass of the reference's line search makes alpha_index + 1 rollouts (ilqr.py:322-353).  Algorithmic flop
@@ -339,6 +337,7 @@ def other_config_rates():
                                       "flop_per_algorithmic_byte": flop / max(its_c, 1.0) / (4 * (2 * (T + 1) * n + 2 * T * n + (T + 1))),
                                       "note": "dense count of SURVEY.md 8(d) with the measured rollouts; the ridge is 157.3 TF / 8 TB/s = 19.7 flop/B"}
         del tr, rows
+        line["workload_version"] = w5["version"]
         res[f"cfg5_{kind}_ilqr_n32"] = line
     # the reference's own env configs (hvac6.config.json n = 6, res4.config.json n = 4) at a large batch
     for name, env, x0r, kernel_tag in (("hvac6", HVAC.load(dict(problems.HVAC6_CONFIG)), problems.HVAC6_X0, "ilqr_adjoint_mfma_kernel<3, 1"),

@@ -279,7 +279,7 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
  * Columns: see TFMPC_TR_*.  trace == NULL: identical to tfmpc_ilqr_solve_f32.  With a trace the solve runs on a
  * kernel that records one (the HVAC / Reservoir shared-env kernel, the 2-D lane-group kernel, else the generic
  * wave kernel): same algorithm, possibly another kernel than the untraced call would pick. */
-#define TFMPC_TRACE_COLS 10
+#define TFMPC_TRACE_COLS 11
 #define TFMPC_TR_ITERATION 0  /* the reference's loop index `iteration` (ilqr.py:227) of this pass            */
 #define TFMPC_TR_MU 1         /* mu handed to _backward (ilqr.py:240), before a local Cholesky-failure bump   */
 #define TFMPC_TR_DELTA 2      /* delta at that point                                                          */
@@ -291,6 +291,8 @@ int tfmpc_ilqr_solve_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B,
 #define TFMPC_TR_J 7          /* its total cost J (ilqr.py:205-210)                                           */
 #define TFMPC_TR_ACCEPTED 8   /* 1 = z >= c1 (ilqr.py:351-353), 0 = all step sizes rejected, -1 = no line search */
 #define TFMPC_TR_RESIDUAL 9   /* ilqr.py:206 of that rollout (-1 without line search)                         */
+#define TFMPC_TR_LEVEL 10     /* local regularisation bumps _backward needed before the pass factorised
+                                 (ilqr.py:305-309; 0 = at TFMPC_TR_MU itself): the level whose gains the pass used */
 int tfmpc_ilqr_solve_trace_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B, int T,
                                const float *x0, const float *u_init,
                                float *states, float *actions, float *costs,

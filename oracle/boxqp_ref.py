@@ -20,11 +20,17 @@ def get_qp_indices(g, low, high, x, eps=1e-6):
 
 
 def projected_newton_qp(H, q, low, high, x, dtype=np.float64, eps=1e-6,
-                        return_trace=False):
+                        return_trace=False, monitor=None):
     """optimization.py:6-101.  Returns ``(x, Hfree, free, clamped)`` exactly as
     the reference does: ``free/clamped`` are those of the LAST index evaluation
     and ``Hfree`` the lower Cholesky factor of the last factorised ``H_ff``.
-    """
+
+    ``monitor(kind, distance, scale)`` (test hook, tests/trace_oracle.py): called at the
+    two comparisons of OBJECTIVE VALUES the loop takes -- "improvement" (:27-29: the
+    distance of ``old_value - value`` from ``rtol |old_value|``) and "armijo" (:86: the
+    distance of ``vc - old_value`` from ``armijo step sdotg``) -- with ``scale`` = the sum
+    of the magnitudes of the terms of the objective at the point (what its rounding
+    error is proportional to).  Changes nothing in the iteration."""
     H = np.asarray(H, dtype=dtype)
     q = np.asarray(q, dtype=dtype).reshape(-1, 1)
     low = np.asarray(low, dtype=dtype).reshape(-1, 1)
@@ -33,6 +39,10 @@ def projected_newton_qp(H, q, low, high, x, dtype=np.float64, eps=1e-6,
 
     def fobj(x):                                           # :8-11
         return (dtype(0.5) * (x.T @ (H @ x)) + q.T @ x).reshape(())
+
+    def fscale(x):                                         # (monitor only)
+        ax = np.abs(x).astype(np.float64)
+        return float((0.5 * (ax.T @ (np.abs(H).astype(np.float64) @ ax)) + np.abs(q).astype(np.float64).T @ ax).reshape(()))
 
     max_iterations = 100                                   # :13-17
     rtol = dtype(1e-8)
@@ -48,7 +58,10 @@ def projected_newton_qp(H, q, low, high, x, dtype=np.float64, eps=1e-6,
     old_value = value
     trace = []
 
+    moved = True
     for iteration in range(max_iterations):                # :24
+        if monitor is not None and iteration > 0 and moved:     # (an iterate that did not move has value == old_value in every program)
+            monitor("improvement", float(old_value - value) - float(rtol * np.abs(old_value)), fscale(x))
         if iteration > 0 and (old_value - value) < rtol * np.abs(old_value):
             trace.append("improvement")
             break
@@ -95,13 +108,18 @@ def projected_newton_qp(H, q, low, high, x, dtype=np.float64, eps=1e-6,
         step = dtype(1.0)                                      # :82-95
         xc = np.clip(x + step * search, low, high)
         vc = fobj(xc)
+        if monitor is not None:
+            monitor("armijo", float(vc - old_value) - float(armijo * step * sdotg), fscale(xc))
         while (vc - old_value) / (step * sdotg) < armijo:
             step = step * step_dec
             xc = np.clip(x + step * search, low, high)
             vc = fobj(xc)
             if step < min_step:
                 break
+            if monitor is not None:
+                monitor("armijo", float(vc - old_value) - float(armijo * step * sdotg), fscale(xc))
 
+        moved = bool(np.any(xc != x))
         x = xc                                                 # :98-99
         value = vc
     else:

@@ -26,6 +26,10 @@ SELECTOR_MARGIN = 3e-7 # (per time step of the horizon: the costate V_x it is fo
                        #     V_x = 0 -- is 0 in every program; Reservoir's Q_u,i = x_i (V_x,i+1 - V_x,i) cancels to rounding level
                        #     somewhere in most sweeps: equal cost gradients on neighbouring reservoirs)
 QP_MARGIN = 1e-4       # ... and the box-QP's clamp test: |gradient entry| of a coordinate on its bound / max |gradient entry|
+QP_VALUE_MARGIN = 32 * 2.0 ** -24   # ... and the box-QP's comparisons of OBJECTIVE VALUES (optimization.py:27-29 improvement < rtol |value|, :86 the
+                       #     Armijo test): distance from flipping relative to the sum of the magnitudes of the objective's ~72 terms -- what an fp32
+                       #     evaluation's rounding error is proportional to.  rtol = 1e-8 is BELOW fp32's resolution, so on a QP whose value is large an
+                       #     fp32 program stops when its own rounding says so; opt-in (`_PivotLog(value_tests=True)`, tests/teacher_forced.py)
 PIVOT_MARGIN = 1e-4    # ... and a Cholesky factorisation: smallest pivot relative to its own diagonal entry (or, when it fails, the
                        #     most negative eigenvalue of the unit-diagonal scaling) -- "positive definite or not" is a decision too (ilqr.py:305)
 
@@ -34,8 +38,9 @@ class _PivotLog:
     """While installed, every ``np.linalg.cholesky`` call of the restatement (ilqr_ref._cholesky, boxqp_ref) leaves how far
     its matrix was from the other outcome: success -> min_i pivot_i / A_ii, failure -> |lambda_min| of the unit-diagonal scaling."""
 
-    def __init__(self):
+    def __init__(self, value_tests=False):
         self.values, self.kept, self.failures, self.qp_values = [], [], 0, []
+        self.value_tests, self.value_margin = value_tests, np.inf      # smallest margin of a box-QP value comparison (see QP_VALUE_MARGIN)
         self._orig = None
 
     def __enter__(self):
@@ -61,6 +66,7 @@ class _PivotLog:
                 self.values = [lam]
                 self.kept, self.values = self.kept + self.values, []
                 self.qp_values, last[0] = [], np.inf        # ... and so did its clamp tests
+                self.value_margin = np.inf                  # ... and its value comparisons
                 self.failures += 1
                 raise
             self.values.append(float(np.min(np.diagonal(L).astype(np.float64) ** 2 / diag)))
@@ -81,8 +87,13 @@ class _PivotLog:
                 last[0] = float(np.min(np.abs(g[at_bound]))) / max(float(np.max(np.abs(g))), 1e-30)
             return self._indices(g, low, high, x, eps=eps)
 
+        def monitor(kind, distance, scale):
+            self.value_margin = min(self.value_margin, abs(distance) / max(QP_VALUE_MARGIN * scale, 1e-300))
+
         def logged_qp(*args, **kwargs):
             last[0] = np.inf
+            if self.value_tests:
+                kwargs = dict(kwargs, monitor=monitor)
             try:
                 return self._qp(*args, **kwargs)
             finally:
@@ -103,6 +114,10 @@ class _PivotLog:
         v, f, q = (min(both) if both else np.inf), self.failures, (min(self.qp_values) if self.qp_values else np.inf)
         self.values, self.kept, self.failures, self.qp_values = [], [], 0, []
         return v, f, q
+
+    def take_value_margin(self):
+        v, self.value_margin = self.value_margin, np.inf
+        return v
 
 
 def make_env(kind, cfg, dtype):

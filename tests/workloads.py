@@ -80,6 +80,25 @@ def literal_dims(B, n=32, m=16, horizon=100):
                 text=f"iLQR.solve on LQEnv(0.9/sqrt(n) F, f, C, c), n={n} m={m} T={horizon} B={B}, zero start")
 
 
+def cfg5(kind, B, n=32, horizon=100):
+    """BASELINE configs[4] on the reference's HVAC / Reservoir envs at n = m = 32, T = 100: parameters from the recipes
+    of the reference's tests/conftest.py:35-63 / :83-127 (tests/problems.py), one env shared by the batch; x0 = 10.0 (HVAC,
+    hvac6.config.json:32) or U(50, 75) per reservoir (res4.config.json:20), start actions = one scalar uniform per step (ilqr.py:70).
+    `bench.py` solves it with ``iLQR(env, max_iterations=12)``."""
+    from tfmpc.envs.hvac import HVAC
+    from tfmpc.envs.reservoir import Reservoir
+    from tfmpc.solvers.ilqr import iLQR
+    if kind == "hvac":
+        cfg = dict(problems.hvac_config(n, seed=5))
+        env, x0 = HVAC.load(dict(cfg)), np.full((B, n, 1), 10.0, dtype=np.float32)
+    else:
+        cfg = dict(problems.reservoir_config(n, seed=5))
+        env, x0 = Reservoir.load(dict(cfg)), np.random.default_rng(55).uniform(50, 75, size=(B, n, 1)).astype(np.float32)
+    u0 = iLQR(env).random_actions(horizon, B, seed=5)
+    return dict(version=f"cfg5/{kind}-r5", kind=kind, cfg=cfg, env=env, x0=torch.as_tensor(x0, device="cuda"), u0=u0, T=horizon,
+                text=f"{kind} n=m={n} T={horizon} B={B}, shared env, <= 12 iterations")
+
+
 def solver_of(w, **kwargs):
     from tfmpc.envs.lq import LQEnv
     from tfmpc.solvers.ilqr import iLQR

@@ -241,6 +241,7 @@ __global__ __launch_bounds__(kWave) void ilqr_solve_kernel(TfmpcEnv env, TfmpcIl
             // _backward (:285-315): retry with a LOCAL regularisation bump on Cholesky failure
             float mu_l = mu, delta_l = delta;
             BackwardResult r;
+            int level = 0;                                                 // local bumps before the sweep factorised (trace column)
             for (int retry = 0;; ++retry) {
                 if constexpr (kAdjoint) r = backward_pass_adjoint<KIND>(s, e, T, xhat, uhat, kg);
                 else r = backward_pass<BLK>(s, prov, T, mu_l, bounded, e.low, e.high, Kg, kg);
@@ -250,11 +251,12 @@ __global__ __launch_bounds__(kWave) void ilqr_solve_kernel(TfmpcEnv env, TfmpcIl
                 delta_l = fmaxf(cfg.delta_0, delta_l * cfg.delta_0);       // :308-309
                 mu_l = fmaxf(cfg.mu_min, mu_l * delta_l);
                 if (retry >= 40) { give_up = true; break; }
+                ++level;
                 wsync();
             }
             if (give_up) break;
             if (r.g_norm < cfg.atol) {                                     // :243-248
-                if (lane == 0) trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, r.J, r.g_norm, -1, 0.0f, 0.0f, -1, -1.0f);
+                if (lane == 0) trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, r.J, r.g_norm, -1, 0.0f, 0.0f, -1, -1.0f, level);
                 converged = true;
                 break;
             }
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(kWave) void ilqr_solve_kernel(TfmpcEnv env, TfmpcIl
             const bool small_step = residual < cfg.atol;                  // :253-257 (taken even if rejected)
             if (lane == 0)
                 trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, r.J, r.g_norm, ai_last,
-                            ai_last >= 0 ? cfg.alphas[ai_last] : 0.0f, J, accept ? 1 : 0, residual);
+                            ai_last >= 0 ? cfg.alphas[ai_last] : 0.0f, J, accept ? 1 : 0, residual, level);
             if (small_step || accept) {
                 for (int idx = lane; idx < (T + 1) * n; idx += kWave) xhat[idx] = xc[idx];
                 for (int idx = lane; idx < T * m; idx += kWave) uhat[idx] = uc[idx];

@@ -962,6 +962,7 @@ __global__ __launch_bounds__(64, TFMPC_GROUP_LANE_EU) void ilqr_group_solve_kern
             // ---- one pass through the body of ilqr.py:238-270 ------------------------------------------------------------
             float mu_l = mu, delta_l = delta;
             LaneBackward r;
+            int level = 0;                                                       // local bumps before the sweep factorised (trace column)
             for (int retry = 0;; ++retry) {                                      // :285-315
                 r = backward_lane<KIND, N, M, Store, true>(env, T, mu_l, bounded, low, high, st TFMPC_PROBE_PASS);
                 status |= r.flags;
@@ -970,11 +971,12 @@ __global__ __launch_bounds__(64, TFMPC_GROUP_LANE_EU) void ilqr_group_solve_kern
                 delta_l = fmaxf(cfg.delta_0, delta_l * cfg.delta_0);
                 mu_l = fmaxf(cfg.mu_min, mu_l * delta_l);
                 if (retry >= 40) { give_up = true; break; }
+                ++level;
             }
             if (give_up) {
                 finished = true;
             } else if (r.g_norm < cfg.atol) {                                    // :243-248
-                if (leader) trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, r.J, r.g_norm, -1, 0.0f, 0.0f, -1, -1.0f);
+                if (leader) trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, r.J, r.g_norm, -1, 0.0f, 0.0f, -1, -1.0f, level);
                 finished = true;
             } else {
                 // all step sizes at once, one per lane (ilqr.py:322-353), candidates into the scratch columns
@@ -994,7 +996,7 @@ __global__ __launch_bounds__(64, TFMPC_GROUP_LANE_EU) void ilqr_group_solve_kern
                 if (a.trace.rows) {
                     const float J_chosen = __shfl(J, grp * G + chosen, 64);
                     if (leader) trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, r.J, r.g_norm, chosen,
-                                            cfg.alphas[chosen], J_chosen, accept ? 1 : 0, res_chosen);
+                                            cfg.alphas[chosen], J_chosen, accept ? 1 : 0, res_chosen, level);
                 }
                 if (small_step || accept) {
                     // adopt the chosen lane's candidate: its scratch column becomes the nominal trajectory

@@ -694,7 +694,7 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
             if (r.g_norm < cfg.atol) {                                      // :243-248
                 if (a.trace.rows) {
                     const float J_conv = sum_costs(cnom);
-                    if (lane == 0) trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, J_conv, r.g_norm, -1, 0.0f, 0.0f, -1, -1.0f);
+                    if (lane == 0) trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, J_conv, r.g_norm, -1, 0.0f, 0.0f, -1, -1.0f, level);
                 }
                 converged = true;
                 break;
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
             const bool small_step = residual < cfg.atol;                   // :253-257 (taken even if rejected)
             if (lane == 0)
                 trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, J_hat, r.g_norm, ai_last,
-                            ai_last >= 0 ? cfg.alphas[ai_last] : 0.0f, J_last, accept ? 1 : 0, residual);
+                            ai_last >= 0 ? cfg.alphas[ai_last] : 0.0f, J_last, accept ? 1 : 0, residual, level);
             if (small_step || accept) {
                 float *tz = nom; nom = cand; cand = tz;
                 float *tcst = cnom; cnom = ccand; ccand = tcst;

@@ -18,7 +18,7 @@ struct TraceArgs {
 // called by ONE lane of the instance, once per pass, with row = the number of passes before this one
 __device__ __forceinline__ void trace_write(const TraceArgs &t, size_t b, int row, int iteration, float mu, float delta,
                                             float J_hat, float g_norm, int alpha_index, float alpha, float J, int accepted,
-                                            float residual)
+                                            float residual, int level = 0)
 {
     if (!t.rows) return;
     if (row < t.max_rows) {
@@ -33,6 +33,7 @@ __device__ __forceinline__ void trace_write(const TraceArgs &t, size_t b, int ro
         r[TFMPC_TR_J] = J;
         r[TFMPC_TR_ACCEPTED] = (float)accepted;
         r[TFMPC_TR_RESIDUAL] = residual;
+        r[TFMPC_TR_LEVEL] = (float)level;
     }
     t.len[b] = row + 1;
 }

@@ -47,7 +47,7 @@ for _name in ("backward", "forward", "solve"):       # twins for a non-symmetric
 ENV_LQ, ENV_NAVLQR, ENV_NAVIGATION, ENV_HVAC, ENV_RESERVOIR = range(5)
 ENV_MAX_PARAMS = 10
 MAX_ALPHAS = 16
-TRACE_COLS = 10          # TFMPC_TRACE_COLS
+TRACE_COLS = 11          # TFMPC_TRACE_COLS
 
 
 class TfmpcEnv(ctypes.Structure):

@@ -30,7 +30,7 @@ from tfmpc.envs.diffenv import CostApprox, FinalCostApprox, TransitionApprox
 from tfmpc.utils import trajectory
 
 
-TRACE_COLUMNS = ("iteration", "mu", "delta", "J_hat", "g_norm", "alpha_index", "alpha", "J", "accepted", "residual")
+TRACE_COLUMNS = ("iteration", "mu", "delta", "J_hat", "g_norm", "alpha_index", "alpha", "J", "accepted", "residual", "level")
 
 
 def trace_records(trace, trace_len):
@@ -47,7 +47,8 @@ def trace_records(trace, trace_len):
             rows.append(dict(iteration=int(r[0]), mu=float(r[1]), delta=float(r[2]), J_hat=float(r[3]), g_norm=float(r[4]),
                              alpha_index=int(r[5]) if searched else None, alpha=float(r[6]) if searched else None,
                              J=float(r[7]) if searched else None, accepted=bool(r[8] > 0) if searched else None,
-                             residual=float(r[9]) if searched else None))
+                             residual=float(r[9]) if searched else None,
+                             level=int(r[10])))      # local regularisation bumps before the pass factorised (ilqr.py:305-309)
         out.append(rows)
     return out
 
@@ -584,6 +585,7 @@ class iLQR:
             while bool(pending.any()):
                 mu_l, delta_l = mu.clone(), delta.clone()   # _backward's local retry (ilqr.py:285-315)
                 gave_up = torch.zeros_like(pending)
+                level = torch.zeros(B, device=dev)          # local bumps before the pass factorised (trace column `level`)
                 for retry in range(41):                     # the fused kernels give up after retry 40 too
                     K, k, _, dV1, dV2 = self.backward(T, uh.unsqueeze(-1), tm, cm, fm, mu=mu_l)
                     failed = ((self.last_status & _hip.ST_NOT_PD) != 0) & pending
@@ -595,6 +597,7 @@ class iLQR:
                         break
                     delta_l = torch.where(failed, torch.clamp(delta_l * d0, min=d0), delta_l)
                     mu_l = torch.where(failed, torch.clamp(mu_l * delta_l, min=mu_min), mu_l)
+                    level = level + failed.float()
                 if bool(gave_up.any()):
                     status[gave_up] |= _hip.ST_MAX_ATTEMPTS
                     pending = pending & ~gave_up
@@ -624,7 +627,7 @@ class iLQR:
                     vals = torch.stack([iterations.float(), mu, delta, J_hat, g_norm,
                                         torch.where(ls, chosen.float(), torch.full_like(mu, -1.0)), searched * alphas[chosen],
                                         searched * J[ar, chosen], torch.where(ls, accepted.float(), torch.full_like(mu, -1.0)),
-                                        torch.where(ls, res[ar, chosen], torch.full_like(mu, -1.0))], dim=1)
+                                        torch.where(ls, res[ar, chosen], torch.full_like(mu, -1.0)), level], dim=1)
                     put = pending & (row < trace_rows)
                     trace[ar[put], row[put]] = vals[put]
                     trace_len = torch.where(pending, (row + 1).int(), trace_len)
