@@ -40,6 +40,11 @@ extern "C" {
 #define TFMPC_ST_NAN 0x4          /* a non-finite value reached an output                        */
 #define TFMPC_ST_QP_MAXITER 0x8   /* box-QP hit its 100-iteration cap (optimization.py:13)       */
 #define TFMPC_ST_MAX_ATTEMPTS 0x10 /* iLQR: backward/line-search attempt cap reached             */
+#define TFMPC_ST_ENV_FLAG 0x40     /* TfmpcEnv::coupling_shift promised a chain that `downstream` is not: nothing was computed   */
+#define TFMPC_ST_QP_LATER_NOT_PD 0x20 /* tfmpc_boxqp_f32: a factorisation AFTER the first failed; the loop broke out there as
+                                         optimization.py:47-51 does: x and free are those at the break.  (Inside iLQR the QP starts at the box
+                                         centre, ilqr.py:369, where every coordinate is free: the first factorisation is of the whole H, and a
+                                         positive definite H has no indefinite principal block -- the case needs a boundary start or rounding.) */
 
 /* Library / device information ------------------------------------------------ */
 int tfmpc_version(void);
@@ -189,7 +194,12 @@ int tfmpc_lqr_solve_general_f32(int B, int n, int m, int T,
 typedef struct TfmpcEnv {
     int32_t kind, n, m, n_zones, bounded;
     int32_t any_finite_bound;   /* 1 if any entry of low/high is finite (forward clips, ilqr.py:197) */
-    int32_t reserved1, reserved2;
+    int32_t coupling_shift;     /* RESERVOIR only, a PROMISE by the caller: +1 = `downstream` is the chain i -> i + 1 (D[i][i+1] = 1, every other
+                                   entry 0), -1 = the chain i -> i - 1, 0 = no statement (any matrix).  Every config the reference holds
+                                   is a chain (tests/conftest.py:70-75, reservoir/res4.config.json:13-18); with the promise a large batch runs an
+                                   instantiation without coupling products.  Checked on the device against p7 before anything is computed:
+                                   a broken promise leaves TFMPC_ST_ENV_FLAG in status[b] and the outputs untouched. */
+    int32_t reserved2;
     const float *low, *high;
     const float *p[TFMPC_ENV_MAX_PARAMS];
     int64_t stride[TFMPC_ENV_MAX_PARAMS];

@@ -15,7 +15,7 @@ import pytest
 import torch
 
 import problems
-from oracle import envs_ref, ilqr_ref
+from oracle import boxqp_ref, envs_ref, ilqr_ref
 from tfmpc import _hip
 from tfmpc.envs import make_env
 from tfmpc.envs.hvac import HVAC
@@ -350,6 +350,32 @@ def test_boxqp_dense_matches_oracle(golden):
         x, _, free, _ = optimization.projected_newton_qp(H, q[:, None], low[:, None], high[:, None], x0[:, None])
         assert np.abs(_np(x)[:, 0] - x_ref).max() < 2e-4, i
         assert np.array_equal(free[:, 0].cpu().numpy(), free_ref), i
+
+
+def test_boxqp_later_factorisation_failure_breaks_out_like_the_reference():
+    """optimization.py:47-51: when a factorisation AFTER the first fails (the free set grew onto an indefinite block), the reference logs
+    and breaks out of the loop -- x and the free mask are those at the break.  Constructed: H indefinite on coordinates (0, 1),
+    coordinate 1 starts clamped at its upper bound (first free set {0, 2}: positive definite); the Newton step on coordinate 0 turns the
+    gradient of coordinate 1 inward, the free set becomes everything, H itself does not factorise.  The restatement and the device return
+    the same point and mask; the device says so in its status (TFMPC_ST_QP_LATER_NOT_PD).  From iLQR the case cannot arise in exact
+    arithmetic: the QP starts at the box centre (ilqr.py:369), where the first factorisation is of the whole H."""
+    H = np.array([[1.0, 2.0, 0.0], [2.0, 1.0, 0.0], [0.0, 0.0, 2.0]])
+    q = np.array([[-2.5], [-1.5], [-1.0]])
+    low, high, x0 = -np.ones((3, 1)), np.ones((3, 1)), np.array([[0.0], [1.0], [0.0]])
+    for dtype in (np.float32, np.float64):
+        xr, Hf, fr, cl, tr = boxqp_ref.projected_newton_qp(H, q, low, high, x0, dtype=dtype, return_trace=True)
+        assert tr == ["not_pd"] and Hf.shape == (2, 2) and fr.all() and np.allclose(xr[:, 0], [0.5, 1.0, 0.5])
+    x, Hfree, free, clamped = optimization.projected_newton_qp(H, q, low, high, x0)
+    assert int(optimization.projected_newton_qp.last_status[0]) == _hip.ST_QP_LATER_NOT_PD
+    assert np.allclose(_np(x)[:, 0], [0.5, 1.0, 0.5], atol=1e-6) and bool(free.all()) and not bool(clamped.any()) and Hfree is None
+    # batched, next to a problem that is fine: one flag, the other instance untouched
+    Hb = np.stack([H, 2 * np.eye(3)])
+    xb, _, fb, _ = optimization.projected_newton_qp(Hb, np.stack([q, q]), np.stack([low, low]), np.stack([high, high]), np.stack([x0, x0]))
+    assert optimization.projected_newton_qp.last_status.tolist() == [_hip.ST_QP_LATER_NOT_PD, 0]
+    assert np.allclose(_np(xb)[1, :, 0], [1.0, 0.75, 0.5], atol=1e-5)
+    # the first factorisation failing is the other case: an exception (single instance), as the reference's UnboundLocalError -> exit
+    with pytest.raises(ValueError):
+        optimization.projected_newton_qp(H, q, low, high, np.zeros((3, 1)))
 
 
 def test_non_pd_quu_raises_like_the_reference():

@@ -910,7 +910,8 @@ template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_RESERVOIR, NT, LEAN> {
             unpr(gx, e, -pr(LP, e) * below + pr(HP, e) * above - pr(SP, e) * f32x2{sgnf_(d.x), sgnf_(d.y)});
         }
     }
-    __device__ __forceinline__ void step(const Operand &A, const float (&x)[NV], const float (&u)[NV], int qo,
+    template <class OP>
+    __device__ __forceinline__ void step(const OP &A, const float (&x)[NV], const float (&u)[NV], int qo,
                                          float (&xn)[NV]) const
     {
         float z[NV], inflow[NV], rain[NV];
@@ -929,7 +930,8 @@ template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_RESERVOIR, NT, LEAN> {
             unpr(xn, e, xi + pr(rain, e) + pr(inflow, e) - vaporated - pr(u, e) * xi);    // :56-60
         }
     }
-    __device__ __forceinline__ void adjoint(const Operand &A, const float (&xh)[NV], const float (&uh)[NV],
+    template <class OP>
+    __device__ __forceinline__ void adjoint(const OP &A, const float (&xh)[NV], const float (&uh)[NV],
                                             const float (&vx)[NV], int qo, float (&Qx)[NV], float (&Qu)[NV]) const
     {
         float Y[NV], Dii[NV], gx[NV];
@@ -951,6 +953,68 @@ template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_RESERVOIR, NT, LEAN> {
         }
     }
 };
+
+// Round 5: Reservoir whose `downstream` matrix the CALLER states to be a chain (TfmpcEnv::coupling_shift = +1: reservoir i drains into
+// i + 1, -1: into i - 1 -- every config the reference holds, tests/conftest.py:70-75, res4.config.json:13-18): the coupling products are
+// row moves at COMPILE time (shift_apply), so the instantiation carries no operand fragments, no LDS slab for their low-order parts (14.9
+// instead of 18.9 KB) and no product code: 11.2 - 11.3 against 11.6 ms on a cfg5 batch (tools/probes/r5_cfg5_chain_ab.sh).  What it was built
+// for -- a register budget for THREE waves per SIMD with a two-deep ring (10.9 KB of LDS) -- does not fit: at 168 registers the compiler
+// spills 130 (two step sizes per pass: 26.4 ms) or 113 (one: 16.8 ms, and no longer the same bits); profiles/r05_cfg5_budget.md.
+// Internal template tag only (genv.kind stays TFMPC_ENV_RESERVOIR); the kernel checks the promise
+// against the matrix before it computes anything (TFMPC_ST_ENV_FLAG).  Same arithmetic as the run-time shift path: the same bits.
+constexpr int kEnvReservoirChain = 100;
+struct MatShift { int shift, leak_mask; };
+__device__ __forceinline__ void mat_apply(const MatShift &A, const float (&z)[8], float (&acc)[8]) { shift_apply(A.shift, A.leak_mask, z, acc); }
+__device__ __forceinline__ void force_dense(MatShift &, bool) {}
+template <int NT, bool LEAN> struct EnvM<kEnvReservoirChain, NT, LEAN> : EnvM<TFMPC_ENV_RESERVOIR, NT, LEAN> {
+    static_assert(NT == 2, "the one-tile forms keep the run-time test");
+    using Operand = MatShift;
+    static constexpr bool kChain = true;
+#ifndef TFMPC_CHAIN_ALPHAS
+#define TFMPC_CHAIN_ALPHAS 2
+#endif
+    static constexpr int kSearchAlphas = TFMPC_CHAIN_ALPHAS;      // step sizes per line-search pass (see the note at the register budget)
+    __device__ __forceinline__ static int leak(int shift, int n, int q)
+    {
+        if (!(shift < 0 && n < 32)) return 0;
+        int mask = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mask |= (16 * (e >> 2) + 4 * q + (e & 3) == n) ? (1 << e) : 0;
+        return __any(mask != 0) ? (mask | 0x100) : 0;
+    }
+    // forward: D^T (row R receives z[R - dir]); backward: D without its diagonal (row R receives V_x[R + dir])
+    template <int PK>
+    __device__ __forceinline__ void load_forward(const TfmpcEnv &g, int, int q, Operand &A, u32x4 *) const
+    {
+        A.shift = -g.coupling_shift;
+        A.leak_mask = leak(A.shift, g.n, q);
+    }
+    template <int PK>
+    __device__ __forceinline__ void load_backward(const TfmpcEnv &g, int, int q, Operand &A, u32x4 *) const
+    {
+        A.shift = g.coupling_shift;
+        A.leak_mask = leak(A.shift, g.n, q);
+    }
+    // is `downstream` the chain the caller promised?  (every lane looks at 16 entries of each 16 x 16 tile of the 32 x 32 block)
+    __device__ __forceinline__ static bool promise_holds(const TfmpcEnv &g, int lane)
+    {
+        const float *D = g.p[7];
+        const int n = g.n, i = lane & 15, q = lane >> 4, dir = g.coupling_shift;
+        bool ok = dir == 1 || dir == -1;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int R = 16 * a + i, C = 16 * b + 4 * q + r;
+                    if (R < n && C < n) ok = ok && D[R * n + C] == ((C == R + dir) ? 1.0f : 0.0f);      // (a zero diagonal too)
+                }
+        return __all(ok);
+    }
+};
+template <int KIND, int NT, bool LEAN> struct EnvTraits { static constexpr bool kChain = false; };
+template <int NT, bool LEAN> struct EnvTraits<kEnvReservoirChain, NT, LEAN> { static constexpr bool kChain = true; };
 
 #ifdef TFMPC_CFG5_TRACE
 // probe builds only (tools/probes/cfg5_trace.py): per instance and sweep, the accepted step-size index and, for every
@@ -1012,7 +1076,12 @@ template <int KIND, int NT, int VW, int PK, bool BF16 = false, int NW = 1>
 #ifndef TFMPC_GROUP_EU
 #define TFMPC_GROUP_EU 4               // A/B builds: the register target (waves per SIMD) of the multi-wave one-tile forms
 #endif
-__global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW > 1 && NT == 1 ? (NW > 2 ? TFMPC_GROUP_EU : 4) : (NT == 1 && PK == 1 ? 3 : 2), NW > 1 && NT == 1 ? (NW > 2 ? TFMPC_GROUP_EU : 4) : (NT == 1 && PK == 1 ? 3 : 2)))) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
+#ifndef TFMPC_TWO_TILE_EU
+#define TFMPC_TWO_TILE_EU(KIND_) 2     // the register target of the one-wave two-tile forms (cfg5); A/B builds override (round 5: THREE was tried on the
+                                       // Reservoir chain form -- 168 registers + 113 .. 130 spilled: 16.8 .. 26.4 ms against 11.7, profiles/r05_cfg5_budget.md)
+#endif
+#define TFMPC_AM_EU (NW > 1 && NT == 1 ? (NW > 2 ? TFMPC_GROUP_EU : 4) : (NT == 1 && PK == 1 ? 3 : (NT == 2 && NW == 1 ? TFMPC_TWO_TILE_EU(KIND) : 2)))
+__global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMPC_AM_EU, TFMPC_AM_EU))) void ilqr_adjoint_mfma_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, AdjointSolveArgs a)
 {
     constexpr int NV = 4 * NT;
     using TT = typename std::conditional<BF16, bf16_t, float>::type;      // element type of the trajectories in HBM
@@ -1032,14 +1101,18 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
     const bool live = b_raw < a.B;                       // the last group may carry empty columns: they compute on the
     const size_t b = live ? b_raw : a.B - 1;             // last instance's data and store nothing
     __shared__ __attribute__((aligned(16))) float rows[kRowSlots * kRowLd];
-    __shared__ u32x4 op_rest_all[NW][NT == 2 ? 4 * kWave : 1];  // MatOp<2, true>: the non-leading parts of the operand, per wave
+    constexpr bool kChain = EnvTraits<KIND, NT, (NW > 1)>::kChain;       // Reservoir chain: no operand at all (see EnvM<kEnvReservoirChain>)
+    __shared__ u32x4 op_rest_all[NW][NT == 2 && !kChain ? 4 * kWave : 1];  // MatOp<2, true>: the non-leading parts of the operand, per wave
     __shared__ float x_sweep[NW > 1 ? 4 : 1][kWave];           // wave 0 -> the others: J_hat, dV1, g_norm, max |k|
     __shared__ float x_pass[2][NW][2][kWave];                  // [pass parity][wave][J | cut short][lane]
     u32x4 *const op_rest = op_rest_all[wv];
     // the LDS-DMA input ring of this wave (fp32 containers): [slot][x tiles | u tiles][lane] 16-byte pieces, the stage
     // cost and the selector byte of a slot.  Depth 3 with two tiles keeps 8 groups per CU inside the 160 KB.
     constexpr bool kLdsRing = !BF16;
-    constexpr int kRingDepth = NT == 2 ? 3 : 4;
+#ifndef TFMPC_CHAIN_RING
+#define TFMPC_CHAIN_RING 3
+#endif
+    constexpr int kRingDepth = NT == 2 ? (kChain ? TFMPC_CHAIN_RING : 3) : 4;
     __shared__ f32x4 ring_v_all[NW][kLdsRing ? kRingDepth : 1][2 * NT][kWave];
     __shared__ float ring_c_all[NW][kLdsRing ? kRingDepth : 1][kWave];
     __shared__ unsigned ring_k_all[NW][kLdsRing ? kRingDepth : 1][kWave];    // (a sub-dword LDS-DMA still strides the lanes by 4 bytes)
@@ -1048,6 +1121,13 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
     unsigned (*const ring_k)[kWave] = ring_k_all[wv];
     EnvM<KIND, NT, (NW > 1)> env;
     env.load(genv, lane, ql, rows);                      // (every wave of the group writes the same values)
+    if constexpr (kChain) {
+        // the caller's promise (TfmpcEnv::coupling_shift) against the matrix itself, before anything is computed on it
+        if (!EnvM<KIND, NT, (NW > 1)>::promise_holds(genv, lane)) {                  // (wave-uniform)
+            if (wv == 0 && ql == 0 && live) { a.iterations[b] = 0; a.status[b] = TFMPC_ST_ENV_FLAG; }
+            return;
+        }
+    }
     if (lane < kRowLd) {
         rows[kSlotALow * kRowLd + lane] = (lane < m) ? genv.low[lane] : 0.0f;
         rows[kSlotAHigh * kRowLd + lane] = (lane < m) ? genv.high[lane] : 0.0f;
@@ -1637,9 +1717,9 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW >
 
 }  // namespace
 
-// ---- host side.  The instantiations are spread over EIGHT translation units (Makefile: this file compiled with
-// -DTFMPC_AM_PART=0..7 = (HVAC | Reservoir) x (two tiles | one tile with 1, 2, 4 instances per column), 18 kernels each, built in
-// parallel); part 0 also carries the host functions.  Without the macro (tools/probes) everything is one unit.
+// ---- host side.  The instantiations are spread over NINE translation units (Makefile: this file compiled with
+// -DTFMPC_AM_PART=0..7 = (HVAC | Reservoir) x (two tiles | one tile with 1, 2, 4 instances per column), 18 kernels each, and part 8 = the
+// Reservoir-chain form, built in parallel); part 0 also carries the host functions.  Without the macro (tools/probes) everything is one unit.
 #ifndef TFMPC_AM_PART
 #define TFMPC_AM_PART -1
 #endif
@@ -1713,6 +1793,18 @@ bool ilqr_adjoint_mfma_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg
     int ilqr_adjoint_mfma_launch_part##P(const TfmpcEnv &, const TfmpcIlqrConfig &, const AdjointSolveArgs &, hipStream_t, int, int, dim3, dim3);
 TFMPC_AM_PART_DECL(0) TFMPC_AM_PART_DECL(1) TFMPC_AM_PART_DECL(2) TFMPC_AM_PART_DECL(3)
 TFMPC_AM_PART_DECL(4) TFMPC_AM_PART_DECL(5) TFMPC_AM_PART_DECL(6) TFMPC_AM_PART_DECL(7)
+TFMPC_AM_PART_DECL(8)
+#if TFMPC_AM_PART < 0 || TFMPC_AM_PART == 8
+// the Reservoir chain (EnvM<kEnvReservoirChain>): one-wave groups, fp32 containers, two tiles -- the form a full cfg5 batch takes
+int ilqr_adjoint_mfma_launch_part8(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const AdjointSolveArgs &a, hipStream_t stream,
+                                   int vw, int, dim3 grid, dim3 block)
+{
+    if (vw == 4) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<kEnvReservoirChain, 2, 4, 1, false, 1>), grid, block, 0, stream, env, cfg, a);
+    else if (vw == 2) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<kEnvReservoirChain, 2, 2, 1, false, 1>), grid, block, 0, stream, env, cfg, a);
+    else hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<kEnvReservoirChain, 2, 1, 1, false, 1>), grid, block, 0, stream, env, cfg, a);
+    return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
+}
+#endif
 #if TFMPC_AM_PART < 0 || TFMPC_AM_PART == 0
 TFMPC_AM_PART_FN(0, TFMPC_ENV_HVAC, 2, 1)
 #endif
@@ -1771,7 +1863,12 @@ int ilqr_adjoint_mfma_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, co
              : (groups <= 256 ? 8 : (groups <= 512 ? 4 : (groups <= 1024 && env.n <= 16 ? 2 : 1)));
     if (cfg.storage_bf16 && nw > 2) nw = 2;                          // (16-bit containers: the one- and two-wave forms)
     const dim3 block(kWave * nw), grid((a.B + kCols * pk - 1) / (kCols * pk));
-    const int part = (env.kind == TFMPC_ENV_HVAC ? 0 : 4) + (env.n > 16 ? 0 : (pk == 1 ? 1 : (pk == 2 ? 2 : 3)));
+    int part = (env.kind == TFMPC_ENV_HVAC ? 0 : 4) + (env.n > 16 ? 0 : (pk == 1 ? 1 : (pk == 2 ? 2 : 3)));
+    // Reservoir with a promised chain topology, in the form a large batch takes (one wave per group, fp32 containers, two tiles): the
+    // compile-time shift instantiation.  TFMPC_COSTATE_COUPLING=dense|runtime keeps the general kernel (A/B timing, bit-identity tests).
+    if (part == 4 && nw == 1 && !cfg.storage_bf16 && (env.coupling_shift == 1 || env.coupling_shift == -1) && !a.dense_coupling &&
+        !option_is(kOptCostateCoupling, "runtime"))
+        part = 8;
     switch (part) {
     case 0: return ilqr_adjoint_mfma_launch_part0(env, cfg, a, stream, vw, nw, grid, block);
     case 1: return ilqr_adjoint_mfma_launch_part1(env, cfg, a, stream, vw, nw, grid, block);
@@ -1780,6 +1877,7 @@ int ilqr_adjoint_mfma_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, co
     case 4: return ilqr_adjoint_mfma_launch_part4(env, cfg, a, stream, vw, nw, grid, block);
     case 5: return ilqr_adjoint_mfma_launch_part5(env, cfg, a, stream, vw, nw, grid, block);
     case 6: return ilqr_adjoint_mfma_launch_part6(env, cfg, a, stream, vw, nw, grid, block);
+    case 8: return ilqr_adjoint_mfma_launch_part8(env, cfg, a, stream, vw, nw, grid, block);
     default: return ilqr_adjoint_mfma_launch_part7(env, cfg, a, stream, vw, nw, grid, block);
     }
 }

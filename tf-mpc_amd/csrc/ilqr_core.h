@@ -158,7 +158,7 @@ __device__ inline int boxqp(IlqrSmem &s, const float *H, int ldh, const float *q
         wsync();
         // factorise H_ff (Cholesky in the reference, :40-51) and solve for the Newton step
         const int bad = qp_solve_free(s, H, ldh, s.qfree, 1, [&](int i, int) { return s.qgc[i]; });
-        if (bad) { rc = (it == 0) ? TFMPC_ST_NOT_PD : 0; break; }
+        if (bad) { rc = (it == 0) ? TFMPC_ST_NOT_PD : TFMPC_ST_QP_LATER_NOT_PD; break; }     // :47-51: the first failure raises, a later one breaks out
         const float n_free = wave_sum((float)n_free_part);
         if (n_free == 0.0f) { rc = 0; break; }                                                    // :53-55
         if (sqrtf(wave_sum(gn_part)) < eps) { rc = 0; break; }                                    // :58-62
@@ -291,7 +291,10 @@ __device__ inline BackwardResult backward_pass(IlqrSmem &s, Provider &prov, int 
             }
             wsync();
             const int rc = boxqp(s, s.Quur, ldm, s.Qu);
-            if (rc == TFMPC_ST_NOT_PD) { r.failed = 1; return r; }
+            // a LATER factorisation failure inside the QP (optimization.py:47-51 breaks out; ilqr.py:375-385 would then pair the stale factor
+            // with the new free mask) fails the sweep like the first: the final free set is not positive definite, so K cannot be built
+            // from it.  Unreachable in exact arithmetic: the QP starts at the box centre, all coordinates free (tfmpc_hip.h).
+            if (rc == TFMPC_ST_NOT_PD || rc == TFMPC_ST_QP_LATER_NOT_PD) { r.failed = 1; return r; }
             r.flags |= rc;
             wsync();
             // K_free = -H_ff^-1 Q~ux[free], clamped rows 0                          (:375-385)

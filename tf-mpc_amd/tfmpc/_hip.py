@@ -17,7 +17,7 @@ _lib = None
 ERRORS = {-1: "bad argument", -2: "shape not supported by any kernel variant",
           -3: "kernel launch failed", -4: "workspace too small"}
 
-ST_SINGULAR, ST_NOT_PD, ST_NAN, ST_QP_MAXITER, ST_MAX_ATTEMPTS = 1, 2, 4, 8, 16
+ST_SINGULAR, ST_NOT_PD, ST_NAN, ST_QP_MAXITER, ST_MAX_ATTEMPTS, ST_QP_LATER_NOT_PD, ST_ENV_FLAG = 1, 2, 4, 8, 16, 32, 64
 
 _P, _I, _L, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t
 
@@ -54,7 +54,7 @@ class TfmpcEnv(ctypes.Structure):
     """``struct TfmpcEnv`` of include/tfmpc_hip.h."""
     _fields_ = [("kind", ctypes.c_int32), ("n", ctypes.c_int32), ("m", ctypes.c_int32),
                 ("n_zones", ctypes.c_int32), ("bounded", ctypes.c_int32),
-                ("any_finite_bound", ctypes.c_int32), ("reserved1", ctypes.c_int32), ("reserved2", ctypes.c_int32),
+                ("any_finite_bound", ctypes.c_int32), ("coupling_shift", ctypes.c_int32), ("reserved2", ctypes.c_int32),
                 ("low", ctypes.c_void_p), ("high", ctypes.c_void_p),
                 ("p", ctypes.c_void_p * ENV_MAX_PARAMS), ("stride", ctypes.c_int64 * ENV_MAX_PARAMS),
                 ("scalar", ctypes.c_float * 4)]

@@ -76,6 +76,7 @@ class DiffEnv:
         env = _hip.TfmpcEnv()
         env.kind, env.n, env.m = int(self.kind), int(self.state_size), int(self.action_size)
         env.n_zones = int(self.n_zones)
+        env.coupling_shift = int(getattr(self, "coupling_shift", 0))      # Reservoir: a chain topology, stated to the kernels (tfmpc_hip.h)
         env.bounded = int(self.action_space.is_bounded())
         env.any_finite_bound = int(bool(np.any(np.isfinite(self.action_space.low)) or
                                         np.any(np.isfinite(self.action_space.high))))

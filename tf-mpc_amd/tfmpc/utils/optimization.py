@@ -42,7 +42,12 @@ def projected_newton_qp(H, q, low, high, x, eps=1e-6, alpha_0=1.0, rho=0.5, c=1e
         return xo.unsqueeze(-1), None, free_b.unsqueeze(-1), (~free_b).unsqueeze(-1)
     if int(status[0]) & _hip.ST_NOT_PD:
         raise ValueError("[boxQP] Hessian is not positive definite.")
+    projected_newton_qp.last_status = status
     idx = torch.nonzero(free_b[0]).flatten()
+    if int(status[0]) & _hip.ST_QP_LATER_NOT_PD:
+        # a factorisation after the first failed: the reference breaks out (optimization.py:47-51) and returns the factor of the
+        # PREVIOUS free set next to the free mask of the failing one; the stale factor is not reproduced here (None)
+        return xo[0].unsqueeze(-1), None, free_b[0].unsqueeze(-1), (~free_b[0]).unsqueeze(-1)
     Hfree = torch.linalg.cholesky(Hb[0][idx][:, idx]) if idx.numel() else Hb[0][:0, :0]
     return xo[0].unsqueeze(-1), Hfree, free_b[0].unsqueeze(-1), (~free_b[0]).unsqueeze(-1)
 
