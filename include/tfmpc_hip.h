@@ -70,6 +70,10 @@ const char *tfmpc_lqr_kernel_name(int n, int m, int T);
  * tiny 2-D envs that can be another kernel than the untraced solve takes (the LQ env's matrix-core kernels record their own trace
  * since round 4), which is what this call lets a caller report next to the trace (the CLI's -v writes it into trace.log). */
 const char *tfmpc_ilqr_last_kernel_name(void);
+/* Workgroups of the calling thread's last PERSISTENT lane-group launch (the 2-D envs of BASELINE configs[3] beyond 4 096 instances: the grid
+ * is what the device holds at once for that launch's LDS size, and the groups pull instances from a queue); 0 before the first.  A
+ * diagnostic: the grid must follow the horizon and the device of each launch, not those of the process's first launch. */
+int tfmpc_ilqr_last_group_grid(void);
 
 /* ---------------------------------------------------------------- LQR --------
  * Problem (tfmpc/solvers/lqr.py:18-57): x' = F [x;u] + f, stage cost

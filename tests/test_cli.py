@@ -52,10 +52,22 @@ def test_lqr_and_navlin_print_the_trajectory_table():
     assert "Trajectory(init=" in result.output and result.output.count("\n") >= 14
     result = CliRunner().invoke(tfmpc_cli.cli, ["navlin", "0.0 0.0", "8.0 -9.0", "-b", "5.0", "-hr", "10"])
     assert result.exit_code == 0, result.output
-    rows = [line for line in result.output.splitlines() if line.strip().startswith("9 ")]
-    assert len(rows) == 1                                        # last step of the table
-    final = [float(v) for v in rows[0].split("|")[1].strip(" []").split(",")]
-    assert abs(final[0] - 8.0) < 1.5 and abs(final[1] + 9.0) < 1.5
+    # the whole table against the restatement's (oracle/lqr_ref.py: lqr.py:59-166 with v0.7.0's terminal condition V_T = C_xx, v_T = c_x --
+    # first action 2.8654 / -3.2236; the README's own table is the older zero-terminal-value version and is pinned in
+    # tests/test_host_lqr.py), every printed number to the four decimals it is printed with
+    import re
+    from oracle import lqr_ref
+    from tfmpc.utils.trajectory import Trajectory
+    goal = np.array([[8.0], [-9.0]])
+    F, f = np.concatenate([np.eye(2), np.eye(2)], axis=1), np.zeros((2, 1))
+    C, c = np.diag([2.0, 2.0, 10.0, 10.0]), np.concatenate([-2 * goal, np.zeros((2, 1))])         # envs/__init__.py:21-30 at beta = 5
+    xs, us, cs, _, _ = lqr_ref.solve(F, f, C, c, np.zeros((2, 1)), 10)
+    table = lambda text: [[float(v) for v in re.findall(r"-?\d+\.\d+", line)] for line in text.splitlines() if re.match(r"\s*\d+\s*\|", line)]
+    got, want = table(result.output), table(str(Trajectory(xs, us, cs)))
+    assert len(got) == len(want) == 10 and all(len(r) == 5 for r in got)
+    err = np.abs(np.array(got) - np.array(want))
+    assert err[:, :4].max() <= 1.5e-4 and err[:, 4].max() <= 5e-4, (got[0], want[0])       # (stage costs ~145 carry ~1e-5 of fp32 rounding on top of the print)
+    assert want[0][:4] == [2.8654, -3.2236, 2.8654, -3.2236]
 
 
 @pytest.mark.gpu

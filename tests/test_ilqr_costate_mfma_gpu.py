@@ -275,3 +275,63 @@ def test_a_downstream_matrix_that_is_no_chain_keeps_the_products(force_kernel, n
     chain = iLQR(Reservoir.load(dict(problems.reservoir_config(n, seed=n))), max_iterations=5)
     force_kernel("costate_mfma")
     assert not torch.equal(chain.solve_device(x0, T, u_init=u0)["states"], out["costate_mfma"]["states"])
+
+
+@pytest.mark.parametrize("n,T,B,direction", [(32, 60, 64, 1), (32, 60, 37, -1), (20, 40, 33, 1), (17, 25, 16, -1), (31, 12, 5, 1)])
+def test_compile_time_chain_instantiation_is_the_general_kernel_bit_for_bit(force_kernel, n, T, B, direction):
+    """Round 5: a Reservoir env whose `downstream` is a chain says so (TfmpcEnv.coupling_shift = +1: i drains into i + 1, -1: into i - 1;
+    tfmpc.envs.reservoir sets it from the config) and a one-wave two-tile launch takes the instantiation whose coupling is a row move at
+    COMPILE time (ilqr_adjoint_mfma.hip: EnvM<kEnvReservoirChain>).  TFMPC_COSTATE_COUPLING=runtime keeps the general kernel (run-time shift
+    test), =dense its products: all three and the wave kernel return the same bits, in both directions, also for n < 32 (padding rows)."""
+    cfg = dict(problems.reservoir_config(n, seed=n))
+    if direction < 0:
+        cfg["downstream"] = np.array(cfg["downstream"]).T.tolist()
+    env = Reservoir.load(cfg)
+    assert env.coupling_shift == direction
+    x0 = np.random.default_rng(n).uniform(20.0, 90.0, size=(B, n, 1)).astype(np.float32)
+    solver = iLQR(env, max_iterations=8)
+    u0 = solver.random_actions(T, B, seed=n)
+    force_kernel("costate_mfma")
+    out = {}
+    with _hip.option("TFMPC_COSTATE_WAVES", "1"):
+        for mode in (None, "runtime", "dense"):
+            with _hip.option("TFMPC_COSTATE_COUPLING", mode):
+                o = solver.solve_device(x0, T, u_init=u0, trace_rows=24)
+                torch.cuda.synchronize()
+                out[mode] = {k: v.clone() for k, v in o.items() if torch.is_tensor(v) and k != "workspace"}
+    force_kernel("wave")
+    wave = solver.solve_device(x0, T, u_init=u0)
+    torch.cuda.synchronize()
+    for mode in ("runtime", "dense"):
+        for key in ("iterations", "status", "states", "actions", "costs", "trace_len"):
+            assert torch.equal(out[None][key], out[mode][key]), (mode, key)
+        assert torch.equal(torch.nan_to_num(out[None]["trace"]), torch.nan_to_num(out[mode]["trace"]))
+    for key in ("iterations", "status", "states", "actions", "costs"):
+        assert torch.equal(out[None][key], wave[key]), key
+    assert int(out[None]["iterations"].max()) >= 2 and bool(torch.isfinite(out[None]["costs"]).all())
+
+
+def test_a_broken_chain_promise_is_refused_on_the_device(force_kernel):
+    """TfmpcEnv.coupling_shift is a promise by the caller; the chain instantiation checks it against the matrix before it computes anything
+    and leaves TFMPC_ST_ENV_FLAG in every instance's status.  (tfmpc.envs.reservoir derives the field from the matrix, so only a caller of
+    the C ABI can get this wrong; here the field is overwritten by hand.)"""
+    n, T, B = 32, 20, 24
+    cfg = dict(problems.reservoir_config(n, seed=3))
+    D = np.array(cfg["downstream"])
+    D[5, 6] = 0.0                                                     # two chains: not a shift of the whole state
+    cfg["downstream"] = D.tolist()
+    env = Reservoir.load(cfg)
+    assert env.coupling_shift == 0
+    x0 = np.random.default_rng(1).uniform(20.0, 90.0, size=(B, n, 1)).astype(np.float32)
+    solver = iLQR(env, max_iterations=3)
+    u0 = solver.random_actions(T, B, seed=1)
+    force_kernel("costate_mfma")
+    with _hip.option("TFMPC_COSTATE_WAVES", "1"):
+        good = solver.solve_device(x0, T, u_init=u0)
+        torch.cuda.synchronize()
+        assert int(good["status"].abs().sum()) == 0
+        env.coupling_shift = 1                                        # the false statement
+        env._c_env_cache = None
+        bad = iLQR(env, max_iterations=3).solve_device(x0, T, u_init=u0)
+        torch.cuda.synchronize()
+    assert bad["status"].tolist() == [_hip.ST_ENV_FLAG] * B

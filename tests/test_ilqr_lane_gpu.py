@@ -162,6 +162,25 @@ def test_instance_queue_of_the_persistent_groups(force_kernel):
     assert int(ref["iterations"].max()) >= 30 and int(ref["iterations"].min()) <= 3     # the spread the queue exists for
 
 
+def test_persistent_grid_follows_the_horizon_of_each_launch(force_kernel):
+    """the persistent grid (wavefronts the chip holds at once) depends on the launch's dynamic LDS, i.e. on the horizon
+    (~112 T bytes per wavefront).  It used to be frozen at the first launch of the process: a first solve at a long horizon left every
+    later T = 50 launch with a third of the wavefronts.  Now cached per (device, LDS bytes): a long-horizon launch FIRST, then T = 50 --
+    the second grid must be the larger one, and a T = 50 launch that comes before / after agrees with it."""
+    lib = _hip.require_gpu()
+    rng = np.random.default_rng(5)
+    B = 16384
+    solver = iLQR(Navigation.load(problems.NAV_CONFIG), max_iterations=2)
+    x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
+    grids = {}
+    for T in (400, 50, 400, 50):
+        solver.solve_device(x0, T, u_init=solver.random_actions(T, B, seed=1))
+        torch.cuda.synchronize()
+        grids.setdefault(T, []).append(int(lib.tfmpc_ilqr_last_group_grid()))
+    assert grids[50][0] == grids[50][1] and grids[400][0] == grids[400][1], grids
+    assert grids[50][0] >= 2 * grids[400][0] > 0, grids
+
+
 def test_two_variable_boxqp_closed_form_against_the_restatement():
     """The lane kernels' box-QP for two actions (closed form over the nine candidate active sets, iteration as fall-back;
     reached through tfmpc_boxqp_f32 at m = 2) against oracle/boxqp_ref.py (optimization.py:6-101 restated) on 4 000 random

@@ -267,4 +267,4 @@ def test_solve_trace_true_on_an_lq_env_stays_on_the_matrix_core_kernel():
     assert solver.last_kernel.startswith("lq_mfma (matrix cores)")            # tfmpc_ilqr_last_kernel_name: traced or not
     with _hip.option("TFMPC_ILQR_KERNEL", "wave"):
         traj_w, it_w = solver.solve(x0, w["T"], show_progress=False, u_init=u0)
-    assert it_w == it and not np.array_equal(traj_w.states, traj.states)     # another program: other rounding
+    assert it_w == it and not solver.last_kernel.startswith("lq_mfma")       # another kernel (told apart by its name, not by its rounding)

@@ -11,16 +11,20 @@ import concurrent.futures
 import os
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import check_ring_waits  # noqa: E402
 
 
+@pytest.mark.skipif(check_ring_waits.hipcc_path() is None, reason="needs the device compiler (hipcc) to produce the assembly")
 def test_the_cfg5_kernels_wait_for_what_the_compiler_emits():
+    """Parts 0, 4 and 8: HVAC, Reservoir and the Reservoir chain instantiation (round 5) at two tiles."""
     with concurrent.futures.ThreadPoolExecutor(max_workers=2) as pool:       # (the work is in hipcc child processes)
-        results = list(pool.map(check_ring_waits.check_part, (0, 4)))
-    for part, (findings, checked) in zip((0, 4), results):
-        assert checked >= 20, (part, checked)                                # the loops were found at all
+        results = list(pool.map(check_ring_waits.check_part, (0, 4, 8)))
+    for part, (findings, checked) in zip((0, 4, 8), results):
+        assert checked >= (3 if part == 8 else 20), (part, checked)                                # the loops were found at all
         assert not findings, (part, findings[:3])
 
 

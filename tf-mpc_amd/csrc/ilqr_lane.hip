@@ -11,7 +11,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "envs.h"
 #include "lqr_kernels.h"
@@ -1098,16 +1100,31 @@ size_t ilqr_lane_extra_workspace_bytes(int B, int n, int m, int T)
     return blocks * (size_t)ScratchSink<2, 2>::rows(T) * 64 * sizeof(float) + 256 + kQueueBytes;      // + the instance queue's counter
 }
 
-// Wavefronts of the group kernel the chip holds at once (what a persistent grid is sized by), per variant; asked once per process.
+// Wavefronts of the group kernel the chip holds at once (what a persistent grid is sized by).  The answer depends on the kernel variant, on
+// the DEVICE and on the dynamic LDS of the launch -- which grows with the horizon (~112 T bytes) -- so it is cached per (device, LDS bytes)
+// and not per process: a first solve at a long horizon (few blocks per CU) must not size the grid of every later T = 50 launch
+// (a call-order-dependent 2-3 x loss).  The two driver queries cost microseconds on a miss.
 template <class Kern>
 static int resident_blocks(Kern kern, size_t lds)
 {
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
+    struct Entry { int dev; size_t lds; int blocks; };
+    static std::mutex lock;
+    static std::vector<Entry> cache;            // per kernel variant (this function is a template)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    std::lock_guard<std::mutex> g(lock);
+    for (const Entry &e : cache)
+        if (e.dev == dev && e.lds == lds) return e.blocks;
+    int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), 64, lds) != hipSuccess || per_cu < 1) per_cu = 8;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return per_cu * 256;
-    return per_cu * prop.multiProcessorCount;
+    if (dev < 0 || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    const int blocks = per_cu * cus;
+    if (dev >= 0) cache.push_back(Entry{dev, lds, blocks});
+    return blocks;
 }
+
+// grid of the last persistent group launch of this thread (tfmpc_ilqr_last_group_grid: a diagnostic, like tfmpc_ilqr_last_kernel_name)
+static thread_local int g_last_group_grid = 0;
 
 template <int KIND>
 static int group_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const SolveArgsLane &a, hipStream_t stream)
@@ -1122,8 +1139,9 @@ static int group_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const S
     } else {
         // persistent grid: as many wavefronts as are resident at once (or fewer, if the batch is smaller); the groups
         // pull instances from the queue until it is empty
-        static const int resident = resident_blocks(ilqr_group_solve_kernel<KIND, 2, 2, 4>, lds4);
+        const int resident = resident_blocks(ilqr_group_solve_kernel<KIND, 2, 2, 4>, lds4);
         const int blocks = std::min((B + 3) / 4, resident);
+        g_last_group_grid = blocks;
         hipLaunchKernelGGL((ilqr_group_solve_kernel<KIND, 2, 2, 4>), dim3(blocks), block, lds4, stream, env, cfg, a);
     }
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
@@ -1172,3 +1190,5 @@ int ilqr_lane_solve_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, int 
 }
 
 }  // namespace tfmpc
+
+extern "C" int tfmpc_ilqr_last_group_grid(void) { return tfmpc::g_last_group_grid; }

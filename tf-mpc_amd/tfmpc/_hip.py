@@ -27,6 +27,7 @@ _SIGNATURES = {
     "tfmpc_get_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]),
     "tfmpc_lqr_kernel_name": (ctypes.c_char_p, [_I, _I, _I]),
     "tfmpc_ilqr_last_kernel_name": (ctypes.c_char_p, []),
+    "tfmpc_ilqr_last_group_grid": (ctypes.c_int, []),
     "tfmpc_lqr_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "tfmpc_lqr_backward_f32": (_I, [_I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L,
                                     _P, _P, _P, _P, _P, _P, _P]),

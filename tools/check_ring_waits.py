@@ -21,7 +21,7 @@ FLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -am
 def assembly(part):
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "x.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, f"-DTFMPC_AM_PART={part}", "--cuda-device-only", "-S", SRC, "-o", out],
+        subprocess.run([hipcc_path(), *FLAGS, f"-DTFMPC_AM_PART={part}", "--cuda-device-only", "-S", SRC, "-o", out],
                        check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         return open(out).read()
 
@@ -95,6 +95,15 @@ def check_kernel(name, items):
                             f"vector-memory instructions per step: " + ("the wait counts MORE operations than a step issues -- it would return early"
                                                                          if n > k * vm else "the wait is not a whole number of steps' loads"))
     return findings, checked
+
+
+def hipcc_path():
+    """The device compiler: PATH, then $ROCM_PATH/bin, then /opt/rocm/bin; None if there is none (a CPU-only box without ROCm)."""
+    import shutil
+    for cand in (shutil.which("hipcc"), os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
 
 
 def check_part(part):

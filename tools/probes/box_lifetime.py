@@ -1,5 +1,5 @@
 """Control-limited kernel, 65 536 problems: where the sweeps and rollouts of the long-running instances go (probe build:
-hipcc ... -DTFMPC_BOX_PROBE ilqr_lq_box_mfma.hip, loaded through TFMPC_LIB).  A rejected line search is followed by a pass
+tools/probes/build_boxprobe.sh: ilqr_lq_box_mfma.hip with -DTFMPC_BOX_PROBE, loaded through TFMPC_LIB).  A rejected line search is followed by a pass
 that probes the SAME regularisation levels shifted by one (mu <- max(mu_min, mu delta) is the local bump's own step, ilqr.py:267-270
 vs :308-309) on the SAME nominal trajectory: counted here as 'repeats'."""
 import ctypes, os, sys
@@ -11,8 +11,9 @@ from tfmpc import _hip
 from tfmpc.envs.lq import LQEnv
 from tfmpc.solvers.ilqr import iLQR
 B = 65536
+SCALE = float(os.environ.get("BOX_F_SCALE", "0.25"))         # 0.25: bench.py's `control_limited`; 0.18: its stable-open-loop variant (tests/workloads.py)
 F, f, C, c, x0 = problems.make_lqr_batch_fast(B, 16, 8, seed=4321)
-s = iLQR(LQEnv(0.25 * F, f, C, c, low=-0.5, high=0.5))
+s = iLQR(LQEnv(SCALE * F, f, C, c, low=-0.5, high=0.5))
 u0 = torch.zeros(B, 50, 8, 1, device="cuda")
 x0 = x0[..., None].astype(np.float32)
 lib = _hip.load()
