@@ -42,6 +42,7 @@ import torch
 import torch.distributed as dist
 
 N_STATE, N_ACTION, HORIZON, BATCH = 16, 8, 50, 65536
+CPU_BASELINES = True             # (--no-cpu-baseline clears it: profiling runs)
 PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md:41-42 (vector == f32-MFMA dense peak)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md:36 (spec)
 
@@ -121,6 +122,52 @@ def pmc_traffic(kernel_substring, per_launch_units, units):
     return None
 
 
+def pmc_executed(kernel_substring):
+    """What the kernel EXECUTED per launch, from the newest committed PMC summary taken on its current sources (else None): share of the
+    SIMD cycles the vector unit / the matrix unit was busy (SQ_ACTIVE_INST_VALU x 4, SQ_VALU_MFMA_BUSY_CYCLES over 1 024 SIMDs x
+    GRBM_GUI_ACTIVE / 8) and a wave's share of its residence spent in s_waitcnt -- the issue-side yardstick of the kernels whose
+    algorithmic-byte or dense-flop fractions say nothing about headroom (latency- / issue-bound formulations)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        for name, c in d.get("counters_per_launch", {}).items():
+            if kernel_substring in name and "SQ_ACTIVE_INST_VALU" in c and c.get("GRBM_GUI_ACTIVE"):
+                key = max((k for k in KERNEL_SOURCES if k in kernel_substring or kernel_substring in k), key=len, default=None)
+                if not _summary_is_current(d, key):
+                    return None
+                simd_cycles = 1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0
+                return {"valu_busy_frac": 4.0 * c["SQ_ACTIVE_INST_VALU"] / simd_cycles,
+                        "mfma_busy_frac": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / simd_cycles,
+                        "wave_time_in_waitcnt_frac": (c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAVE_CYCLES") else None,
+                        "valu_instructions_per_launch": c.get("SQ_INSTS_VALU"), "source": "profiles/" + os.path.basename(path)}
+    return None
+
+
+def ilqr_cpu_baseline(kind, cfgs, x0, u0, T, max_iterations, instances, what):
+    """`cpu_baseline` of a secondary iLQR line: the fp32 numpy restatement of the reference (oracle/ilqr_ref.py: ilqr.py:214-283, one
+    problem at a time -- the reference's own execution model, minus TensorFlow's dispatch) on the FIRST `instances` instances of the
+    same workload, one core.  A stated baseline, not a target."""
+    import trace_oracle
+    from oracle import ilqr_ref
+    x0 = np.asarray(x0[:instances].cpu() if hasattr(x0, "cpu") else x0[:instances], dtype=np.float32)
+    u0 = np.asarray(u0[:instances].cpu() if hasattr(u0, "cpu") else u0[:instances], dtype=np.float32)
+    its, t0 = 0, time.perf_counter()
+    with np.errstate(all="ignore"):
+        for b in range(len(x0)):
+            o = ilqr_ref.ILQRRef(trace_oracle.make_env(kind, cfgs[b] if isinstance(cfgs, list) else cfgs, np.float32), dtype=np.float32,
+                                 max_iterations=max_iterations)
+            try:
+                its += o.solve(x0[b].reshape(-1, 1), T, u_init=u0[b].reshape(T, -1, 1))[3] + 1
+            except Exception:                                 # noqa: BLE001 -- (regularisation diverged on an fp32-unposable instance)
+                its += max_iterations
+    dt = time.perf_counter() - t0
+    return {"value": its / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{len(x0)} instances of {what}, fp32 numpy restatement of ilqr.py (oracle/ilqr_ref.py), one at a time, {dt:.1f} s"}
+
+
 def roofline_hbm(alg_bytes, seconds, traffic):
     gbs = alg_bytes / seconds / 1e9
     return {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
@@ -164,8 +211,12 @@ def ilqr_api_rate(n, m, T, B, reps=5):
 
     # the workloads are defined in tests/workloads.py, the module the decision-trace parity tests draw them from
     # (tests/test_ilqr_lq_trace_gpu.py); `workload_version` says which definition a number belongs to
-    res = api_line(workloads.ilqr_api_warm(B, n, m, T))
+    w_warm = workloads.ilqr_api_warm(B, n, m, T)
+    res = api_line(w_warm)
+    if CPU_BASELINES:
+        res["cpu_baseline"] = ilqr_cpu_baseline("lq", [workloads.instance_cfg(w_warm, b) for b in range(8)], w_warm["x0"], w_warm["u0"], T, 100, 8, w_warm["version"])
     res["roofline"]["traffic"] = pmc_traffic("ilqr_lq_mfma_kernel", 65536, B)
+    res["roofline"]["executed"] = pmc_executed("ilqr_lq_mfma_kernel")
     res["roofline"]["kernel"] = "ilqr_lq_mfma_kernel (profiles/r04_ilqr_api_kernel_stats.csv: tools/ilqr_api_once.py under rocprofv3)"
     # the same problems from zero actions: the first rollout runs open loop through an unstable system, several step sizes are tried
     cold = api_line(workloads.ilqr_api_cold(B, n, m, T))
@@ -190,6 +241,23 @@ def ilqr_api_rate(n, m, T, B, reps=5):
     wl_run, wl = wl, workloads.control_limited_stable(B, n, m, T)
     stable = limited("linear probe 0, 1, 2, ... (ilqr.py:285-315; the default)")
     stable["workload"], stable["workload_version"] = wl["text"], wl["version"]
+    stable["executed"] = pmc_executed("ilqr_lq_box_mfma")
+    if CPU_BASELINES:
+        stable["cpu_baseline"] = ilqr_cpu_baseline("lq", [workloads.instance_cfg(wl, b) for b in range(8)], wl["x0"], wl["u0"], T, 100, 8, wl["version"])
+    # ... and with a box so wide (+-2) that the box-QP rarely clamps while the rollout's clip still bites: the one LQ line on which the line
+    # search BACKTRACKS (an LQ problem's Newton step is exact, so the unbounded lines above accept the first step size every time);
+    # rollouts per iteration measured from the decision trace of the same solve
+    wl = workloads.control_limited_stable(B, n, m, T, bound=2.0)
+    wide = limited("linear probe (default)")
+    tr = workloads.solver_of(wl).solve_device(wl["x0"], wl["T"], u_init=wl["u0"], trace_rows=170)
+    rows, ln = tr["trace"], tr["trace_len"]
+    valid = torch.arange(rows.shape[1], device=rows.device)[None, :] < ln[:, None]
+    searched = valid & (rows[..., 8] >= 0)
+    wide["rollouts_per_iteration_measured"] = float((rows[..., 5] + 1)[searched].sum()) / max(float((tr["iterations"].double() + 1).sum()), 1.0)
+    wide["passes_whose_line_search_backtracked"] = int((searched & (rows[..., 5] > 0)).sum())
+    wide["workload"], wide["workload_version"] = wl["text"] + " -- box widened to +-2", wl["version"] + "+box2"
+    del tr, rows
+    stable["wide_box_variant"] = wide
     wl = wl_run
     res["control_limited"] = limited("linear probe 0, 1, 2, ... (ilqr.py:285-315; the default)")
     res["control_limited"]["stable_open_loop_variant"] = stable
@@ -296,6 +364,17 @@ def other_config_rates():
     x0 = rng.uniform(0, 10, size=(Bn, 2, 1)).astype(np.float32)
     u0 = solver.random_actions(50, Bn, seed=4)
     res["cfg4_navigation_ilqr"] = ilqr_line(solver, x0, 50, u0, 2, alg_bytes=1820, pmc=("ilqr_group_solve", 142719))
+    ex4 = pmc_executed("ilqr_group_solve")
+    if ex4 is not None:
+        # HBM is the wrong yardstick for this kernel (30 GB/s of 8 TB/s): it is bound by the issue and latency of its own instruction stream.
+        # Issue side: the rate the same instruction stream would reach with the vector unit busy every cycle.
+        r4 = res["cfg4_navigation_ilqr"]
+        r4["roofline_issue_side"] = {"bound": "valu_issue", "achieved": r4["iterations_per_s"], "unit": "iterations/s",
+                                     "peak": r4["iterations_per_s"] / max(ex4["valu_busy_frac"], 1e-9), "frac": ex4["valu_busy_frac"],
+                                     "executed": ex4, "note": "frac = share of the SIMD cycles the vector unit is busy in the profiled launch "
+                                                              "(single batch: 3 072 waves, a straggler's dependent iterations set the time)"}
+    if CPU_BASELINES:
+        res["cfg4_navigation_ilqr"]["cpu_baseline"] = ilqr_cpu_baseline("navigation", problems.NAV_CONFIG, x0, u0, 50, 100, 4, "Navigation (nav.config.json), T=50")
     res["cfg4_navigation_ilqr"]["note"] = ("one launch lasts as long as its slowest instance (median 8 iterations, p99 20, max 87: "
                                            "profiles/r02_cfg4_iteration_histogram.json); a larger launch keeps the chip full (below); round 3: "
                                            "closed-form two-variable box-QP, hardware sqrt / exp2 / rcp in the env")
@@ -332,12 +411,17 @@ def other_config_rates():
         tfl = flop / (line["ms_per_batch"] * 1e-3) / 1e12
         line["rollouts_per_iteration_measured"] = rollouts / max(its_c, 1.0)
         line["backward_passes_per_iteration_measured"] = passes / max(its_c, 1.0)
-        line["roofline_flop_side"] = {"bound": "mfma", "achieved": tfl, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tfl / PEAK_F32_TFLOPS,
+        # NOT a utilisation figure: SURVEY's dense count (4 n^2 per step and product) divided by time; the kernel evaluates the env's
+        # Jacobians in closed form and, on Reservoir, replaces the products by row moves -- see `executed` for what the units did
+        line["algorithmic_flop_rate"] = {"bound": "mfma", "achieved": tfl, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tfl / PEAK_F32_TFLOPS,
                                       "algorithmic_flop": flop, "algorithmic_flop_per_iteration": flop / max(its_c, 1.0),
                                       "flop_per_algorithmic_byte": flop / max(its_c, 1.0) / (4 * (2 * (T + 1) * n + 2 * T * n + (T + 1))),
                                       "note": "dense count of SURVEY.md 8(d) with the measured rollouts; the ridge is 157.3 TF / 8 TB/s = 19.7 flop/B"}
         del tr, rows
         line["workload_version"] = w5["version"]
+        line["executed"] = pmc_executed(kernel_tag)
+        if CPU_BASELINES:
+            line["cpu_baseline"] = ilqr_cpu_baseline(kind, w5["cfg"], x0, u0c, T, 12, 3, w5["version"])
         res[f"cfg5_{kind}_ilqr_n32"] = line
     # the reference's own env configs (hvac6.config.json n = 6, res4.config.json n = 4) at a large batch
     for name, env, x0r, kernel_tag in (("hvac6", HVAC.load(dict(problems.HVAC6_CONFIG)), problems.HVAC6_X0, "ilqr_adjoint_mfma_kernel<3, 1"),
@@ -537,12 +621,12 @@ def summarise_extras(extra):
            "cfg4_one_launch_8x16384_Mit_s": r3((get(oc, "cfg4_navigation_ilqr", "one_launch_of_8x16384_instances", "iterations_per_s") or 0) / 1e6),
            "bf16_sweep": get(extra, "bf16_storage_sweep") if isinstance(extra, dict) and "error" not in (extra.get("bf16_storage_sweep") or {}) else None,
            "torchenv_kit_s": r3((get(extra, "torchenv_generic_env", "iterations_per_s") or 0) / 1e3),
-           "format": "[ms per batch, roofline frac (, flop-side frac)]"}
+           "format": "[ms per batch, roofline frac (, algorithmic flop rate / fp32 peak)]"}
     for key, short in (("cfg5_hvac_ilqr_n32", "cfg5_hvac"), ("cfg5_reservoir_ilqr_n32", "cfg5_reservoir"), ("hvac6_reference_config_ilqr", "hvac6"),
                        ("res4_reference_config_ilqr", "res4"), ("cfg5_literal_dims_ilqr_lq_n32_m16", "literal_dims"), ("lqr_n32_m16", "lqr_n32_m16")):
         v = [r3(get(oc, key, "ms_per_batch")), r3(get(oc, key, "roofline", "frac"))]
-        if get(oc, key, "roofline_flop_side", "frac") is not None:
-            v.append(r3(get(oc, key, "roofline_flop_side", "frac")))
+        if get(oc, key, "algorithmic_flop_rate", "frac") is not None:
+            v.append(r3(get(oc, key, "algorithmic_flop_rate", "frac")))
         out[short] = v
     if isinstance(out.get("bf16_sweep"), dict):
         out["bf16_sweep"] = {k.replace("hvac_", "").replace("_state_rel_err_vs_fp64", "").replace("_total_cost_rel_diff_bf16_vs_fp32", "_cost"): r3(v)
@@ -556,6 +640,8 @@ def extras_only(args):
     if not sys.stdin.readline():
         return 1                                              # the parent went away before the headline was measured
     n, m, T, B = N_STATE, N_ACTION, HORIZON, args.batch
+    global CPU_BASELINES
+    CPU_BASELINES = not args.no_cpu_baseline
     extra = {}
     try:
         extra["ilqr_api"] = ilqr_api_rate(n, m, T, B)
@@ -750,7 +836,11 @@ def main():
                        "kernel": kernel},
             "timestep_iterations_per_s": value * T,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": achieved / PEAK_F32_TFLOPS,
+                         "peak_note": "fp32 peak (vector == f32-MFMA dense peak); the default kernel's products run as bf16x3 on the bf16 matrix "
+                                      "pipe (dense peak ~2.5 PFLOP/s), so this is the fp32-equivalent rate against the fp32 yardstick -- "
+                                      "`strict_f32_variant` is the like-for-like figure",
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_unit": "HBM bytes per launch (PMC, profiles/)",
                          "traffic_note": "algorithmic bytes + the gain round trip: K_t, k_t (27.2 KB per solve) are produced "
                                          "backwards and consumed forwards, written once and read once = 3.57 GB per launch "
@@ -788,7 +878,15 @@ def main():
             line["extra"] = collect_extras(extras_child)
             # the secondary numbers once more, compact and LAST in the line: a log that keeps only the tail of the line still shows them
             line["extra_summary"] = summarise_extras(line["extra"])
-        print(json.dumps(line), flush=True)
+        # five keys FIRST in the line (a log that keeps only the head of the line still shows them), the full blocks follow
+        sx = line.get("extra_summary") or {}
+        first = {"summary": {"headline_frac_of_fp32_peak": round(achieved / PEAK_F32_TFLOPS, 4),
+                             "strict_f32_variant_frac": None if f32_ms is None else round(line["strict_f32_variant"]["frac"], 4),
+                             "lqr_mfma_option": line["lqr_mfma_option"],
+                             "ilqr_api_warm_ms_frac": sx.get("ilqr_api_warm"),
+                             "secondary_ms_frac": {k: sx.get(k) for k in ("cfg5_hvac", "cfg5_reservoir", "hvac6", "res4", "literal_dims") if k in sx}}}
+        first.update(line)
+        print(json.dumps(first), flush=True)
 
     if use_dist:
         dist.barrier()

@@ -106,7 +106,7 @@ def test_extra_summary_is_compact_and_survives_missing_entries():
     full = bench.summarise_extras({
         "ilqr_api": {"ms_per_batch": 5.4588, "roofline": {"frac": 0.35744}, "cold_start": {"ms_per_batch": 5.57, "roofline": {"frac": 0.357}},
                      "control_limited": {"ms_per_batch": 512.6, "stable_open_loop_variant": {"ms_per_batch": 88.86}}},
-        "other_configs": {"cfg5_hvac_ilqr_n32": {"ms_per_batch": 13.147, "roofline": {"frac": 0.1938}, "roofline_flop_side": {"frac": 0.4294}},
+        "other_configs": {"cfg5_hvac_ilqr_n32": {"ms_per_batch": 13.147, "roofline": {"frac": 0.1938}, "algorithmic_flop_rate": {"frac": 0.4294}},
                           "cfg4_navigation_ilqr": {"ms_per_batch": 9.19, "one_launch_of_8x16384_instances": {"iterations_per_s": 56.14e6}}},
         "bf16_storage_sweep": {"error": "x"}})
     assert full["ilqr_api_warm"] == [5.46, 0.357] and full["cfg5_hvac"] == [13.1, 0.194, 0.429] and full["cfg4_one_launch_8x16384_Mit_s"] == 56.1

@@ -164,7 +164,7 @@ def test_instance_queue_of_the_persistent_groups(force_kernel):
 
 def test_persistent_grid_follows_the_horizon_of_each_launch(force_kernel):
     """the persistent grid (wavefronts the chip holds at once) depends on the launch's dynamic LDS, i.e. on the horizon
-    (~112 T bytes per wavefront).  It used to be frozen at the first launch of the process: a first solve at a long horizon left every
+    (~208 T bytes per wavefront).  It used to be frozen at the first launch of the process: a first solve at a long horizon left every
     later T = 50 launch with a third of the wavefronts.  Now cached per (device, LDS bytes): a long-horizon launch FIRST, then T = 50 --
     the second grid must be the larger one, and a T = 50 launch that comes before / after agrees with it."""
     lib = _hip.require_gpu()
@@ -173,12 +173,12 @@ def test_persistent_grid_follows_the_horizon_of_each_launch(force_kernel):
     solver = iLQR(Navigation.load(problems.NAV_CONFIG), max_iterations=2)
     x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
     grids = {}
-    for T in (400, 50, 400, 50):
+    for T in (200, 50, 200, 50):          # 41.8 KB against 10.5 KB of LDS per wavefront (208 T + 32 bytes)
         solver.solve_device(x0, T, u_init=solver.random_actions(T, B, seed=1))
         torch.cuda.synchronize()
         grids.setdefault(T, []).append(int(lib.tfmpc_ilqr_last_group_grid()))
-    assert grids[50][0] == grids[50][1] and grids[400][0] == grids[400][1], grids
-    assert grids[50][0] >= 2 * grids[400][0] > 0, grids
+    assert grids[50][0] == grids[50][1] and grids[200][0] == grids[200][1], grids
+    assert grids[50][0] >= 2 * grids[200][0] > 0, grids
 
 
 def test_two_variable_boxqp_closed_form_against_the_restatement():

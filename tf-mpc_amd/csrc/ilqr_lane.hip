@@ -1101,7 +1101,7 @@ size_t ilqr_lane_extra_workspace_bytes(int B, int n, int m, int T)
 }
 
 // Wavefronts of the group kernel the chip holds at once (what a persistent grid is sized by).  The answer depends on the kernel variant, on
-// the DEVICE and on the dynamic LDS of the launch -- which grows with the horizon (~112 T bytes) -- so it is cached per (device, LDS bytes)
+// the DEVICE and on the dynamic LDS of the launch -- which grows with the horizon (~208 T bytes) -- so it is cached per (device, LDS bytes)
 // and not per process: a first solve at a long horizon (few blocks per CU) must not size the grid of every later T = 50 launch
 // (a call-order-dependent 2-3 x loss).  The two driver queries cost microseconds on a miss.
 template <class Kern>
