@@ -314,6 +314,46 @@ def torchenv_rate(B=1024, T=40):
                     "the built-in envs run fused"}
 
 
+def deviceenv_rate(B=16384, T=50):
+    """Secondary number (SURVEY.md 8f N2 at hot-path speed, round 5): BASELINE configs[3]'s Navigation env given as C++ DEVICE source
+    (tests/deviceenv_sources.py) to tfmpc.envs.deviceenv.DeviceEnv -- compiled with hipcc when first used, derivatives by forward-mode dual
+    numbers one direction per lane, the fused wave-per-instance solve kernel -- beside the same env on the built-in kernels."""
+    import deviceenv_sources as sources
+    import problems
+    from tfmpc import _hip
+    from tfmpc.envs.deviceenv import DeviceEnv
+    from tfmpc.envs.navigation import Navigation
+    from tfmpc.solvers.ilqr import iLQR
+    cfg = problems.NAV_CONFIG
+    rng = np.random.default_rng(4)
+    x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
+    builtin = iLQR(Navigation.load(cfg))
+    u0 = builtin.random_actions(T, B, seed=4)
+    t0 = time.perf_counter()
+    user = iLQR(DeviceEnv(sources.NAVIGATION, 2, 2, params=sources.navigation_params(cfg), low=np.array(cfg["low"]), high=np.array(cfg["high"])))
+    user.env._library()
+    ready = time.perf_counter() - t0
+
+    def timed(solver, option=None):
+        with _hip.option("TFMPC_ILQR_KERNEL", option):
+            out = solver.solve_device(x0, T, u_init=u0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = solver.solve_device(x0, T, u_init=u0, workspace=out["workspace"])
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        return dt, float((out["iterations"].double() + 1).sum())
+    dt_u, its_u = timed(user)
+    dt_w, its_w = timed(builtin, "wave")
+    dt_g, its_g = timed(builtin)
+    return {"iterations_per_s": its_u / dt_u, "ms_per_batch": dt_u * 1e3, "mean_iterations": its_u / B, "batch": B, "horizon": T,
+            "library_ready_s": ready, "kernel": user.last_kernel,
+            "same_env_builtin_generic_wave_kernel_ms": dt_w * 1e3, "same_env_builtin_lane_group_kernel_ms": dt_g * 1e3,
+            "workload": "Navigation (nav.config.json) as DeviceEnv source: transition / cost / final_cost as C++ device functions, derivatives by dual numbers",
+            "note": "a user env runs at the speed of a built-in env on the generic wave kernel; the 2-D envs' own lane-group kernel "
+                    "(16 lanes per instance) is a specialisation no user env gets"}
+
+
 def other_config_rates():
     """Secondary numbers (not `value`): the other BASELINE.json configs, timed launches after a warm-up --
     cfg2 navlin LQR (B=4096), cfg4 Navigation iLQR (B=16384: single batch, AND one launch of 8 x 16384 instances through the persistent kernel), cfg5 HVAC / Reservoir
@@ -621,6 +661,7 @@ def summarise_extras(extra):
            "cfg4_one_launch_8x16384_Mit_s": r3((get(oc, "cfg4_navigation_ilqr", "one_launch_of_8x16384_instances", "iterations_per_s") or 0) / 1e6),
            "bf16_sweep": get(extra, "bf16_storage_sweep") if isinstance(extra, dict) and "error" not in (extra.get("bf16_storage_sweep") or {}) else None,
            "torchenv_kit_s": r3((get(extra, "torchenv_generic_env", "iterations_per_s") or 0) / 1e3),
+           "deviceenv_Mit_s": r3((get(extra, "deviceenv_user_env", "iterations_per_s") or 0) / 1e6),
            "format": "[ms per batch, roofline frac (, algorithmic flop rate / fp32 peak)]"}
     for key, short in (("cfg5_hvac_ilqr_n32", "cfg5_hvac"), ("cfg5_reservoir_ilqr_n32", "cfg5_reservoir"), ("hvac6_reference_config_ilqr", "hvac6"),
                        ("res4_reference_config_ilqr", "res4"), ("cfg5_literal_dims_ilqr_lq_n32_m16", "literal_dims"), ("lqr_n32_m16", "lqr_n32_m16")):
@@ -659,6 +700,10 @@ def extras_only(args):
             extra["torchenv_generic_env"] = torchenv_rate()
         except Exception as exc:                              # noqa: BLE001
             extra["torchenv_generic_env"] = {"error": repr(exc)}
+        try:
+            extra["deviceenv_user_env"] = deviceenv_rate()
+        except Exception as exc:                              # noqa: BLE001
+            extra["deviceenv_user_env"] = {"error": repr(exc)}
     except Exception as exc:                                  # noqa: BLE001
         extra["other_configs_error"] = repr(exc)
     if not args.no_cpu_baseline:

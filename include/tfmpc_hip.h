@@ -180,6 +180,12 @@ int tfmpc_lqr_solve_general_f32(int B, int n, int m, int T,
 #define TFMPC_ENV_NAVIGATION 2  /* tfmpc/envs/navigation/__init__.py:9-74  (cec=True)                   */
 #define TFMPC_ENV_HVAC 3        /* tfmpc/envs/hvac/__init__.py:8-149                                    */
 #define TFMPC_ENV_RESERVOIR 4   /* tfmpc/envs/reservoir/__init__.py:9-105 (cec=True)                    */
+#define TFMPC_ENV_USER 5        /* ANY differentiable env (tfmpc/envs/diffenv.py:13-101 differentiates whatever it is handed): transition /
+                                   cost / final_cost given as device functions, derivatives by forward-mode dual numbers in the kernel.  Not
+                                   served by this library's entry points (TFMPC_ERR_ARG): tfmpc.envs.deviceenv compiles csrc/user_env_kernels.hip.in
+                                   around the user's source into a companion library that exports tfmpc_userenv_* twins of the env-dependent
+                                   entry points (rollout, derivatives, forward, solve_trace; same signatures).  p0 = the env's parameter
+                                   floats, n_zones of them per instance. */
 #define TFMPC_ENV_MAX_PARAMS 10
 #define TFMPC_MAX_ALPHAS 16
 

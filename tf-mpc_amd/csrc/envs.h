@@ -47,6 +47,7 @@ __host__ __device__ inline int env_param_len(int kind, int i, int n, int m, int 
     case TFMPC_ENV_NAVIGATION: { const int len[3] = {n, zones * n, zones}; return i < 3 ? len[i] : 0; }
     case TFMPC_ENV_HVAC: return i < 8 ? n : (i == 8 ? n * n : 0);
     case TFMPC_ENV_RESERVOIR: return i < 7 ? n : (i == 7 ? n * n : 0);
+    case TFMPC_ENV_USER: return i == 0 ? zones : 0;          // p0: the user env's parameter floats, TfmpcEnv::n_zones of them (user_env.h)
     }
     return 0;
 }

@@ -1,0 +1,265 @@
+// user_env.h -- Env<TFMPC_ENV_USER>: "any differentiable env" (the reference differentiates whatever transition / cost it is handed,
+// tfmpc/envs/diffenv.py:13-101) as DEVICE code at hot-path speed.  The user writes three device functions, templated on the scalar type:
+//
+//     template <class S> __device__ void transition(const float *p, const S *x, const S *u, S *x_next);   // x_next[TFMPC_USER_N]
+//     template <class S> __device__ S    cost(const float *p, const S *x, const S *u);
+//     template <class S> __device__ S    final_cost(const float *p, const S *x);
+//
+// (`p`: the instance's parameter floats; arithmetic, comparisons, sqrt exp log sin cos tanh abs pow max min on S.)  tfmpc.envs.deviceenv
+// wraps them into a translation unit (user_env_kernels.hip.in) that is compiled with hipcc when the env is first used and instantiates the
+// SAME wave-per-instance kernels the built-in envs run (ilqr_wave_kernels.h) on this Env.  The derivatives iLQR needs
+// (ilqr.py:84-92: f_x, f_u, l_x, l_u, l_xx, l_uu, l_ux; final l_x, l_xx) come from FORWARD-mode automatic differentiation, one direction per
+// LANE: lane j evaluates `transition` on dual numbers seeded with e_j and holds column j of [f_x | f_u]; lane (i, j) evaluates `cost` on
+// second-order duals seeded with (e_i, e_j) and holds l_i, l_j and l_ij -- so a whole linearisation costs about one evaluation of each
+// function, all 64 lanes busy.  Semantics of the reference's GradientTape.batch_jacobian with unconnected_gradients=ZERO
+// (diffenv.py:21-24,40-72): an output that does not depend on an input has derivative 0; max / min / abs differentiate like TensorFlow's
+// (ties of max(a, b) go to the FIRST argument, |y|' = sign(y) with 0 at 0: SURVEY.md Appendix A.3).
+//
+// Included TWICE by the translation unit (user_env_kernels.hip.in): first for the dual numbers (before the user's source, which may name
+// them), then -- with TFMPC_USER_ENV_DEFINE, TFMPC_USER_N, TFMPC_USER_M and the three functions in namespace tfmpc_user defined -- for the Env.
+#ifndef TFMPC_USER_ENV_AD_H
+#define TFMPC_USER_ENV_AD_H
+
+#include <hip/hip_runtime.h>
+
+#include "envs.h"
+
+namespace tfmpc {
+namespace ad {
+
+// value + one infinitesimal direction; nested once (Dual<Dual<float>>) it carries two directions and their mixed second derivative
+template <class T> struct Dual {
+    T v, d;
+    __device__ Dual() {}
+    __device__ Dual(float c) : v(c), d(0.0f) {}
+    __device__ Dual(T v_, T d_) : v(v_), d(d_) {}
+};
+
+__device__ __forceinline__ float prim(float x) { return x; }
+template <class T> __device__ __forceinline__ float prim(const Dual<T> &a) { return prim(a.v); }
+
+template <class T> __device__ __forceinline__ Dual<T> operator+(const Dual<T> &a, const Dual<T> &b) { return Dual<T>(a.v + b.v, a.d + b.d); }
+template <class T> __device__ __forceinline__ Dual<T> operator-(const Dual<T> &a, const Dual<T> &b) { return Dual<T>(a.v - b.v, a.d - b.d); }
+template <class T> __device__ __forceinline__ Dual<T> operator*(const Dual<T> &a, const Dual<T> &b) { return Dual<T>(a.v * b.v, a.d * b.v + a.v * b.d); }
+template <class T> __device__ __forceinline__ Dual<T> operator/(const Dual<T> &a, const Dual<T> &b)
+{
+    const T q = a.v / b.v;
+    return Dual<T>(q, (a.d - q * b.d) / b.v);
+}
+template <class T> __device__ __forceinline__ Dual<T> operator-(const Dual<T> &a) { return Dual<T>(-a.v, -a.d); }
+template <class T> __device__ __forceinline__ Dual<T> operator+(const Dual<T> &a) { return a; }
+// mixed with plain floats (parameters, literals)
+template <class T> __device__ __forceinline__ Dual<T> operator+(const Dual<T> &a, float b) { return Dual<T>(a.v + b, a.d); }
+template <class T> __device__ __forceinline__ Dual<T> operator+(float a, const Dual<T> &b) { return Dual<T>(a + b.v, b.d); }
+template <class T> __device__ __forceinline__ Dual<T> operator-(const Dual<T> &a, float b) { return Dual<T>(a.v - b, a.d); }
+template <class T> __device__ __forceinline__ Dual<T> operator-(float a, const Dual<T> &b) { return Dual<T>(a - b.v, -b.d); }
+template <class T> __device__ __forceinline__ Dual<T> operator*(const Dual<T> &a, float b) { return Dual<T>(a.v * b, a.d * b); }
+template <class T> __device__ __forceinline__ Dual<T> operator*(float a, const Dual<T> &b) { return Dual<T>(a * b.v, a * b.d); }
+template <class T> __device__ __forceinline__ Dual<T> operator/(const Dual<T> &a, float b) { return Dual<T>(a.v / b, a.d / b); }
+template <class T> __device__ __forceinline__ Dual<T> operator/(float a, const Dual<T> &b)
+{
+    const T q = a / b.v;
+    return Dual<T>(q, -(q * b.d) / b.v);
+}
+template <class T> __device__ __forceinline__ Dual<T> &operator+=(Dual<T> &a, const Dual<T> &b) { a = a + b; return a; }
+template <class T> __device__ __forceinline__ Dual<T> &operator-=(Dual<T> &a, const Dual<T> &b) { a = a - b; return a; }
+template <class T> __device__ __forceinline__ Dual<T> &operator*=(Dual<T> &a, const Dual<T> &b) { a = a * b; return a; }
+template <class T> __device__ __forceinline__ Dual<T> &operator/=(Dual<T> &a, const Dual<T> &b) { a = a / b; return a; }
+template <class T> __device__ __forceinline__ Dual<T> &operator+=(Dual<T> &a, float b) { a = a + b; return a; }
+template <class T> __device__ __forceinline__ Dual<T> &operator-=(Dual<T> &a, float b) { a = a - b; return a; }
+template <class T> __device__ __forceinline__ Dual<T> &operator*=(Dual<T> &a, float b) { a = a * b; return a; }
+template <class T> __device__ __forceinline__ Dual<T> &operator/=(Dual<T> &a, float b) { a = a / b; return a; }
+// comparisons look at the value (the branch a float program would take)
+#define TFMPC_AD_CMP(OP)                                                                                                          \
+    template <class T> __device__ __forceinline__ bool operator OP(const Dual<T> &a, const Dual<T> &b) { return prim(a) OP prim(b); } \
+    template <class T> __device__ __forceinline__ bool operator OP(const Dual<T> &a, float b) { return prim(a) OP b; }            \
+    template <class T> __device__ __forceinline__ bool operator OP(float a, const Dual<T> &b) { return a OP prim(b); }
+TFMPC_AD_CMP(<) TFMPC_AD_CMP(>) TFMPC_AD_CMP(<=) TFMPC_AD_CMP(>=) TFMPC_AD_CMP(==) TFMPC_AD_CMP(!=)
+#undef TFMPC_AD_CMP
+
+// elementary functions: f(a) = f(v) + f'(v) d, written on T so that they nest.  (User code calls sqrt / exp / ... unqualified: argument-
+// dependent lookup finds the overloads below for duals and HIP's own float overloads for floats; in here the float case goes through the
+// underscore names, because inside this namespace the templates would hide the global functions.)
+__device__ __forceinline__ float sqrt_(float x) { return ::sqrtf(x); }
+__device__ __forceinline__ float exp_(float x) { return ::expf(x); }
+__device__ __forceinline__ float log_(float x) { return ::logf(x); }
+__device__ __forceinline__ float sin_(float x) { return ::sinf(x); }
+__device__ __forceinline__ float cos_(float x) { return ::cosf(x); }
+__device__ __forceinline__ float tanh_(float x) { return ::tanhf(x); }
+__device__ __forceinline__ float pow_(float x, float p) { return ::powf(x, p); }
+__device__ __forceinline__ float abs_(float x) { return ::fabsf(x); }
+template <class T> __device__ __forceinline__ Dual<T> sqrt(const Dual<T> &a);
+template <class T> __device__ __forceinline__ Dual<T> exp(const Dual<T> &a);
+template <class T> __device__ __forceinline__ Dual<T> log(const Dual<T> &a);
+template <class T> __device__ __forceinline__ Dual<T> sin(const Dual<T> &a);
+template <class T> __device__ __forceinline__ Dual<T> cos(const Dual<T> &a);
+template <class T> __device__ __forceinline__ Dual<T> tanh(const Dual<T> &a);
+template <class T> __device__ __forceinline__ Dual<T> pow(const Dual<T> &a, float p);
+template <class T> __device__ __forceinline__ Dual<T> abs(const Dual<T> &a);
+template <class T> __device__ __forceinline__ Dual<T> sqrt_(const Dual<T> &a) { return sqrt(a); }
+template <class T> __device__ __forceinline__ Dual<T> exp_(const Dual<T> &a) { return exp(a); }
+template <class T> __device__ __forceinline__ Dual<T> log_(const Dual<T> &a) { return log(a); }
+template <class T> __device__ __forceinline__ Dual<T> sin_(const Dual<T> &a) { return sin(a); }
+template <class T> __device__ __forceinline__ Dual<T> cos_(const Dual<T> &a) { return cos(a); }
+template <class T> __device__ __forceinline__ Dual<T> tanh_(const Dual<T> &a) { return tanh(a); }
+template <class T> __device__ __forceinline__ Dual<T> pow_(const Dual<T> &a, float p) { return pow(a, p); }
+template <class T> __device__ __forceinline__ Dual<T> abs_(const Dual<T> &a) { return abs(a); }
+template <class T> __device__ __forceinline__ Dual<T> sqrt(const Dual<T> &a) { const T s = sqrt_(a.v); return Dual<T>(s, a.d / (2.0f * s)); }
+template <class T> __device__ __forceinline__ Dual<T> exp(const Dual<T> &a) { const T e = exp_(a.v); return Dual<T>(e, a.d * e); }
+template <class T> __device__ __forceinline__ Dual<T> log(const Dual<T> &a) { return Dual<T>(log_(a.v), a.d / a.v); }
+template <class T> __device__ __forceinline__ Dual<T> sin(const Dual<T> &a) { return Dual<T>(sin_(a.v), a.d * cos_(a.v)); }
+template <class T> __device__ __forceinline__ Dual<T> cos(const Dual<T> &a) { return Dual<T>(cos_(a.v), -(a.d * sin_(a.v))); }
+template <class T> __device__ __forceinline__ Dual<T> tanh(const Dual<T> &a) { const T t = tanh_(a.v); return Dual<T>(t, a.d * (1.0f - t * t)); }
+template <class T> __device__ __forceinline__ Dual<T> pow(const Dual<T> &a, float p) { return Dual<T>(pow_(a.v, p), a.d * (p * pow_(a.v, p - 1.0f))); }
+// |y|' = sign(y), 0 at 0; max / min: a tie goes to the first argument (TensorFlow's gradients: SURVEY.md Appendix A.3)
+template <class T> __device__ __forceinline__ Dual<T> abs(const Dual<T> &a)
+{
+    const float y = prim(a);
+    return y > 0.0f ? a : (y < 0.0f ? -a : Dual<T>(abs_(a.v), a.d * 0.0f));
+}
+template <class T> __device__ __forceinline__ Dual<T> fabs(const Dual<T> &a) { return abs(a); }
+template <class T> __device__ __forceinline__ Dual<T> max(const Dual<T> &a, const Dual<T> &b) { return prim(a) >= prim(b) ? a : b; }
+template <class T> __device__ __forceinline__ Dual<T> min(const Dual<T> &a, const Dual<T> &b) { return prim(a) <= prim(b) ? a : b; }
+template <class T> __device__ __forceinline__ Dual<T> max(const Dual<T> &a, float b) { return prim(a) >= b ? a : Dual<T>(b); }
+template <class T> __device__ __forceinline__ Dual<T> max(float a, const Dual<T> &b) { return a >= prim(b) ? Dual<T>(a) : b; }
+template <class T> __device__ __forceinline__ Dual<T> min(const Dual<T> &a, float b) { return prim(a) <= b ? a : Dual<T>(b); }
+template <class T> __device__ __forceinline__ Dual<T> min(float a, const Dual<T> &b) { return a <= prim(b) ? Dual<T>(a) : b; }
+template <class T> __device__ __forceinline__ Dual<T> fmax(const Dual<T> &a, const Dual<T> &b) { return max(a, b); }
+template <class T> __device__ __forceinline__ Dual<T> fmin(const Dual<T> &a, const Dual<T> &b) { return min(a, b); }
+
+using D1 = Dual<float>;
+using D2 = Dual<Dual<float>>;
+
+}  // namespace ad
+}  // namespace tfmpc
+
+#endif      // TFMPC_USER_ENV_AD_H
+
+#if defined(TFMPC_USER_ENV_DEFINE) && !defined(TFMPC_USER_ENV_DEFINED)
+#define TFMPC_USER_ENV_DEFINED
+
+namespace tfmpc {
+
+// The instance's parameter floats are p[0] (TfmpcEnv::n_zones of them: envs.h:env_param_len), copied to LDS like every env's.
+template <> struct Env<TFMPC_ENV_USER> {
+    static constexpr bool kPiecewiseLinearCost = false;
+    static constexpr int N = TFMPC_USER_N, M = TFMPC_USER_M, D = N + M;
+
+    template <class S>
+    static __device__ __forceinline__ void seed_point(const float *x, const float *u, S (&xs)[N], S (&us)[M])
+    {
+#pragma unroll
+        for (int i = 0; i < N; ++i) xs[i] = S(x[i]);
+#pragma unroll
+        for (int a = 0; a < M; ++a) us[a] = S(u ? u[a] : 0.0f);
+    }
+
+    // every lane evaluates the same float program (wave-uniform results); lane 0 stores
+    static __device__ void transition(const EnvLds &e, const float *x, const float *u, float *xn)
+    {
+        float xs[N], us[M], out[N];
+        seed_point(x, u, xs, us);
+        tfmpc_user::transition<float>(e.p[0], xs, us, out);
+        if (lane_id() == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) xn[i] = out[i];
+        }
+    }
+    static __device__ float cost(const EnvLds &e, const float *x, const float *u)
+    {
+        float xs[N], us[M];
+        seed_point(x, u, xs, us);
+        return tfmpc_user::cost<float>(e.p[0], xs, us);
+    }
+    static __device__ float final_cost(const EnvLds &e, const float *x)
+    {
+        float xs[N], us[M];
+        seed_point(x, nullptr, xs, us);
+        return tfmpc_user::final_cost<float>(e.p[0], xs);
+    }
+
+    // pair index -> (i, j), i <= j < d, row-major over the upper triangle
+    static __device__ __forceinline__ void unpair(int pidx, int d, int &i, int &j)
+    {
+        i = 0;
+        int rem = pidx;
+        while (rem >= d - i) { rem -= d - i; ++i; }
+        j = i + rem;
+    }
+
+    static __device__ float linearize(const EnvLds &e, const float *x, const float *u, float *fx, float *fu,
+                                      float *lx, float *lu, float *lxx, float *luu, float *lux)
+    {
+        using ad::D1;
+        using ad::D2;
+        const int lane = lane_id(), ldn = odd_ld(N), ldm = odd_ld(M);
+        const float *p = e.p[0];
+        // [f_x | f_u]: lane j holds column j (diffenv.py:21-24)
+        for (int base = 0; base < D; base += kWave) {
+            const int j = base + lane;
+            D1 xs[N], us[M], out[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) xs[i] = D1(x[i], i == j ? 1.0f : 0.0f);
+#pragma unroll
+            for (int a = 0; a < M; ++a) us[a] = D1(u[a], N + a == j ? 1.0f : 0.0f);
+            tfmpc_user::transition<D1>(p, xs, us, out);
+            if (j < N) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) fx[i * ldn + j] = out[i].d;
+            } else if (j < D) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) fu[i * ldm + (j - N)] = out[i].d;
+            }
+        }
+        // gradient and Hessian of the stage cost: lane (i, j) holds l_i, l_j, l_ij (diffenv.py:40-72)
+        float l = 0.0f;
+        constexpr int P = D * (D + 1) / 2;
+        for (int base = 0; base < P; base += kWave) {
+            int i, j;
+            unpair(base + lane < P ? base + lane : P - 1, D, i, j);
+            D2 xs[N], us[M];
+#pragma unroll
+            for (int k = 0; k < N; ++k) xs[k] = D2(D1(x[k], k == i ? 1.0f : 0.0f), D1(k == j ? 1.0f : 0.0f, 0.0f));
+#pragma unroll
+            for (int a = 0; a < M; ++a) us[a] = D2(D1(u[a], N + a == i ? 1.0f : 0.0f), D1(N + a == j ? 1.0f : 0.0f, 0.0f));
+            const D2 c = tfmpc_user::cost<D2>(p, xs, us);
+            l = c.v.v;
+            if (base + lane < P) {
+                const float h = c.d.d;
+                if (j < N) { lxx[i * ldn + j] = h; lxx[j * ldn + i] = h; }
+                else if (i >= N) { luu[(i - N) * ldm + (j - N)] = h; luu[(j - N) * ldm + (i - N)] = h; }
+                else lux[(j - N) * ldn + i] = h;                                  // l_ux[a][i] = d2 l / du_a dx_i
+                if (i == j) { if (i < N) lx[i] = c.v.d; else lu[i - N] = c.v.d; }
+            }
+        }
+        return l;
+    }
+
+    static __device__ float final_quad(const EnvLds &e, const float *x, float *lx, float *lxx)
+    {
+        using ad::D1;
+        using ad::D2;
+        const int lane = lane_id(), ldn = odd_ld(N);
+        float l = 0.0f;
+        constexpr int P = N * (N + 1) / 2;
+        for (int base = 0; base < P; base += kWave) {
+            int i, j;
+            unpair(base + lane < P ? base + lane : P - 1, N, i, j);
+            D2 xs[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) xs[k] = D2(D1(x[k], k == i ? 1.0f : 0.0f), D1(k == j ? 1.0f : 0.0f, 0.0f));
+            const D2 c = tfmpc_user::final_cost<D2>(e.p[0], xs);
+            l = c.v.v;
+            if (base + lane < P) {
+                lxx[i * ldn + j] = c.d.d;
+                lxx[j * ldn + i] = c.d.d;
+                if (i == j) lx[i] = c.v.d;
+            }
+        }
+        return l;
+    }
+};
+
+}  // namespace tfmpc
+
+#endif      // TFMPC_USER_ENV_DEFINE

@@ -45,7 +45,7 @@ _SIGNATURES = {
 for _name in ("backward", "forward", "solve"):       # twins for a non-symmetric C (tfmpc_hip.h PRECONDITION)
     _SIGNATURES[f"tfmpc_lqr_{_name}_general_f32"] = _SIGNATURES[f"tfmpc_lqr_{_name}_f32"]
 
-ENV_LQ, ENV_NAVLQR, ENV_NAVIGATION, ENV_HVAC, ENV_RESERVOIR = range(5)
+ENV_LQ, ENV_NAVLQR, ENV_NAVIGATION, ENV_HVAC, ENV_RESERVOIR, ENV_USER = range(6)
 ENV_MAX_PARAMS = 10
 MAX_ALPHAS = 16
 TRACE_COLS = 11          # TFMPC_TRACE_COLS

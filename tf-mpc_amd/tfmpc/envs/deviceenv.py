@@ -1,0 +1,145 @@
+"""Any differentiable env at hot-path speed: ``transition`` / ``cost`` / ``final_cost`` written as DEVICE functions.
+
+The reference differentiates whatever ``transition`` / ``cost`` it is handed (``tfmpc/envs/diffenv.py:13-101``:
+``GradientTape.batch_jacobian``).  ``tfmpc.envs.torchenv.TorchEnv`` restores that for torch functions, but drives the solve
+from the host (two orders of magnitude off the fused kernels).  A ``DeviceEnv`` takes the three functions as C++ device source,
+templated on the scalar type::
+
+    template <class S> __device__ void transition(const float *p, const S *x, const S *u, S *x_next);
+    template <class S> __device__ S    cost(const float *p, const S *x, const S *u);
+    template <class S> __device__ S    final_cost(const float *p, const S *x);
+
+(``p``: the env's parameter floats -- ``params`` below, shared by the batch ``[P]`` or one row per instance ``[B, P]``; on ``S``:
+arithmetic, comparisons, ``sqrt exp log sin cos tanh abs pow max min``.)  On first use the source is wrapped into
+``csrc/user_env_kernels.hip.in`` and compiled with ``hipcc`` into a companion library (cached by source hash under
+``tfmpc/_lib/userenv/``) that instantiates the SAME wave-per-instance kernels the built-in envs run -- start rollout,
+linearisation, regularised backward pass with the box-QP, line search, the whole ``iLQR.solve`` loop in one launch -- on an env whose
+Jacobians and Hessians come from forward-mode dual numbers evaluated one direction per lane (``csrc/user_env.h``); the
+reference's ``unconnected_gradients=ZERO`` semantics.  Every ``DiffEnv`` method and ``tfmpc.solvers.ilqr.iLQR`` work unchanged.
+Needs ``hipcc`` at run time (``$ROCM_PATH/bin`` or ``PATH``); without it use ``TorchEnv``."""
+
+import ctypes
+import hashlib
+import os
+import shutil
+import subprocess
+
+import numpy as np
+
+from tfmpc import _hip
+from tfmpc.envs.diffenv import Box, DiffEnv
+
+_CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "csrc"))
+_CACHE = os.path.join(os.path.dirname(_hip.lib_path()), "userenv")
+_FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-shared"]      # csrc/Makefile's, one TU
+_TWINS = {"tfmpc_ilqr_rollout_f32": "tfmpc_userenv_rollout_f32", "tfmpc_ilqr_derivatives_f32": "tfmpc_userenv_derivatives_f32",
+          "tfmpc_ilqr_forward_f32": "tfmpc_userenv_forward_f32", "tfmpc_ilqr_solve_trace_f32": "tfmpc_userenv_solve_trace_f32",
+          "tfmpc_ilqr_workspace_bytes": "tfmpc_userenv_workspace_bytes"}
+_loaded = {}
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def translation_unit(source, state_size, action_size):
+    with open(os.path.join(_CSRC, "user_env_kernels.hip.in")) as fh:
+        text = fh.read()
+    return (text.replace("@STATE_SIZE@", str(int(state_size))).replace("@ACTION_SIZE@", str(int(action_size)))
+            .replace("@CSRC@", _CSRC).replace("@SOURCE@", source))
+
+
+def _stamp(text):
+    """Hash of everything the compiled library depends on: the translation unit and the device headers it includes."""
+    h = hashlib.sha256(text.encode())
+    for name in sorted(os.listdir(_CSRC)):
+        if name.endswith(".h"):
+            with open(os.path.join(_CSRC, name), "rb") as fh:
+                h.update(fh.read())
+    with open(os.path.join(_CSRC, "..", "..", "include", "tfmpc_hip.h"), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def build(source, state_size, action_size):
+    """Compile (or find in the cache) the companion library of a user env; returns its path.  Works without a GPU."""
+    text = translation_unit(source, state_size, action_size)
+    folder = os.path.join(_CACHE, _stamp(text))
+    lib = os.path.join(folder, "libtfmpc_userenv.so")
+    if os.path.exists(lib):
+        return lib
+    hipcc = hipcc_path()
+    if hipcc is None:
+        raise RuntimeError("tfmpc.envs.deviceenv: no hipcc found ($ROCM_PATH/bin, PATH): a DeviceEnv is compiled when it is first "
+                           "used; give the env as torch functions instead (tfmpc.envs.torchenv.TorchEnv)")
+    os.makedirs(folder, exist_ok=True)
+    src = os.path.join(folder, "env.hip")
+    with open(src, "w") as fh:
+        fh.write(text)
+    tmp = lib + f".{os.getpid()}.tmp"
+    proc = subprocess.run([hipcc, *_FLAGS, src, "-o", tmp], capture_output=True, text=True)
+    if proc.returncode != 0:
+        errors = "\n".join(l for l in proc.stderr.splitlines() if "warning" not in l)[:4000]      # (the first error is the informative one)
+        raise RuntimeError(f"tfmpc.envs.deviceenv: the env's source does not compile:\n{errors}")
+    os.replace(tmp, lib)                       # (atomic: several processes may build the same env at once)
+    return lib
+
+
+class _UserLibrary:
+    """The main library with its env-dependent iLQR entry points replaced by the companion library's twins."""
+
+    def __init__(self, path):
+        self._main = _hip.require_gpu()
+        self._user = ctypes.CDLL(path)
+        for name, twin in _TWINS.items():
+            fn = getattr(self._user, twin)
+            fn.restype, fn.argtypes = _hip._SIGNATURES[name]
+            setattr(self, name, fn)
+        self.path = path
+
+    def tfmpc_ilqr_last_kernel_name(self):
+        return b"wave (one instance per wave, user env compiled as device code)"
+
+    def __getattr__(self, name):               # everything that does not depend on the env (backward pass, box-QP, LQR, options)
+        return getattr(self._main, name)
+
+
+class DeviceEnv(DiffEnv):
+    kind = _hip.ENV_USER
+
+    def __init__(self, source, state_size, action_size, params=(), low=None, high=None):
+        self.source = str(source)
+        self._n, self._m = int(state_size), int(action_size)
+        self.params = np.asarray(params, dtype=np.float32)
+        if self.params.ndim not in (1, 2):
+            raise ValueError("params: [P] floats shared by the batch, or [B, P] (one row per instance)")
+        self.n_zones = int(self.params.shape[-1])                 # TfmpcEnv.n_zones carries P for this kind (include/tfmpc_hip.h)
+        lo = -np.inf if low is None else low
+        hi = np.inf if high is None else high
+        self.action_space = Box(lo, hi, (self._m, 1))
+        self._lib = None
+
+    @property
+    def state_size(self):
+        return self._n
+
+    @property
+    def action_size(self):
+        return self._m
+
+    def _params(self):
+        return [(self.params if self.n_zones else np.zeros((1,), dtype=np.float32), 1)]
+
+    def _library(self):
+        if self._lib is None:
+            path = build(self.source, self._n, self._m)
+            if path not in _loaded:
+                _loaded[path] = _UserLibrary(path)
+            self._lib = _loaded[path]
+        return self._lib
+
+    def __repr__(self):
+        return f"DeviceEnv(n={self._n}, m={self._m}, params={self.n_zones})"

@@ -61,6 +61,10 @@ class DiffEnv:
             self.device = _hip.default_device()
         return self.device
 
+    def _library(self):
+        """The library whose entry points serve this env (a DeviceEnv answers with its companion library, envs/deviceenv.py)."""
+        return _hip.require_gpu()
+
     def env_batch_size(self):
         sizes = {np.shape(a)[0] for a, rank in self._params() if np.ndim(a) == rank + 1}
         if len(sizes) > 1:
@@ -106,7 +110,7 @@ class DiffEnv:
         return (t.unsqueeze(0), False) if t.dim() == 1 else (t, True)
 
     def _step(self, state, action):
-        lib = _hip.require_gpu()
+        lib = self._library()
         n, m = self.state_size, self.action_size
         x, bx = self._cols(state, n)
         if action is None:
@@ -143,7 +147,7 @@ class DiffEnv:
         return c if batched else c[0]
 
     def final_cost(self, state, batch=False):
-        lib = _hip.require_gpu()
+        lib = self._library()
         x, batched = self._cols(state, self.state_size)
         x = x.contiguous()
         env, keep = self.c_env()
@@ -157,7 +161,7 @@ class DiffEnv:
 
     def _derivatives(self, state, action, want):
         """One derivatives launch with T = 1 per row of the (time-)batch."""
-        lib = _hip.require_gpu()
+        lib = self._library()
         n, m = self.state_size, self.action_size
         x, bx = self._cols(state, n)
         u, bu = self._cols(action, m) if action is not None else (torch.zeros((x.shape[0], m), device=x.device), False)

@@ -171,6 +171,11 @@ class iLQR:
         return self._bound("high")
 
     # -- helpers --------------------------------------------------------------------------
+    def _library(self):
+        """The library that serves the env's kernels: the product library, or a DeviceEnv's companion library (envs/deviceenv.py)."""
+        hook = getattr(self.env, "_library", None)
+        return hook() if hook is not None else _hip.require_gpu()
+
     def _alphas(self):
         return np.geomspace(1.0, self.alpha_min, 11)                       # ilqr.py:322
 
@@ -216,7 +221,7 @@ class iLQR:
 
     # -- ilqr.py:53-82 -----------------------------------------------------------------------
     def start(self, x0, T, u_init=None, seed=None):
-        lib = _hip.require_gpu()
+        lib = self._library()
         T = int(T)
         if self._generic_env:
             return self._start_torch(x0, T, u_init, seed)
@@ -240,7 +245,7 @@ class iLQR:
 
     # -- ilqr.py:84-92 -----------------------------------------------------------------------
     def derivatives(self, states, actions):
-        lib = _hip.require_gpu()
+        lib = self._library()
         if self._generic_env:
             xs = _f32(states, self.device)
             us = _f32(actions, self.device)
@@ -313,7 +318,7 @@ class iLQR:
 
     # -- ilqr.py:174-212 ---------------------------------------------------------------------
     def forward(self, x, u, K, k, alpha=1.0):
-        lib = _hip.require_gpu()
+        lib = self._library()
         n, m = self.env.state_size, self.env.action_size
         dev = self.device
         if self._generic_env:
@@ -351,7 +356,7 @@ class iLQR:
         ``trace_rows > 0``: also the decision trace of every instance -- ``trace[B, trace_rows, TRACE_COLS]`` (one row
         per backward pass + line search, columns ``TRACE_COLUMNS``; rows never written are NaN) and ``trace_len[B]``
         (passes made): what the reference logs per pass of ilqr.py:238-279 (``tfmpc_ilqr_solve_trace_f32``)."""
-        lib = _hip.require_gpu()
+        lib = self._library()
         T = int(T)
         n, m = self.env.state_size, self.env.action_size
         dev = self.device
