@@ -103,12 +103,23 @@ __device__ int *g_box_counts = nullptr;
 #ifndef TFMPC_BOX_EU                 // waves per SIMD the register budget is sized for (A/B builds)
 #define TFMPC_BOX_EU 2
 #endif
+constexpr int kProbeStride = 32;      // the sample of the first-pass probe: every 32nd instance (2 048 of 65 536)
+constexpr int kProbeHeavy = 3;        // ... and how many of them must need a regularisation level >= 1 for the whole batch to be probed and sorted
 template <bool BRACKET, int MODE = 0>
 __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = (MODE == 0 && a.order) ? a.order[blockIdx.x] : blockIdx.x;
+    // MODE 2 (round 5): the first-pass probe on a SAMPLE, every kProbeStride-th instance; MODE 1 then runs on the whole batch only if the
+    // sample met heavy instances (the flag behind the two int slabs of wsq, box_decide_kernel) -- a batch without them (the stable-open-loop
+    // variant of bench.py: 12 of 65 536) paid 10.8 of its 91 ms for a sort that moved nothing.
+    const int b = (MODE == 0 && a.order) ? a.order[blockIdx.x] : (MODE == 2 ? blockIdx.x * kProbeStride : blockIdx.x);
     const int lane = threadIdx.x;
+    if constexpr (MODE == 1) {
+        if (reinterpret_cast<const int32_t *>(a.wsq)[2 * (size_t)a.B] == 0) {         // (wave-uniform) nothing heavy in the sample: no sort
+            if (lane == 0) reinterpret_cast<int32_t *>(a.wsq)[b] = 0;
+            return;
+        }
+    }
     const int i = lane & 15, q = lane >> 4;
     const int r8 = lane & 7;                       // QP: the row this lane owns
     const int c32 = lane & 31;                     // elimination: the column this lane owns
@@ -682,7 +693,7 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
 #ifdef TFMPC_BOX_PROBE
             if (first_level < 0) first_level = level;
 #endif
-            if constexpr (MODE == 1) {
+            if constexpr (MODE == 1 || MODE == 2) {
                 if (lane == 0) reinterpret_cast<int32_t *>(a.wsq)[b] = give_up ? 41 : level;
                 return;
             }
@@ -797,9 +808,26 @@ namespace {
 // whole batch; those instances all end their FIRST backward pass on level 8 .. 11 (tools/probes/box_lifetime.py), which a probe
 // launch finds for ~5 % of the work.  A counting sort by that level (descending; one workgroup) gives the block -> instance table.
 // Results do not depend on the order (instances are independent): bit-identical to the unsorted launch.
+// flag <- 1 if at least kProbeHeavy of the sampled instances ended their first backward pass on a level >= 1
+__global__ __launch_bounds__(1024) void box_decide_kernel(const int32_t *level, int32_t *flag, int B)
+{
+    __shared__ int heavy;
+    if (threadIdx.x == 0) heavy = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int b = threadIdx.x * kProbeStride; b < B; b += 1024 * kProbeStride) mine += level[b] >= 1 ? 1 : 0;
+    if (mine) atomicAdd(&heavy, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) *flag = heavy >= kProbeHeavy ? 1 : 0;
+}
+
 __global__ __launch_bounds__(1024) void box_order_kernel(const int32_t *level, int32_t *order, int B)
 {
     __shared__ int hist[64], base[64];
+    if (level[2 * (size_t)B] == 0) {                          // (uniform) nothing heavy in the sample: blocks in instance order
+        for (int b = threadIdx.x; b < B; b += 1024) order[b] = b;
+        return;
+    }
     if (threadIdx.x < 64) hist[threadIdx.x] = 0;
     __syncthreads();
     for (int b = threadIdx.x; b < B; b += 1024) atomicAdd(&hist[min(max(level[b], 0), 63)], 1);
@@ -821,8 +849,15 @@ int ilqr_lq_box_mfma_launch(const IlqrLqArgs &a, hipStream_t stream)
     IlqrLqArgs run = a;
     run.order = nullptr;
     // more instances than resident waves (2 per SIMD x 1 024 SIMDs), and room for two ints per instance in the wsq slab
-    if (a.B > 4096 && (size_t)a.T * a.env.m >= 2 && a.wsq && !option_is(kOptIlqrRetry, "unsorted") && !bracket) {
-        int32_t *level = reinterpret_cast<int32_t *>(a.wsq), *order = level + a.B;
+    if (a.B > 4096 && (size_t)a.T * a.env.m >= 3 && a.wsq && !option_is(kOptIlqrRetry, "unsorted") && !bracket) {
+        int32_t *level = reinterpret_cast<int32_t *>(a.wsq), *order = level + a.B, *flag = level + 2 * (size_t)a.B;
+        // sample -> decide -> (whole batch, or nothing) -> order: TFMPC_ILQR_RETRY=sorted skips the sample and always sorts (A/B timing)
+        if (option_is(kOptIlqrRetry, "sorted")) {
+            if (hipMemsetAsync(flag, 0xFF, sizeof(int32_t), stream) != hipSuccess) return TFMPC_ERR_LAUNCH;
+        } else {
+            hipLaunchKernelGGL((ilqr_lq_box_mfma_kernel<false, 2>), dim3((a.B + kProbeStride - 1) / kProbeStride), dim3(kWave), lds, stream, a);
+            hipLaunchKernelGGL(box_decide_kernel, dim3(1), dim3(1024), 0, stream, level, flag, a.B);
+        }
         hipLaunchKernelGGL((ilqr_lq_box_mfma_kernel<false, 1>), dim3(a.B), dim3(kWave), lds, stream, a);
         hipLaunchKernelGGL(box_order_kernel, dim3(1), dim3(1024), 0, stream, level, order, a.B);
         run.order = order;
