@@ -103,7 +103,19 @@ def test_navigation_whole_solves_match_the_builtin_kernel_and_the_restatement():
     out = s_user.solve_device(x0, T, u_init=u0, trace_rows=170)
     ref = s_builtin.solve_device(x0, T, u_init=u0)
     torch.cuda.synchronize()
-    assert s_user.last_kernel.startswith("wave") and "user env" in s_user.last_kernel
+    assert s_user.last_kernel.startswith("lane_group") and "user env" in s_user.last_kernel      # n = m = 2: 16 lanes per instance
+    # ... and the generic wave kernel on the same user env (what any other shape runs on): the same solve up to the two kernels' rounding
+    user._library().force_wave_kernel(True)
+    try:
+        wave = s_user.solve_device(x0, T, u_init=u0)
+        torch.cuda.synchronize()
+        assert s_user.last_kernel.startswith("wave") and "user env" in s_user.last_kernel
+    finally:
+        user._library().force_wave_kernel(False)
+    agree = (wave["iterations"] == out["iterations"]).cpu().numpy()
+    assert agree.mean() >= 0.9, agree.mean()
+    cw = _np(wave["costs"]).sum(1)
+    assert np.median(np.abs(cw - _np(out["costs"]).sum(1)) / np.abs(cw)) <= 1e-5
     assert int((out["status"] & ~_hip.ST_NOT_PD).abs().sum()) == 0
     same = (out["iterations"] == ref["iterations"]).cpu().numpy()
     assert same.mean() >= 0.9, same.mean()

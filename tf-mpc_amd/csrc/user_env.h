@@ -262,4 +262,112 @@ template <> struct Env<TFMPC_ENV_USER> {
 
 }  // namespace tfmpc
 
+// ---- tiny user envs (n = m = 2): the lane-group kernel (16 lanes per instance, all step sizes of the line search at once, persistent groups +
+// instance queue: ilqr_lane_kernels.h) on LaneEnv<TFMPC_ENV_USER>.  One lane evaluates the user's functions as ordinary scalar code; the whole
+// quadratic model of a timestep is the "precomputed part" of the linearisation (kPre floats), which the kernel evaluates for all timesteps at once,
+// one per lane, whenever the nominal trajectory changes -- D dual evaluations of `transition` and D (D + 1) / 2 second-order ones of `cost` each.
+#if TFMPC_USER_N == 2 && TFMPC_USER_M == 2
+#include "ilqr_lane_kernels.h"
+
+namespace tfmpc {
+
+template <int N, int M>
+struct LaneEnv<TFMPC_ENV_USER, N, M> {
+    static constexpr int D = N + M;
+    static constexpr int kFx = 0, kFu = kFx + N * N, kLx = kFu + N * M, kLu = kLx + N, kLxx = kLu + M, kLuu = kLxx + N * N,
+                         kLux = kLuu + M * M, kL = kLux + M * N, kPre = kL + 1;
+    const float *p;
+    __device__ void load(const TfmpcEnv &g, int b) { p = g.p[0] + (size_t)b * g.stride[0]; }
+    __device__ void transition(const float *x, const float *u, float *xn) const { tfmpc_user::transition<float>(p, x, u, xn); }
+    __device__ float cost(const float *x, const float *u) const { return tfmpc_user::cost<float>(p, x, u); }
+    __device__ float final_cost(const float *x) const { return tfmpc_user::final_cost<float>(p, x); }
+    __device__ void prelinearize(const float *x, const float *u, float *pre) const
+    {
+        using ad::D1;
+        using ad::D2;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {                                   // column j of [f_x | f_u]
+            D1 xs[N], us[M], out[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) xs[i] = D1(x[i], i == j ? 1.0f : 0.0f);
+#pragma unroll
+            for (int a = 0; a < M; ++a) us[a] = D1(u[a], N + a == j ? 1.0f : 0.0f);
+            tfmpc_user::transition<D1>(p, xs, us, out);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                if (j < N) pre[kFx + i * N + j] = out[i].d;
+                else pre[kFu + i * M + (j - N)] = out[i].d;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+#pragma unroll
+            for (int j = i; j < D; ++j) {                               // l_i, l_j, l_ij
+                D2 xs[N], us[M];
+#pragma unroll
+                for (int k = 0; k < N; ++k) xs[k] = D2(D1(x[k], k == i ? 1.0f : 0.0f), D1(k == j ? 1.0f : 0.0f, 0.0f));
+#pragma unroll
+                for (int a = 0; a < M; ++a) us[a] = D2(D1(u[a], N + a == i ? 1.0f : 0.0f), D1(N + a == j ? 1.0f : 0.0f, 0.0f));
+                const D2 c = tfmpc_user::cost<D2>(p, xs, us);
+                const float h = c.d.d;
+                if (j < N) { pre[kLxx + i * N + j] = h; pre[kLxx + j * N + i] = h; }
+                else if (i >= N) { pre[kLuu + (i - N) * M + (j - N)] = h; pre[kLuu + (j - N) * M + (i - N)] = h; }
+                else pre[kLux + (j - N) * N + i] = h;
+                if (i == j) { if (i < N) pre[kLx + i] = c.v.d; else pre[kLu + i - N] = c.v.d; }
+                if (i == 0 && j == 0) pre[kL] = c.v.v;
+            }
+        }
+    }
+    __device__ void linearize_pre(const float *pre, const float *, const float *, LaneModel<N, M> &md) const
+    {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            md.lx[i] = pre[kLx + i];
+#pragma unroll
+            for (int j = 0; j < N; ++j) { md.fx(i, j) = pre[kFx + i * N + j]; md.lxx(i, j) = pre[kLxx + i * N + j]; }
+#pragma unroll
+            for (int a = 0; a < M; ++a) md.fu(i, a) = pre[kFu + i * M + a];
+        }
+#pragma unroll
+        for (int a = 0; a < M; ++a) {
+            md.lu[a] = pre[kLu + a];
+#pragma unroll
+            for (int c = 0; c < M; ++c) md.luu(a, c) = pre[kLuu + a * M + c];
+#pragma unroll
+            for (int j = 0; j < N; ++j) md.lux(a, j) = pre[kLux + a * N + j];
+        }
+        md.l = pre[kL];
+    }
+    __device__ void linearize(const float *x, const float *u, LaneModel<N, M> &md) const
+    {
+        float pre[kPre];
+        prelinearize(x, u, pre);
+        linearize_pre(pre, x, u, md);
+    }
+    __device__ float final_quad(const float *x, float *lx, small::Mat<N, N> &lxx) const
+    {
+        using ad::D1;
+        using ad::D2;
+        float l = 0.0f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+            for (int j = i; j < N; ++j) {
+                D2 xs[N];
+#pragma unroll
+                for (int k = 0; k < N; ++k) xs[k] = D2(D1(x[k], k == i ? 1.0f : 0.0f), D1(k == j ? 1.0f : 0.0f, 0.0f));
+                const D2 c = tfmpc_user::final_cost<D2>(p, xs);
+                lxx(i, j) = c.d.d;
+                lxx(j, i) = c.d.d;
+                if (i == j) lx[i] = c.v.d;
+                l = c.v.v;
+            }
+        }
+        return l;
+    }
+};
+
+}  // namespace tfmpc
+#endif      // 2 x 2
+
 #endif      // TFMPC_USER_ENV_DEFINE

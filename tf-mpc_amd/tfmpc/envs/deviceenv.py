@@ -100,8 +100,17 @@ class _UserLibrary:
             setattr(self, name, fn)
         self.path = path
 
+        self._user.tfmpc_userenv_last_kernel_name.restype = ctypes.c_char_p
+        self._user.tfmpc_userenv_last_kernel_name.argtypes = []
+        self._user.tfmpc_userenv_set_wave_kernel.argtypes = [ctypes.c_int]
+        self._user.tfmpc_userenv_set_wave_kernel.restype = None
+
     def tfmpc_ilqr_last_kernel_name(self):
-        return b"wave (one instance per wave, user env compiled as device code)"
+        return self._user.tfmpc_userenv_last_kernel_name()
+
+    def force_wave_kernel(self, on):
+        """A tiny (2 x 2) user env runs the lane-group kernel; ``True`` keeps the generic wave kernel (A/B timing, tests)."""
+        self._user.tfmpc_userenv_set_wave_kernel(int(bool(on)))
 
     def __getattr__(self, name):               # everything that does not depend on the env (backward pass, box-QP, LQR, options)
         return getattr(self._main, name)

@@ -29,7 +29,10 @@ def timed(solver, option=None):
             ts.append(time.perf_counter() - t0)
     its = float((out["iterations"].double() + 1).sum())
     return min(ts) * 1e3, its / min(ts), its / B
-for name, solver, opt in (("built-in env, lane-group kernel (default)", builtin, None), ("built-in env, generic wave kernel", builtin, "wave"),
-                          ("DeviceEnv source, wave kernel + dual numbers", user, None)):
+for name, solver, opt, wave in (("built-in env, lane-group kernel (default)", builtin, None, False), ("built-in env, generic wave kernel", builtin, "wave", False),
+                                ("DeviceEnv source, lane-group kernel + dual numbers (default for n = m = 2)", user, None, False),
+                                ("DeviceEnv source, generic wave kernel + dual numbers (any shape)", user, None, True)):
+    user.env._library().force_wave_kernel(wave)
     ms, rate, mean_it = timed(solver, opt)
-    print(f"{name}: {ms:.2f} ms per {B} solves, {rate / 1e6:.2f} M it/s, mean iterations {mean_it:.2f}", flush=True)
+    print(f"{name}: {ms:.2f} ms per {B} solves, {rate / 1e6:.2f} M it/s, mean iterations {mean_it:.2f} [{solver.last_kernel}]", flush=True)
+user.env._library().force_wave_kernel(False)
