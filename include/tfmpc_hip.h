@@ -208,7 +208,9 @@ typedef struct TfmpcEnv {
                                    entry 0), -1 = the chain i -> i - 1, 0 = no statement (any matrix).  Every config the reference holds
                                    is a chain (tests/conftest.py:70-75, reservoir/res4.config.json:13-18); with the promise a large batch runs an
                                    instantiation without coupling products.  Checked on the device against p7 before anything is computed:
-                                   a broken promise leaves TFMPC_ST_ENV_FLAG in status[b] and the outputs untouched. */
+                                   a broken promise leaves TFMPC_ST_ENV_FLAG in status[b] and the outputs untouched.  (Row moves
+                                   equal the products for FINITE states; a product spreads one row's Inf / NaN into every row, a row move
+                                   hands it to the neighbour only: a DIVERGING instance's status can differ from TFMPC_COSTATE_COUPLING=dense.) */
     int32_t reserved2;
     const float *low, *high;
     const float *p[TFMPC_ENV_MAX_PARAMS];
