@@ -241,7 +241,7 @@ def ilqr_api_rate(n, m, T, B, reps=5):
     wl_run, wl = wl, workloads.control_limited_stable(B, n, m, T)
     stable = limited("linear probe 0, 1, 2, ... (ilqr.py:285-315; the default)")
     stable["workload"], stable["workload_version"] = wl["text"], wl["version"]
-    stable["executed"] = pmc_executed("ilqr_lq_box_mfma")
+    stable["executed"] = pmc_executed("ilqr_lq_box_mfma_kernel<false, 0>")      # (the main launch, not the sample probe)
     if CPU_BASELINES:
         stable["cpu_baseline"] = ilqr_cpu_baseline("lq", [workloads.instance_cfg(wl, b) for b in range(8)], wl["x0"], wl["u0"], T, 100, 8, wl["version"])
     # ... and with a box so wide (+-2) that the box-QP rarely clamps while the rollout's clip still bites: the one LQ line on which the line
@@ -437,7 +437,7 @@ def other_config_rates():
         "persistent lane groups + instance queue; round 3: 8 streams x 16 384 = 51.1 M it/s (profiles/r03_cfg4_sustained.json)")
     del x8, u8
     # cfg5: n = m = 32, T = 100 -> read x, u 25.7 KB + write x, u, c 26.1 KB = 51.8 KB per iteration
-    for kind, kernel_tag in (("hvac", "ilqr_adjoint_mfma_kernel<3, 2"), ("reservoir", "ilqr_adjoint_mfma_kernel<4, 2")):     # two-tile instantiations
+    for kind, kernel_tag in (("hvac", "ilqr_adjoint_mfma_kernel<3, 2"), ("reservoir", "ilqr_adjoint_mfma_kernel<100, 2")):     # two-tile instantiations (Reservoir: the chain form, tag 100)
         n, T, B = 32, 100, 32768
         w5 = workloads.cfg5(kind, B, n, T)            # the same problems tests/test_ilqr_teacher_forced_gpu.py holds against the restatement
         env, x0, u0c = w5["env"], w5["x0"], w5["u0"]
