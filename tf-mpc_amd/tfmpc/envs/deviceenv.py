@@ -49,7 +49,7 @@ def translation_unit(source, state_size, action_size):
     with open(os.path.join(_CSRC, "user_env_kernels.hip.in")) as fh:
         text = fh.read()
     return (text.replace("@STATE_SIZE@", str(int(state_size))).replace("@ACTION_SIZE@", str(int(action_size)))
-            .replace("@CSRC@", _CSRC).replace("@SOURCE@", source))
+            .replace("@SOURCE@", source))       # (the headers are found through -I: the text, hence the cache key, does not depend on where the tree lives)
 
 
 def _stamp(text):
@@ -80,7 +80,7 @@ def build(source, state_size, action_size):
     with open(src, "w") as fh:
         fh.write(text)
     tmp = lib + f".{os.getpid()}.tmp"
-    proc = subprocess.run([hipcc, *_FLAGS, src, "-o", tmp], capture_output=True, text=True)
+    proc = subprocess.run([hipcc, *_FLAGS, "-I", _CSRC, src, "-o", tmp], capture_output=True, text=True)
     if proc.returncode != 0:
         errors = "\n".join(l for l in proc.stderr.splitlines() if "warning" not in l)[:4000]      # (the first error is the informative one)
         raise RuntimeError(f"tfmpc.envs.deviceenv: the env's source does not compile:\n{errors}")
