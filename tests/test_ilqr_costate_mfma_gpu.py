@@ -335,3 +335,33 @@ def test_a_broken_chain_promise_is_refused_on_the_device(force_kernel):
         bad = iLQR(env, max_iterations=3).solve_device(x0, T, u_init=u0)
         torch.cuda.synchronize()
     assert bad["status"].tolist() == [_hip.ST_ENV_FLAG] * B
+
+
+def test_a_diverging_instance_stays_in_its_column(force_kernel):
+    """a row move equals the matrix product only for FINITE states -- the product spreads one row's Inf / NaN into every
+    row of ITS column (0 x Inf), the move hands it to the neighbouring row only -- so a diverging instance may end differently in the
+    chain / run-time-shift / dense forms (include/tfmpc_hip.h says so).  What must hold in every form: the instance is flagged
+    (TFMPC_ST_NAN) and the fifteen instances that share its wavefront are the bits they are without it."""
+    n, T, B = 32, 30, 40
+    env, x0 = _env("reservoir", n, B, 5)
+    x0 = x0.copy()
+    bad = 21
+    clean = x0.copy()
+    x0[bad, 3, 0] = 3.0e38                                   # overflows in the first steps
+    solver = iLQR(env, max_iterations=4)
+    u0 = solver.random_actions(T, B, seed=6)
+    force_kernel("costate_mfma")
+    outs = {}
+    with _hip.option("TFMPC_COSTATE_WAVES", "1"):
+        ref = solver.solve_device(clean, T, u_init=u0)
+        torch.cuda.synchronize()
+        for mode in (None, "runtime", "dense"):
+            with _hip.option("TFMPC_COSTATE_COUPLING", mode):
+                o = solver.solve_device(x0, T, u_init=u0)
+                torch.cuda.synchronize()
+                outs[mode] = {k: v.clone() for k, v in o.items() if torch.is_tensor(v) and k != "workspace"}
+    others = [b for b in range(B) if b != bad]
+    for mode, o in outs.items():
+        assert int(o["status"][bad]) & _hip.ST_NAN, (mode, int(o["status"][bad]))
+        for key in ("iterations", "status", "states", "actions", "costs"):
+            assert torch.equal(o[key][others], ref[key][others]), (mode, key)
