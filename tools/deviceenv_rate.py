@@ -28,11 +28,12 @@ def timed(solver, option=None):
             t0 = time.perf_counter(); out = solver.solve_device(x0, T, u_init=u0, workspace=out["workspace"]); torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
     its = float((out["iterations"].double() + 1).sum())
+    timed.max_it = int(out["iterations"].max()) + 1
     return min(ts) * 1e3, its / min(ts), its / B
 for name, solver, opt, wave in (("built-in env, lane-group kernel (default)", builtin, None, False), ("built-in env, generic wave kernel", builtin, "wave", False),
                                 ("DeviceEnv source, lane-group kernel + dual numbers (default for n = m = 2)", user, None, False),
                                 ("DeviceEnv source, generic wave kernel + dual numbers (any shape)", user, None, True)):
     user.env._library().force_wave_kernel(wave)
     ms, rate, mean_it = timed(solver, opt)
-    print(f"{name}: {ms:.2f} ms per {B} solves, {rate / 1e6:.2f} M it/s, mean iterations {mean_it:.2f} [{solver.last_kernel}]", flush=True)
+    print(f"{name}: {ms:.2f} ms per {B} solves, {rate / 1e6:.2f} M it/s, mean iterations {mean_it:.2f}, slowest instance {timed.max_it} iterations = {ms * 1e3 / timed.max_it:.1f} us each [{solver.last_kernel}]", flush=True)
 user.env._library().force_wave_kernel(False)
