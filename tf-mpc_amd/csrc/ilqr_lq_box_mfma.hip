@@ -86,7 +86,10 @@ __device__ __forceinline__ float max8(float v)           // non-negative values
 //   kVt  [16][20] V_xx transpose staging
 constexpr int kMs = 0, kKs = 256, kPs = 512, kVt = 768, kVtLd = 20, kDyn = kVt + 16 * kVtLd;
 constexpr int kZero = kMs + 25 * 8, kQx = kMs + 28 * 8;
-constexpr int kZld = 26;
+// Floats per trajectory row z_t = [x(16) | u(8)].  24 (round 5; 26 before): THREE trajectory buffers (nominal + two line-search candidates) then
+// fit the 20 KB a wave may take with two waves per SIMD resident (19.7 KB at T = 50); the conflict-free padding measured nothing in the
+// sister kernel (ilqr_lq_mfma.hip).
+constexpr int kZld = 24;
 
 __device__ __forceinline__ float sgn(float y) { return (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f); }
 
@@ -103,6 +106,10 @@ __device__ int *g_box_counts = nullptr;
 #ifndef TFMPC_BOX_EU                 // waves per SIMD the register budget is sized for (A/B builds)
 #define TFMPC_BOX_EU 2
 #endif
+#ifndef TFMPC_BOX_SINGLE_ROLLOUTS
+#define TFMPC_BOX_SINGLE_ROLLOUTS 0            // A/B builds: 1 = one step size per rollout pass as before round 5
+#endif
+constexpr bool kSingleRollouts = TFMPC_BOX_SINGLE_ROLLOUTS != 0;
 constexpr int kProbeStride = 32;      // the sample of the first-pass probe: every 32nd instance (2 048 of 65 536)
 constexpr int kProbeHeavy = 3;        // ... and how many of them must need a regularisation level >= 1 for the whole batch to be probed and sorted
 template <bool BRACKET, int MODE = 0>
@@ -128,10 +135,12 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
     const TfmpcIlqrConfig &cfg = a.cfg;
     const bool bounded = a.env.bounded != 0;
 
-    float *bufA = lds + kDyn;                    // [(T+1)][26]
+    float *bufA = lds + kDyn;                    // [(T+1)][kZld]
     float *bufB = bufA + Tp * kZld;
-    float *costA = bufB + Tp * kZld;             // [T+1]
+    float *bufC = bufB + Tp * kZld;              // the second candidate of a two-step-size rollout
+    float *costA = bufC + Tp * kZld;             // [T+1]
     float *costB = costA + ((Tp + 3) & ~3);
+    float *costC = costB + ((Tp + 3) & ~3);
 
     const float *Fg = a.env.p[0] + (size_t)b * a.env.stride[0];
     const float *fg = a.env.p[1] + (size_t)b * a.env.stride[1];
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
     };
 
     // ---- start (ilqr.py:218): roll the env under the injected actions --------------------
-    float *nom = bufA, *cand = bufB, *cnom = costA, *ccand = costB;
+    float *nom = bufA, *cand = bufB, *cand2 = bufC, *cnom = costA, *ccand = costB, *ccand2 = costC;
     if (lane < N) nom[lane] = (lane < n) ? a.x0[(size_t)b * n + lane] : 0.0f;
     for (int idx = lane; idx < T * M; idx += kWave) {
         const int t = idx >> 3, ua = idx & 7;
@@ -618,6 +627,61 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
         __syncthreads();
         J = sum_costs(ccand);
     };
+    // TWO step sizes in one pass (round 5), into `cand` (alphaA) and `cand2` (alphaB).  A rollout is one wave's dependent chain of T steps with two
+    // LDS round trips each (~1 100 cycles per step); a line search that backtracks runs up to eleven of them one after the other -- the instances that
+    // set the launch time do (tools/probes/r5_box_straggler.py: 8 - 11 rollouts in every pass).  Two independent chains in the same loop overlap each
+    // other's latency and share the gain loads; each chain's arithmetic is `forward`'s, operation for operation: same bits per step size.
+    auto forward2 = [&](float alphaA, float alphaB, float &JA, float &resA, float &JB, float &resB) {
+        if (lane < N) { cand[lane] = nom[lane]; cand2[lane] = nom[lane]; }
+        if (lane < M) { cand[T * kZld + N + lane] = 0.0f; cand2[T * kZld + N + lane] = 0.0f; }
+        float rmaxA = 0.0f, rmaxB = 0.0f;
+        const bool row = ka < m;
+        auto load_gain = [&](int t, float &gx, float &gy, float &gk) {
+            gx = (row && 2 * jc < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc] : 0.0f;
+            gy = (row && 2 * jc + 1 < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] : 0.0f;
+            gk = row ? kg[(size_t)t * m + ka] : 0.0f;
+        };
+        float Kxn = 0.0f, Kyn = 0.0f, kkn = 0.0f;
+        load_gain(0, Kxn, Kyn, kkn);
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const float *zh = nom + t * kZld;
+            float *ztA = cand + t * kZld, *ztB = cand2 + t * kZld;
+            const float Kx = Kxn, Ky = Kyn, kk = kkn;
+            if (t + 1 < T) load_gain(t + 1, Kxn, Kyn, kkn);
+            const float2 xh = *reinterpret_cast<const float2 *>(&zh[2 * jc]);
+            const float2 xvA = *reinterpret_cast<const float2 *>(&ztA[2 * jc]);
+            const float2 xvB = *reinterpret_cast<const float2 *>(&ztB[2 * jc]);
+            float duA = fmaf(Kx, xvA.x - xh.x, Ky * (xvA.y - xh.y));           // K (x - x_hat)  :193-194
+            float duB = fmaf(Kx, xvB.x - xh.x, Ky * (xvB.y - xh.y));
+            duA += dpp<kDppXor1>(duA);
+            duB += dpp<kDppXor1>(duB);
+            duA += dpp<kDppXor2>(duA);
+            duB += dpp<kDppXor2>(duB);
+            duA += dpp<kDppHalfMirror>(duA);
+            duB += dpp<kDppHalfMirror>(duB);
+            duA = fmaf(alphaA, kk, duA);
+            duB = fmaf(alphaB, kk, duB);
+            rmaxA = fmaxf(rmaxA, fabsf(duA));                                  // :206 (before the clip)
+            rmaxB = fmaxf(rmaxB, fabsf(duB));
+            if (jc == 0) {
+                const float uh = zh[N + ka];
+                ztA[N + ka] = fminf(fmaxf(uh + duA, low_k), high_k);           // :196-197
+                ztB[N + ka] = fminf(fmaxf(uh + duB, low_k), high_k);
+            }
+            __syncthreads();
+            const float xnA = next_state(ztA), xnB = next_state(ztB);
+            if (fc == 0) { ztA[kZld + fi] = xnA; ztB[kZld + fi] = xnB; }
+            __syncthreads();
+        }
+        resA = wave_max(rmaxA);
+        resB = wave_max(rmaxB);
+        cz_pass(cand, Tp, ccand, false);
+        cz_pass(cand2, Tp, ccand2, false);
+        __syncthreads();
+        JA = sum_costs(ccand);
+        JB = sum_costs(ccand2);
+    };
 
     // ---- iLQR.solve (ilqr.py:214-283) ------------------------------------------------------------------------------
     float mu = 0.0f, delta = 1.0f;                                         // :215-216
@@ -714,31 +778,58 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
             bool accept = false;
             float residual = 0.0f, J_last = 0.0f;
             int ai_last = -1;
-            for (int ai = 0; ai < cfg.n_alphas; ++ai) {                     // _forward :317-355
-                const float alpha = cfg.alphas[ai];
-                float J;
-                ai_last = ai;
+            bool last_in_second = false;                                    // which buffer holds the LAST rollout (:253-257 may adopt it even if rejected)
+            auto passes = [&](float alpha, float J) {                       // :339-353
+                const float delta_J = -alpha * (r.dV1 + alpha * r.dV2);
+                const float dcost = J_hat - J;
+                const float z = (delta_J > 0.0f) ? dcost / delta_J : sgn(dcost);
+                return z >= cfg.c1;
+            };
+            // _forward :317-355.  The first step size alone (most passes accept it); after a rejection the rest in PAIRS (forward2): the pair's
+            // smaller index is tested first, so the step size accepted -- and every number logged -- is the sequential search's.
+            for (int ai = 0; ai < cfg.n_alphas && !accept;) {
 #ifdef TFMPC_BOX_PROBE
                 const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
 #endif
-                forward(alpha, J, residual);
+                if (ai == 0 || ai + 1 >= cfg.n_alphas || kSingleRollouts) {
+                    float J;
+                    forward(cfg.alphas[ai], J, residual);
+                    ai_last = ai; J_last = J; last_in_second = false;
+                    accept = passes(cfg.alphas[ai], J);
+                    ai += 1;
+#ifdef TFMPC_BOX_PROBE
+                    ++n_roll; if (repeats > 0) ++n_roll_rep;
+#endif
+                } else {
+                    float JA, JB, resA, resB;
+                    forward2(cfg.alphas[ai], cfg.alphas[ai + 1], JA, resA, JB, resB);
+                    if (passes(cfg.alphas[ai], JA)) {
+                        ai_last = ai; J_last = JA; residual = resA; last_in_second = false; accept = true;
+                    } else {
+                        ai_last = ai + 1; J_last = JB; residual = resB; last_in_second = true;
+                        accept = passes(cfg.alphas[ai + 1], JB);
+                    }
+                    ai += 2;
+#ifdef TFMPC_BOX_PROBE
+                    n_roll += 2; if (repeats > 0) n_roll_rep += 2;
+#endif
+                }
 #ifdef TFMPC_BOX_PROBE
                 cyc_rollouts += __builtin_amdgcn_s_memtime() - tr0;
-                ++n_roll; if (repeats > 0) ++n_roll_rep;
 #endif
-                J_last = J;
-                const float delta_J = -alpha * (r.dV1 + alpha * r.dV2);     // :339
-                const float dcost = J_hat - J;
-                const float z = (delta_J > 0.0f) ? dcost / delta_J : sgn(dcost);   // :342-346
-                if (z >= cfg.c1) { accept = true; break; }                  // :351-353
             }
             const bool small_step = residual < cfg.atol;                   // :253-257 (taken even if rejected)
             if (lane == 0)
                 trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, J_hat, r.g_norm, ai_last,
                             ai_last >= 0 ? cfg.alphas[ai_last] : 0.0f, J_last, accept ? 1 : 0, residual, level);
-            if (small_step || accept) {
-                float *tz = nom; nom = cand; cand = tz;
-                float *tcst = cnom; cnom = ccand; ccand = tcst;
+            if (small_step || accept) {                                    // the last rollout's buffer becomes the nominal one
+                if (last_in_second) {
+                    float *tz = nom; nom = cand2; cand2 = tz;
+                    float *tcst = cnom; cnom = ccand2; ccand2 = tcst;
+                } else {
+                    float *tz = nom; nom = cand; cand = tz;
+                    float *tcst = cnom; cnom = ccand; ccand = tcst;
+                }
             }
             if (small_step) { converged = true; break; }
             if (accept) {                                                   // :259-266
@@ -783,7 +874,7 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
 size_t box_lds_bytes(int T)
 {
     const size_t Tp = T + 1;
-    return (kDyn + 2 * Tp * kZld + 2 * ((Tp + 3) & ~(size_t)3) + 8) * sizeof(float);
+    return (kDyn + 3 * Tp * kZld + 3 * ((Tp + 3) & ~(size_t)3) + 8) * sizeof(float);
 }
 
 }  // namespace
