@@ -65,3 +65,49 @@ def reservoir_params(cfg):
     rain = g("rain_shape") * g("rain_scale")
     return np.concatenate([g("max_res_cap"), g("lower_bound"), g("upper_bound"), -g("low_penalty"), -g("high_penalty"),
                            -g("set_point_penalty"), rain, g("downstream")]).astype(np.float32)
+
+
+# tfmpc/solvers/lqr.py:36-57 as an env (the LQ env of the iLQR API line): p = F[n][n+m], f[n], C[n+m][n+m], c[n+m] -- per instance
+def lq_source(n, m):
+    return """
+constexpr int n = %d, m = %d, d = n + m;
+template <class S> __device__ void transition(const float *p, const S *x, const S *u, S *x_next)      // :36-39
+{
+    const float *F = p, *f = p + n * d;
+    for (int i = 0; i < n; ++i) {
+        S s = S(f[i]);
+        for (int j = 0; j < n; ++j) s = s + F[i * d + j] * x[j];
+        for (int j = 0; j < m; ++j) s = s + F[i * d + n + j] * u[j];
+        x_next[i] = s;
+    }
+}
+template <class S> __device__ S cost(const float *p, const S *x, const S *u)                           // :41-47
+{
+    const float *C = p + n * d + n, *c = C + d * d;
+    S total = S(0.0f);
+    for (int r = 0; r < d; ++r) {
+        S cz = S(0.0f);
+        for (int j = 0; j < n; ++j) cz = cz + C[r * d + j] * x[j];
+        for (int j = 0; j < m; ++j) cz = cz + C[r * d + n + j] * u[j];
+        const S zr = r < n ? x[r] : u[r - n];
+        total = total + zr * (0.5f * cz + c[r]);
+    }
+    return total;
+}
+template <class S> __device__ S final_cost(const float *p, const S *x)                                 // :49-57
+{
+    const float *C = p + n * d + n, *c = C + d * d;
+    S total = S(0.0f);
+    for (int r = 0; r < n; ++r) {
+        S cz = S(0.0f);
+        for (int j = 0; j < n; ++j) cz = cz + C[r * d + j] * x[j];
+        total = total + x[r] * (0.5f * cz + c[r]);
+    }
+    return total;
+}
+""" % (n, m)
+
+
+def lq_params(F, f, C, c):
+    B = F.shape[0]
+    return np.concatenate([F.reshape(B, -1), f.reshape(B, -1), C.reshape(B, -1), c.reshape(B, -1)], axis=1).astype(np.float32)

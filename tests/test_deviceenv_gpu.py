@@ -178,3 +178,39 @@ def test_per_instance_parameters_and_unbounded_actions():
         xs, us, cs, it = o.solve(x0[b].astype(np.float64), T, u_init=u0[b].astype(np.float64))
         got = _np(out["costs"][b]).sum()
         assert abs(got - cs.sum()) <= 5e-3 * abs(cs.sum()) + 1e-3, (b, got, cs.sum(), it, int(out["iterations"][b]))
+
+
+@pytest.mark.gpu
+@needs_hipcc
+@pytest.mark.parametrize("n,m,T,bound", [(6, 3, 15, None), (8, 4, 20, 0.4), (16, 8, 20, None)])
+def test_lq_env_as_device_source_against_the_builtin_lq_env(n, m, T, bound):
+    """A DENSE env of another shape than 2 x 2 (the generic wave kernel; from n = 12 on with the backward products on the matrix cores): the LQ
+    env of /root/reference/tfmpc/solvers/lqr.py:36-57 written as DeviceEnv source with per-instance parameters against the built-in LQ env on the
+    same wave kernel -- derivatives (here the dual numbers must reproduce F and the symmetric part of C exactly up to rounding) and whole solves,
+    unbounded (Cholesky controller) and control-limited (box-QP)."""
+    from tfmpc.envs.lq import LQEnv
+    B = 24
+    F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=5 * n + m)
+    F = F * 0.25 * np.sqrt(16.0 / n)
+    low, high = (None, None) if bound is None else (-bound, bound)
+    builtin = LQEnv(F, f, C, c, low=low, high=high)
+    user = DeviceEnv(sources.lq_source(n, m), n, m, params=sources.lq_params(F, f, C, c), low=low, high=high)
+    rng = np.random.default_rng(1)
+    u0 = np.clip(0.1 * rng.normal(size=(B, T, m, 1)), -(bound or 1.0), bound or 1.0).astype(np.float32)
+    x0 = x0.astype(np.float32)[..., None]
+    xs = iLQR(builtin).start(x0, T, u_init=u0)[0]
+    got, ref = iLQR(user).derivatives(xs, u0), iLQR(builtin).derivatives(xs, u0)
+    torch.cuda.synchronize()
+    for a, b_ in zip([v for tup in got for v in tup], [v for tup in ref for v in tup]):
+        a, b_ = _np(a), _np(b_)
+        assert np.abs(a - b_).max() <= 2e-5 * max(np.abs(b_).max(), 1.0)
+    with _hip.option("TFMPC_ILQR_KERNEL", "wave"):
+        ref_out = iLQR(builtin, max_iterations=8).solve_device(x0, T, u_init=u0)
+    out = iLQR(user, max_iterations=8).solve_device(x0, T, u_init=u0)
+    torch.cuda.synchronize()
+    assert int((out["status"] & ~_hip.ST_NOT_PD).abs().sum()) == 0
+    same = (out["iterations"] == ref_out["iterations"]).cpu().numpy()
+    assert same.mean() >= 0.8, same.mean()
+    cu, cb = _np(out["costs"]).sum(1), _np(ref_out["costs"]).sum(1)
+    assert np.median(np.abs(cu - cb) / np.abs(cb)) <= 1e-4, np.median(np.abs(cu - cb) / np.abs(cb))
+    assert np.abs(_np(out["states"]) - _np(ref_out["states"]))[same].max() <= 5e-3 * np.abs(_np(ref_out["states"])).max()
