@@ -109,6 +109,33 @@ __device__ __forceinline__ void dma1(const void *g, unsigned lds)           // 1
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
 }
+// four 16-byte pieces per lane, 1 KB apart in memory AND in LDS (the instruction offset moves both addresses): one M0 set-up
+__device__ __forceinline__ void dma16x4(const void *g, unsigned lds)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+}
+// bit E of `bits` ? a : b in two instructions that touch no condition register (compare + select is four issue slots with its hazard no-ops)
+template <int E>
+__device__ __forceinline__ float select_bit(unsigned bits, float a, float b)
+{
+    int m;
+    float r;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(bits), "n"(E));      // the bit, sign-extended: 0 | ~0
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));  // (m & a) | (~m & b)
+    return r;
+}
+template <int NV, int E = 0>
+__device__ __forceinline__ void select_bits(unsigned bits, const float (&a)[NV], const float (&b)[NV], float (&o)[NV])
+{
+    if constexpr (E < NV) {
+        o[E] = select_bit<E>(bits, a[E], b[E]);
+        select_bits<NV, E + 1>(bits, a, b, o);
+    }
+}
 template <int N>
 __device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // a slot's LDS reads have delivered before the slot is refilled
@@ -375,29 +402,24 @@ __device__ __forceinline__ ZParts split_rows(const float (&z)[8])
 // One tile, PK instances per column (rows 4 q + r of a lane; an instance owns 16 / PK consecutive rows = 4 / PK lane quarters):
 // the shift of MatOp<2, true> inside every instance's rows.  Replaces four DEPENDENT v_mfma_f32_16x16x4_f32 (~130 cycles of
 // latency on the critical path of a step of the small-env kernels, which are bound by one wave's instruction latency).
+// Round 5: no branch on the direction -- both moves are selects under a wave-uniform mask (one fetch across the lane quarters, from the side the
+// direction names): the small-env kernels are bound by ONE wave's instruction count, branches and register copies included (~4 cycles each).
 __device__ __forceinline__ void shift_apply1(int shift, int leak_mask, int pk, const float (&z)[4], float (&acc)[4])
 {
     const int QS = 4 / pk;                           // lane quarters per instance (wave-uniform)
     const int lane = lane_id(), q = lane >> 4;
-    float o[4];
-    if (shift < 0) {                                 // wave-uniform: o[R] = z[R - 1]
-        float t = 0.0f;
-        if (QS > 1) {
-            t = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane - 16) & 63) << 2, __builtin_bit_cast(int, z[3])));
-            t = (q % QS == 0) ? 0.0f : t;
-        }
-        o[0] = t; o[1] = z[0]; o[2] = z[1]; o[3] = z[2];
-        if (leak_mask) {
+    const bool down = shift < 0;                     // wave-uniform: o[R] = z[R - 1], else o[R] = z[R + 1]
+    float t = 0.0f;
+    if (QS > 1) {
+        t = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((down ? lane - 16 : lane + 16) & 63) << 2,
+                                                                   __builtin_bit_cast(int, down ? z[3] : z[0])));
+        t = (q % QS == (down ? 0 : QS - 1)) ? 0.0f : t;
+    }
+    float o[4] = {down ? t : z[1], down ? z[0] : z[2], down ? z[1] : z[3], down ? z[2] : t};
+    if (leak_mask) {                                 // (only ever set for shift < 0; wave-uniform through bit 8)
+        asm volatile("" ::: "memory");               // stays a branch: if-converted it is eight selects on every step of every env that has no such row
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = ((leak_mask >> e) & 1) ? 0.0f : o[e];
-        }
-    } else {                                         // o[R] = z[R + 1]
-        float t = 0.0f;
-        if (QS > 1) {
-            t = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, __builtin_bit_cast(int, z[0])));
-            t = (q % QS == QS - 1) ? 0.0f : t;
-        }
-        o[0] = z[1]; o[1] = z[2]; o[2] = z[3]; o[3] = t;
+        for (int e = 0; e < 4; ++e) o[e] = ((leak_mask >> e) & 1) ? 0.0f : o[e];
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] += o[e];
@@ -496,7 +518,7 @@ __device__ __forceinline__ void mat_apply(const MatOp<2, true> &A, const float (
 // TFMPC_COSTATE_COUPLING=dense (AdjointSolveArgs::dense_coupling): keep the products also for a shift matrix
 __device__ __forceinline__ void force_dense(MatOp<2, false> &, bool) {}
 __device__ __forceinline__ void force_dense(MatOp<2, true> &A, bool dense) { if (dense) A.shift = 0; }
-template <bool S> __device__ __forceinline__ void force_dense(MatOp<1, S> &A, bool dense) { if (dense) A.shift = 0; }
+template <bool S> __device__ __forceinline__ void force_dense(MatOp<1, S> &A, bool dense) { A.shift = __builtin_amdgcn_readfirstlane(dense ? 0 : A.shift); }     // (wave-uniform: a scalar register)
 
 // A copy of a lane-dependent index the optimiser cannot see through: what is computed from it inside a loop stays
 // inside (hoisted out, the 16 operand addresses of each phase would stay live across the whole solve).
@@ -624,12 +646,14 @@ __device__ __forceinline__ void lds_rows(const float *lds, int slot, int qo, flo
 }
 constexpr int kSlotALow = 6, kSlotAHigh = 7;          // action bounds (both envs)
 
-template <int KIND, int NT, bool LEAN = false> struct EnvM;
+// ROWREGS (round 5; the multi-wave one-tile groups): the env's constant rows are read from LDS ONCE (cache_rows) and stay in registers -- a lone wave pays
+// ~4 cycles for every instruction it issues, LDS reads and their waits included, and one tile leaves the registers for it (two tiles do not)
+template <int KIND, int NT, bool LEAN = false, bool ROWREGS = false> struct EnvM;
 
 // ---------------------------------------------------------------------------------- HVAC ----
 // x' = x + rcap (heating + [A x + c0])   with  A = G - diag(gsum + k_out + k_hall),  c0 = k_out t_out + k_hall t_hall
 // (hvac/__init__.py:69-89, :131-149);  Q_x = l_x + V_x - u am CAP w + A^T w,  w = rcap V_x;  Q_u = COST am + am CAP (TEMP - x) w
-template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_HVAC, NT, LEAN> {
+template <int NT, bool LEAN, bool ROWREGS> struct EnvM<TFMPC_ENV_HVAC, NT, LEAN, ROWREGS> {
     static constexpr int NV = 4 * NT;
     static constexpr float CAP_AIR = 1.006f, COST_AIR = 1.0f, TEMP_AIR = 40.0f, TIME_DELTA = 1.0f;
     static constexpr float PENALTY = 20000.0f, SET_POINT_PENALTY = 10.0f;
@@ -644,7 +668,22 @@ template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_HVAC, NT, LEAN> {
     static constexpr int kSearchAlphas = NT == 2 ? 3 : 2;
 #endif
     float lo[NV], hi[NV], am[NV], rcap[NV];
+    float c_rows[1][NV];                               // ROWREGS: the LDS rows, in registers
     const float *lds;
+    __device__ __forceinline__ void cache_rows(int qo)
+    {
+        if constexpr (ROWREGS) lds_rows<NT>(lds, kC0, qo, c_rows[0]);         // (kC0 == 0, the only row)
+    }
+    template <int SLOT>
+    __device__ __forceinline__ void row(int qo, float (&o)[NV]) const
+    {
+        if constexpr (ROWREGS) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) o[e] = c_rows[SLOT][e];
+        } else {
+            lds_rows<NT>(lds, SLOT, qo, o);
+        }
+    }
 
     // A[R][C] = G[R][C] - (R == C) (gsum_R + k_out_R + k_hall_R); the operands of a phase are loaded when it starts
     // (they come from L2) so that the two sets are never live together
@@ -694,6 +733,10 @@ template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_HVAC, NT, LEAN> {
     {
 #pragma unroll
         for (int e = 0; e < NV; ++e) { opaque_f(lo[e]); opaque_f(hi[e]); opaque_f(am[e]); opaque_f(rcap[e]); }
+        if constexpr (ROWREGS) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) opaque_f(c_rows[0][e]);
+        }
     }
     // every stage / final cost is >= 0 for actions in [0, 1] (then partial cost sums never decrease)
     __device__ __forceinline__ bool costs_nonnegative() const
@@ -747,7 +790,7 @@ template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_HVAC, NT, LEAN> {
                                          float (&xn)[NV]) const
     {
         float acc[NV];
-        lds_rows<NT>(lds, kC0, qo, acc);
+        row<kC0>(qo, acc);
 #ifndef TFMPC_PROBE_NO_MATRIX_PRODUCT      // probe builds (tools/probes/cfg5_phases.py): what the bf16x3 product costs a step
         mat_apply(A, x, acc);
 #endif
@@ -804,7 +847,7 @@ template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_HVAC, NT, LEAN> {
 
 // ----------------------------------------------------------------------------- RESERVOIR ----
 // element-wise expressions in the order of ilqr_adjoint.hip / envs.h (reservoir/__init__.py:47-105)
-template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_RESERVOIR, NT, LEAN> {
+template <int NT, bool LEAN, bool ROWREGS> struct EnvM<TFMPC_ENV_RESERVOIR, NT, LEAN, ROWREGS> {
     static constexpr int NV = 4 * NT;
     static constexpr int kRain = 0, kDii = 1, kLP = 2, kHP = 3, kSP = 4;      // LDS slots
     // see EnvM<HVAC>.  Two tiles, round 2: with a column's rows contiguous in the buffers the single-step-size search that
@@ -818,7 +861,25 @@ template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_RESERVOIR, NT, LEAN> {
     static constexpr int kSearchAlphas = 2;
 #endif
     float rcap[NV], lo[NV], hi[NV];                  // 1 / max_res_cap: x / cap is x times the rounded reciprocal everywhere
+    float c_rows[ROWREGS ? 5 : 1][NV];               // ROWREGS: the five LDS rows, in registers
     const float *lds;
+    __device__ __forceinline__ void cache_rows(int qo)
+    {
+        if constexpr (ROWREGS) {
+#pragma unroll
+            for (int sl = 0; sl < 5; ++sl) lds_rows<NT>(lds, sl, qo, c_rows[sl]);
+        }
+    }
+    template <int SLOT>
+    __device__ __forceinline__ void row(int qo, float (&o)[NV]) const
+    {
+        if constexpr (ROWREGS) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) o[e] = c_rows[SLOT][e];
+        } else {
+            lds_rows<NT>(lds, SLOT, qo, o);
+        }
+    }
 
     // forward: D^T (inflow = D^T (u x)); backward: D without its diagonal.  Loaded when a phase starts (from L2), so
     // the two operand sets are never live together.
@@ -861,6 +922,12 @@ template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_RESERVOIR, NT, LEAN> {
     {
 #pragma unroll
         for (int e = 0; e < NV; ++e) { opaque_f(lo[e]); opaque_f(hi[e]); opaque_f(rcap[e]); }
+        if constexpr (ROWREGS) {
+#pragma unroll
+            for (int sl = 0; sl < 5; ++sl)
+#pragma unroll
+                for (int e = 0; e < NV; ++e) opaque_f(c_rows[sl][e]);
+        }
     }
     __device__ __forceinline__ bool costs_nonnegative() const          // see EnvM<HVAC>
     {
@@ -879,9 +946,9 @@ template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_RESERVOIR, NT, LEAN> {
     __device__ __forceinline__ void stage_costs(const float (&x)[NV], const float (&)[NV], int qo, float (&c)[NV]) const
     {
         float LP[NV], HP[NV], SP[NV];                                                     // reservoir :63-79
-        lds_rows<NT>(lds, kLP, qo, LP);
-        lds_rows<NT>(lds, kHP, qo, HP);
-        lds_rows<NT>(lds, kSP, qo, SP);
+        row<kLP>(qo, LP);
+        row<kHP>(qo, HP);
+        row<kSP>(qo, SP);
 #pragma unroll
         for (int e = 0; e < NV; e += 2) {
             const f32x2 X = pr(x, e), LO = pr(lo, e), HI = pr(hi, e);
@@ -899,9 +966,9 @@ template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_RESERVOIR, NT, LEAN> {
     __device__ __forceinline__ void grads(const float (&x)[NV], int qo, float (&gx)[NV]) const
     {
         float LP[NV], HP[NV], SP[NV];
-        lds_rows<NT>(lds, kLP, qo, LP);
-        lds_rows<NT>(lds, kHP, qo, HP);
-        lds_rows<NT>(lds, kSP, qo, SP);
+        row<kLP>(qo, LP);
+        row<kHP>(qo, HP);
+        row<kSP>(qo, SP);
 #pragma unroll
         for (int e = 0; e < NV; e += 2) {
             const f32x2 X = pr(x, e), LO = pr(lo, e), HI = pr(hi, e);
@@ -918,7 +985,7 @@ template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_RESERVOIR, NT, LEAN> {
 #pragma unroll
         for (int e = 0; e < NV; e += 2) { unpr(z, e, pr(u, e) * pr(x, e)); inflow[e] = 0.0f; inflow[e + 1] = 0.0f; }
         mat_apply(A, z, inflow);
-        lds_rows<NT>(lds, kRain, qo, rain);
+        row<kRain>(qo, rain);
         float r[NV], sr[NV];
 #pragma unroll
         for (int e = 0; e < NV; e += 2) unpr(r, e, pr(x, e) * pr(rcap, e));
@@ -930,15 +997,16 @@ template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_RESERVOIR, NT, LEAN> {
             unpr(xn, e, xi + pr(rain, e) + pr(inflow, e) - vaporated - pr(u, e) * xi);    // :56-60
         }
     }
-    template <class OP>
-    __device__ __forceinline__ void adjoint(const OP &A, const float (&xh)[NV], const float (&uh)[NV],
-                                            const float (&vx)[NV], int qo, float (&Qx)[NV], float (&Qu)[NV]) const
+    // `adjoint` in two parts.  What does not depend on V_x -- Q_x = u Y + cA V_x + l_x and Q_u = x Y + cB V_x with Y = the coupling product,
+    // cA = D_ii u + (1 - (r cos r + sin r) / 2 - u), cB = D_ii x - x: the trigonometry, the cost gradient, ~250 of a sweep step's ~320
+    // instructions -- can be evaluated for every step of the horizon at once; what is left of the recursion is four multiply-adds per
+    // row pair.  The multi-wave one-tile groups do exactly that (`kSweepCoefficients` in the kernel); every other form calls `adjoint`.
+    // Same expressions in the same order either way: the same bits.
+    __device__ __forceinline__ void adjoint_coefficients(const float (&xh)[NV], const float (&uh)[NV], int qo, float (&cA)[NV],
+                                                         float (&cB)[NV], float (&gx)[NV]) const
     {
-        float Y[NV], Dii[NV], gx[NV];
-#pragma unroll
-        for (int e = 0; e < NV; ++e) Y[e] = 0.0f;
-        mat_apply(A, vx, Y);                                                          // sum_{k != i} D[i][k] V_x[k]
-        lds_rows<NT>(lds, kDii, qo, Dii);
+        float Dii[NV];
+        row<kDii>(qo, Dii);
         grads(xh, qo, gx);
         float r[NV], sr[NV], cr[NV];
 #pragma unroll
@@ -946,11 +1014,35 @@ template <int NT, bool LEAN> struct EnvM<TFMPC_ENV_RESERVOIR, NT, LEAN> {
         sincos_vec<NV>(r, sr, cr);
 #pragma unroll
         for (int e = 0; e < NV; e += 2) {
-            const f32x2 uj = pr(uh, e), xa = pr(xh, e), V = pr(vx, e), Yp = pr(Y, e), D = pr(Dii, e);
+            const f32x2 uj = pr(uh, e), xa = pr(xh, e), D = pr(Dii, e);
             const f32x2 diag_extra = 1.0f - 0.5f * (pr(cr, e) * pr(r, e) + pr(sr, e)) - uj;
-            unpr(Qx, e, fma2(uj, Yp, fma2(D * uj + diag_extra, V, pr(gx, e))));
-            unpr(Qu, e, fma2(xa, Yp, fma2(D * xa - xa, V, splat(0.0f))));
+            unpr(cA, e, D * uj + diag_extra);
+            unpr(cB, e, D * xa - xa);
         }
+    }
+    template <class OP>
+    __device__ __forceinline__ void adjoint_apply(const OP &A, const float (&xh)[NV], const float (&uh)[NV], const float (&vx)[NV],
+                                                  const float (&cA)[NV], const float (&cB)[NV], const float (&gx)[NV],
+                                                  float (&Qx)[NV], float (&Qu)[NV]) const
+    {
+        float Y[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) Y[e] = 0.0f;
+        mat_apply(A, vx, Y);                                                          // sum_{k != i} D[i][k] V_x[k]
+#pragma unroll
+        for (int e = 0; e < NV; e += 2) {
+            const f32x2 V = pr(vx, e), Yp = pr(Y, e);
+            unpr(Qx, e, fma2(pr(uh, e), Yp, fma2(pr(cA, e), V, pr(gx, e))));
+            unpr(Qu, e, fma2(pr(xh, e), Yp, fma2(pr(cB, e), V, splat(0.0f))));
+        }
+    }
+    template <class OP>
+    __device__ __forceinline__ void adjoint(const OP &A, const float (&xh)[NV], const float (&uh)[NV],
+                                            const float (&vx)[NV], int qo, float (&Qx)[NV], float (&Qu)[NV]) const
+    {
+        float cA[NV], cB[NV], gx[NV];
+        adjoint_coefficients(xh, uh, qo, cA, cB, gx);
+        adjoint_apply(A, xh, uh, vx, cA, cB, gx, Qx, Qu);
     }
 };
 
@@ -966,7 +1058,7 @@ constexpr int kEnvReservoirChain = 100;
 struct MatShift { int shift, leak_mask; };
 __device__ __forceinline__ void mat_apply(const MatShift &A, const float (&z)[8], float (&acc)[8]) { shift_apply(A.shift, A.leak_mask, z, acc); }
 __device__ __forceinline__ void force_dense(MatShift &, bool) {}
-template <int NT, bool LEAN> struct EnvM<kEnvReservoirChain, NT, LEAN> : EnvM<TFMPC_ENV_RESERVOIR, NT, LEAN> {
+template <int NT, bool LEAN, bool ROWREGS> struct EnvM<kEnvReservoirChain, NT, LEAN, ROWREGS> : EnvM<TFMPC_ENV_RESERVOIR, NT, LEAN, ROWREGS> {
     static_assert(NT == 2, "the one-tile forms keep the run-time test");
     using Operand = MatShift;
     static constexpr bool kChain = true;
@@ -1036,6 +1128,10 @@ __device__ unsigned long long *g_cfg5_phases = nullptr;
 // size then runs as one segment per wave, each from its checkpoint (see the kernel).
 constexpr int kMaxGroupWaves = 8;
 __host__ __device__ constexpr size_t adjoint_mfma_checkpoint_floats(int NT) { return (size_t)kMaxGroupWaves * (kMaxGroupWaves - 1) * NT * kTileElems; }
+// the sweep coefficients of a one-tile group (Reservoir, `kSweepCoefficients` in the kernel): [time step][cA | cB | l_x | 1 / (|u| + 1)][lane]
+// 16-byte pieces behind the checkpoint tiles
+constexpr int kCoefPieces = 4;
+__host__ __device__ constexpr size_t adjoint_mfma_coefficient_floats(int NT, int T) { return NT == 1 ? (size_t)T * kCoefPieces * kTileElems : 0; }
 // bytes of one wave's slice of the wave-major workspace (sized for fp32 containers; the 16-bit ones use half of each buffer)
 __host__ __device__ constexpr size_t adjoint_mfma_wave_bytes(int NT, int T)
 {
@@ -1044,7 +1140,7 @@ __host__ __device__ constexpr size_t adjoint_mfma_wave_bytes(int NT, int T)
     // is a constant the LDS-DMA ring's s_waitcnt vmcnt(N) can count (see `rollout`)
     return (2 * ((size_t)(T + 1) * NT * kTileElems + (size_t)T * NT * kTileElems + (size_t)(T + 1) * kCostLd) * sizeof(float) +
             (size_t)T * kWave + 255 + ((size_t)NT * kTileElems + kCostLd) * sizeof(float) +
-            adjoint_mfma_checkpoint_floats(NT) * sizeof(float)) & ~(size_t)255;
+            (adjoint_mfma_checkpoint_floats(NT) + adjoint_mfma_coefficient_floats(NT, T)) * sizeof(float)) & ~(size_t)255;
 }
 
 // ---- round 3: groups of NW waves, one step-size chain per wave ----------------------------------------------------------
@@ -1102,6 +1198,12 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
     const size_t b = live ? b_raw : a.B - 1;             // last instance's data and store nothing
     __shared__ __attribute__((aligned(16))) float rows[kRowSlots * kRowLd];
     constexpr bool kChain = EnvTraits<KIND, NT, (NW > 1)>::kChain;       // Reservoir chain: no operand at all (see EnvM<kEnvReservoirChain>)
+#ifdef TFMPC_NO_ROW_REGISTERS          // A/B builds
+    constexpr bool kRowRegs = false;
+#else
+    constexpr bool kRowRegs = NT == 1 && NW >= 4 && !BF16;              // the env's constant rows and the action bounds in registers (see EnvM)
+#endif
+    using Env = EnvM<KIND, NT, (NW > 1), kRowRegs>;
     __shared__ u32x4 op_rest_all[NW][NT == 2 && !kChain ? 4 * kWave : 1];  // MatOp<2, true>: the non-leading parts of the operand, per wave
     __shared__ float x_sweep[NW > 1 ? 4 : 1][kWave];           // wave 0 -> the others: J_hat, dV1, g_norm, max |k|
     __shared__ float x_pass[2][NW][2][kWave];                  // [pass parity][wave][J | cut short][lane]
@@ -1116,14 +1218,18 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
     __shared__ f32x4 ring_v_all[NW][kLdsRing ? kRingDepth : 1][2 * NT][kWave];
     __shared__ float ring_c_all[NW][kLdsRing ? kRingDepth : 1][kWave];
     __shared__ unsigned ring_k_all[NW][kLdsRing ? kRingDepth : 1][kWave];    // (a sub-dword LDS-DMA still strides the lanes by 4 bytes)
+    auto ring_next = [](int slot_) {                    // (scalar arithmetic; a power-of-two depth wraps with a mask)
+        if constexpr ((kRingDepth & (kRingDepth - 1)) == 0) return (slot_ + 1) & (kRingDepth - 1);
+        else return slot_ + 1 == kRingDepth ? 0 : slot_ + 1;
+    };
     f32x4 (*const ring_v)[2 * NT][kWave] = ring_v_all[wv];
     float (*const ring_c)[kWave] = ring_c_all[wv];
     unsigned (*const ring_k)[kWave] = ring_k_all[wv];
-    EnvM<KIND, NT, (NW > 1)> env;
+    Env env;
     env.load(genv, lane, ql, rows);                      // (every wave of the group writes the same values)
     if constexpr (kChain) {
         // the caller's promise (TfmpcEnv::coupling_shift) against the matrix itself, before anything is computed on it
-        if (!EnvM<KIND, NT, (NW > 1)>::promise_holds(genv, lane)) {                  // (wave-uniform)
+        if (!Env::promise_holds(genv, lane)) {                  // (wave-uniform)
             if (wv == 0 && ql == 0 && live) { a.iterations[b] = 0; a.status[b] = TFMPC_ST_ENV_FLAG; }
             return;
         }
@@ -1133,6 +1239,21 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
         rows[kSlotAHigh * kRowLd + lane] = (lane < m) ? genv.high[lane] : 0.0f;
     }
     group_sync<NW>();
+    env.cache_rows(ql);
+    float alow_c[NV], ahigh_c[NV];                       // kRowRegs: the action bounds of this lane's rows, read once
+    if constexpr (kRowRegs) {
+        lds_rows<NT>(rows, kSlotALow, ql, alow_c);
+        lds_rows<NT>(rows, kSlotAHigh, ql, ahigh_c);
+    }
+    auto bounds = [&](int qo, float (&alow)[NV], float (&ahigh)[NV]) {
+        if constexpr (kRowRegs) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) { alow[e] = alow_c[e]; ahigh[e] = ahigh_c[e]; }
+        } else {
+            lds_rows<NT>(rows, kSlotALow, qo, alow);
+            lds_rows<NT>(rows, kSlotAHigh, qo, ahigh);
+        }
+    };
 #ifdef TFMPC_STAGGER
     // A/B builds: every other group starts late, so that the store-heavy phase of one half of the chip (the stored rollout
     // of a full cfg5 batch asks for ~6 TB/s when all groups run it at once) meets the line-search passes of the other
@@ -1140,7 +1261,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
         for (int i = 0; i < TFMPC_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
     const bool early_exit = cfg.c1 == 0.0f && env.costs_nonnegative();     // see `rollout`
-    const bool fused_cost = EnvM<KIND, NT, (NW > 1)>::kFusedSearchCost && env.bounds_ordered();
+    const bool fused_cost = Env::kFusedSearchCost && env.bounds_ordered();
 
     // trajectories of this group, wave-major (see ldw): two buffers of states / actions / stage costs in the group's slice
     // of the workspace, the nominal one is [flip]; at the end the nominal trajectory is copied (16-bit containers:
@@ -1160,6 +1281,19 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
     TT *const trash = reinterpret_cast<TT *>(wave_ws + ((2 * (kXs + kUs + kCs) * sizeof(float) + (size_t)T * kWave + 15) & ~(size_t)15));
     // the checkpoint tiles behind the trash slot: [chain of the pass][segment boundary - 1][tile][lane] 16-byte pieces, fp32
     float *const ckpt = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(trash) + ((size_t)NT * kTileElems + kCostLd) * sizeof(float));
+    // Round 5, Reservoir in one tile, groups of four / eight waves: the costate sweep in two parts (EnvM::adjoint_coefficients).  A group's iteration
+    // is a chain of dependent 100-step phases on a chip with idle SIMDs, and the sweep was the one phase still running on ONE wave: ~320
+    // instructions a step at one wave's issue rate (1 500 cycles; 44 % of a res4 solve, profiles/r03_small_env_phase_split.txt).  Now ALL
+    // waves of the group evaluate what does not depend on V_x -- the trigonometry, l_x, the two diagonal coefficients, 1 / (|u| + 1) of the
+    // stationarity measure -- for alternate time steps into the workspace, and wave 0 runs the recursion proper on them (the LDS-DMA ring
+    // carries them with x_hat, u_hat; their slots are the rings of waves 1, 2, idle during the sweep).  Same expressions, same order: same bits.
+#ifdef TFMPC_NO_SWEEP_COEFFICIENTS     // A/B builds
+    constexpr bool kSweepCoefficients = false;
+#else
+    constexpr bool kSweepCoefficients = KIND == TFMPC_ENV_RESERVOIR && NT == 1 && NW >= 4 && kLdsRing;
+#endif
+    static_assert(!kSweepCoefficients || (kRingDepth * kCoefPieces * kWave * sizeof(f32x4) <= 2 * sizeof(ring_v_all[0])), "the coefficient ring lives in the rings of waves 1 and 2");
+    float *const coef = ckpt + adjoint_mfma_checkpoint_floats(NT);      // [t][piece][lane] 16-byte pieces
     const int t_seg = NW > 1 ? (T + NW - 1) / NW : T;    // segment w of a stored rollout: steps [w t_seg, min((w + 1) t_seg, T))
     const float *const x0p = a.x0 + b * n;
     int flip = 0;
@@ -1200,7 +1334,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
         constexpr int NA = decltype(n_alpha)::value;
         constexpr bool DEFER = SEARCH && !STORE;            // only J matters: lane-partial cost sums
         static_assert(!STORE || NA == 1, "only a single rollout is stored");
-        typename EnvM<KIND, NT, (NW > 1)>::Operand A;
+        typename Env::Operand A;
         env.fence();
         env.template load_forward<PK>(genv, opaque(j), opaque(q), A, op_rest);
         force_dense(A, a.dense_coupling != 0);
@@ -1226,7 +1360,8 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
             for (int e = 0; e < NV; ++e) x[k][e] = x[0][e];
         }
         // the column's partial cost of a deferred pass: this lane's pairs, then the lanes of the column
-        auto partial = [&](int k) { return tile_sum<PK>((jacc[k][0].x + jacc[k][0].y) + (jacc[k][1].x + jacc[k][1].y)); };
+        // (the first sum is hidden from the vectoriser, which pairs the two up through four register copies)
+        auto partial = [&](int k) { float s0 = jacc[k][0].x + jacc[k][0].y; opaque_f(s0); return tile_sum<PK>(s0 + (jacc[k][1].x + jacc[k][1].y)); };
         auto request = [&](int t, float (&u_)[NV], unsigned &k_) {
             if constexpr (SEARCH) {
                 ldw<NT>(uh, t, wl, u_);
@@ -1248,7 +1383,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
         // Either ring is refilled UNCONDITIONALLY (the time index clamped to the horizon; the last steps re-read step
         // T - 1): the register ring because behind a condition the compiler merges "old value or loaded value" through
         // copies, the LDS ring because its waits count the loads of the younger steps.
-        int slot = 0;                                       // LDS ring: the slot of the current step
+        int slot = 0, pslot = kRingDepth - 1;               // LDS ring: the slot of the current step, of the step before it
         if constexpr (RING) {
 #pragma unroll
             for (int d = 0; d < kRingDepth - 1; ++d)
@@ -1271,7 +1406,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                 bool open = false;                       // a trying column whose partial cost may still end at or below J_hat
 #pragma unroll
                 for (int k = 0; k < NA; ++k) open = open || (trying && !((DEFER ? partial(k) : J[k]) > reject_above));
-                if (!__any(open)) { stopped = true; break; }
+                if (__builtin_amdgcn_ballot_w64(open) == 0) { stopped = true; break; }      // (__any materialises an integer per lane first)
             }
 #pragma unroll
             for (int d = 0; d < kAheadRoll; ++d) {
@@ -1291,7 +1426,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                         // step t + depth - 1 goes into the slot the previous step has just read; then the loads of THIS
                         // step have landed once at most the (depth - 1) younger steps' are outstanding
                         const int ahead = t + kRingDepth - 1;
-                        issue(slot == 0 ? kRingDepth - 1 : slot - 1, ahead < t_hi ? ahead : t_hi - 1);
+                        issue(pslot, ahead < t_hi ? ahead : t_hi - 1);
                         // (a stored rollout also issues kStores stores per step, unconditionally: they are younger than the
                         // loads waited for and stay in flight too -- counted without them, every step waited for the previous
                         // step's stores to be acknowledged by the memory system, ~2 us: the stored rollout, one chain, took as
@@ -1306,16 +1441,17 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                             ur[0][4 * b] = v[0]; ur[0][4 * b + 1] = v[1]; ur[0][4 * b + 2] = v[2]; ur[0][4 * b + 3] = v[3];
                         }
                         kb[0] = ring_k[slot][lane] & 0xFFu;
-                        slot = slot + 1 == kRingDepth ? 0 : slot + 1;
+                        pslot = slot, slot = ring_next(slot);
                     }
                     if (SEARCH) {
                         float alow[NV], ahigh[NV];
-                        lds_rows<NT>(rows, kSlotALow, qo, alow);
-                        lds_rows<NT>(rows, kSlotAHigh, qo, ahigh);
+                        bounds(qo, alow, ahigh);
+                        float bnd[NV];
+                        select_bits<NV>(kb[dd], alow, ahigh, bnd);              // the bound the sweep's selector bit names
 #pragma unroll
                         for (int e = 0; e < NV; e += 2) {
                             const f32x2 uh_e = pr(ur[dd], e);
-                            const f32x2 bound = {((kb[dd] >> e) & 1u) ? alow[e] : ahigh[e], ((kb[dd] >> (e + 1)) & 1u) ? alow[e + 1] : ahigh[e + 1]};
+                            const f32x2 bound = pr(bnd, e);
                             const f32x2 kt = bound - uh_e;                                                   // :140-141
 #pragma unroll
                             for (int k = 0; k < NA; ++k) {
@@ -1422,14 +1558,43 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
         TT *const xc = xbuf[flip ^ 1], *const uc = ubuf[flip ^ 1], *const cc = cbuf[flip ^ 1];
         // ---- backward (ilqr.py:94-172 on the bang-bang branch): costate recursion, all columns (wave 0) ----
         float rJ = 0.0f, dV1 = 0.0f, g_norm = 0.0f, kmax = 0.0f;
+        if constexpr (kSweepCoefficients) {
+            TFMPC_PHASE_BEGIN();
+            wait_vmem<0>();                  // (the tail loads of this wave's last rollout have landed: wave 0 is about to use the rings of waves 1, 2)
+            __syncthreads();                 // the nominal trajectory (wave 0's start / one-piece rollout) is visible to the group
+            env.fence();
+            const int qo = opaque(ql);
+            float xa[NV], ua[NV], xn[NV], un[NV];
+            if (wv < T) { ldw<NT>(xhat, wv, wl, xa); ldw<NT>(uhat, wv, wl, ua); }
+            for (int t = wv; t < T; t += NW) {
+                const int tn = t + NW < T ? t + NW : t;
+                ldw<NT>(xhat, tn, wl, xn);                                      // the next step of this wave, a step ahead
+                ldw<NT>(uhat, tn, wl, un);
+                float cA[NV], cB[NV], gx[NV];
+                env.adjoint_coefficients(xa, ua, qo, cA, cB, gx);
+                f32x4 *const dst = reinterpret_cast<f32x4 *>(coef + (size_t)t * kCoefPieces * kTileElems) + lane;
+                gst(dst, f32x4{cA[0], cA[1], cA[2], cA[3]});
+                gst(dst + kWave, f32x4{cB[0], cB[1], cB[2], cB[3]});
+                gst(dst + 2 * kWave, f32x4{gx[0], gx[1], gx[2], gx[3]});
+                f32x4 rd;
+#pragma unroll
+                for (int e = 0; e < NV; ++e) rd[e] = __builtin_amdgcn_rcpf(fabsf(ua[e]) + 1.0f);      // (see the sweep: |k| / (|u| + 1))
+                gst(dst + 3 * kWave, rd);
+#pragma unroll
+                for (int e = 0; e < NV; ++e) { xa[e] = xn[e]; ua[e] = un[e]; }
+            }
+            __syncthreads();                 // the coefficients of all steps are visible to wave 0
+            TFMPC_PHASE_END(4);
+        }
         if (wv == 0) {
             TFMPC_PHASE_BEGIN();
-            typename EnvM<KIND, NT, (NW > 1)>::Operand A;
+            typename Env::Operand A;
             env.fence();
             env.template load_backward<PK>(genv, opaque(j), opaque(q), A, op_rest);
             force_dense(A, a.dense_coupling != 0);
             constexpr bool RING = kLdsRing;
-            constexpr int kSlots = RING ? 1 : kAhead, kLoads = 2 * NT + 1;
+            constexpr int kSlots = RING ? 1 : kAhead, kLoads = 2 * NT + 1 + (kSweepCoefficients ? kCoefPieces : 0);
+            f32x4 (*const ring_e)[kWave] = reinterpret_cast<f32x4 (*)[kWave]>(&ring_v_all[NW > 1 ? 1 : 0][0][0][0]);   // [slot][piece][lane], see kSweepCoefficients
             float vx[NV], xT[NV], p1[NV], ka[NV], xr[kSlots][NV], ur[kSlots][NV], lr[kSlots];
             ldw<NT>(xhat, T, wl, xT);
             env.grads(xT, opaque(ql), vx);                     // V_x = l_x^f
@@ -1452,9 +1617,11 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
 #pragma unroll
                     for (int b = 0; b < NT; ++b) dma16(su + 16 * b, lds_addr_of(&ring_v[slot][NT + b][0]));
                     dma4(reinterpret_cast<const float *>(chat) + (size_t)t * kCostLd, lds_addr_of(&ring_c[slot][0]));
+                    if constexpr (kSweepCoefficients)
+                        dma16x4(coef + (size_t)t * kCoefPieces * kTileElems + 4 * lane, lds_addr_of(&ring_e[slot * kCoefPieces][0]));
                 }
             };
-            int slot = 0;
+            int slot = 0, pslot = kRingDepth - 1;
             if constexpr (RING) {
 #pragma unroll
                 for (int d = 0; d < kRingDepth - 1; ++d)
@@ -1476,9 +1643,10 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                     if (t >= 0) {
                         const int qo = opaque(ql);
                         const int dd = RING ? 0 : d;
+                        f32x4 ce[kCoefPieces];
                         if constexpr (RING) {
                             const int ahead = t - (kRingDepth - 1);
-                            issue(slot == 0 ? kRingDepth - 1 : slot - 1, ahead >= 0 ? ahead : 0);
+                            issue(pslot, ahead >= 0 ? ahead : 0);
                             // (the selector store of a step is younger than the loads issued at that step's start: the stores
                             // of the last depth - 1 steps stay in flight -- uncounted, every wait also asked for one load of the NEXT step)
                             if (RING && t <= T - kRingDepth) wait_vmem<(kRingDepth - 1) * (kLoads + 1)>();
@@ -1490,7 +1658,11 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                                 ur[0][4 * b] = vu_[0]; ur[0][4 * b + 1] = vu_[1]; ur[0][4 * b + 2] = vu_[2]; ur[0][4 * b + 3] = vu_[3];
                             }
                             lr[0] = ring_c[slot][lane];
-                            slot = slot + 1 == kRingDepth ? 0 : slot + 1;
+                            if constexpr (kSweepCoefficients) {
+#pragma unroll
+                                for (int k = 0; k < kCoefPieces; ++k) ce[k] = ring_e[slot * kCoefPieces + k][lane];
+                            }
+                            pslot = slot, slot = ring_next(slot);
                         }
                         float xh[NV], uh[NV];
 #pragma unroll
@@ -1502,9 +1674,14 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                             __builtin_amdgcn_sched_barrier(0);
                         }
                         float Qx[NV], Qu[NV], gm[NV], alow[NV], ahigh[NV];
-                        env.adjoint(A, xh, uh, vx, qo, Qx, Qu);
-                        lds_rows<NT>(rows, kSlotALow, qo, alow);
-                        lds_rows<NT>(rows, kSlotAHigh, qo, ahigh);
+                        if constexpr (kSweepCoefficients) {
+                            const float cA[NV] = {ce[0][0], ce[0][1], ce[0][2], ce[0][3]}, cB[NV] = {ce[1][0], ce[1][1], ce[1][2], ce[1][3]},
+                                        gx[NV] = {ce[2][0], ce[2][1], ce[2][2], ce[2][3]};
+                            env.adjoint_apply(A, xh, uh, vx, cA, cB, gx, Qx, Qu);
+                        } else {
+                            env.adjoint(A, xh, uh, vx, qo, Qx, Qu);
+                        }
+                        bounds(qo, alow, ahigh);
                         unsigned sel = 0;
 #pragma unroll
                         for (int e = 0; e < NV; e += 2) {
@@ -1517,8 +1694,13 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                             const f32x2 den = abs2(pr(uh, e)) + 1.0f;
                             // |k| / (|u| + 1) (:243-245) with the hardware reciprocal (1 ulp) instead of an IEEE division
                             // (8 per step were ~130 instructions): g_norm is only ever compared with atol
-                            gm[e] = akt.x * __builtin_amdgcn_rcpf(den.x);
-                            gm[e + 1] = akt.y * __builtin_amdgcn_rcpf(den.y);
+                            if constexpr (kSweepCoefficients) {
+                                gm[e] = akt.x * ce[3][e];
+                                gm[e + 1] = akt.y * ce[3][e + 1];
+                            } else {
+                                gm[e] = akt.x * __builtin_amdgcn_rcpf(den.x);
+                                gm[e + 1] = akt.y * __builtin_amdgcn_rcpf(den.y);
+                            }
                             vx[e] = Qx[e];                                                          // V_x <- Q_x
                             vx[e + 1] = Qx[e + 1];
                         }
@@ -1535,6 +1717,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
             kmax = col_max<NT, PK>(ka);
             dV1 = col_sum<NT, PK>(p1);
             g_norm = T > 0 ? gsum / (float)T : 0.0f;
+            if constexpr (kSweepCoefficients) wait_vmem<0>();     // (the ring's tail loads: their slots go back to waves 1, 2)
             TFMPC_PHASE_END(1);
             if constexpr (NW > 1) { x_sweep[0][lane] = rJ; x_sweep[1][lane] = dV1; x_sweep[2][lane] = g_norm; x_sweep[3][lane] = kmax; }
         }
@@ -1548,7 +1731,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
         bool accept = false;
         float residual = 0.0f, alpha_last = 0.0f;          // alpha_last: the step size of this column's last rollout
         float J_last = 0.0f;                               // ... and its cost, position: the decision trace
-        int index_last = -1;
+        int index_last = -1, chain_last = 0;               // chain_last: ... and which chain of its pass that was (the checkpoints)
         const bool active = !done;
         const float mu_pass = mu, delta_pass = delta;
         const int row_pass = iteration + attempts;
@@ -1610,7 +1793,11 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
             if (NW > 1) {                                                      // the group's J(alpha) of this pass, in step-size order
 #pragma unroll
                 for (int k = 0; k < NA; ++k) x_pass[parity][wv][k][lane] = J[k];
-                __syncthreads();
+                {
+                    TFMPC_PHASE_BEGIN();
+                    __syncthreads();
+                    TFMPC_PHASE_END(5);      // (probe builds: how long wave 0 waits for the group's slowest chain)
+                }
 #pragma unroll
                 for (int w = 0; w < NW; ++w)
 #pragma unroll
@@ -1635,6 +1822,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                     alpha_last = alpha;
                     J_last = Jall[k];
                     index_last = ai + k;
+                    chain_last = k;
                     if (z >= cfg.c1) { accept = true; last_index = ai + k; }   // :351-353
 #ifdef TFMPC_CFG5_TRACE
                     if (NW == 1 && g_cfg5_trace && q == 0 && live && iteration + attempts < 16 && ai + k < 11) {
@@ -1655,12 +1843,16 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
             if (kSegments && !__any(take && !accept)) {
                 TFMPC_PHASE_BEGIN();
                 const int lo = wv * t_seg, hi = lo + t_seg < T ? lo + t_seg : T;
-                const int kacc = take ? index_last % NAP : 0;                 // the accepted chain of its pass
+                const int kacc = take ? chain_last : 0;                       // the accepted chain of its pass
                 if (lo < hi)
                     rollout(std::true_type{}, std::true_type{}, one_t{}, al, uhat, take && !complete, xc, uc, cc, J, false, 0.0f, false, nullptr,
                             nullptr, lo, hi, ckpt + ((size_t)kacc * (kMaxGroupWaves - 1) + (wv > 0 ? wv - 1 : 0)) * NT * kTileElems);
                 TFMPC_PHASE_END(3);
-                group_sync<NW>();                  // every segment is visible to wave 0's sweep
+                {
+                    TFMPC_PHASE_BEGIN();
+                    group_sync<NW>();              // every segment is visible to wave 0's sweep
+                    TFMPC_PHASE_END(6);
+                }
             } else if (wv == 0) {
                 TFMPC_PHASE_BEGIN();
                 rollout(std::true_type{}, std::true_type{}, one_t{}, al, uhat, take && !complete, xc, uc, cc, J);
@@ -1700,9 +1892,9 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
         }
     }
 #ifdef TFMPC_PHASE_PROBE
-    if (g_cfg5_phases && wv == 0 && lane == 0) {
-        unsigned long long *out = g_cfg5_phases + (size_t)blockIdx.x * 16;
-        for (int i = 0; i < 4; ++i) { out[i] = phase_acc[i]; out[8 + i] = phase_cnt[i]; }
+    if (g_cfg5_phases && lane == 0) {                      // [group][wave of the group (8 slots)][16]
+        unsigned long long *out = g_cfg5_phases + ((size_t)blockIdx.x * kMaxGroupWaves + wv) * 16;
+        for (int i = 0; i < 7; ++i) { out[i == 5 ? 7 : i] = phase_acc[i]; out[8 + i] = phase_cnt[i]; }      // (4: the sweep's coefficient phase, 5 -> slot 7 / 6: barrier waits; slot 5: the kernel)
         out[5] = __builtin_amdgcn_s_memtime() - kernel_t0;
     }
 #endif

@@ -13,7 +13,7 @@ from tfmpc.solvers.ilqr import iLQR
 n, T = 32, 100
 lib = _hip.load()
 lib.tfmpc_debug_cfg5_phases.argtypes = [ctypes.c_void_p]
-names = ["start rollout", "sweeps", "search passes", "stored rollouts"]
+names = ["start rollout", "sweeps", "search passes", "stored rollouts", "sweep coefficients", "wait: pass exchange", "wait: segments"]
 SMALL = os.environ.get("PHASES_SMALL")                      # the reference's own configs (hvac6, res4) instead of n = 32
 for B in [int(v) for v in sys.argv[1:]] or (32768, 16384, 16):
     rng = np.random.default_rng(4)
@@ -29,13 +29,19 @@ for B in [int(v) for v in sys.argv[1:]] or (32768, 16384, 16):
         s = iLQR(env, max_iterations=12); u0 = s.random_actions(T, B, seed=5)
         per = 16 * (4 if env.state_size <= 4 else (2 if env.state_size <= 8 else 1))
         groups = (B + per - 1) // per
-        buf = torch.zeros((groups, 16), dtype=torch.int64, device="cuda")
+        buf = torch.zeros((groups, 8, 16), dtype=torch.int64, device="cuda")       # [group][wave of the group][slot]
         assert lib.tfmpc_debug_cfg5_phases(buf.data_ptr()) == 0
         out = s.solve_device(x0, T, u_init=u0); torch.cuda.synchronize()
         out = s.solve_device(x0, T, u_init=u0, workspace=out["workspace"]); torch.cuda.synchronize()
-        p = buf.cpu().numpy().astype(np.float64)
+        pw = buf.cpu().numpy().astype(np.float64)
+        p = pw[:, 0]                                       # wave 0 runs every phase
         tot = p[:, 5].mean()
         print(f"{kind} B={B}: kernel {tot / 1e3:.0f} k ticks per group (s_memtime ticks)")
         for i, nm in enumerate(names):
             c = p[:, 8 + i].mean()
+            i = 7 if i == 5 else i          # (slot 5 holds the kernel's total)
             print(f"   {nm:16s} {100 * p[:, i].mean() / tot:5.1f} %   {c:6.1f} calls, {p[:, i].mean() / max(c, 1):9.0f} ticks per call")
+        nw = int((pw[:, :, 5].mean(axis=0) > 0).sum())
+        if nw > 1:                                         # multi-wave groups: the line-search rollouts wave by wave
+            print("   search rollouts by wave: " + ", ".join(f"{pw[:, w, 2].mean() / max(pw[:, w, 10].mean(), 1) / 1e3:.0f} k x {pw[:, w, 10].mean():.1f}" for w in range(nw)))
+            print("   stored segments by wave: " + ", ".join(f"{pw[:, w, 3].mean() / max(pw[:, w, 11].mean(), 1) / 1e3:.1f} k" for w in range(nw)))
