@@ -109,13 +109,12 @@ __device__ __forceinline__ void dma1(const void *g, unsigned lds)           // 1
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
 }
-// four 16-byte pieces per lane, 1 KB apart in memory AND in LDS (the instruction offset moves both addresses): one M0 set-up
-__device__ __forceinline__ void dma16x4(const void *g, unsigned lds)
+// three 16-byte pieces per lane, 1 KB apart in memory AND in LDS (the instruction offset moves both addresses): one M0 set-up
+__device__ __forceinline__ void dma16x3(const void *g, unsigned lds)
 {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
 }
 // bit E of `bits` ? a : b in two instructions that touch no condition register (compare + select is four issue slots with its hazard no-ops)
@@ -786,14 +785,19 @@ template <int NT, bool LEAN, bool ROWREGS> struct EnvM<TFMPC_ENV_HVAC, NT, LEAN,
     }
     // x' = x + rcap (air CAP (TEMP - x) + [A x + c0]) with the two outer operations fused (one rounding each instead of
     // two: 4 packed instructions per row pair instead of 6; round 3 -- this env was never bit-tied to the wave kernels)
-    __device__ __forceinline__ void step(const Operand &A, const float (&x)[NV], const float (&u)[NV], int qo,
-                                         float (&xn)[NV]) const
+    // The product A x + c0 needs the state only: the one-tile kernels issue it when a step STARTS (state_product), so that its four dependent
+    // matrix instructions (40 cycles each, ~10 % of a small-env step) run under the ring's wait and the control's arithmetic instead of in front of
+    // the final multiply-adds (round 5).  Two tiles keep the one-piece `step`: their schedule and register budget are cfg5's.
+    static constexpr bool kProductOfStateOnly = true;
+    __device__ __forceinline__ void state_product(const Operand &A, const float (&x)[NV], int qo, float (&acc)[NV]) const
     {
-        float acc[NV];
         row<kC0>(qo, acc);
 #ifndef TFMPC_PROBE_NO_MATRIX_PRODUCT      // probe builds (tools/probes/cfg5_phases.py): what the bf16x3 product costs a step
         mat_apply(A, x, acc);
 #endif
+    }
+    __device__ __forceinline__ void step_with(const float (&acc)[NV], const float (&x)[NV], const float (&u)[NV], float (&xn)[NV]) const
+    {
 #pragma unroll
         for (int e = 0; e < NV; e += 2) {
             const f32x2 X = pr(x, e);
@@ -801,6 +805,13 @@ template <int NT, bool LEAN, bool ROWREGS> struct EnvM<TFMPC_ENV_HVAC, NT, LEAN,
             const f32x2 h = air * (TEMP_AIR - X);                                         // :74 (x CAP_AIR in the next line)
             unpr(xn, e, fma2(pr(rcap, e), fma2(h, splat(CAP_AIR), pr(acc, e)), X));       // :80-88
         }
+    }
+    __device__ __forceinline__ void step(const Operand &A, const float (&x)[NV], const float (&u)[NV], int qo,
+                                         float (&xn)[NV]) const
+    {
+        float acc[NV];
+        state_product(A, x, qo, acc);
+        step_with(acc, x, u, xn);
     }
     // A line-search rollout only needs J = sum of all stage costs: the costs of a lane's rows are accumulated straight
     // into two running pairs (no per-row cost values, no per-step column sum); the column sum is taken when the pass
@@ -961,6 +972,7 @@ template <int NT, bool LEAN, bool ROWREGS> struct EnvM<TFMPC_ENV_RESERVOIR, NT, 
     }
     __device__ __forceinline__ void final_costs(const float (&x)[NV], int qo, float (&c)[NV]) const { stage_costs(x, x, qo, c); }   // :81-83
     static constexpr bool kFusedSearchCost = false;       // the per-row costs keep the wave kernels' expression (and bits)
+    static constexpr bool kProductOfStateOnly = false;    // (the coupling product is of u x: nothing to start early)
     __device__ __forceinline__ bool bounds_ordered() const { return true; }
     __device__ __forceinline__ void cost_accumulate(const float (&)[NV], const float (&)[NV], int, f32x2 (&)[2]) const {}
     __device__ __forceinline__ void grads(const float (&x)[NV], int qo, float (&gx)[NV]) const
@@ -998,12 +1010,12 @@ template <int NT, bool LEAN, bool ROWREGS> struct EnvM<TFMPC_ENV_RESERVOIR, NT, 
         }
     }
     // `adjoint` in two parts.  What does not depend on V_x -- Q_x = u Y + cA V_x + l_x and Q_u = x Y + cB V_x with Y = the coupling product,
-    // cA = D_ii u + (1 - (r cos r + sin r) / 2 - u), cB = D_ii x - x: the trigonometry, the cost gradient, ~250 of a sweep step's ~320
+    // cA = D_ii u + (1 - (r cos r + sin r) / 2 - u), cB = D_ii x - x: the trigonometry and the cost gradient, ~250 of a sweep step's ~320
     // instructions -- can be evaluated for every step of the horizon at once; what is left of the recursion is four multiply-adds per
-    // row pair.  The multi-wave one-tile groups do exactly that (`kSweepCoefficients` in the kernel); every other form calls `adjoint`.
-    // Same expressions in the same order either way: the same bits.
+    // row pair (and cB, two instructions a pair: not worth a fourth piece of memory traffic).  The multi-wave one-tile groups do exactly that
+    // (`kSweepCoefficients` in the kernel); every other form calls `adjoint`.  Same expressions in the same order either way: the same bits.
     __device__ __forceinline__ void adjoint_coefficients(const float (&xh)[NV], const float (&uh)[NV], int qo, float (&cA)[NV],
-                                                         float (&cB)[NV], float (&gx)[NV]) const
+                                                         float (&gx)[NV]) const
     {
         float Dii[NV];
         row<kDii>(qo, Dii);
@@ -1014,35 +1026,34 @@ template <int NT, bool LEAN, bool ROWREGS> struct EnvM<TFMPC_ENV_RESERVOIR, NT, 
         sincos_vec<NV>(r, sr, cr);
 #pragma unroll
         for (int e = 0; e < NV; e += 2) {
-            const f32x2 uj = pr(uh, e), xa = pr(xh, e), D = pr(Dii, e);
+            const f32x2 uj = pr(uh, e), D = pr(Dii, e);
             const f32x2 diag_extra = 1.0f - 0.5f * (pr(cr, e) * pr(r, e) + pr(sr, e)) - uj;
             unpr(cA, e, D * uj + diag_extra);
-            unpr(cB, e, D * xa - xa);
         }
     }
     template <class OP>
-    __device__ __forceinline__ void adjoint_apply(const OP &A, const float (&xh)[NV], const float (&uh)[NV], const float (&vx)[NV],
-                                                  const float (&cA)[NV], const float (&cB)[NV], const float (&gx)[NV],
-                                                  float (&Qx)[NV], float (&Qu)[NV]) const
+    __device__ __forceinline__ void adjoint_apply(const OP &A, const float (&xh)[NV], const float (&uh)[NV], const float (&vx)[NV], int qo,
+                                                  const float (&cA)[NV], const float (&gx)[NV], float (&Qx)[NV], float (&Qu)[NV]) const
     {
-        float Y[NV];
+        float Y[NV], Dii[NV];
 #pragma unroll
         for (int e = 0; e < NV; ++e) Y[e] = 0.0f;
         mat_apply(A, vx, Y);                                                          // sum_{k != i} D[i][k] V_x[k]
+        row<kDii>(qo, Dii);
 #pragma unroll
         for (int e = 0; e < NV; e += 2) {
-            const f32x2 V = pr(vx, e), Yp = pr(Y, e);
+            const f32x2 V = pr(vx, e), Yp = pr(Y, e), xa = pr(xh, e);
             unpr(Qx, e, fma2(pr(uh, e), Yp, fma2(pr(cA, e), V, pr(gx, e))));
-            unpr(Qu, e, fma2(pr(xh, e), Yp, fma2(pr(cB, e), V, splat(0.0f))));
+            unpr(Qu, e, fma2(xa, Yp, fma2(pr(Dii, e) * xa - xa, V, splat(0.0f))));
         }
     }
     template <class OP>
     __device__ __forceinline__ void adjoint(const OP &A, const float (&xh)[NV], const float (&uh)[NV],
                                             const float (&vx)[NV], int qo, float (&Qx)[NV], float (&Qu)[NV]) const
     {
-        float cA[NV], cB[NV], gx[NV];
-        adjoint_coefficients(xh, uh, qo, cA, cB, gx);
-        adjoint_apply(A, xh, uh, vx, cA, cB, gx, Qx, Qu);
+        float cA[NV], gx[NV];
+        adjoint_coefficients(xh, uh, qo, cA, gx);
+        adjoint_apply(A, xh, uh, vx, qo, cA, gx, Qx, Qu);
     }
 };
 
@@ -1128,9 +1139,9 @@ __device__ unsigned long long *g_cfg5_phases = nullptr;
 // size then runs as one segment per wave, each from its checkpoint (see the kernel).
 constexpr int kMaxGroupWaves = 8;
 __host__ __device__ constexpr size_t adjoint_mfma_checkpoint_floats(int NT) { return (size_t)kMaxGroupWaves * (kMaxGroupWaves - 1) * NT * kTileElems; }
-// the sweep coefficients of a one-tile group (Reservoir, `kSweepCoefficients` in the kernel): [time step][cA | cB | l_x | 1 / (|u| + 1)][lane]
+// the sweep coefficients of a one-tile group (Reservoir, `kSweepCoefficients` in the kernel): [time step][cA | l_x | 1 / (|u| + 1)][lane]
 // 16-byte pieces behind the checkpoint tiles
-constexpr int kCoefPieces = 4;
+constexpr int kCoefPieces = 3;
 __host__ __device__ constexpr size_t adjoint_mfma_coefficient_floats(int NT, int T) { return NT == 1 ? (size_t)T * kCoefPieces * kTileElems : 0; }
 // bytes of one wave's slice of the wave-major workspace (sized for fp32 containers; the 16-bit ones use half of each buffer)
 __host__ __device__ constexpr size_t adjoint_mfma_wave_bytes(int NT, int T)
@@ -1284,7 +1295,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
     // Round 5, Reservoir in one tile, groups of four / eight waves: the costate sweep in two parts (EnvM::adjoint_coefficients).  A group's iteration
     // is a chain of dependent 100-step phases on a chip with idle SIMDs, and the sweep was the one phase still running on ONE wave: ~320
     // instructions a step at one wave's issue rate (1 500 cycles; 44 % of a res4 solve, profiles/r03_small_env_phase_split.txt).  Now ALL
-    // waves of the group evaluate what does not depend on V_x -- the trigonometry, l_x, the two diagonal coefficients, 1 / (|u| + 1) of the
+    // waves of the group evaluate what does not depend on V_x -- the trigonometry, l_x, the diagonal coefficient that carries them, 1 / (|u| + 1) of the
     // stationarity measure -- for alternate time steps into the workspace, and wave 0 runs the recursion proper on them (the LDS-DMA ring
     // carries them with x_hat, u_hat; their slots are the rings of waves 1, 2, idle during the sweep).  Same expressions, same order: same bits.
 #ifdef TFMPC_NO_SWEEP_COEFFICIENTS     // A/B builds
@@ -1359,6 +1370,13 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
 #pragma unroll
             for (int e = 0; e < NV; ++e) x[k][e] = x[0][e];
         }
+        // x_0 is USED here, before the ring's first DMA is issued: the compiler then waits for its load now.  Left to the first use inside the
+        // time loop, the wait it places there is an s_waitcnt vmcnt(0) on every trip -- it cannot count the ring's loads, which it does not see --
+        // and drains the whole ring on every second step (found in the multi-wave search loops, round 5: tools/probes/vmwaits.py)
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+#pragma unroll
+            for (int e = 0; e < NV; ++e) opaque_f(x[k][e]);
         // the column's partial cost of a deferred pass: this lane's pairs, then the lanes of the column
         // (the first sum is hidden from the vectoriser, which pairs the two up through four register copies)
         auto partial = [&](int k) { float s0 = jacc[k][0].x + jacc[k][0].y; opaque_f(s0); return tile_sum<PK>(s0 + (jacc[k][1].x + jacc[k][1].y)); };
@@ -1416,6 +1434,12 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                     const int qo = opaque(ql);
                     float u[NA][NV];
                     const int dd = RING ? 0 : d;                // the register ring's slot of this unrolled step
+                    constexpr bool kEarlyProduct = NT == 1 && Env::kProductOfStateOnly;      // (see EnvM<HVAC>::state_product)
+                    float pre[NA][NV];
+                    if constexpr (kEarlyProduct) {
+#pragma unroll
+                        for (int k = 0; k < NA; ++k) env.state_product(A, x[k], qo, pre[k]);
+                    }
                     if (NW > 1 && DEFER && ck_out && t == ck_next) {    // (wave-uniform; uncounted stores only make the ring's waits longer)
 #pragma unroll
                         for (int k = 0; k < NA; ++k) stw<NT>(ck_out + ((size_t)k * (kMaxGroupWaves - 1) + ck_slot) * NT * kTileElems, 0, wl, trying, x[k]);
@@ -1482,7 +1506,8 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
 #pragma unroll
                                 for (int e = 0; e < NV; e += 2) jacc[k][(e >> 1) & 1] += pr(cp, e);
                             }
-                            env.step(A, x[k], u[k], qo, xn);
+                            if constexpr (kEarlyProduct) env.step_with(pre[k], x[k], u[k], xn);
+                            else env.step(A, x[k], u[k], qo, xn);
 #ifdef TFMPC_CFG5_TRACE
                             if (trace_fa[k] < 0 && partial(k) > reject_above) trace_fa[k] = t;
 #endif
@@ -1490,7 +1515,8 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                             float cp[NV];
                             env.stage_costs(x[k], u[k], qo, cp);
                             const float c = col_sum<NT, PK>(cp);
-                            env.step(A, x[k], u[k], qo, xn);
+                            if constexpr (kEarlyProduct) env.step_with(pre[k], x[k], u[k], xn);
+                            else env.step(A, x[k], u[k], qo, xn);
                             J[k] += c;
                             if (STORE) {
                                 if constexpr (RING) {
@@ -1570,16 +1596,15 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                 const int tn = t + NW < T ? t + NW : t;
                 ldw<NT>(xhat, tn, wl, xn);                                      // the next step of this wave, a step ahead
                 ldw<NT>(uhat, tn, wl, un);
-                float cA[NV], cB[NV], gx[NV];
-                env.adjoint_coefficients(xa, ua, qo, cA, cB, gx);
+                float cA[NV], gx[NV];
+                env.adjoint_coefficients(xa, ua, qo, cA, gx);
                 f32x4 *const dst = reinterpret_cast<f32x4 *>(coef + (size_t)t * kCoefPieces * kTileElems) + lane;
                 gst(dst, f32x4{cA[0], cA[1], cA[2], cA[3]});
-                gst(dst + kWave, f32x4{cB[0], cB[1], cB[2], cB[3]});
-                gst(dst + 2 * kWave, f32x4{gx[0], gx[1], gx[2], gx[3]});
+                gst(dst + kWave, f32x4{gx[0], gx[1], gx[2], gx[3]});
                 f32x4 rd;
 #pragma unroll
                 for (int e = 0; e < NV; ++e) rd[e] = __builtin_amdgcn_rcpf(fabsf(ua[e]) + 1.0f);      // (see the sweep: |k| / (|u| + 1))
-                gst(dst + 3 * kWave, rd);
+                gst(dst + 2 * kWave, rd);
 #pragma unroll
                 for (int e = 0; e < NV; ++e) { xa[e] = xn[e]; ua[e] = un[e]; }
             }
@@ -1618,7 +1643,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                     for (int b = 0; b < NT; ++b) dma16(su + 16 * b, lds_addr_of(&ring_v[slot][NT + b][0]));
                     dma4(reinterpret_cast<const float *>(chat) + (size_t)t * kCostLd, lds_addr_of(&ring_c[slot][0]));
                     if constexpr (kSweepCoefficients)
-                        dma16x4(coef + (size_t)t * kCoefPieces * kTileElems + 4 * lane, lds_addr_of(&ring_e[slot * kCoefPieces][0]));
+                        dma16x3(coef + (size_t)t * kCoefPieces * kTileElems + 4 * lane, lds_addr_of(&ring_e[slot * kCoefPieces][0]));
                 }
             };
             int slot = 0, pslot = kRingDepth - 1;
@@ -1675,9 +1700,8 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                         }
                         float Qx[NV], Qu[NV], gm[NV], alow[NV], ahigh[NV];
                         if constexpr (kSweepCoefficients) {
-                            const float cA[NV] = {ce[0][0], ce[0][1], ce[0][2], ce[0][3]}, cB[NV] = {ce[1][0], ce[1][1], ce[1][2], ce[1][3]},
-                                        gx[NV] = {ce[2][0], ce[2][1], ce[2][2], ce[2][3]};
-                            env.adjoint_apply(A, xh, uh, vx, cA, cB, gx, Qx, Qu);
+                            const float cA[NV] = {ce[0][0], ce[0][1], ce[0][2], ce[0][3]}, gx[NV] = {ce[1][0], ce[1][1], ce[1][2], ce[1][3]};
+                            env.adjoint_apply(A, xh, uh, vx, qo, cA, gx, Qx, Qu);
                         } else {
                             env.adjoint(A, xh, uh, vx, qo, Qx, Qu);
                         }
@@ -1695,8 +1719,8 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                             // |k| / (|u| + 1) (:243-245) with the hardware reciprocal (1 ulp) instead of an IEEE division
                             // (8 per step were ~130 instructions): g_norm is only ever compared with atol
                             if constexpr (kSweepCoefficients) {
-                                gm[e] = akt.x * ce[3][e];
-                                gm[e + 1] = akt.y * ce[3][e + 1];
+                                gm[e] = akt.x * ce[2][e];
+                                gm[e + 1] = akt.y * ce[2][e + 1];
                             } else {
                                 gm[e] = akt.x * __builtin_amdgcn_rcpf(den.x);
                                 gm[e + 1] = akt.y * __builtin_amdgcn_rcpf(den.y);
