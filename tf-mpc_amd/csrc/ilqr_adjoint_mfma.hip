@@ -1457,6 +1457,11 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                         // long as a search pass with two)
                         // (the loads of THIS step were issued at the start of step t - (depth - 1), BEFORE that step's stores: the
                         // stores of the last depth - 1 steps are younger and stay in flight; that many exist from step depth - 1 on)
+#ifdef TFMPC_PROBE_NO_RING_READS        // probe builds (timing only, wrong results): what the ring's wait and its LDS reads cost a step
+#pragma unroll
+                        for (int e = 0; e < NV; ++e) { ur[0][e] = 0.25f; opaque_f(ur[0][e]); }
+                        kb[0] = 5u + (unsigned)t;
+#else
                         if (STORE && t - t_lo >= kRingDepth - 1) wait_vmem<(kRingDepth - 1) * (kLoads + 2 * NT + 1)>();
                         else wait_vmem<(kRingDepth - 1) * kLoads>();
 #pragma unroll
@@ -1465,6 +1470,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                             ur[0][4 * b] = v[0]; ur[0][4 * b + 1] = v[1]; ur[0][4 * b + 2] = v[2]; ur[0][4 * b + 3] = v[3];
                         }
                         kb[0] = ring_k[slot][lane] & 0xFFu;
+#endif
                         pslot = slot, slot = ring_next(slot);
                     }
                     if (SEARCH) {

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 SRC=${1:-lqr_block.hip}
 mkdir -p $ROOT/tools/probes/ab
 make -j8 -C $ROOT/tf-mpc_amd/csrc > /dev/null
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -DTFMPC_PHASE_PROBE -DTFMPC_CFG5_TRACE \
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -DTFMPC_PHASE_PROBE -DTFMPC_CFG5_TRACE $PROBE_EXTRA \
     -c $ROOT/tf-mpc_amd/csrc/$SRC -o $ROOT/tools/probes/ab/probe.o
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $ROOT/tools/probes/ab/lib_probe.so $ROOT/tools/probes/ab/probe.o \
     $(ls $ROOT/tf-mpc_amd/csrc/build/*.o | grep -v "/${SRC%.hip}\(\.p[0-9]\)\?\.o")
