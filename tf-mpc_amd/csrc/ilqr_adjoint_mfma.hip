@@ -1434,7 +1434,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                     const int qo = opaque(ql);
                     float u[NA][NV];
                     const int dd = RING ? 0 : d;                // the register ring's slot of this unrolled step
-                    constexpr bool kEarlyProduct = NT == 1 && Env::kProductOfStateOnly;      // (see EnvM<HVAC>::state_product)
+                    constexpr bool kEarlyProduct = NT == 1 && NW > 1 && Env::kProductOfStateOnly;      // (see EnvM<HVAC>::state_product; one-wave groups share their SIMD with two others and have no registers to park it in)
                     float pre[NA][NV];
                     if constexpr (kEarlyProduct) {
 #pragma unroll
