@@ -1009,6 +1009,33 @@ template <int NT, bool LEAN, bool ROWREGS> struct EnvM<TFMPC_ENV_RESERVOIR, NT, 
             unpr(xn, e, xi + pr(rain, e) + pr(inflow, e) - vaporated - pr(u, e) * xi);    // :56-60
         }
     }
+    // `step` and `adjoint_coefficients` of the same (x, u) in one piece (the stored rollouts of the forms with kSweepCoefficients): ONE evaluation of
+    // sine and cosine serves the evaporation and the diagonal coefficient -- the same sin_small / cos_small / general path per argument, so both
+    // results carry the bits the separate calls give.
+    template <class OP>
+    __device__ __forceinline__ void step_with_coefficients(const OP &A, const float (&x)[NV], const float (&u)[NV], int qo, float (&xn)[NV],
+                                                           float (&cA)[NV], float (&gx)[NV]) const
+    {
+        float z[NV], inflow[NV], rain[NV], Dii[NV];
+#pragma unroll
+        for (int e = 0; e < NV; e += 2) { unpr(z, e, pr(u, e) * pr(x, e)); inflow[e] = 0.0f; inflow[e + 1] = 0.0f; }
+        mat_apply(A, z, inflow);
+        row<kRain>(qo, rain);
+        row<kDii>(qo, Dii);
+        grads(x, qo, gx);
+        float r[NV], sr[NV], cr[NV];
+#pragma unroll
+        for (int e = 0; e < NV; e += 2) unpr(r, e, pr(x, e) * pr(rcap, e));
+        sincos_vec<NV>(r, sr, cr);
+#pragma unroll
+        for (int e = 0; e < NV; e += 2) {
+            const f32x2 xi = pr(x, e), uj = pr(u, e);
+            const f32x2 vaporated = 0.5f * pr(sr, e) * xi;                                // :87
+            unpr(xn, e, xi + pr(rain, e) + pr(inflow, e) - vaporated - uj * xi);          // :56-60
+            const f32x2 diag_extra = 1.0f - 0.5f * (pr(cr, e) * pr(r, e) + pr(sr, e)) - uj;
+            unpr(cA, e, pr(Dii, e) * uj + diag_extra);
+        }
+    }
     // `adjoint` in two parts.  What does not depend on V_x -- Q_x = u Y + cA V_x + l_x and Q_u = x Y + cB V_x with Y = the coupling product,
     // cA = D_ii u + (1 - (r cos r + sin r) / 2 - u), cB = D_ii x - x: the trigonometry and the cost gradient, ~250 of a sweep step's ~320
     // instructions -- can be evaluated for every step of the horizon at once; what is left of the recursion is four multiply-adds per
@@ -1222,6 +1249,20 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
     // the LDS-DMA input ring of this wave (fp32 containers): [slot][x tiles | u tiles][lane] 16-byte pieces, the stage
     // cost and the selector byte of a slot.  Depth 3 with two tiles keeps 8 groups per CU inside the 160 KB.
     constexpr bool kLdsRing = !BF16;
+    // Round 5, Reservoir in one tile, groups of four / eight waves: the costate sweep in two parts (EnvM::adjoint_coefficients).  A group's iteration
+    // is a chain of dependent 100-step phases on a chip with idle SIMDs, and the sweep was the one phase still running on ONE wave: ~320
+    // instructions a step at one wave's issue rate (1 500 cycles; 44 % of a res4 solve, profiles/r03_small_env_phase_split.txt).  What does not
+    // depend on V_x -- the trigonometry, l_x, the diagonal coefficient that carries them, 1 / (|u| + 1) of the stationarity measure -- is a function of
+    // the nominal trajectory alone, and every nominal trajectory comes out of a STORED rollout (the start rollout; the accepted step size rolled out
+    // as one segment of the horizon per wave): that rollout, which has x_t, u_t and the sine of the evaporation in registers, writes the three
+    // 16-byte pieces per lane next to the trajectory, and wave 0 runs the recursion proper on them (the LDS-DMA ring carries them with x_hat, u_hat).
+    // Same expressions, same order: same bits.  (First built as a pass of its own in front of the sweep, all waves on alternate time steps: 27 k cycles
+    // per iteration, bound by the memory system -- 256 groups wrote and re-read at once; in the stored rollout it is ~90 instruction slots a step.)
+#ifdef TFMPC_NO_SWEEP_COEFFICIENTS     // A/B builds
+    constexpr bool kSweepCoefficients = false;
+#else
+    constexpr bool kSweepCoefficients = KIND == TFMPC_ENV_RESERVOIR && NT == 1 && NW >= 4 && kLdsRing;
+#endif
 #ifndef TFMPC_CHAIN_RING
 #define TFMPC_CHAIN_RING 3
 #endif
@@ -1229,6 +1270,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
     __shared__ f32x4 ring_v_all[NW][kLdsRing ? kRingDepth : 1][2 * NT][kWave];
     __shared__ float ring_c_all[NW][kLdsRing ? kRingDepth : 1][kWave];
     __shared__ unsigned ring_k_all[NW][kLdsRing ? kRingDepth : 1][kWave];    // (a sub-dword LDS-DMA still strides the lanes by 4 bytes)
+    __shared__ f32x4 ring_e[kSweepCoefficients ? kRingDepth * kCoefPieces : 1][kWave];      // wave 0's ring of the sweep coefficients: [slot][piece][lane]
     auto ring_next = [](int slot_) {                    // (scalar arithmetic; a power-of-two depth wraps with a mask)
         if constexpr ((kRingDepth & (kRingDepth - 1)) == 0) return (slot_ + 1) & (kRingDepth - 1);
         else return slot_ + 1 == kRingDepth ? 0 : slot_ + 1;
@@ -1292,18 +1334,6 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
     TT *const trash = reinterpret_cast<TT *>(wave_ws + ((2 * (kXs + kUs + kCs) * sizeof(float) + (size_t)T * kWave + 15) & ~(size_t)15));
     // the checkpoint tiles behind the trash slot: [chain of the pass][segment boundary - 1][tile][lane] 16-byte pieces, fp32
     float *const ckpt = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(trash) + ((size_t)NT * kTileElems + kCostLd) * sizeof(float));
-    // Round 5, Reservoir in one tile, groups of four / eight waves: the costate sweep in two parts (EnvM::adjoint_coefficients).  A group's iteration
-    // is a chain of dependent 100-step phases on a chip with idle SIMDs, and the sweep was the one phase still running on ONE wave: ~320
-    // instructions a step at one wave's issue rate (1 500 cycles; 44 % of a res4 solve, profiles/r03_small_env_phase_split.txt).  Now ALL
-    // waves of the group evaluate what does not depend on V_x -- the trigonometry, l_x, the diagonal coefficient that carries them, 1 / (|u| + 1) of the
-    // stationarity measure -- for alternate time steps into the workspace, and wave 0 runs the recursion proper on them (the LDS-DMA ring
-    // carries them with x_hat, u_hat; their slots are the rings of waves 1, 2, idle during the sweep).  Same expressions, same order: same bits.
-#ifdef TFMPC_NO_SWEEP_COEFFICIENTS     // A/B builds
-    constexpr bool kSweepCoefficients = false;
-#else
-    constexpr bool kSweepCoefficients = KIND == TFMPC_ENV_RESERVOIR && NT == 1 && NW >= 4 && kLdsRing;
-#endif
-    static_assert(!kSweepCoefficients || (kRingDepth * kCoefPieces * kWave * sizeof(f32x4) <= 2 * sizeof(ring_v_all[0])), "the coefficient ring lives in the rings of waves 1 and 2");
     float *const coef = ckpt + adjoint_mfma_checkpoint_floats(NT);      // [t][piece][lane] 16-byte pieces
     const int t_seg = NW > 1 ? (T + NW - 1) / NW : T;    // segment w of a stored rollout: steps [w t_seg, min((w + 1) t_seg, T))
     const float *const x0p = a.x0 + b * n;
@@ -1462,7 +1492,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                         for (int e = 0; e < NV; ++e) { ur[0][e] = 0.25f; opaque_f(ur[0][e]); }
                         kb[0] = 5u + (unsigned)t;
 #else
-                        if (STORE && t - t_lo >= kRingDepth - 1) wait_vmem<(kRingDepth - 1) * (kLoads + 2 * NT + 1)>();
+                        if (STORE && t - t_lo >= kRingDepth - 1) wait_vmem<(kRingDepth - 1) * (kLoads + 2 * NT + 1 + (kSweepCoefficients ? kCoefPieces : 0))>();
                         else wait_vmem<(kRingDepth - 1) * kLoads>();
 #pragma unroll
                         for (int b = 0; b < NT; ++b) {
@@ -1521,8 +1551,14 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                             float cp[NV];
                             env.stage_costs(x[k], u[k], qo, cp);
                             const float c = col_sum<NT, PK>(cp);
-                            if constexpr (kEarlyProduct) env.step_with(pre[k], x[k], u[k], xn);
-                            else env.step(A, x[k], u[k], qo, xn);
+                            float cA[NV], gx[NV];                               // (kSweepCoefficients: the next sweep's coefficients of step t)
+                            if constexpr (kSweepCoefficients) {                 // (Reservoir: no early product)
+                                if constexpr (STORE) env.step_with_coefficients(A, x[k], u[k], qo, xn, cA, gx);
+                                else env.step(A, x[k], u[k], qo, xn);
+                            } else {
+                                if constexpr (kEarlyProduct) env.step_with(pre[k], x[k], u[k], xn);
+                                else env.step(A, x[k], u[k], qo, xn);
+                            }
                             J[k] += c;
                             if (STORE) {
                                 if constexpr (RING) {
@@ -1535,6 +1571,17 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                                     stw<NT>(us, t, wl, keep, u[k]);
                                     stw<NT>(xs, t + 1, wl, keep, xn);
                                     if (keep && ql == 0) stc(cs + (size_t)t * kCostLd, c);
+                                }
+                                if constexpr (kSweepCoefficients) {             // (see kSweepCoefficients)
+                                    f32x4 rd;
+#pragma unroll
+                                    for (int e = 0; e < NV; ++e) rd[e] = __builtin_amdgcn_rcpf(fabsf(u[k][e]) + 1.0f);      // (see the sweep: |k| / (|u| + 1))
+                                    f32x4 *const dst = reinterpret_cast<f32x4 *>(keep ? coef + (size_t)t * kCoefPieces * kTileElems : reinterpret_cast<float *>(trash)) + lane;
+                                    if (RING || keep) {                         // (the LDS-DMA ring counts its stores: issued on every step, as above)
+                                        gst(dst, f32x4{cA[0], cA[1], cA[2], cA[3]});
+                                        gst(keep ? dst + kWave : dst, f32x4{gx[0], gx[1], gx[2], gx[3]});
+                                        gst(keep ? dst + 2 * kWave : dst, rd);
+                                    }
                                 }
                             }
                         }
@@ -1590,33 +1637,6 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
         TT *const xc = xbuf[flip ^ 1], *const uc = ubuf[flip ^ 1], *const cc = cbuf[flip ^ 1];
         // ---- backward (ilqr.py:94-172 on the bang-bang branch): costate recursion, all columns (wave 0) ----
         float rJ = 0.0f, dV1 = 0.0f, g_norm = 0.0f, kmax = 0.0f;
-        if constexpr (kSweepCoefficients) {
-            TFMPC_PHASE_BEGIN();
-            wait_vmem<0>();                  // (the tail loads of this wave's last rollout have landed: wave 0 is about to use the rings of waves 1, 2)
-            __syncthreads();                 // the nominal trajectory (wave 0's start / one-piece rollout) is visible to the group
-            env.fence();
-            const int qo = opaque(ql);
-            float xa[NV], ua[NV], xn[NV], un[NV];
-            if (wv < T) { ldw<NT>(xhat, wv, wl, xa); ldw<NT>(uhat, wv, wl, ua); }
-            for (int t = wv; t < T; t += NW) {
-                const int tn = t + NW < T ? t + NW : t;
-                ldw<NT>(xhat, tn, wl, xn);                                      // the next step of this wave, a step ahead
-                ldw<NT>(uhat, tn, wl, un);
-                float cA[NV], gx[NV];
-                env.adjoint_coefficients(xa, ua, qo, cA, gx);
-                f32x4 *const dst = reinterpret_cast<f32x4 *>(coef + (size_t)t * kCoefPieces * kTileElems) + lane;
-                gst(dst, f32x4{cA[0], cA[1], cA[2], cA[3]});
-                gst(dst + kWave, f32x4{gx[0], gx[1], gx[2], gx[3]});
-                f32x4 rd;
-#pragma unroll
-                for (int e = 0; e < NV; ++e) rd[e] = __builtin_amdgcn_rcpf(fabsf(ua[e]) + 1.0f);      // (see the sweep: |k| / (|u| + 1))
-                gst(dst + 2 * kWave, rd);
-#pragma unroll
-                for (int e = 0; e < NV; ++e) { xa[e] = xn[e]; ua[e] = un[e]; }
-            }
-            __syncthreads();                 // the coefficients of all steps are visible to wave 0
-            TFMPC_PHASE_END(4);
-        }
         if (wv == 0) {
             TFMPC_PHASE_BEGIN();
             typename Env::Operand A;
@@ -1625,7 +1645,6 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
             force_dense(A, a.dense_coupling != 0);
             constexpr bool RING = kLdsRing;
             constexpr int kSlots = RING ? 1 : kAhead, kLoads = 2 * NT + 1 + (kSweepCoefficients ? kCoefPieces : 0);
-            f32x4 (*const ring_e)[kWave] = reinterpret_cast<f32x4 (*)[kWave]>(&ring_v_all[NW > 1 ? 1 : 0][0][0][0]);   // [slot][piece][lane], see kSweepCoefficients
             float vx[NV], xT[NV], p1[NV], ka[NV], xr[kSlots][NV], ur[kSlots][NV], lr[kSlots];
             ldw<NT>(xhat, T, wl, xT);
             env.grads(xT, opaque(ql), vx);                     // V_x = l_x^f
@@ -1747,7 +1766,6 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
             kmax = col_max<NT, PK>(ka);
             dV1 = col_sum<NT, PK>(p1);
             g_norm = T > 0 ? gsum / (float)T : 0.0f;
-            if constexpr (kSweepCoefficients) wait_vmem<0>();     // (the ring's tail loads: their slots go back to waves 1, 2)
             TFMPC_PHASE_END(1);
             if constexpr (NW > 1) { x_sweep[0][lane] = rJ; x_sweep[1][lane] = dV1; x_sweep[2][lane] = g_norm; x_sweep[3][lane] = kmax; }
         }
