@@ -1293,6 +1293,16 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
     }
     group_sync<NW>();
     env.cache_rows(ql);
+    // kRowRegs: both matrix operands stay resident too (one tile: four registers each).  Loaded per phase -- as the two-tile forms must, for their
+    // registers -- a phase starts with the operand's round trip to L2 (HVAC: a dependent chain of n loads for the diagonal): 2 - 5 k cycles, three
+    // phases per iteration of a group whose whole iteration is ~300 k.
+    typename Env::Operand A_fwd, A_bwd;
+    if constexpr (kRowRegs) {
+        env.template load_forward<PK>(genv, j, q, A_fwd, op_rest);
+        force_dense(A_fwd, a.dense_coupling != 0);
+        env.template load_backward<PK>(genv, j, q, A_bwd, op_rest);
+        force_dense(A_bwd, a.dense_coupling != 0);
+    }
     float alow_c[NV], ahigh_c[NV];                       // kRowRegs: the action bounds of this lane's rows, read once
     if constexpr (kRowRegs) {
         lds_rows<NT>(rows, kSlotALow, ql, alow_c);
@@ -1338,6 +1348,11 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
     const int t_seg = NW > 1 ? (T + NW - 1) / NW : T;    // segment w of a stored rollout: steps [w t_seg, min((w + 1) t_seg, T))
     const float *const x0p = a.x0 + b * n;
     int flip = 0;
+    // x_0 resident as well -- where the compiler keeps the array in registers: behind the partial-piece loads (VW < 4) and in the HVAC forms it
+    // ends up in scratch memory (40 scratch instructions in the code object, one store per time step: hvac6 2.21 -> 2.33 ms)
+    constexpr bool kResidentX0 = kRowRegs && VW == 4 && KIND != TFMPC_ENV_HVAC;
+    float x0_c[NV];
+    if constexpr (kResidentX0) ldv<NT, VW>(x0p, n, ql, x0_c);
 
     // One rollout of every column from x0.  SEARCH: u_t = clip(u_hat_t + alpha k_t) (ilqr.py:193-197), else the
     // injected start actions (:53-82).  The bang-bang gain is k_t = bound - u_hat_t (:140-141), so the sweep leaves ONE
@@ -1377,14 +1392,23 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
         static_assert(!STORE || NA == 1, "only a single rollout is stored");
         typename Env::Operand A;
         env.fence();
-        env.template load_forward<PK>(genv, opaque(j), opaque(q), A, op_rest);
-        force_dense(A, a.dense_coupling != 0);
+        if constexpr (kRowRegs) {
+            A = A_fwd;
+        } else {
+            env.template load_forward<PK>(genv, opaque(j), opaque(q), A, op_rest);
+            force_dense(A, a.dense_coupling != 0);
+        }
         constexpr bool RING = SEARCH && kLdsRing;           // wave-major fp32 inputs: the LDS-DMA ring; else a register ring
         constexpr int kSlots = RING ? 1 : kAheadRoll, kLoads = NT + 1;      // kLoads: DMA instructions per step
         float x[NA][NV], ur[kSlots][NV], J[NA];
         f32x2 jacc[NA][2];
         unsigned kb[kSlots];
-        ldv<NT, VW>(x0p, n, ql, x[0]);
+        if constexpr (kResidentX0) {                         // (one round trip to L2 less per rollout)
+#pragma unroll
+            for (int e = 0; e < NV; ++e) x[0][e] = x0_c[e];
+        } else {
+            ldv<NT, VW>(x0p, n, ql, x[0]);
+        }
         if (STORE && t_lo > 0) {
             float xc_[NV];
             ldw<NT>(ck_in, 0, wl, xc_);
@@ -1641,8 +1665,12 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
             TFMPC_PHASE_BEGIN();
             typename Env::Operand A;
             env.fence();
-            env.template load_backward<PK>(genv, opaque(j), opaque(q), A, op_rest);
-            force_dense(A, a.dense_coupling != 0);
+            if constexpr (kRowRegs) {
+                A = A_bwd;
+            } else {
+                env.template load_backward<PK>(genv, opaque(j), opaque(q), A, op_rest);
+                force_dense(A, a.dense_coupling != 0);
+            }
             constexpr bool RING = kLdsRing;
             constexpr int kSlots = RING ? 1 : kAhead, kLoads = 2 * NT + 1 + (kSweepCoefficients ? kCoefPieces : 0);
             float vx[NV], xT[NV], p1[NV], ka[NV], xr[kSlots][NV], ur[kSlots][NV], lr[kSlots];
