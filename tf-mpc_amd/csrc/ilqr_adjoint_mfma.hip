@@ -1409,28 +1409,41 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
         } else {
             ldv<NT, VW>(x0p, n, ql, x[0]);
         }
-        if (STORE && t_lo > 0) {
-            float xc_[NV];
-            ldw<NT>(ck_in, 0, wl, xc_);
-#pragma unroll
-            for (int e = 0; e < NV; ++e) x[0][e] = keep ? xc_[e] : x[0][e];       // (lanes without a checkpoint compute on finite values)
+        float xck[kRowRegs ? NV : 1];
+        if constexpr (kRowRegs) {
+            if (STORE && t_lo > 0) ldw<NT>(ck_in, 0, wl, xck);   // (requested here; used in `adopt_start`, behind the ring's first DMAs)
         }
-        if (STORE && t_lo == 0) stw<NT>(xs, 0, wl, keep, x[0]);
         int ck_next = t_seg, ck_slot = 0;                   // ck_out: the next boundary and its tile
+        // The start state of this rollout is USED before the time loop: the compiler then waits for its loads here.  Left to the first use inside
+        // the loop, the wait it places there is an s_waitcnt vmcnt(0) on every trip -- it cannot count the ring's loads, which it does not see --
+        // and drains the whole ring on every second step (found in the multi-wave search loops, round 5: tools/probes/vmwaits.py).  The forms with
+        // registers to spare (kRowRegs) do it BEHIND the ring's first DMAs, so that the two round trips overlap.
+        auto adopt_start = [&]() {
+            if (STORE && t_lo > 0) {
+                if constexpr (kRowRegs) {
 #pragma unroll
-        for (int k = 0; k < NA; ++k) {
-            J[k] = 0.0f;
-            jacc[k][0] = jacc[k][1] = splat(0.0f);
+                    for (int e = 0; e < NV; ++e) x[0][e] = keep ? xck[e] : x[0][e];   // (lanes without a checkpoint compute on finite values)
+                } else {
+                    float xc_[NV];
+                    ldw<NT>(ck_in, 0, wl, xc_);
 #pragma unroll
-            for (int e = 0; e < NV; ++e) x[k][e] = x[0][e];
-        }
-        // x_0 is USED here, before the ring's first DMA is issued: the compiler then waits for its load now.  Left to the first use inside the
-        // time loop, the wait it places there is an s_waitcnt vmcnt(0) on every trip -- it cannot count the ring's loads, which it does not see --
-        // and drains the whole ring on every second step (found in the multi-wave search loops, round 5: tools/probes/vmwaits.py)
+                    for (int e = 0; e < NV; ++e) x[0][e] = keep ? xc_[e] : x[0][e];
+                }
+            }
+            if (STORE && t_lo == 0) stw<NT>(xs, 0, wl, keep, x[0]);
 #pragma unroll
-        for (int k = 0; k < NA; ++k)
+            for (int k = 0; k < NA; ++k) {
+                J[k] = 0.0f;
+                jacc[k][0] = jacc[k][1] = splat(0.0f);
 #pragma unroll
-            for (int e = 0; e < NV; ++e) opaque_f(x[k][e]);
+                for (int e = 0; e < NV; ++e) x[k][e] = x[0][e];
+            }
+#pragma unroll
+            for (int k = 0; k < NA; ++k)
+#pragma unroll
+                for (int e = 0; e < NV; ++e) opaque_f(x[k][e]);
+        };
+        if constexpr (!kRowRegs) adopt_start();
         // the column's partial cost of a deferred pass: this lane's pairs, then the lanes of the column
         // (the first sum is hidden from the vectoriser, which pairs the two up through four register copies)
         auto partial = [&](int k) { float s0 = jacc[k][0].x + jacc[k][0].y; opaque_f(s0); return tile_sum<PK>(s0 + (jacc[k][1].x + jacc[k][1].y)); };
@@ -1469,6 +1482,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                 if (T > 0) request(d < T ? d : T - 1, ur[d], kb[d]);
             }
         }
+        if constexpr (kRowRegs) adopt_start();
         bool stopped = false;
 #ifdef TFMPC_CFG5_TRACE
         trace_fa[0] = trace_fa[1] = trace_fa[2] = trace_fa[3] = -1;
