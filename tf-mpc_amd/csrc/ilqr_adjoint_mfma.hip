@@ -1689,10 +1689,16 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
             constexpr int kSlots = RING ? 1 : kAhead, kLoads = 2 * NT + 1 + (kSweepCoefficients ? kCoefPieces : 0);
             float vx[NV], xT[NV], p1[NV], ka[NV], xr[kSlots][NV], ur[kSlots][NV], lr[kSlots];
             ldw<NT>(xhat, T, wl, xT);
-            env.grads(xT, opaque(ql), vx);                     // V_x = l_x^f
+            rJ = ldc(chat + (size_t)T * kCostLd);                                    // the stage costs of the nominal trajectory are the l_t
+            // V_x = l_x^f.  (kRowRegs: x_T and l_T are requested above and first USED behind the ring's first DMAs -- the round trips overlap;
+            // used before the time loop either way, see `rollout`.)
+            auto adopt_final = [&]() {
+                env.grads(xT, opaque(ql), vx);
+                opaque_f(rJ);
+            };
+            if constexpr (!kRowRegs) env.grads(xT, opaque(ql), vx);
 #pragma unroll
             for (int e = 0; e < NV; ++e) { p1[e] = 0.0f; ka[e] = 0.0f; }
-            rJ = ldc(chat + (size_t)T * kCostLd);                                    // the stage costs of the nominal trajectory are the l_t
             float gsum = 0.0f;
             auto request = [&](int t, float (&x_)[NV], float (&u_)[NV], float &l_) {
                 ldw<NT>(xhat, t, wl, x_);
@@ -1727,6 +1733,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                     if (T > 0) request(T - 1 - d >= 0 ? T - 1 - d : 0, xr[d], ur[d], lr[d]);      // (unconditional refills: see `rollout`)
                 }
             }
+            if constexpr (kRowRegs) adopt_final();
             for (int t0 = T - 1; t0 >= 0; t0 -= kAhead) {
 #pragma unroll
                 for (int d = 0; d < kAhead; ++d) {
