@@ -410,8 +410,12 @@ __device__ __forceinline__ void shift_apply1(int shift, int leak_mask, int pk, c
     const bool down = shift < 0;                     // wave-uniform: o[R] = z[R - 1], else o[R] = z[R + 1]
     float t = 0.0f;
     if (QS > 1) {
+        // (the two candidates as opaque register values: a select between two ELEMENTS of `z` is rewritten into an indexed load, and with that the
+        // array -- a lane's state -- moves to scratch memory)
+        float z_first = z[0], z_last = z[3];
+        asm volatile("" : "+v"(z_first), "+v"(z_last));
         t = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((down ? lane - 16 : lane + 16) & 63) << 2,
-                                                                   __builtin_bit_cast(int, down ? z[3] : z[0])));
+                                                                   __builtin_bit_cast(int, down ? z_last : z_first)));
         t = (q % QS == (down ? 0 : QS - 1)) ? 0.0f : t;
     }
     float o[4] = {down ? t : z[1], down ? z[0] : z[2], down ? z[1] : z[3], down ? z[2] : t};
@@ -1348,9 +1352,8 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
     const int t_seg = NW > 1 ? (T + NW - 1) / NW : T;    // segment w of a stored rollout: steps [w t_seg, min((w + 1) t_seg, T))
     const float *const x0p = a.x0 + b * n;
     int flip = 0;
-    // x_0 resident as well -- where the compiler keeps the array in registers: behind the partial-piece loads (VW < 4) and in the HVAC forms it
-    // ends up in scratch memory (40 scratch instructions in the code object, one store per time step: hvac6 2.21 -> 2.33 ms)
-    constexpr bool kResidentX0 = kRowRegs && VW == 4 && KIND != TFMPC_ENV_HVAC;
+    // x_0 resident as well (check the code object for scratch_ instructions after touching this: see shift_apply1's note on indexed loads)
+    constexpr bool kResidentX0 = kRowRegs;
     float x0_c[NV];
     if constexpr (kResidentX0) ldv<NT, VW>(x0p, n, ql, x0_c);
 
