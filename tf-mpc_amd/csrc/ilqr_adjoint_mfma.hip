@@ -660,7 +660,7 @@ template <int NT, bool LEAN, bool ROWREGS> struct EnvM<TFMPC_ENV_HVAC, NT, LEAN,
     static constexpr int NV = 4 * NT;
     static constexpr float CAP_AIR = 1.006f, COST_AIR = 1.0f, TEMP_AIR = 40.0f, TIME_DELTA = 1.0f;
     static constexpr float PENALTY = 20000.0f, SET_POINT_PENALTY = 10.0f;
-    static constexpr int kC0 = 0;                       // LDS slot
+    static constexpr int kC0 = 0, kDiag = 1;            // LDS slots
     // step sizes per line-search pass: two independent chains give a wave something to issue while the other chain waits
     // (cfg5 HVAC: 20.1 -> 16.6 ms in round 1; one step size per pass with stored candidates, re-tried in round 2: 18.0 vs 14.1 ms)
 #ifdef TFMPC_SEARCH_ALPHAS            // A/B builds: step sizes per line-search pass of a one-wave group
@@ -690,16 +690,13 @@ template <int NT, bool LEAN, bool ROWREGS> struct EnvM<TFMPC_ENV_HVAC, NT, LEAN,
 
     // A[R][C] = G[R][C] - (R == C) (gsum_R + k_out_R + k_hall_R); the operands of a phase are loaded when it starts
     // (they come from L2) so that the two sets are never live together
-    static __device__ __forceinline__ float el(const TfmpcEnv &g, int R, int C)
+    // (round 5: the diagonal's gsum_R + k_out_R + k_hall_R comes from an LDS row that `load` fills once per kernel -- summed per phase it was a
+    // chain of n DEPENDENT loads, load -> wait -> add, in front of every rollout and sweep: ~20 k cycles at n = 32)
+    __device__ __forceinline__ float el(const TfmpcEnv &g, int R, int C) const
     {
-        const int n = g.n;
         const float *G = g.p[8];
-        float v = G[R * n + C];
-        if (R == C) {
-            float gs = 0.0f;
-            for (int k = 0; k < n; ++k) gs += G[R * n + k];
-            v -= gs + g.p[4][R] + g.p[5][R];
-        }
+        float v = G[R * g.n + C];
+        if (R == C) v -= lds[kDiag * kRowLd + R];
         return v;
     }
     using Operand = MatOp<NT, LEAN>;                    // LEAN (multi-wave groups): non-leading parts in LDS
@@ -719,7 +716,13 @@ template <int NT, bool LEAN, bool ROWREGS> struct EnvM<TFMPC_ENV_HVAC, NT, LEAN,
         const float *pt_out = g.p[0], *pt_hall = g.p[1], *plo = g.p[2], *phi = g.p[3], *pk_out = g.p[4], *pk_hall = g.p[5],
                     *pcap = g.p[6], *pam = g.p[7];
         lds = lds_;
-        if (lane < kRowLd) lds_[kC0 * kRowLd + lane] = (lane < n) ? pk_out[lane] * pt_out[lane] + pk_hall[lane] * pt_hall[lane] : 0.0f;
+        if (lane < kRowLd) {
+            lds_[kC0 * kRowLd + lane] = (lane < n) ? pk_out[lane] * pt_out[lane] + pk_hall[lane] * pt_hall[lane] : 0.0f;
+            float gs = 0.0f;                             // sum_k G[R][k] in the order of k, then + k_out_R + k_hall_R: the diagonal of A is G[R][R] minus this
+            if (lane < n)
+                for (int k = 0; k < n; ++k) gs += g.p[8][lane * n + k];
+            lds_[kDiag * kRowLd + lane] = (lane < n) ? gs + pk_out[lane] + pk_hall[lane] : 0.0f;
+        }
         load_rows<NT>(plo, n, q, 0.0f, lo);
         load_rows<NT>(phi, n, q, 0.0f, hi);
         load_rows<NT>(pam, n, q, 0.0f, am);
