@@ -91,6 +91,9 @@ def check_kernel(name, items):
                 continue                                       # "the loads of the younger steps": exactly what the compiler emitted
             if k * dma < n <= k * vm:
                 continue                                       # loads + stores of the younger steps: no more than are really issued
+            if n * (k + 1) == k * dma and steps == 1:
+                continue                                       # a ring's PROLOGUE with its first, peeled step (no time loop of its own left around it): depth
+                                                               # steps' loads issued, the wait leaves the depth - 1 younger steps' in flight
             findings.append(f"{name[:70]}: loop [{lo}..{hi}]: vmcnt({n}) with ring depth {k + 1}, {dma} DMA loads and {vm - dma} other "
                             f"vector-memory instructions per step: " + ("the wait counts MORE operations than a step issues -- it would return early"
                                                                          if n > k * vm else "the wait is not a whole number of steps' loads"))
