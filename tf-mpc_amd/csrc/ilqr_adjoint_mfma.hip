@@ -1230,7 +1230,14 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
     static_assert(NW == 1 || NW == 2 || NW == 4 || NW == 8, "waves per sixteen-column group");
     static_assert(NW <= kMaxGroupWaves, "checkpoint tiles");
     const int lane = lane_id(), j = lane & 15, q = lane >> 4, n = genv.n, m = n, T = a.T;
-    const int wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // this wave within its group
+    // this wave within its group.  The LOGICAL wave 0 -- which runs the start rollout and the costate recursion alone -- is a different hardware wave in
+    // every other round of 256 groups: two groups that share a CU then do not put their lone phases on the same SIMD (A/B: TFMPC_NO_WAVE_ROTATION)
+#ifdef TFMPC_NO_WAVE_ROTATION
+    const int wave_rot = 0;
+#else
+    const int wave_rot = NW > 1 ? ((int)(blockIdx.x >> 8) * (NW / 2)) & (NW - 1) : 0;
+#endif
+    const int wv = NW == 1 ? 0 : (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + wave_rot) & (NW - 1);
     // PK instances per column (n <= 16 / PK): lane quarter q belongs to sub-instance q / (4 / PK) and holds its rows
     // 4 ql .. 4 ql + 3, ql = q mod (4 / PK).  Everything below indexes rows with ql; only the MFMA operands know q.
     const int ql = q & (4 / PK - 1);
