@@ -96,20 +96,68 @@ struct LaneEnv<TFMPC_ENV_NAVLQR, N, N> {                 // envs/lqr/navigation/
 template <int N>
 struct LaneEnv<TFMPC_ENV_NAVIGATION, N, N> {             // envs/navigation/__init__.py:34-74
     float goal[N];
-    const float *center, *decay;   // shared by the batch (uniform addresses -> scalar loads)
+    const float *center, *decay;   // shared by the batch
     int zones;
+    // Round 5: the first kZoneRegs zones' centres and decays are read ONCE per instance into registers.  Read where they are used they were two or
+    // three vector loads -- a round trip to the cache each, with its wait -- per zone and evaluation: in every step of every rollout, and six
+    // evaluations per step of the linearisation (the env object lives in vector registers, so the "uniform" addresses were not scalar loads).
+#ifdef TFMPC_NAV_ZONES_FROM_MEMORY     // A/B builds
+    static constexpr int kZoneRegs = 0;
+#else
+    static constexpr int kZoneRegs = 4;
+#endif
+    float zc[kZoneRegs > 0 ? kZoneRegs : 1][N], zd[kZoneRegs > 0 ? kZoneRegs : 1];
     __device__ void load(const TfmpcEnv &g, int b)
     {
 #pragma unroll
         for (int i = 0; i < N; ++i) goal[i] = g.p[0][(size_t)b * g.stride[0] + i];
         center = g.p[1]; decay = g.p[2]; zones = g.n_zones;
+#pragma unroll
+        for (int z = 0; z < kZoneRegs; ++z) {
+            zd[z] = z < zones ? decay[z] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < N; ++i) zc[z][i] = z < zones ? center[z * N + i] : 0.0f;
+        }
     }
     __device__ float zone_lambda(const float *x, int z, float *r_out, float *ex_out) const
     {
+        float c[N], dz = 0.0f;
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < kZoneRegs; ++k)                // (a select chain over the resident zones: `z` is wave-uniform, the compiler keeps it scalar)
+            if (z == k) {
+                found = true;
+                dz = zd[k];
+#pragma unroll
+                for (int i = 0; i < N; ++i) c[i] = zc[k][i];
+            }
+        if (!found) {
+            dz = decay[z];
+#pragma unroll
+            for (int i = 0; i < N; ++i) c[i] = center[z * N + i];
+        }
         float r2 = 0.0f;
 #pragma unroll
-        for (int i = 0; i < N; ++i) { const float d = x[i] - center[z * N + i]; r2 = fmaf(d, d, r2); }
-        return nav_zone_lambda(r2, decay[z], r_out, ex_out);          // envs.h: the same expression in every kernel
+        for (int i = 0; i < N; ++i) { const float d = x[i] - c[i]; r2 = fmaf(d, d, r2); }
+        return nav_zone_lambda(r2, dz, r_out, ex_out);                // envs.h: the same expression in every kernel
+    }
+    __device__ float zone_decay(int z) const
+    {
+        float dz = 0.0f;
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < kZoneRegs; ++k)
+            if (z == k) { found = true; dz = zd[k]; }
+        return found ? dz : decay[z];
+    }
+    __device__ float zone_center(int z, int i) const
+    {
+        float v = 0.0f;
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < kZoneRegs; ++k)
+            if (z == k) { found = true; v = zc[k][i]; }
+        return found ? v : center[z * N + i];
     }
     __device__ float deceleration(const float *x, float *grad) const
     {
@@ -121,12 +169,12 @@ struct LaneEnv<TFMPC_ENV_NAVIGATION, N, N> {             // envs/navigation/__in
             for (int z = 0; z < zones; ++z) {
                 float r, ex;
                 zone_lambda(x, z, &r, &ex);
-                const float h = nav_zone_slope(decay[z], ex);
+                const float h = nav_zone_slope(zone_decay(z), ex);
                 float others = 1.0f;
                 for (int y = 0; y < zones; ++y)
                     if (y != z) others *= zone_lambda(x, y, nullptr, nullptr);
 #pragma unroll
-                for (int i = 0; i < N; ++i) grad[i] += h * (x[i] - center[z * N + i]) * env_rcp(r) * others;
+                for (int i = 0; i < N; ++i) grad[i] += h * (x[i] - zone_center(z, i)) * env_rcp(r) * others;
             }
         }
         return lam;

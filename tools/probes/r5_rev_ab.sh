@@ -23,7 +23,7 @@ if [ "$1" = build ]; then
 fi
 if [ "$1" = buildfile ]; then      # tools/probes/r5_rev_ab.sh buildfile <rev> <source.hip>: ONE other source of csrc as committed at <rev>
   REV=$2; SRC=$3
-  git -C $ROOT show $REV:tf-mpc_amd/csrc/$SRC > $ROOT/tf-mpc_amd/csrc/.ab_rev.hip
+  if [ "$REV" = WORK ]; then cp $ROOT/tf-mpc_amd/csrc/$SRC $ROOT/tf-mpc_amd/csrc/.ab_rev.hip; else git -C $ROOT show $REV:tf-mpc_amd/csrc/$SRC > $ROOT/tf-mpc_amd/csrc/.ab_rev.hip; fi
   /opt/rocm/bin/hipcc $FLAGS $AB_FLAGS -x hip -c $ROOT/tf-mpc_amd/csrc/.ab_rev.hip -o $ROOT/tools/probes/ab/rev_file.o 2>/dev/null
   rm -f $ROOT/tf-mpc_amd/csrc/.ab_rev.hip
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $ROOT/tools/probes/ab/lib_rev.so $ROOT/tools/probes/ab/rev_file.o $(ls $ROOT/tf-mpc_amd/csrc/build/*.o | grep -v "/${SRC%.hip}\.o")
