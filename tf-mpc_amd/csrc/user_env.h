@@ -276,11 +276,25 @@ struct LaneEnv<TFMPC_ENV_USER, N, M> {
     static constexpr int D = N + M;
     static constexpr int kFx = 0, kFu = kFx + N * N, kLx = kFu + N * M, kLu = kLx + N, kLxx = kLu + M, kLuu = kLxx + N * N,
                          kLux = kLuu + M * M, kL = kLux + M * N, kPre = kL + 1;
-    const float *p;
-    __device__ void load(const TfmpcEnv &g, int b) { p = g.p[0] + (size_t)b * g.stride[0]; }
-    __device__ void transition(const float *x, const float *u, float *xn) const { tfmpc_user::transition<float>(p, x, u, xn); }
-    __device__ float cost(const float *x, const float *u) const { return tfmpc_user::cost<float>(p, x, u); }
-    __device__ float final_cost(const float *x) const { return tfmpc_user::final_cost<float>(p, x); }
+    // A small parameter vector (TFMPC_USER_P <= 16 floats, stated by the Python side) is read ONCE per instance into registers: through the pointer
+    // every use is a vector load with its wait (the env object lives in vector registers) -- in every step of every rollout (round 5; the built-in
+    // Navigation env had the same habit, ilqr_lane_kernels.h).  Constant indices in the user's source then cost nothing.
+#ifndef TFMPC_USER_P
+#define TFMPC_USER_P 0
+#endif
+    static constexpr int kP = (TFMPC_USER_P > 0 && TFMPC_USER_P <= 16) ? TFMPC_USER_P : 0;
+    const float *pg;
+    float pr[kP > 0 ? kP : 1];
+    __device__ void load(const TfmpcEnv &g, int b)
+    {
+        pg = g.p[0] + (size_t)b * g.stride[0];
+#pragma unroll
+        for (int i = 0; i < kP; ++i) pr[i] = pg[i];
+    }
+    __device__ const float *params() const { return kP > 0 ? pr : pg; }
+    __device__ void transition(const float *x, const float *u, float *xn) const { tfmpc_user::transition<float>(params(), x, u, xn); }
+    __device__ float cost(const float *x, const float *u) const { return tfmpc_user::cost<float>(params(), x, u); }
+    __device__ float final_cost(const float *x) const { return tfmpc_user::final_cost<float>(params(), x); }
     __device__ void prelinearize(const float *x, const float *u, float *pre) const
     {
         using ad::D1;
@@ -292,7 +306,7 @@ struct LaneEnv<TFMPC_ENV_USER, N, M> {
             for (int i = 0; i < N; ++i) xs[i] = D1(x[i], i == j ? 1.0f : 0.0f);
 #pragma unroll
             for (int a = 0; a < M; ++a) us[a] = D1(u[a], N + a == j ? 1.0f : 0.0f);
-            tfmpc_user::transition<D1>(p, xs, us, out);
+            tfmpc_user::transition<D1>(params(), xs, us, out);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 if (j < N) pre[kFx + i * N + j] = out[i].d;
@@ -308,7 +322,7 @@ struct LaneEnv<TFMPC_ENV_USER, N, M> {
                 for (int k = 0; k < N; ++k) xs[k] = D2(D1(x[k], k == i ? 1.0f : 0.0f), D1(k == j ? 1.0f : 0.0f, 0.0f));
 #pragma unroll
                 for (int a = 0; a < M; ++a) us[a] = D2(D1(u[a], N + a == i ? 1.0f : 0.0f), D1(N + a == j ? 1.0f : 0.0f, 0.0f));
-                const D2 c = tfmpc_user::cost<D2>(p, xs, us);
+                const D2 c = tfmpc_user::cost<D2>(params(), xs, us);
                 const float h = c.d.d;
                 if (j < N) { pre[kLxx + i * N + j] = h; pre[kLxx + j * N + i] = h; }
                 else if (i >= N) { pre[kLuu + (i - N) * M + (j - N)] = h; pre[kLuu + (j - N) * M + (i - N)] = h; }
@@ -356,7 +370,7 @@ struct LaneEnv<TFMPC_ENV_USER, N, M> {
                 D2 xs[N];
 #pragma unroll
                 for (int k = 0; k < N; ++k) xs[k] = D2(D1(x[k], k == i ? 1.0f : 0.0f), D1(k == j ? 1.0f : 0.0f, 0.0f));
-                const D2 c = tfmpc_user::final_cost<D2>(p, xs);
+                const D2 c = tfmpc_user::final_cost<D2>(params(), xs);
                 lxx(i, j) = c.d.d;
                 lxx(j, i) = c.d.d;
                 if (i == j) lx[i] = c.v.d;

@@ -45,10 +45,13 @@ def hipcc_path():
     return None
 
 
-def translation_unit(source, state_size, action_size):
+def translation_unit(source, state_size, action_size, param_count=0):
+    """``param_count``: the env's parameter floats per instance, if known (a small parameter vector is then held in registers by the 2 x 2
+    lane-group kernel instead of being read through the pointer at every use, csrc/user_env.h)."""
     with open(os.path.join(_CSRC, "user_env_kernels.hip.in")) as fh:
         text = fh.read()
     return (text.replace("@STATE_SIZE@", str(int(state_size))).replace("@ACTION_SIZE@", str(int(action_size)))
+            .replace("@PARAM_COUNT@", str(int(param_count)))
             .replace("@SOURCE@", source))       # (the headers are found through -I: the text, hence the cache key, does not depend on where the tree lives)
 
 
@@ -64,9 +67,9 @@ def _stamp(text):
     return h.hexdigest()[:16]
 
 
-def build(source, state_size, action_size):
+def build(source, state_size, action_size, param_count=0):
     """Compile (or find in the cache) the companion library of a user env; returns its path.  Works without a GPU."""
-    text = translation_unit(source, state_size, action_size)
+    text = translation_unit(source, state_size, action_size, param_count)
     folder = os.path.join(_CACHE, _stamp(text))
     lib = os.path.join(folder, "libtfmpc_userenv.so")
     if os.path.exists(lib):
@@ -144,7 +147,7 @@ class DeviceEnv(DiffEnv):
 
     def _library(self):
         if self._lib is None:
-            path = build(self.source, self._n, self._m)
+            path = build(self.source, self._n, self._m, self.n_zones)
             if path not in _loaded:
                 _loaded[path] = _UserLibrary(path)
             self._lib = _loaded[path]
