@@ -177,7 +177,10 @@ class iLQR:
         return hook() if hook is not None else _hip.require_gpu()
 
     def _alphas(self):
-        return np.geomspace(1.0, self.alpha_min, 11)                       # ilqr.py:322
+        cached = getattr(self, "_alphas_cache", None)                      # (numpy's geomspace is ~20 us: half of a solve_device call's host time)
+        if cached is None or cached[0] != self.alpha_min:
+            cached = self._alphas_cache = (self.alpha_min, np.geomspace(1.0, self.alpha_min, 11))      # ilqr.py:322
+        return cached[1]
 
     def _c_config(self):
         cfg = _hip.TfmpcIlqrConfig()
