@@ -12,5 +12,7 @@ t0 = time.perf_counter()
 out = s.solve_device(w["x0"], w["T"], u_init=w["u0"], workspace=out["workspace"]); torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 it = (out["iterations"] + 1).float()
-print(f"{w['version']}: {dt * 1e3:.2f} ms per 65 536 solves, mean iterations {float(it.mean()):.2f}, p50/p90/p99/p99.9/max "
+import hashlib
+sha = hashlib.sha256(out["states"].cpu().numpy().tobytes() + out["actions"].cpu().numpy().tobytes() + out["iterations"].cpu().numpy().tobytes()).hexdigest()[:12]
+print(f"{w['version']}: {dt * 1e3:.2f} ms per 65 536 solves, sha {sha}, mean iterations {float(it.mean()):.2f}, p50/p90/p99/p99.9/max "
       f"{[float(torch.quantile(it, q)) for q in (0.5, 0.9, 0.99, 0.999, 1.0)]}, status != 0: {int((out['status'] != 0).sum())}")
