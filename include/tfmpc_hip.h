@@ -56,7 +56,10 @@ int tfmpc_version(void);
  * does -- another regularisation path on ~0.5 % of the instances; unsorted: that kernel launches its blocks in instance order instead of
  * starting the instances whose first backward pass probes most levels first -- same results, for A/B timing) and TFMPC_COSTATE_COUPLING
  * (dense: the 16-per-wave Reservoir kernel multiplies by its `downstream` matrix also when that matrix is a shift -- a chain of
- * reservoirs, every config the reference holds -- instead of moving rows; same bits, for A/B timing and tests) are read ONCE per process, at the first use of the library; afterwards only
+ * reservoirs, every config the reference holds -- instead of moving rows; same bits, for A/B timing and tests), TFMPC_BOX_HELPERS (off | number of
+ * helper teams, default 16: a control-limited batch of more than 4 096 instances without heavy ones in the launcher's sample lends five helper
+ * blocks to each of its longest-running instances, which roll out the step sizes of a line search side by side -- same bits) and
+ * TFMPC_BOX_HELP_AFTER (passes before an instance may claim a team, default 24) are read ONCE per process, at the first use of the library; afterwards only
  * this call changes them (value NULL or "" = back to the dispatcher's own choice).  Returns TFMPC_ERR_ARG
  * for an unknown name.  Process-wide; not meant to be flipped while other threads launch. */
 int tfmpc_set_option(const char *name, const char *value);

@@ -199,3 +199,38 @@ def test_heavy_first_block_order_changes_no_result():
     for key in ("states", "actions", "costs", "iterations", "status"):
         assert torch.equal(outs[None][key], outs["unsorted"][key]), key
     assert int(((outs[None]["status"] & _hip.ST_NOT_PD) != 0).sum()) > 0          # some instances did probe levels > 0
+
+
+def _board_header(workspace, B, n, m, T):
+    """The helper teams' board (ilqr_lq_box_mfma.hip: BoxBoardHeader) read back from the caller's workspace: it sits in the candidate-trajectory
+    slab behind the gain slabs K[B][T][m][n], k[B][T][m], on the next 256-byte boundary."""
+    raw = workspace.view(torch.uint8)
+    off = B * T * m * n * 4 + B * T * m * 4
+    off += (-(raw.data_ptr() + off)) % 256
+    return raw[off:off + 256].cpu().numpy().view(np.int32)
+
+
+def test_helper_teams_change_no_result():
+    """A batch WITHOUT heavy instances in the launcher's sample runs with helper teams (round 5): an instance that has made TFMPC_BOX_HELP_AFTER
+    passes claims a team of five helper blocks, which roll out the step sizes 2 .. 11 of each of its line searches beside its own 0 and 1; the
+    decision is the sequential search's.  With the threshold lowered to 2 (1) the sixteen (three) teams are contended for from the first
+    milliseconds and change hands many times (claim, release, the helpers' operand reload); every output and the whole decision
+    trace must equal the launch without helpers (TFMPC_BOX_HELPERS=off) bit for bit."""
+    B, n, m, T, bound = 5003, 16, 8, 50, 0.5
+    F, f, C, c, x0 = _problem(B, n, m, seed=78, scale=0.18)         # (0.18 F: the stable open loop, no heavy instances)
+    solver = iLQR(LQEnv(F, f, C, c, low=-bound, high=bound), max_iterations=20)
+    x0d = torch.as_tensor(x0[..., None], device="cuda")
+    u0 = torch.zeros(B, T, m, 1, device="cuda")
+    outs, claims = {}, {}
+    for mode, after in (("off", None), (None, "2"), ("3", "1")):
+        with _hip.option("TFMPC_BOX_HELPERS", mode), _hip.option("TFMPC_BOX_HELP_AFTER", after):
+            o = solver.solve_device(x0d, T, u_init=u0, trace_rows=24)
+            torch.cuda.synchronize()
+            outs[mode] = {k: v.clone() for k, v in o.items() if torch.is_tensor(v) and k != "workspace"}
+            claims[mode] = int(_board_header(o["workspace"], B, n, m, T)[2]) if mode != "off" else 0
+    assert claims[None] > 2 * 16 and claims["3"] > 2 * 3, claims                 # the teams were used, and changed hands ...
+    for mode in (None, "3"):
+        for key in ("states", "actions", "costs", "iterations", "status", "trace_len"):
+            assert torch.equal(outs[mode][key], outs["off"][key]), (mode, key)   # ... and changed nothing
+        assert torch.equal(torch.nan_to_num(outs[mode]["trace"]), torch.nan_to_num(outs["off"]["trace"])), mode
+    assert int((outs["off"]["iterations"] >= 2).sum()) > B // 2

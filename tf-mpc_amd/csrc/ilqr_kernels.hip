@@ -284,6 +284,8 @@ int tfmpc_ilqr_solve_trace_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, 
             // control-limited LQ problems: box-QP in registers, the complete solve loop in one kernel
             IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk, a.wsu};
             la.trace = tr;
+            la.board = a.wsx;                           // (the candidate-trajectory slab: unused by this kernel)
+            la.board_bytes = (size_t)B * (T + 1) * n * sizeof(float);
             g_last_ilqr_kernel = "lq_box_mfma (matrix cores, control-limited)";
             return ilqr_lq_box_mfma_launch(la, st);
         }

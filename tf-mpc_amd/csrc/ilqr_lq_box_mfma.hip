@@ -112,15 +112,111 @@ __device__ int *g_box_counts = nullptr;
 constexpr bool kSingleRollouts = TFMPC_BOX_SINGLE_ROLLOUTS != 0;
 constexpr int kProbeStride = 32;      // the sample of the first-pass probe: every 32nd instance (2 048 of 65 536)
 constexpr int kProbeHeavy = 3;        // ... and how many of them must need a regularisation level >= 1 for the whole batch to be probed and sorted
-template <bool BRACKET, int MODE = 0>
+// ---- helper teams (round 5) ------------------------------------------------------------------------------------------------------
+// A launch lasts as long as its longest instance, and that instance is one wave's DEPENDENT chain: the stable-open-loop batch of bench.py
+// (65 536 solves) is ~34 ms of chip time and one instance of 142 passes -- 142 sweeps and ~1 330 line-search rollouts, 73 ms -- during most
+// of which the chip is empty.  What can run beside that chain are the step sizes of ONE line search: the first kBoxTeamBlocks x teams blocks
+// of the grid are HELPERS (one wave each, same code, same LDS).  They wait on a board in HBM; an instance that has made kBoxHelpAfter (24) passes
+// claims a free team, and from then on posts its nominal trajectory after every sweep (the gains are in its HBM workspace already), rolls out
+// step sizes 0 and 1 itself while helper r rolls out 2 + 2 r and 3 + 2 r for the same instance -- its own registers loaded with the instance's
+// F, C as every block loads them, `forward2` as the owner would run it: the same bits per step size -- and takes the decision the sequential
+// search takes: the lowest index that passes, else the last one; the chosen candidate comes back through the board.  An owner never waits
+// for a helper that is not resident (a team is claimable once all its blocks have checked in), helpers leave when every owner has finished.
+// Release / acquire at agent scope on both sides (the XCDs' L2s are not coherent with each other for plain accesses).
+constexpr int kBoxHelpers = 5;          // helper blocks per team: with the owner's pair, 12 step sizes in one round (the reference's 11)
+constexpr int kBoxHelpAfter = 24;       // passes an instance makes on its own first (p99 of a well-posed batch is 6; at 8 the sixteen teams of the
+                                        // stable-open-loop batch went to 236 instances that end within 8 - 19 passes, none to the one that makes 142)
+struct BoxBoardHeader { int finished, claimed, claims_total, pad[61]; };      // (claims_total: for the tests)
+struct BoxTeam {
+    int owner;                          // instance + 1 that holds the team, 0: free
+    int seq;                            // number of the request posted last (never reset within a launch)
+    int req_b;                          // ... and its instance
+    int present;                        // helper blocks that have checked in
+    int done[8];                        // done[r]: the last request helper r has answered
+    float res[8][4];                    // its J and residual for the step sizes 2 + 2 r, 3 + 2 r
+    int pad[20];
+};
+static_assert(sizeof(BoxBoardHeader) == 256 && sizeof(BoxTeam) == 256, "board layout");
+__host__ __device__ inline size_t box_traj_floats(int T) { return (size_t)(T + 1) * kZld; }
+__host__ __device__ inline size_t box_cost_floats(int T) { return (size_t)((T + 1 + 3) & ~3); }
+__host__ __device__ inline size_t box_team_floats(int T) { return box_traj_floats(T) + 2 * kBoxHelpers * (box_traj_floats(T) + box_cost_floats(T)); }
+__host__ __device__ inline size_t box_board_bytes(int teams, int T) { return sizeof(BoxBoardHeader) + (size_t)teams * (sizeof(BoxTeam) + box_team_floats(T) * sizeof(float)); }
+__device__ __forceinline__ int ld_acquire(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_relaxed(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_relaxed(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// What a rollout needs of ONE instance, in the lane layout of the kernel below (F rows for x' = F z + f: 4 lanes per row; the A operand of the C Z
+// product; c): every block loads them when it starts, a helper again when its team changes hands.
+__device__ __forceinline__ void box_rollout_operands(const float *Fg, const float *fg, const float *Cg, const float *cg, int n, int m, int lane,
+                                                     float (&Fr)[6], float &f_i, float (&Ca0)[6], float (&Ca1)[6], f32x4 &cq0, f32x4 &cq1)
+{
+    const int d = n + m, i = lane & 15, q = lane >> 4, fi = lane >> 2, fc = lane & 3;
+    auto Fz = [&](int row, int zc) {               // [F_x | F_u] in the padded 16 | 8 layout
+        if (zc < N) return (row < n && zc < n) ? Fg[row * d + zc] : 0.0f;
+        return (row < n && zc - N < m) ? Fg[row * d + n + zc - N] : 0.0f;
+    };
+    auto zmap = [&](int zi) { return zi < N ? (zi < n ? zi : -1) : (zi - N < m ? n + zi - N : -1); };
+    auto Cs = [&](int zr, int zc) {
+        const int r = zmap(zr), c_ = zmap(zc);
+        return (r >= 0 && c_ >= 0) ? 0.5f * (Cg[r * d + c_] + Cg[c_ * d + r]) : 0.0f;
+    };
+    auto cz = [&](int zr) { const int r = zmap(zr); return r >= 0 ? cg[r] : 0.0f; };
+#pragma unroll
+    for (int j = 0; j < 6; ++j) Fr[j] = Fz(fi, 6 * fc + j);
+    f_i = fi < n ? fg[fi] : 0.0f;
+#pragma unroll
+    for (int s2 = 0; s2 < 6; ++s2) {
+        Ca0[s2] = Cs(i, 4 * s2 + q);
+        Ca1[s2] = (i < M) ? Cs(N + i, 4 * s2 + q) : 0.0f;
+    }
+    cq0 = f32x4{cz(4 * q), cz(4 * q + 1), cz(4 * q + 2), cz(4 * q + 3)};
+    cq1 = (q < 2) ? f32x4{cz(N + 4 * q), cz(N + 4 * q + 1), cz(N + 4 * q + 2), cz(N + 4 * q + 3)} : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+}
+
+template <bool BRACKET, int MODE = 0, bool TEAMS = false>
 __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // MODE 2 (round 5): the first-pass probe on a SAMPLE, every kProbeStride-th instance; MODE 1 then runs on the whole batch only if the
     // sample met heavy instances (the flag behind the two int slabs of wsq, box_decide_kernel) -- a batch without them (the stable-open-loop
     // variant of bench.py: 12 of 65 536) paid 10.8 of its 91 ms for a sort that moved nothing.
-    const int b = (MODE == 0 && a.order) ? a.order[blockIdx.x] : (MODE == 2 ? blockIdx.x * kProbeStride : blockIdx.x);
     const int lane = threadIdx.x;
+    if constexpr (MODE == 0) {
+        // (two instantiations follow the sample's verdict, see the launcher: the one whose turn it is not leaves at once)
+        if (a.gate && (a.gate[0] != 0) != (a.gate_value != 0)) return;
+    }
+    // helper teams (see above): the TEAMS instantiation only
+    const int n_helpers = TEAMS ? a.helper_teams * kBoxHelpers : 0;
+    const bool helper = TEAMS && (int)blockIdx.x < n_helpers;
+    BoxBoardHeader *const board = reinterpret_cast<BoxBoardHeader *>(a.board);
+    BoxTeam *const teams = reinterpret_cast<BoxTeam *>(board + 1);
+    float *const team_bufs = reinterpret_cast<float *>(teams + (n_helpers ? a.helper_teams : 0));
+    const size_t trajF = box_traj_floats(a.T), costF = box_cost_floats(a.T), teamF = box_team_floats(a.T);
+    BoxTeam *tm = nullptr;              // a helper's team; an owner's once it has claimed one
+    float *tbuf = nullptr;              // its buffers: nominal | per helper: candidate A, costs A, candidate B, costs B
+    int team = -1, my_seq = 0;
+    const int role = helper ? (int)blockIdx.x % kBoxHelpers : 0;
+    auto next_request = [&](int last) {                 // helper: the number of the next request, or -1 when every owner has finished
+        for (;;) {
+            const int s_ = __builtin_amdgcn_readfirstlane(ld_acquire(&tm->seq));
+            if (s_ != last) return s_;
+            if (ld_relaxed(&board->finished) >= a.B) return -1;
+            __builtin_amdgcn_s_sleep(8);
+        }
+    };
+    const int owner_index = (int)blockIdx.x - n_helpers;
+    int b = 0;
+    if (helper) {
+        team = (int)blockIdx.x / kBoxHelpers;
+        tm = teams + team;
+        tbuf = team_bufs + (size_t)team * teamF;
+        if (lane == 0) __hip_atomic_fetch_add(&tm->present, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        my_seq = next_request(0);
+        if (my_seq < 0) return;
+        b = __builtin_amdgcn_readfirstlane(tm->req_b);
+    } else {
+        b = (MODE == 0 && a.order) ? a.order[owner_index] : (MODE == 2 ? owner_index * kProbeStride : owner_index);
+    }
     if constexpr (MODE == 1) {
         if (reinterpret_cast<const int32_t *>(a.wsq)[2 * (size_t)a.B] == 0) {         // (wave-uniform) nothing heavy in the sample: no sort
             if (lane == 0) reinterpret_cast<int32_t *>(a.wsq)[b] = 0;
@@ -174,25 +270,11 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
     }
     const int fi = lane >> 2, fc = lane & 3;       // F rows for x' = F z + f
     const int ka = lane >> 3, jc = lane & 7;       // K rows for du = K dx
-    float Fr[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int zc = 6 * fc + j;
-        Fr[j] = zc < N ? Fxx(fi, zc) : Fxu(fi, zc - N);
-    }
-    const float f_i = fi < n ? fg[fi] : 0.0f;
+    // what a ROLLOUT needs of the instance (a helper loads these again when its team changes hands; the sweep's operands are the owner's alone)
+    float Fr[6], f_i;
     float Ca0[6], Ca1[6];                          // A operand of C Z (k = 4s + q)
     f32x4 cq0, cq1;
-#pragma unroll
-    for (int s2 = 0; s2 < 6; ++s2) {
-        Ca0[s2] = Cs(i, 4 * s2 + q);
-        Ca1[s2] = (i < M) ? Cs(N + i, 4 * s2 + q) : 0.0f;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        cq0[r] = cz(4 * q + r);
-        cq1[r] = (q < 2) ? cz(N + 4 * q + r) : 0.0f;
-    }
+    box_rollout_operands(Fg, fg, Cg, cg, n, m, lane, Fr, f_i, Ca0, Ca1, cq0, cq1);
     const ConstFrag Fc0 = const_frag(f32x4{Fb0[0], Fb0[1], Fb0[2], Fb0[3]});
     const ConstFrag Fc1 = const_frag(f32x4{Fb1[0], Fb1[1], Fb1[2], Fb1[3]});
     // Gram matrices of the regularisation, constant on this env (ilqr.py:127,133-134 with f_x, f_u fixed):
@@ -279,19 +361,21 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
 
     // ---- start (ilqr.py:218): roll the env under the injected actions --------------------
     float *nom = bufA, *cand = bufB, *cand2 = bufC, *cnom = costA, *ccand = costB, *ccand2 = costC;
-    if (lane < N) nom[lane] = (lane < n) ? a.x0[(size_t)b * n + lane] : 0.0f;
-    for (int idx = lane; idx < T * M; idx += kWave) {
-        const int t = idx >> 3, ua = idx & 7;
-        nom[t * kZld + N + ua] = (ua < m) ? a.u_init[((size_t)b * T + t) * m + ua] : 0.0f;
-    }
-    if (lane < M) nom[T * kZld + N + lane] = 0.0f;
-    __syncthreads();
-    for (int t = 0; t < T; ++t) {
-        const float xn = next_state(nom + t * kZld);
-        if (fc == 0) nom[(t + 1) * kZld + fi] = xn;
+    if (!helper) {
+        if (lane < N) nom[lane] = (lane < n) ? a.x0[(size_t)b * n + lane] : 0.0f;
+        for (int idx = lane; idx < T * M; idx += kWave) {
+            const int t = idx >> 3, ua = idx & 7;
+            nom[t * kZld + N + ua] = (ua < m) ? a.u_init[((size_t)b * T + t) * m + ua] : 0.0f;
+        }
+        if (lane < M) nom[T * kZld + N + lane] = 0.0f;
         __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const float xn = next_state(nom + t * kZld);
+            if (fc == 0) nom[(t + 1) * kZld + fi] = xn;
+            __syncthreads();
+        }
+        cz_pass(nom, Tp, cnom, false);
     }
-    cz_pass(nom, Tp, cnom, false);
     __syncthreads();
 
     // ---- projected-Newton box-QP (optimization.py:6-101) of one timestep, in registers -----------------
@@ -683,6 +767,71 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
         JB = sum_costs(ccand2);
     };
 
+    // ---- helper teams: LDS <-> board copies (16-byte pieces; every buffer starts on a 16-byte boundary) ---------------------------
+    auto copy16 = [&](float *dst, const float *src, size_t floats) {
+        for (size_t idx = lane; idx < floats / 4; idx += kWave)
+            reinterpret_cast<f32x4 *>(dst)[idx] = reinterpret_cast<const f32x4 *>(src)[idx];
+    };
+    auto helper_bufs = [&](int r, int second) { return tbuf + trajF + (size_t)(2 * r + second) * (trajF + costF); };
+    if (helper) {
+        for (;;) {
+            // request my_seq of instance b: the nominal trajectory from the board, the step sizes of this role, both candidates back
+            copy16(nom, tbuf, trajF);
+            __syncthreads();
+            const int ai = 2 + 2 * role;
+            float JA = 0.0f, rA = 0.0f, JB = 0.0f, rB = 0.0f;
+            if (ai + 1 < cfg.n_alphas) forward2(cfg.alphas[ai], cfg.alphas[ai + 1], JA, rA, JB, rB);
+            else if (ai < cfg.n_alphas) forward(cfg.alphas[ai], JA, rA);
+            __syncthreads();
+            if (ai < cfg.n_alphas) {
+                copy16(helper_bufs(role, 0), cand, trajF);
+                copy16(helper_bufs(role, 0) + trajF, ccand, costF);
+            }
+            if (ai + 1 < cfg.n_alphas) {
+                copy16(helper_bufs(role, 1), cand2, trajF);
+                copy16(helper_bufs(role, 1) + trajF, ccand2, costF);
+            }
+            if (lane == 0) { tm->res[role][0] = JA; tm->res[role][1] = rA; tm->res[role][2] = JB; tm->res[role][3] = rB; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) st_relaxed(&tm->done[role], my_seq);
+            my_seq = next_request(my_seq);
+            if (my_seq < 0) return;
+            const int nb = __builtin_amdgcn_readfirstlane(tm->req_b);
+            if (nb != b) {                              // the team has a new owner: that instance's F, f, C, c and gains
+                b = nb;
+                Fg = a.env.p[0] + (size_t)b * a.env.stride[0];
+                fg = a.env.p[1] + (size_t)b * a.env.stride[1];
+                Cg = a.env.p[2] + (size_t)b * a.env.stride[2];
+                cg = a.env.p[3] + (size_t)b * a.env.stride[3];
+                Kg = a.wsK + (size_t)b * T * m * n;
+                kg = a.wsk + (size_t)b * T * m;
+                box_rollout_operands(Fg, fg, Cg, cg, n, m, lane, Fr, f_i, Ca0, Ca1, cq0, cq1);
+            }
+        }
+    }
+    // owner: claim a free team whose helpers are all resident (lane 0's compare-and-swap decides)
+    auto try_claim = [&]() {
+        if (ld_relaxed(&board->claimed) >= a.helper_teams) return;
+        for (int t_ = 0; t_ < a.helper_teams && team < 0; ++t_) {
+            BoxTeam *c = teams + t_;
+            if (ld_relaxed(&c->owner) != 0 || ld_relaxed(&c->present) != kBoxHelpers) continue;
+            int ok = 0;
+            if (lane == 0) {
+                int expected = 0;
+                ok = __hip_atomic_compare_exchange_strong(&c->owner, &expected, b + 1, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+            }
+            ok = __builtin_amdgcn_readfirstlane(ok);
+            if (ok) {
+                team = t_; tm = c; tbuf = team_bufs + (size_t)t_ * teamF;
+                my_seq = __builtin_amdgcn_readfirstlane(ld_acquire(&c->seq));
+                if (lane == 0) {
+                    __hip_atomic_fetch_add(&board->claimed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(&board->claims_total, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    };
+
     // ---- iLQR.solve (ilqr.py:214-283) ------------------------------------------------------------------------------
     float mu = 0.0f, delta = 1.0f;                                         // :215-216
     int status = 0, attempts = 0, iteration = 0;
@@ -700,6 +849,9 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
         // buffer, which the line search overwrites: the gradients live in `cand` during a backward pass and are
         // recomputed for every pass (one C Z product: 6 % of a pass).
         for (;;) {                                                          // :238
+            if constexpr (TEAMS) {
+                if (team < 0 && iteration + attempts >= a.help_after) try_claim();
+            }
             // _backward (:285-315): the first regularisation level of the LOCAL bump sequence mu_l(0) = mu, mu_l(r + 1) =
             // max(mu_min, mu_l(r) delta_l(r + 1)) at which the sweep factorises -- the reference probes r = 0, 1, 2, ...
             // and discards the bump afterwards (quirk Q2), so an instance whose box-QP loses positive definiteness at
@@ -787,11 +939,22 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
             };
             // _forward :317-355.  The first step size alone (most passes accept it); after a rejection the rest in PAIRS (forward2): the pair's
             // smaller index is tested first, so the step size accepted -- and every number logged -- is the sequential search's.
+            if (TEAMS && team >= 0) {
+                // with a team: post the request (nominal trajectory; the gains of this sweep are in HBM) -- once the previous one has been answered
+                // by every helper (one request at a time; they had a whole sweep for it)
+                for (int r_ = 0; r_ < kBoxHelpers && 2 + 2 * r_ < cfg.n_alphas; ++r_)
+                    while (ld_acquire(&tm->done[r_]) != my_seq) __builtin_amdgcn_s_sleep(2);
+                copy16(tbuf, nom, trajF);
+                if (lane == 0) tm->req_b = b;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                ++my_seq;
+                if (lane == 0) st_relaxed(&tm->seq, my_seq);
+            }
             for (int ai = 0; ai < cfg.n_alphas && !accept;) {
 #ifdef TFMPC_BOX_PROBE
                 const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
 #endif
-                if (ai == 0 || ai + 1 >= cfg.n_alphas || kSingleRollouts) {
+                if ((ai == 0 && !(TEAMS && team >= 0)) || ai + 1 >= cfg.n_alphas || kSingleRollouts) {        // (with a team: step sizes 0 and 1 as a pair here)
                     float J;
                     forward(cfg.alphas[ai], J, residual);
                     ai_last = ai; J_last = J; last_in_second = false;
@@ -812,6 +975,33 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
                     ai += 2;
 #ifdef TFMPC_BOX_PROBE
                     n_roll += 2; if (repeats > 0) n_roll_rep += 2;
+#endif
+                }
+                if (TEAMS && team >= 0 && ai <= 2 && !accept) {
+                    // the helpers' answers in index order -- the sequential search's decision: the lowest index that passes, else the last
+                    int from_r = -1, from_second = 0;
+                    for (int r_ = 0; r_ < kBoxHelpers && !accept; ++r_) {
+                        const int ah = 2 + 2 * r_;
+                        if (ah >= cfg.n_alphas) break;
+                        while (ld_acquire(&tm->done[r_]) != my_seq) __builtin_amdgcn_s_sleep(2);
+                        const float JA = tm->res[r_][0], rA = tm->res[r_][1], JB = tm->res[r_][2], rB = tm->res[r_][3];
+                        from_r = r_;
+                        if (passes(cfg.alphas[ah], JA) || ah + 1 >= cfg.n_alphas) {
+                            ai_last = ah; J_last = JA; residual = rA; from_second = 0; accept = passes(cfg.alphas[ah], JA);
+                        } else {
+                            ai_last = ah + 1; J_last = JB; residual = rB; from_second = 1; accept = passes(cfg.alphas[ah + 1], JB);
+                        }
+                    }
+                    if (from_r >= 0) {                                      // the last rollout of the search is a helper's: into `cand`
+                        __syncthreads();
+                        copy16(cand, helper_bufs(from_r, from_second), trajF);
+                        copy16(ccand, helper_bufs(from_r, from_second) + trajF, costF);
+                        last_in_second = false;
+                        __syncthreads();
+                    }
+                    ai = 2 + 2 * kBoxHelpers;                               // (more than 12 step sizes: the rest here, as without a team)
+#ifdef TFMPC_BOX_PROBE
+                    n_roll += ai_last - 1;
 #endif
                 }
 #ifdef TFMPC_BOX_PROBE
@@ -855,6 +1045,16 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
     for (int idx = lane; idx < Tp * n; idx += kWave) xs[idx] = nom[(idx / n) * kZld + idx % n];
     for (int idx = lane; idx < T * m; idx += kWave) us[idx] = nom[(idx / m) * kZld + N + idx % m];
     for (int idx = lane; idx < Tp; idx += kWave) cs[idx] = cnom[idx];
+    if (TEAMS && lane == 0) {
+        if (team >= 0) {
+            // (every helper has answered the last request before the team is free again: the next owner's request finds them waiting)
+            for (int r_ = 0; r_ < kBoxHelpers && 2 + 2 * r_ < cfg.n_alphas; ++r_)
+                while (ld_acquire(&tm->done[r_]) != my_seq) __builtin_amdgcn_s_sleep(2);
+            __hip_atomic_fetch_add(&board->claimed, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&tm->owner, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __hip_atomic_fetch_add(&board->finished, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (lane == 0) {
         const float cT = cnom[T];
         if (!(cT == cT)) status |= TFMPC_ST_NAN;
@@ -939,6 +1139,23 @@ int ilqr_lq_box_mfma_launch(const IlqrLqArgs &a, hipStream_t stream)
     const bool bracket = option_is(kOptIlqrRetry, "bracket");
     IlqrLqArgs run = a;
     run.order = nullptr;
+    // helper teams (see the kernel): a batch that outnumbers the resident waves, a board carved from the caller's workspace (256-byte aligned).
+    // TFMPC_BOX_HELPERS=off | <number of teams>
+    int teams = 0;
+    run.board = nullptr;
+    run.helper_teams = 0;
+    if (a.board && a.B > 4096 && !option_is(kOptBoxHelpers, "off")) {
+        teams = option_int(kOptBoxHelpers, 16);
+        teams = teams < 1 ? 1 : (teams > 32 ? 32 : teams);
+        const uintptr_t p0 = reinterpret_cast<uintptr_t>(a.board), p1 = (p0 + 255) & ~(uintptr_t)255;
+        if (a.board_bytes < (p1 - p0) + box_board_bytes(teams, a.T)) teams = 0;
+        if (teams) {
+            run.board = reinterpret_cast<void *>(p1);
+            run.helper_teams = teams;
+            run.help_after = option_int(kOptBoxHelpAfter, kBoxHelpAfter);       // (TFMPC_BOX_HELP_AFTER: tests lower it to make every instance claim)
+            if (hipMemsetAsync(run.board, 0, sizeof(BoxBoardHeader) + (size_t)teams * sizeof(BoxTeam), stream) != hipSuccess) return TFMPC_ERR_LAUNCH;
+        }
+    }
     // more instances than resident waves (2 per SIMD x 1 024 SIMDs), and room for two ints per instance in the wsq slab
     if (a.B > 4096 && (size_t)a.T * a.env.m >= 3 && a.wsq && !option_is(kOptIlqrRetry, "unsorted") && !bracket) {
         int32_t *level = reinterpret_cast<int32_t *>(a.wsq), *order = level + a.B, *flag = level + 2 * (size_t)a.B;
@@ -953,8 +1170,22 @@ int ilqr_lq_box_mfma_launch(const IlqrLqArgs &a, hipStream_t stream)
         hipLaunchKernelGGL(box_order_kernel, dim3(1), dim3(1024), 0, stream, level, order, a.B);
         run.order = order;
     }
-    if (bracket) hipLaunchKernelGGL((ilqr_lq_box_mfma_kernel<true, 0>), dim3(a.B), dim3(kWave), lds, stream, run);
-    else hipLaunchKernelGGL((ilqr_lq_box_mfma_kernel<false, 0>), dim3(a.B), dim3(kWave), lds, stream, run);
+    if (bracket) {
+        hipLaunchKernelGGL((ilqr_lq_box_mfma_kernel<true, 0>), dim3(a.B), dim3(kWave), lds, stream, run);
+    } else if (teams && run.order) {
+        // The sample's verdict picks the instantiation ON THE DEVICE (no host round trip): a batch with heavy instances in the sample is bound by
+        // chip time and runs sorted, on the plain kernel (thousands of long instances: sixteen teams change nothing, and the team code costs the
+        // sweep registers -- 36 spilled); a batch without them is bound by its longest instance's chain and runs with helper teams.  Both are
+        // launched, each behind the flag; the one whose turn it is not returns in its first instruction (~20 us for 65 536 empty blocks).
+        IlqrLqArgs plain = run, teamed = run;
+        plain.board = nullptr; plain.helper_teams = 0;
+        plain.gate = teamed.gate = reinterpret_cast<const int32_t *>(a.wsq) + 2 * (size_t)a.B;
+        plain.gate_value = 1; teamed.gate_value = 0;
+        hipLaunchKernelGGL((ilqr_lq_box_mfma_kernel<false, 0, true>), dim3(a.B + teams * kBoxHelpers), dim3(kWave), lds, stream, teamed);
+        hipLaunchKernelGGL((ilqr_lq_box_mfma_kernel<false, 0, false>), dim3(a.B), dim3(kWave), lds, stream, plain);
+    } else {
+        hipLaunchKernelGGL((ilqr_lq_box_mfma_kernel<false, 0>), dim3(a.B), dim3(kWave), lds, stream, run);
+    }
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
 }
 

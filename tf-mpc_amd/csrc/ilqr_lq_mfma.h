@@ -26,6 +26,11 @@ struct IlqrLqArgs {
     float *wsx, *wsu, *wsc;      // candidate trajectory x[T+1][n], u[T][m], costs[T+1] (ilqr_lq_mfma32.hip only)
     const int32_t *order;        // ilqr_lq_box_mfma.hip: block -> instance (heavy instances first), or null
     TraceArgs trace;             // optional decision trace (ilqr_trace.h): one row per backward pass + line search; rows == nullptr: none
+    void *board;                 // ilqr_lq_box_mfma.hip: HBM for the helper teams' board (any alignment), or null: no helpers
+    size_t board_bytes;
+    int helper_teams, help_after;   // (set by the launcher) teams of helper blocks; passes an instance makes before it may claim one
+    const int32_t *gate;         // (set by the launcher) MODE 0 runs only if (*gate != 0) == (gate_value != 0); null: always
+    int gate_value;
 };
 
 // Control-limited twin (ilqr_lq_box_mfma.hip): bounded actions or any finite bound; the whole state machine
