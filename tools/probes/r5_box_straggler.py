@@ -25,3 +25,7 @@ for b in order[:3]:
     import collections
     print("    levels:", collections.Counter(r["level"] for r in recs), "alpha_index:", collections.Counter(r["alpha_index"] for r in recs),
           "accepted:", collections.Counter(r["accepted"] for r in recs))
+    # the pass-by-pass pattern (A = accepted, r = rejected with all step sizes tried) and the regularisation level each sweep ended on: runs of
+    # rejections are what a speculative sweep of the NEXT mu could overlap
+    print("    pattern:", "".join("A" if r["accepted"] == 1 else "r" for r in recs))
+    print("    levels :", "".join(str(min(int(r["level"]), 9)) for r in recs))
