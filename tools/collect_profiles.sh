@@ -4,12 +4,12 @@
 R=${1:-r05}
 cd "$(dirname "$0")/.."
 cp gpurun_out/pmc_$R/summary.json profiles/${R}_mfma16x8_pmc_summary.json
-cp $(ls gpurun_out/pmc_$R/stats/*/*_kernel_stats.csv | head -1) profiles/${R}_mfma16x8_kernel_stats.csv
+cp $(ls -t gpurun_out/pmc_$R/stats/*/*_kernel_stats.csv | head -1) profiles/${R}_mfma16x8_kernel_stats.csv
 grep "^{\"summary\"" gpurun_out/pmc_$R/stats.log | tail -1 > profiles/${R}_mfma16x8_bench_under_rocprof.json
 for tag in ilqr_api box box_stable cfg5 small_env large_tile cfg4; do
   d=gpurun_out/pmc_${R}_$tag
   [ -f $d/summary.json ] || continue
   cp $d/summary.json profiles/${R}_${tag}_pmc.json
-  cp $(ls $d/stats/*/*_kernel_stats.csv | head -1) profiles/${R}_${tag}_kernel_stats.csv
+  cp $(ls -t $d/stats/*/*_kernel_stats.csv | head -1) profiles/${R}_${tag}_kernel_stats.csv
 done
 ls -la profiles | grep "${R}_" | awk '{print $5, $9}'
