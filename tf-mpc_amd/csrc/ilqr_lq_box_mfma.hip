@@ -833,6 +833,19 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
         }
     };
 
+    // owner: has helper r answered request my_seq?  A BOUNDED wait (0.2 s of the 100 MHz counter: four thousand rollouts): a helper that is
+    // running answers within one rollout, so the bound never bites -- if it ever did, the owner drops the team for good (it stays claimed: nobody
+    // else gets it) and goes on alone, exactly as without helpers, instead of hanging the launch.
+    bool team_lost = false;
+    auto answered = [&](int r_) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (ld_acquire(&tm->done[r_]) != my_seq) {
+            if (__builtin_amdgcn_s_memtime() - t0 > 20000000ull) return false;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        return true;
+    };
+
     // ---- iLQR.solve (ilqr.py:214-283) ------------------------------------------------------------------------------
     float mu = 0.0f, delta = 1.0f;                                         // :215-216
     int status = 0, attempts = 0, iteration = 0;
@@ -851,7 +864,7 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
         // recomputed for every pass (one C Z product: 6 % of a pass).
         for (;;) {                                                          // :238
             if constexpr (TEAMS) {
-                if (team < 0 && iteration + attempts >= a.help_after) try_claim();
+                if (team < 0 && !team_lost && iteration + attempts >= a.help_after) try_claim();
             }
             // _backward (:285-315): the first regularisation level of the LOCAL bump sequence mu_l(0) = mu, mu_l(r + 1) =
             // max(mu_min, mu_l(r) delta_l(r + 1)) at which the sweep factorises -- the reference probes r = 0, 1, 2, ...
@@ -943,13 +956,17 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
             if (TEAMS && team >= 0) {
                 // with a team: post the request (nominal trajectory; the gains of this sweep are in HBM) -- once the previous one has been answered
                 // by every helper (one request at a time; they had a whole sweep for it)
-                for (int r_ = 0; r_ < kBoxHelpers && 2 + 2 * r_ < cfg.n_alphas; ++r_)
-                    while (ld_acquire(&tm->done[r_]) != my_seq) __builtin_amdgcn_s_sleep(2);
-                copy16(tbuf, nom, trajF);
-                if (lane == 0) tm->req_b = b;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                ++my_seq;
-                if (lane == 0) st_relaxed(&tm->seq, my_seq);
+                for (int r_ = 0; r_ < kBoxHelpers && 2 + 2 * r_ < cfg.n_alphas && !team_lost; ++r_)
+                    if (!answered(r_)) team_lost = true;
+                if (team_lost) {
+                    team = -1;
+                } else {
+                    copy16(tbuf, nom, trajF);
+                    if (lane == 0) tm->req_b = b;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    ++my_seq;
+                    if (lane == 0) st_relaxed(&tm->seq, my_seq);
+                }
             }
             for (int ai = 0; ai < cfg.n_alphas && !accept;) {
 #ifdef TFMPC_BOX_PROBE
@@ -980,11 +997,11 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
                 }
                 if (TEAMS && team >= 0 && ai <= 2 && !accept) {
                     // the helpers' answers in index order -- the sequential search's decision: the lowest index that passes, else the last
-                    int from_r = -1, from_second = 0;
+                    int from_r = -1, from_second = 0, next_ai = 2 + 2 * kBoxHelpers;  // (more than 12 step sizes: the rest here, as without a team)
                     for (int r_ = 0; r_ < kBoxHelpers && !accept; ++r_) {
                         const int ah = 2 + 2 * r_;
                         if (ah >= cfg.n_alphas) break;
-                        while (ld_acquire(&tm->done[r_]) != my_seq) __builtin_amdgcn_s_sleep(2);
+                        if (!answered(r_)) { team_lost = true; next_ai = ah; break; }       // (never seen: the search goes on here, from this index)
                         const float JA = tm->res[r_][0], rA = tm->res[r_][1], JB = tm->res[r_][2], rB = tm->res[r_][3];
                         from_r = r_;
                         if (passes(cfg.alphas[ah], JA) || ah + 1 >= cfg.n_alphas) {
@@ -1000,7 +1017,8 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
                         last_in_second = false;
                         __syncthreads();
                     }
-                    ai = 2 + 2 * kBoxHelpers;                               // (more than 12 step sizes: the rest here, as without a team)
+                    ai = next_ai;
+                    if (team_lost) team = -1;
 #ifdef TFMPC_BOX_PROBE
                     n_roll += ai_last - 1;
 #endif
@@ -1049,10 +1067,12 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
     if (TEAMS && lane == 0) {
         if (team >= 0) {
             // (every helper has answered the last request before the team is free again: the next owner's request finds them waiting)
-            for (int r_ = 0; r_ < kBoxHelpers && 2 + 2 * r_ < cfg.n_alphas; ++r_)
-                while (ld_acquire(&tm->done[r_]) != my_seq) __builtin_amdgcn_s_sleep(2);
-            __hip_atomic_fetch_add(&board->claimed, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&tm->owner, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            bool idle = true;
+            for (int r_ = 0; r_ < kBoxHelpers && 2 + 2 * r_ < cfg.n_alphas && idle; ++r_) idle = answered(r_);
+            if (idle) {
+                __hip_atomic_fetch_add(&board->claimed, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&tm->owner, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         __hip_atomic_fetch_add(&board->finished, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
