@@ -17,9 +17,10 @@ off = B * T * m * n * 4 + B * T * m * 4
 off += (-(base + off)) % 256
 hdr = raw[off:off + 256 + 32 * 256].cpu().numpy().view(np.int32)
 print(f"{name}: n {n} m {m} T {T}; finished {hdr[0]} claimed {hdr[1]}")
-for t in range(32):
+TEAMS = int(os.environ.get('TFMPC_BOX_HELPERS', '16') or 16)      # (the launcher's default; beyond them the slab holds trajectory buffers)
+print(f"claims in total {hdr[2]}")
+for t in range(TEAMS):
     r = hdr[64 + 64 * t: 64 + 64 * (t + 1)]
-    if r[3] == 0 and r[0] == 0: continue
     print(f"  team {t}: owner {r[0]} seq {r[1]} instance {r[2]} present {r[3]} done {list(r[4:9])}")
 it = out["iterations"].cpu().numpy()
 print("iterations: max", it.max(), "instances with >= 8:", int((it >= 8).sum()), "argmax", int(it.argmax()))
