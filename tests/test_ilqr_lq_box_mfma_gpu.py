@@ -234,3 +234,26 @@ def test_helper_teams_change_no_result():
             assert torch.equal(outs[mode][key], outs["off"][key]), (mode, key)   # ... and changed nothing
         assert torch.equal(torch.nan_to_num(outs[mode]["trace"]), torch.nan_to_num(outs["off"]["trace"])), mode
     assert int((outs["off"]["iterations"] >= 2).sum()) > B // 2
+
+
+@pytest.mark.parametrize("n_alphas", [1, 2, 5, 14])
+def test_helper_teams_with_other_step_size_lists(n_alphas):
+    """The C-ABI takes 1 .. 16 step sizes (the reference always 11): with fewer than 12 some helpers of a team have nothing to roll out (a lone last
+    index is a single rollout), with more the owner finishes the list itself behind the helpers' ten.  Same bits as without helpers in every case."""
+    B, n, m, T, bound = 4500, 16, 8, 30, 0.5
+    F, f, C, c, x0 = _problem(B, n, m, seed=79, scale=0.18)
+    solver = iLQR(LQEnv(F, f, C, c, low=-bound, high=bound), max_iterations=12)
+    solver._alphas_cache = (solver.alpha_min, np.geomspace(1.0, 0.05 if n_alphas > 1 else 1.0, n_alphas))       # (what _alphas() hands to the C config)
+    x0d = torch.as_tensor(x0[..., None], device="cuda")
+    u0 = torch.zeros(B, T, m, 1, device="cuda")
+    outs = {}
+    for mode, after in (("off", None), (None, "1")):
+        with _hip.option("TFMPC_BOX_HELPERS", mode), _hip.option("TFMPC_BOX_HELP_AFTER", after):
+            o = solver.solve_device(x0d, T, u_init=u0, trace_rows=16)
+            torch.cuda.synchronize()
+            outs[mode] = {k: v.clone() for k, v in o.items() if torch.is_tensor(v) and k != "workspace"}
+            if mode is None:
+                assert int(_board_header(o["workspace"], B, n, m, T)[2]) > 16
+    for key in ("states", "actions", "costs", "iterations", "status", "trace_len"):
+        assert torch.equal(outs[None][key], outs["off"][key]), key
+    assert torch.equal(torch.nan_to_num(outs[None]["trace"]), torch.nan_to_num(outs["off"]["trace"]))
