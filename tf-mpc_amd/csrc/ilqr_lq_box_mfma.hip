@@ -838,9 +838,9 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
     // else gets it) and goes on alone, exactly as without helpers, instead of hanging the launch.
     bool team_lost = false;
     auto answered = [&](int r_) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // (the constant 100 MHz counter; s_memtime runs at the shader clock)
         while (ld_acquire(&tm->done[r_]) != my_seq) {
-            if (__builtin_amdgcn_s_memtime() - t0 > 20000000ull) return false;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) return false;
             __builtin_amdgcn_s_sleep(2);
         }
         return true;
