@@ -280,7 +280,8 @@ int tfmpc_ilqr_forward_f32(const TfmpcEnv *env, int B, int T, const float *x, co
 /* Scratch of tfmpc_ilqr_solve_f32, a function of the shape alone (the env kind is not known here): per instance the
  * gains K, k and one candidate trajectory; for n = m = 2 a line-search block per wavefront; for n = m <= 32 the two
  * wave-major trajectory buffers of the 16-instances-per-wave HVAC / Reservoir kernel (+ for n <= 16 the coefficients
- * of its two-part costate sweep: 3 KB per group and time step).  The workspace handed to
+ * of its two-part costate sweep: 3 KB per group and time step).  The control-limited LQ kernel keeps its helper teams'
+ * board (TFMPC_BOX_HELPERS: ~60 KB per team) in the candidate-trajectory part: no extra bytes.  The workspace handed to
  * tfmpc_ilqr_solve_f32 must be 256-byte aligned (TFMPC_ERR_WORKSPACE otherwise). */
 size_t tfmpc_ilqr_workspace_bytes(int B, int n, int m, int T);
 
