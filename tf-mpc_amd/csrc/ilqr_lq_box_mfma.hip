@@ -253,7 +253,6 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
         const int r = zmap(zr), c_ = zmap(zc);
         return (r >= 0 && c_ >= 0) ? 0.5f * (Cg[r * d + c_] + Cg[c_ * d + r]) : 0.0f;
     };
-    auto cz = [&](int zr) { const int r = zmap(zr); return r >= 0 ? cg[r] : 0.0f; };
 
     // ---- operands resident in registers for the whole solve ------------------------------
     float Fb0[4], Fb1[4];
