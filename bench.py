@@ -65,7 +65,7 @@ def lqr_bytes_per_solve(n, m, T):
 
 
 # which kernel source a profiled kernel lives in (its PMC summary is only quoted while that file is unchanged)
-KERNEL_SOURCES = {"mfma": ["lqr_mfma16x8.hip", "wave_ldlt8.h", "mfma_bf16x3.h"], "ilqr_group_solve": ["ilqr_lane.hip", "envs.h"],
+KERNEL_SOURCES = {"mfma": ["lqr_mfma16x8.hip", "wave_ldlt8.h", "mfma_bf16x3.h"], "ilqr_group_solve": ["ilqr_lane.hip", "ilqr_lane_kernels.h", "envs.h"],
                   "ilqr_adjoint_mfma": ["ilqr_adjoint_mfma.hip", "trig.h"], "ilqr_lq_mfma_kernel": ["ilqr_lq_mfma.hip", "wave_ldlt8.h"],
                   "ilqr_lq_box_mfma": ["ilqr_lq_box_mfma.hip", "wave_ldlt8.h"], "ilqr_lq_mfma32": ["ilqr_lq_mfma32.hip", "wave_ldlt.h"],
                   "lqr_mfma32x16": ["lqr_mfma32x16.hip", "wave_ldlt.h"]}
@@ -241,7 +241,11 @@ def ilqr_api_rate(n, m, T, B, reps=5):
     wl_run, wl = wl, workloads.control_limited_stable(B, n, m, T)
     stable = limited("linear probe 0, 1, 2, ... (ilqr.py:285-315; the default)")
     stable["workload"], stable["workload_version"] = wl["text"], wl["version"]
-    stable["executed"] = pmc_executed("ilqr_lq_box_mfma_kernel<false, 0>")      # (the main launch, not the sample probe)
+    stable["executed"] = pmc_executed("ilqr_lq_box_mfma_kernel<false, 0, true>")      # (the main launch -- the instantiation with helper teams --, not the sample probe)
+    stable["helper_teams"] = ("16 teams x 5 helper blocks of the same launch roll out the step sizes of the longest instances' line searches side by side "
+                              "(DESIGN.md 3.6; same bits: tests/test_ilqr_lq_box_mfma_gpu.py); TFMPC_BOX_HELPERS=off is the launch without them")
+    with _hip.option("TFMPC_BOX_HELPERS", "off"):
+        stable["without_helper_teams_ms"] = limited("")["ms_per_batch"]
     if CPU_BASELINES:
         stable["cpu_baseline"] = ilqr_cpu_baseline("lq", [workloads.instance_cfg(wl, b) for b in range(8)], wl["x0"], wl["u0"], T, 100, 8, wl["version"])
     # ... and with a box so wide (+-2) that the box-QP rarely clamps while the rollout's clip still bites: the one LQ line on which the line
