@@ -114,15 +114,17 @@ constexpr int kProbeStride = 32;      // the sample of the first-pass probe: eve
 constexpr int kProbeHeavy = 3;        // ... and how many of them must need a regularisation level >= 1 for the whole batch to be probed and sorted
 // ---- helper teams (round 5) ------------------------------------------------------------------------------------------------------
 // A launch lasts as long as its longest instance, and that instance is one wave's DEPENDENT chain: the stable-open-loop batch of bench.py
-// (65 536 solves) is ~34 ms of chip time and one instance of 142 passes -- 142 sweeps and ~1 330 line-search rollouts, 73 ms -- during most
-// of which the chip is empty.  What can run beside that chain are the step sizes of ONE line search: the first kBoxTeamBlocks x teams blocks
-// of the grid are HELPERS (one wave each, same code, same LDS).  They wait on a board in HBM; an instance that has made kBoxHelpAfter (8) passes
-// claims a free team, and from then on posts its nominal trajectory after every sweep (the gains are in its HBM workspace already), rolls out
-// step sizes 0 and 1 itself while helper r rolls out 2 + 2 r and 3 + 2 r for the same instance -- its own registers loaded with the instance's
-// F, C as every block loads them, `forward2` as the owner would run it: the same bits per step size -- and takes the decision the sequential
-// search takes: the lowest index that passes, else the last one; the chosen candidate comes back through the board.  An owner never waits
-// for a helper that is not resident (a team is claimable once all its blocks have checked in), helpers leave when every owner has finished.
-// Release / acquire at agent scope on both sides (the XCDs' L2s are not coherent with each other for plain accesses).
+// (65 536 solves) is ~34 ms of chip time, one instance of 142 passes -- 142 sweeps and ~1 330 line-search rollouts -- and one of 100 that starts
+// late: 73 ms, during most of which the chip is empty.  What can run beside such a chain are the step sizes of ONE line search:
+// the first kBoxHelpers x teams blocks of the grid are HELPERS (one wave each, same code, same LDS).  They wait on a board in HBM; an instance
+// that has made kBoxHelpAfter passes claims a free team, and from then on posts its nominal trajectory after every sweep (the gains are in its
+// HBM workspace already), rolls out step sizes 0 and 1 itself while helper r rolls out 2 + 2 r and 3 + 2 r for the same instance -- its own
+// registers loaded with the instance's F, f, C, c as every block loads them, `forward2` as the owner would run it: the same bits per step size --
+// and takes the decision the sequential search takes: the lowest index that passes, else the last one; the chosen candidate comes back through
+// the board.  An owner never waits for a helper that is not resident (a team is claimable once all its blocks have checked in) and its waits are
+// bounded (`answered`); helpers leave when every owner has finished; a released team is claimed again (the helpers reload the rollout operands).
+// Release / acquire at agent scope on both sides (the XCDs' L2s are not coherent with each other for plain accesses).  The team code costs the
+// sweep registers, so it lives in its own instantiation (TEAMS), launched for batches whose sample shows no heavy instances (see the launcher).
 constexpr int kBoxHelpers = 5;          // helper blocks per team: with the owner's pair, 12 step sizes in one round (the reference's 11)
 constexpr int kBoxHelpAfter = 8;        // passes an instance makes on its own first (p99 of a well-posed batch is 6).  Teams are handed on: the 236 instances of
                                         // the stable-open-loop batch that pass 8 and end within 8 - 19 release theirs long before the one that makes 142 asks

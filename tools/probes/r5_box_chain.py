@@ -18,3 +18,9 @@ for b in (22144, 56392, 62458):
     tot = c[b, 9] + c[b, 10]
     print(f"instance {b}: sweeps {c[b, 0]} ({c[b, 9] * 1024 / 1e6:.1f} Mticks = {100.0 * c[b, 9] / tot:.0f} %, {c[b, 9] * 1024 / 1e3 / max(c[b, 0], 1):.0f} kticks each), rollouts {c[b, 2]} "
           f"(line searches {c[b, 10] * 1024 / 1e6:.1f} Mticks = {100.0 * c[b, 10] / tot:.0f} %), box-QP iterations per sweep step {c[b, 7] / max(c[b, 5] + c[b, 6], 1):.2f}")
+# where a sweep step of the longest instance goes (shader-clock ticks per time step; the probe's own s_memtime reads included)
+for b in (22144, 56392):
+    steps = max(c[b, 5] + c[b, 6], 1); qp_it = max(c[b, 7], 1)
+    print(f"instance {b}: per sweep step {1024 * c[b, 9] / steps:.0f} ticks = box-QP {1024 * c[b, 8] / steps:.0f} ({c[b, 7] / steps:.2f} iterations of "
+          f"{1024 * c[b, 8] / qp_it:.0f}: set-up {1024 * c[b, 14] / qp_it:.0f}, LDL^T {1024 * c[b, 12] / qp_it:.0f}, direction + Armijo + broadcast {1024 * c[b, 13] / qp_it:.0f}; "
+          f"{c[b, 11] / qp_it:.2f} Armijo rounds per iteration) + products / value update {1024 * (c[b, 9] - c[b, 8]) / steps:.0f}")
