@@ -257,3 +257,33 @@ def test_helper_teams_with_other_step_size_lists(n_alphas):
     for key in ("states", "actions", "costs", "iterations", "status", "trace_len"):
         assert torch.equal(outs[None][key], outs["off"][key]), key
     assert torch.equal(torch.nan_to_num(outs[None]["trace"]), torch.nan_to_num(outs["off"]["trace"]))
+
+
+def test_two_launches_with_helper_teams_side_by_side():
+    """Two control-limited batches on two streams at once, each with its own workspace (hence its own board and its own eighty helper blocks spinning
+    beside the other launch's): an owner only ever waits for helpers that are resident, so the launches cannot block each other; same bits as alone."""
+    B, n, m, T, bound = 4700, 16, 8, 40, 0.5
+    cases = []
+    for seed in (91, 92):
+        F, f, C, c, x0 = _problem(B, n, m, seed=seed, scale=0.18)
+        cases.append((iLQR(LQEnv(F, f, C, c, low=-bound, high=bound), max_iterations=15), torch.as_tensor(x0[..., None], device="cuda")))
+    u0 = torch.zeros(B, T, m, 1, device="cuda")
+    keys = ("states", "actions", "costs", "iterations", "status")
+    with _hip.option("TFMPC_BOX_HELP_AFTER", "1"):
+        alone = []
+        for solver, x0d in cases:
+            o = solver.solve_device(x0d, T, u_init=u0)
+            torch.cuda.synchronize()
+            alone.append(({k: o[k].clone() for k in keys}, o["workspace"]))
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        torch.cuda.synchronize()
+        together = []
+        for _ in range(3):                                   # (a few rounds: the overlap is not forced, only made likely)
+            together = []
+            for (solver, x0d), st, (_, ws) in zip(cases, streams, alone):
+                with torch.cuda.stream(st):
+                    together.append(solver.solve_device(x0d, T, u_init=u0, workspace=ws))
+            torch.cuda.synchronize()
+            for (ref, _), o in zip(alone, together):
+                for k in keys:
+                    assert torch.equal(ref[k], o[k]), k
