@@ -50,7 +50,8 @@ extern "C" {
 int tfmpc_version(void);
 /* Kernel-variant overrides for A/B timing and tests.  The environment variables TFMPC_LQR_KERNEL
  * (generic | lane | block), TFMPC_LQR_MFMA (f32 | bf16x3), TFMPC_ILQR_KERNEL (wave | lane | lane1 |
- * lean | lean1 | costate_mfma), TFMPC_COSTATE_WAVES (1 | 2 | 4 | 8: waves per sixteen-instance group of the HVAC /
+ * lean | lean1 | costate_mfma), TFMPC_LQR_WAVES (4 | 5: the register budget -- waves per SIMD -- of the headline LQR kernel's
+ * instantiation; default: chosen from the batch size; same bits), TFMPC_COSTATE_WAVES (1 | 2 | 4 | 8: waves per sixteen-instance group of the HVAC /
  * Reservoir kernel; default: the form that brings the launch to about two waves per SIMD) and TFMPC_ILQR_RETRY (bracket: the control-limited LQ kernel looks for the regularisation level
  * of a failed factorisation around the level of its previous pass instead of probing 0, 1, 2, ... as ilqr.py:285-315
  * does -- another regularisation path on ~0.5 % of the instances; unsorted: that kernel launches its blocks in instance order instead of

@@ -89,3 +89,21 @@ def test_ilqr_entry_points_reject_bad_arguments(lib):
     assert lib.tfmpc_boxqp_f32(4, 0, d, d, d, d, d, d, d, d, NULL) == ERR_ARG
     assert lib.tfmpc_boxqp_f32(4, 3, NULL, d, d, d, d, d, d, d, NULL) == ERR_ARG
     assert lib.tfmpc_boxqp_f32(0, 3, d, d, d, d, d, d, d, d, NULL) == 0
+
+
+def test_every_documented_option_is_known_to_the_library():
+    """tfmpc_set_option / tfmpc_get_option (host code only): every name include/tfmpc_hip.h and INTEGRATION.md document is accepted, the value read
+    back is the value set, an unknown name and an over-long value are argument errors, and the previous override is restored."""
+    names = ("TFMPC_LQR_KERNEL", "TFMPC_LQR_MFMA", "TFMPC_ILQR_KERNEL", "TFMPC_COSTATE_WAVES", "TFMPC_ILQR_RETRY", "TFMPC_COSTATE_COUPLING",
+             "TFMPC_LQR_WAVES", "TFMPC_BOX_HELPERS", "TFMPC_BOX_HELP_AFTER")
+    import os
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "tfmpc_hip.h")).read()
+    for name in names:
+        assert name in header, name                                    # documented where the ABI is
+        before = _hip.get_option(name)
+        with _hip.option(name, "7"):
+            assert _hip.get_option(name) == "7"
+        assert _hip.get_option(name) == before
+    with pytest.raises(ValueError):
+        _hip.set_option("TFMPC_NO_SUCH_OPTION", "1")
+    assert _hip.load().tfmpc_set_option(b"TFMPC_BOX_HELPERS", b"x" * 40) == ERR_ARG
