@@ -34,7 +34,7 @@ struct IlqrLqArgs {
 };
 
 // Control-limited twin (ilqr_lq_box_mfma.hip): bounded actions or any finite bound; the whole state machine
-// (mu > 0, retries, rejections) in the kernel, so no second-chance launch.  Uses wsK, wsk only.
+// (mu > 0, retries, rejections) in the kernel, so no second-chance launch.  Uses wsK, wsk, two ints per instance of wsq (block order) and `board`.
 bool ilqr_lq_box_mfma_supported(const TfmpcEnv &env, int T);
 int ilqr_lq_box_mfma_launch(const IlqrLqArgs &a, hipStream_t stream);
 
