@@ -397,7 +397,8 @@ def other_config_rates():
         out, dt = timed(lambda ws: solver.solve_device(x0, T, u_init=u0, workspace=ws), reps)
         its = float((out["iterations"].double() + 1).sum())
         line = {"ms_per_batch": dt * 1e3, "iterations_per_s": its / dt, "mean_iterations": its / x0.shape[0],
-                "flagged_instances": int((out["status"] != 0).sum()), "batch": int(x0.shape[0]), "horizon": T}
+                "flagged_instances": int((out["status"] != 0).sum()), "batch": int(x0.shape[0]), "horizon": T,
+                "launches_timed": reps}       # (back to back on one stream, one synchronize behind the last: the contract's K steps)
         if alg_bytes is not None:
             line["roofline"] = roofline_hbm(alg_bytes * its, dt, pmc_traffic(pmc[0], pmc[1], its) if pmc else None)
             line["roofline"]["algorithmic_bytes_per_iteration"] = alg_bytes
@@ -407,12 +408,13 @@ def other_config_rates():
     rng = np.random.default_rng(4)
     F, f, C, c, x0n, goal = problems.make_navlin_batch(4096, 5.0)
     lqr = make_lqr_linear_navigation(goal[..., None], 5.0)
-    _, dt = timed(lambda ws: lqr.solve_device(x0n[..., None], 50, workspace=ws), 20)
+    x0n_d = torch.as_tensor(np.ascontiguousarray(x0n[..., None], dtype=np.float32), device="cuda")      # (resident before the timed region)
+    _, dt = timed(lambda ws: lqr.solve_device(x0n_d, 50, workspace=ws), 20)
     res["cfg2_navlin_lqr"] = {"ms_per_batch": dt * 1e3, "solves_per_s": 4096 / dt, "batch": 4096, "horizon": 50}
     # cfg4: n = m = 2, T = 50 -> read x, u 808 B + write x, u, c 1 012 B per iteration
     solver = iLQR(Navigation.load(problems.NAV_CONFIG))
     Bn = 16384
-    x0 = rng.uniform(0, 10, size=(Bn, 2, 1)).astype(np.float32)
+    x0 = torch.as_tensor(rng.uniform(0, 10, size=(Bn, 2, 1)).astype(np.float32), device="cuda")      # (resident before the timed region)
     u0 = solver.random_actions(50, Bn, seed=4)
     res["cfg4_navigation_ilqr"] = ilqr_line(solver, x0, 50, u0, 2, alg_bytes=1820, pmc=("ilqr_group_solve", 142719))
     ex4 = pmc_executed("ilqr_group_solve")
@@ -479,10 +481,10 @@ def other_config_rates():
                                        ("res4", Reservoir.load(dict(problems.RES4_CONFIG)), problems.RES4_X0, "ilqr_adjoint_mfma_kernel<4, 1")):
         B, T = 16384, 100
         n = len(x0r)
-        x0 = (np.array(x0r, dtype=np.float32)[None] * rng.uniform(0.9, 1.1, size=(B, 1, 1))).astype(np.float32)
+        x0 = torch.as_tensor((np.array(x0r, dtype=np.float32)[None] * rng.uniform(0.9, 1.1, size=(B, 1, 1))).astype(np.float32), device="cuda")   # (resident before the timed region, as the contract says: a host array is uploaded by every call, +0.08 ms on a 2 ms launch)
         solver = iLQR(env, max_iterations=12)
         # PMC: profiles/r0x_small_env_pmc.json (tools/small_env_once.py, 16 384 instances x 12 iterations)
-        res[f"{name}_reference_config_ilqr"] = ilqr_line(solver, x0, T, solver.random_actions(T, B, seed=1), 2,
+        res[f"{name}_reference_config_ilqr"] = ilqr_line(solver, x0, T, solver.random_actions(T, B, seed=1), 10,      # (ten launches back to back: one sync's latency over 20 ms, not over 4)
                                                          alg_bytes=4 * (2 * (T + 1) * n + 2 * T * n + (T + 1)),
                                                          pmc=(kernel_tag, 16384 * 12))
     # configs[4] at its literal dims (n = 32, m = 16, T = 100, B = 32 768) as iLQR on the generalised LQ env
