@@ -330,7 +330,7 @@ def deviceenv_rate(B=16384, T=50):
     from tfmpc.solvers.ilqr import iLQR
     cfg = problems.NAV_CONFIG
     rng = np.random.default_rng(4)
-    x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
+    x0 = torch.as_tensor(rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32), device="cuda")      # (resident before the timed regions)
     builtin = iLQR(Navigation.load(cfg))
     u0 = builtin.random_actions(T, B, seed=4)
     t0 = time.perf_counter()
