@@ -448,7 +448,7 @@ def other_config_rates():
         w5 = workloads.cfg5(kind, B, n, T)            # the same problems tests/test_ilqr_teacher_forced_gpu.py holds against the restatement
         env, x0, u0c = w5["env"], w5["x0"], w5["u0"]
         solver = iLQR(env, max_iterations=12)
-        line = ilqr_line(solver, x0, T, u0c, 3, alg_bytes=4 * (2 * (T + 1) * n + 2 * T * n + (T + 1)), pmc=(kernel_tag, 32768 * 12))
+        line = ilqr_line(solver, x0, T, u0c, 8, alg_bytes=4 * (2 * (T + 1) * n + 2 * T * n + (T + 1)), pmc=(kernel_tag, 32768 * 12))
         # The flop side (round 4): rollouts per iteration MEASURED from the decision trace of the same solve (a traced launch returns
         # the same bits): a pass of the reference's line search makes alpha_index + 1 rollouts (ilqr.py:322-353).  Algorithmic flop
         # per iteration, SURVEY.md 8(d) dense count: costate sweep T x 4 n^2 + rollouts x T x (4 n^2 + env), env = 20 n flop per step
