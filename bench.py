@@ -242,7 +242,7 @@ def ilqr_api_rate(n, m, T, B, reps=5):
     stable = limited("linear probe 0, 1, 2, ... (ilqr.py:285-315; the default)")
     stable["workload"], stable["workload_version"] = wl["text"], wl["version"]
     stable["executed"] = pmc_executed("ilqr_lq_box_mfma_kernel<false, 0, true>")      # (the main launch -- the instantiation with helper teams --, not the sample probe)
-    stable["helper_teams"] = ("16 teams x 5 helper blocks of the same launch roll out the step sizes of the longest instances' line searches side by side "
+    stable["helper_teams"] = ("8 teams x 5 helper blocks of the same launch roll out the step sizes of the longest instances' line searches side by side "
                               "(DESIGN.md 3.6; same bits: tests/test_ilqr_lq_box_mfma_gpu.py); TFMPC_BOX_HELPERS=off is the launch without them")
     with _hip.option("TFMPC_BOX_HELPERS", "off"):
         stable["without_helper_teams_ms"] = limited("")["ms_per_batch"]

@@ -58,7 +58,7 @@ int tfmpc_version(void);
  * starting the instances whose first backward pass probes most levels first -- same results, for A/B timing) and TFMPC_COSTATE_COUPLING
  * (dense: the 16-per-wave Reservoir kernel multiplies by its `downstream` matrix also when that matrix is a shift -- a chain of
  * reservoirs, every config the reference holds -- instead of moving rows; same bits, for A/B timing and tests), TFMPC_BOX_HELPERS (off | number of
- * helper teams, default 16: a control-limited batch of more than 4 096 instances without heavy ones in the launcher's sample lends five helper
+ * helper teams, default 8: a control-limited batch of more than 4 096 instances without heavy ones in the launcher's sample lends five helper
  * blocks to each of its longest-running instances, which roll out the step sizes of a line search side by side -- same bits) and
  * TFMPC_BOX_HELP_AFTER (passes before an instance may claim a team, default 8) are read ONCE per process, at the first use of the library; afterwards only
  * this call changes them (value NULL or "" = back to the dispatcher's own choice).  Returns TFMPC_ERR_ARG

@@ -1167,7 +1167,7 @@ int ilqr_lq_box_mfma_launch(const IlqrLqArgs &a, hipStream_t stream)
     run.board = nullptr;
     run.helper_teams = 0;
     if (a.board && a.B > 4096 && !option_is(kOptBoxHelpers, "off")) {
-        teams = option_int(kOptBoxHelpers, 16);
+        teams = option_int(kOptBoxHelpers, 8);       // (stable-open-loop batch, same box, 2 / 4 / 8 / 16 / 32 teams: 60.4 / 59.2 / 59.4 / 60.3 / 63.5 ms)
         teams = teams < 1 ? 1 : (teams > 32 ? 32 : teams);
         const uintptr_t p0 = reinterpret_cast<uintptr_t>(a.board), p1 = (p0 + 255) & ~(uintptr_t)255;
         if (a.board_bytes < (p1 - p0) + box_board_bytes(teams, a.T)) teams = 0;
@@ -1196,7 +1196,7 @@ int ilqr_lq_box_mfma_launch(const IlqrLqArgs &a, hipStream_t stream)
         hipLaunchKernelGGL((ilqr_lq_box_mfma_kernel<true, 0>), dim3(a.B), dim3(kWave), lds, stream, run);
     } else if (teams && run.order) {
         // The sample's verdict picks the instantiation ON THE DEVICE (no host round trip): a batch with heavy instances in the sample is bound by
-        // chip time and runs sorted, on the plain kernel (thousands of long instances: sixteen teams change nothing, and the team code costs the
+        // chip time and runs sorted, on the plain kernel (thousands of long instances: eight teams change nothing, and the team code costs the
         // sweep registers -- 36 spilled); a batch without them is bound by its longest instance's chain and runs with helper teams.  Both are
         // launched, each behind the flag; the one whose turn it is not returns in its first instruction (~20 us for 65 536 empty blocks).
         IlqrLqArgs plain = run, teamed = run;

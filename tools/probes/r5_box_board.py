@@ -17,7 +17,7 @@ off = B * T * m * n * 4 + B * T * m * 4
 off += (-(base + off)) % 256
 hdr = raw[off:off + 256 + 32 * 256].cpu().numpy().view(np.int32)
 print(f"{name}: n {n} m {m} T {T}; finished {hdr[0]} claimed {hdr[1]}")
-TEAMS = int(os.environ.get('TFMPC_BOX_HELPERS', '16') or 16)      # (the launcher's default; beyond them the slab holds trajectory buffers)
+TEAMS = int(os.environ.get('TFMPC_BOX_HELPERS', '8') or 8)      # (the launcher's default; beyond them the slab holds trajectory buffers)
 print(f"claims in total {hdr[2]}")
 for t in range(TEAMS):
     r = hdr[64 + 64 * t: 64 + 64 * (t + 1)]
