@@ -287,3 +287,34 @@ def test_two_launches_with_helper_teams_side_by_side():
             for (ref, _), o in zip(alone, together):
                 for k in keys:
                     assert torch.equal(ref[k], o[k]), k
+
+
+def test_a_captured_launch_with_helper_teams_replays_the_same_bits():
+    """The control-limited launch above 4 096 instances is a memset of the board's header and five kernels (sample, decision, first-pass probe, block
+    order, the two gated instantiations): all of it stream work, so it can be captured into a graph and replayed -- with the eager launch's bits."""
+    B, n, m, T, bound = 4600, 16, 8, 30, 0.5
+    F, f, C, c, x0 = _problem(B, n, m, seed=93, scale=0.18)
+    solver = iLQR(LQEnv(F, f, C, c, low=-bound, high=bound), max_iterations=10)
+    x0d = torch.as_tensor(x0[..., None], device="cuda")
+    u0 = torch.zeros(B, T, m, 1, device="cuda")
+    keys = ("states", "actions", "costs", "iterations", "status")
+    with _hip.option("TFMPC_BOX_HELP_AFTER", "1"):
+        eager = solver.solve_device(x0d, T, u_init=u0)
+        torch.cuda.synchronize()
+        ref = {k: eager[k].clone() for k in keys}
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            solver.solve_device(x0d, T, u_init=u0, workspace=eager["workspace"])          # (warm-up on the capture stream)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph):
+            captured = solver.solve_device(x0d, T, u_init=u0, workspace=eager["workspace"])
+        for _ in range(3):
+            for k in keys:
+                captured[k].zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            for k in keys:
+                assert torch.equal(captured[k], ref[k]), k
