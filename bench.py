@@ -416,7 +416,7 @@ def other_config_rates():
     Bn = 16384
     x0 = torch.as_tensor(rng.uniform(0, 10, size=(Bn, 2, 1)).astype(np.float32), device="cuda")      # (resident before the timed region)
     u0 = solver.random_actions(50, Bn, seed=4)
-    res["cfg4_navigation_ilqr"] = ilqr_line(solver, x0, 50, u0, 2, alg_bytes=1820, pmc=("ilqr_group_solve", 142719))
+    res["cfg4_navigation_ilqr"] = ilqr_line(solver, x0, 50, u0, 5, alg_bytes=1820, pmc=("ilqr_group_solve", 142719))
     ex4 = pmc_executed("ilqr_group_solve")
     if ex4 is not None:
         # HBM is the wrong yardstick for this kernel (30 GB/s of 8 TB/s): it is bound by the issue and latency of its own instruction stream.
