@@ -775,7 +775,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from tfmpc import _hip
-    from tfmpc.parallel import gather_buffers, gather_trajectories
+    from tfmpc.parallel import gather_buffers, gather_results
     from tfmpc.solvers.lqr import LQR
     import problems
 
@@ -834,7 +834,7 @@ def main():
     if use_dist:
         from tfmpc.parallel import check_shard_sizes
         check_shard_sizes(B, B_global)           # start-up agreement on the shard sizes (fails on every rank or none)
-    recv = gather_buffers(out["states"], out["actions"], out["costs"], total=B_global) if use_dist else None
+    recv = gather_buffers(out["states"], out["actions"], out["costs"], total=B_global, status=out["status"]) if use_dist else None
     fence()
     # ONE pair of HIP events around the K launches, on the stream the kernel is launched on: their difference / K is the
     # kernel's average duration INCLUDING the gap to the next launch.  (Rounds 1-4 bracketed every step with its own pair:
@@ -857,7 +857,8 @@ def main():
         fence()
         g0 = time.perf_counter()
         try:
-            gathered = gather_trajectories(out["states"], out["actions"], out["costs"], total=B_global, recv=recv)
+            # (the per-instance status rides in the same packed buffer, bit-cast: still ONE collective)
+            gathered = gather_results(out["states"], out["actions"], out["costs"], status=out["status"], total=B_global, recv=recv)
         except RuntimeError as exc:
             gather_error = repr(exc)
         fence()
@@ -919,14 +920,15 @@ def main():
             line["gathered_states_shape"] = list(gathered[0].shape)
         if gather_ms is not None:
             from tfmpc.parallel import gather_bytes_per_rank
-            per_rank = gather_bytes_per_rank(out["states"], out["actions"], out["costs"])
+            per_rank = gather_bytes_per_rank(out["states"], out["actions"], out["costs"], status=out["status"])
             line["gather"] = {"collective": "ONE dist.gather (RCCL) of the packed trajectories onto rank 0, after the timed steps; "
                                             "shard sizes follow from the block split (no size exchange), receive buffers "
                                             "allocated at start-up",
                               "backend": dist.get_backend(), "world_size": world,
                               "ms": gather_ms, "bytes_per_rank": per_rank, "bytes_total": per_rank * world,
                               "GB_per_s_into_rank0": per_rank * (world - 1) / (gather_ms * 1e-3) / 1e9,
-                              "checked": bool(gathered is not None and torch.equal(gathered[0][:B], out["states"]))
+                              "checked": bool(gathered is not None and torch.equal(gathered[0][:B], out["states"])
+                                              and torch.equal(gathered[4][:B], out["status"]))
                               if world == 1 else None}
         if gather_error is not None:
             line["gather_error"] = gather_error

@@ -330,11 +330,28 @@ def test_a_broken_chain_promise_is_refused_on_the_device(force_kernel):
         good = solver.solve_device(x0, T, u_init=u0)
         torch.cuda.synchronize()
         assert int(good["status"].abs().sum()) == 0
-        env.coupling_shift = 1                                        # the false statement
         env._c_env_cache = None
-        bad = iLQR(env, max_iterations=3).solve_device(x0, T, u_init=u0)
+        env.c_env()[0].coupling_shift = 1                             # the false statement, written into the struct the C ABI receives
+        liar = iLQR(env, max_iterations=3)
+        bad = liar.solve_device(x0, T, u_init=u0)
         torch.cuda.synchronize()
-    assert bad["status"].tolist() == [_hip.ST_ENV_FLAG] * B
+        assert bad["status"].tolist() == [_hip.ST_ENV_FLAG] * B
+        # a refused solve reads as zeros, never as uninitialised memory, and the host API raises
+        assert float(bad["states"].abs().max()) == 0.0 and float(bad["costs"].abs().max()) == 0.0
+        with pytest.raises(ValueError, match="coupling_shift"):
+            liar.solve(x0, T, show_progress=False, u_init=u0)
+
+
+def test_coupling_shift_follows_the_current_downstream_matrix():
+    """`downstream` is a public attribute; the promise handed to the kernels is derived from the matrix as it is NOW."""
+    env = Reservoir.load(dict(problems.reservoir_config(8, seed=3)))
+    assert env.coupling_shift == 1
+    D = np.array(env.downstream)
+    D[2, 3] = 0.0
+    env.downstream = D
+    assert env.coupling_shift == 0
+    env.downstream = np.eye(8, k=-1, dtype=np.float32)
+    assert env.coupling_shift == -1
 
 
 def test_a_diverging_instance_stays_in_its_column(force_kernel):

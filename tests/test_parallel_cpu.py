@@ -128,3 +128,113 @@ def test_two_rank_gather_is_one_collective_when_the_global_batch_is_known(tmp_pa
         mp.spawn(_worker, args=(2, _free_port(), B, 6, 3, 9, out_path, True), nprocs=2, join=True)
         res = torch.load(out_path)
         assert res["ok"] and res["shapes"][0] == (B, 10, 6, 1)
+
+
+# ---- round 6: what iLQR.solve returns beside the trajectory rides in the same gather (iterations[B/G], status[B/G]) ----
+
+def _fake_ilqr_out(x0, T, m):
+    """Stand-in for iLQR.solve_device on a machine without a GPU: a deterministic 'solution' per instance, with int32 columns whose bit
+    patterns are NaNs / denormals when read as fp32 (a gather that did arithmetic on the packed buffer would damage them)."""
+    states, actions, costs = _fake_solve(x0, T, m)
+    key = (x0[:, 0] * 1000.0).to(torch.int32)
+    iterations = key.abs() % 101
+    status = torch.where(key % 3 == 0, torch.full_like(key, 0x7fc00001), key % 64).to(torch.int32)      # 0x7fc00001: a NaN pattern
+    return dict(states=states, actions=actions, costs=costs, iterations=iterations, status=status, batched=True, workspace=None)
+
+
+def _ilqr_worker(rank, world, port, B, n, m, T, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tfmpc.envs.lqr.navigation import NavigationLQR
+        from tfmpc.solvers.ilqr import iLQR
+        x0 = torch.from_numpy(np.random.default_rng(0).normal(size=(B, n)).astype(np.float32))
+        mine = parallel.shard(x0)
+        solver = iLQR.__new__(iLQR)                         # the host class without its device (none here): solve() only orchestrates
+        solver.max_iterations, solver.max_attempts = 100, 10
+        solver.env = type("Env", (), {"c_env": lambda self: (type("E", (), {"coupling_shift": 0})(), [])})()
+        solver.solve_device = lambda x0_, T_, u_init=None, seed=None, trace_rows=0: _fake_ilqr_out(mine, T_, m)
+        with _CountingCollectives() as counted:
+            traj, iterations = solver.solve(mine, T, show_progress=False, gather=True, total=B)
+        assert counted.calls == ["gather"], counted.calls            # ONE collective for trajectory + iterations + status
+        if rank == 0:
+            full = _fake_ilqr_out(x0, T, m)
+            ok = (np.array_equal(traj.states, full["states"][..., 0].numpy()) and np.array_equal(traj.actions, full["actions"][..., 0].numpy())
+                  and np.array_equal(traj.costs, full["costs"].numpy()))                    # (Trajectory squeezes the column axis)
+            ok = ok and iterations.dtype == np.int32 and np.array_equal(iterations, full["iterations"].numpy())
+            ok = ok and solver.last_status.dtype == torch.int32 and torch.equal(solver.last_status, full["status"])
+            torch.save({"ok": bool(ok), "len": len(iterations)}, out_path)
+        else:
+            assert traj is None and iterations is None
+        # the general form (sizes not known up front) carries the columns too
+        out = _fake_ilqr_out(mine, T, m)
+        res = parallel.gather_results(out["states"], out["actions"], out["costs"], iterations=out["iterations"], status=out["status"])
+        if rank == 0:
+            assert torch.equal(res[3], _fake_ilqr_out(x0, T, m)["iterations"]) and torch.equal(res[4], _fake_ilqr_out(x0, T, m)["status"])
+        # receive buffers sized without the int columns are refused before anything is sent (rank 0 only holds buffers)
+        if rank == 0:
+            short = parallel.gather_buffers(out["states"], out["actions"], out["costs"], total=B)
+            try:
+                parallel.gather_results(out["states"], out["actions"], out["costs"], iterations=out["iterations"], status=out["status"],
+                                        total=B, recv=short)
+                raise AssertionError("receive buffers without the int columns were accepted")
+            except ValueError:
+                pass
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_ilqr_solve_gathers_trajectory_iterations_and_status_in_one_collective(tmp_path):
+    for B in (37, 1):
+        out_path = str(tmp_path / f"ilqr_{B}.pt")
+        mp.spawn(_ilqr_worker, args=(2, _free_port(), B, 6, 3, 9, out_path), nprocs=2, join=True)
+        res = torch.load(out_path)
+        assert res["ok"] and res["len"] == B
+
+
+def test_gather_results_refuses_columns_that_are_not_int32_per_instance():
+    s, a, c = _fake_solve(torch.ones(3, 4), 5, 2)
+    import pytest
+    with pytest.raises(ValueError):
+        parallel.gather_results(s, a, c, iterations=torch.zeros(3, dtype=torch.int64))
+    with pytest.raises(ValueError):
+        parallel.gather_results(s, a, c, status=torch.zeros(4, dtype=torch.int32))
+    out = parallel.gather_results(s, a, c, iterations=torch.arange(3, dtype=torch.int32))      # no process group: identity
+    assert out[0] is s and out[3].tolist() == [0, 1, 2] and out[4] is None
+
+
+def _build_worker(idx, source, out_dir):
+    os.environ["TFMPC_USERENV_CACHE"] = out_dir
+    from tfmpc.envs import deviceenv
+    deviceenv._CACHE = os.path.join(out_dir, "primary")            # a fresh cache: every process finds nothing and compiles
+    path = deviceenv.build(source, 2, 2, 8)
+    with open(os.path.join(out_dir, f"path{idx}.txt"), "w") as fh:
+        fh.write(path)
+
+
+def test_ranks_compiling_the_same_device_env_at_once_end_with_one_valid_library(tmp_path):
+    """N ranks of a job reach their first DeviceEnv solve together: each compiles into its own temporary and os.replace()s it onto the
+    same name -- every rank must come back with the same path and a library that loads and exports the twins."""
+    import ctypes
+    import sys
+    from tfmpc.envs import deviceenv
+    if deviceenv.hipcc_path() is None:
+        import pytest
+        pytest.skip("no hipcc in this environment")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import deviceenv_sources as sources
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_build_worker, args=(i, sources.NAVIGATION, str(tmp_path))) for i in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    paths = {open(os.path.join(str(tmp_path), f"path{i}.txt")).read() for i in range(4)}
+    assert len(paths) == 1
+    path = paths.pop()
+    lib = ctypes.CDLL(path)
+    for twin in deviceenv._TWINS.values():
+        assert hasattr(lib, twin), twin
+    leftovers = [f for f in os.listdir(os.path.dirname(path)) if f.endswith(".tmp") or (f.startswith("env.") and f != "env.hip")]
+    assert leftovers == [], leftovers

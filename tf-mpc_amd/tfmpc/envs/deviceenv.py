@@ -19,10 +19,12 @@ reference's ``unconnected_gradients=ZERO`` semantics.  Every ``DiffEnv`` method 
 Needs ``hipcc`` at run time (``$ROCM_PATH/bin`` or ``PATH``); without it use ``TorchEnv``."""
 
 import ctypes
+import functools
 import hashlib
 import os
 import shutil
 import subprocess
+import tempfile
 
 import numpy as np
 
@@ -67,27 +69,78 @@ def _stamp(text):
     return h.hexdigest()[:16]
 
 
+def _clean_env():
+    """The environment hipcc runs in: the caller's minus everything a profiler or tool preload put there.  hipcc execs clang / lld; under
+    rocprofv3 the preloaded tool library would initialise the GPU in the child before that exec -- the pattern this pool forbids."""
+    drop = ("LD_PRELOAD", "HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE", "ROCP_", "ROCPROFILER_", "ROCPROF_", "ROCTX_")
+    return {k: v for k, v in os.environ.items() if not k.startswith(drop)}
+
+
+@functools.lru_cache(maxsize=None)
+def _toolchain_stamp(hipcc):
+    """Flags + compiler version: a toolchain upgrade must not reuse libraries an older compiler produced."""
+    h = hashlib.sha256(" ".join(_FLAGS).encode())
+    try:
+        out = subprocess.run([hipcc, "--version"], capture_output=True, text=True, env=_clean_env(), timeout=60).stdout
+        h.update("\n".join(l for l in out.splitlines() if "version" in l.lower()).encode())     # (not InstalledDir: a path)
+    except (OSError, subprocess.SubprocessError):
+        h.update(b"unknown")
+    return h.hexdigest()[:8]
+
+
+def _cache_roots():
+    """Next to the product library when that directory is writable (so prebuilt libraries travel with the tree), else a per-user cache."""
+    user = os.environ.get("TFMPC_USERENV_CACHE") or os.path.join(
+        os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "tfmpc", "userenv")
+    return [_CACHE, user, os.path.join(tempfile.gettempdir(), f"tfmpc-userenv-{os.getuid()}")]
+
+
 def build(source, state_size, action_size, param_count=0):
-    """Compile (or find in the cache) the companion library of a user env; returns its path.  Works without a GPU."""
+    """Compile (or find in the cache) the companion library of a user env; returns its path.  Works without a GPU.
+    A process that is being PROFILED should find the library prebuilt (``__graft_entry__.build`` does that for the repo's own sources):
+    the compiler is started with the profiler's variables removed, but a profiled run is not the place to compile."""
     text = translation_unit(source, state_size, action_size, param_count)
-    folder = os.path.join(_CACHE, _stamp(text))
-    lib = os.path.join(folder, "libtfmpc_userenv.so")
-    if os.path.exists(lib):
-        return lib
+    stamp = _stamp(text)
     hipcc = hipcc_path()
+    name = "libtfmpc_userenv.so"
+    roots = _cache_roots()
     if hipcc is None:
+        # nothing can be compiled here: any library built from this very source (whatever toolchain) is what there is
+        for root in roots:
+            if os.path.isdir(root):
+                for folder in sorted(os.listdir(root)):
+                    if folder.startswith(stamp) and os.path.exists(os.path.join(root, folder, name)):
+                        return os.path.join(root, folder, name)
         raise RuntimeError("tfmpc.envs.deviceenv: no hipcc found ($ROCM_PATH/bin, PATH): a DeviceEnv is compiled when it is first "
                            "used; give the env as torch functions instead (tfmpc.envs.torchenv.TorchEnv)")
-    os.makedirs(folder, exist_ok=True)
-    src = os.path.join(folder, "env.hip")
+    key = f"{stamp}-{_toolchain_stamp(hipcc)}"
+    for root in roots:
+        if os.path.exists(os.path.join(root, key, name)):
+            return os.path.join(root, key, name)
+    folder = None
+    for root in roots:                           # the first root this process may write to
+        try:
+            os.makedirs(os.path.join(root, key), exist_ok=True)
+            probe = os.path.join(root, key, f".w{os.getpid()}")
+            open(probe, "w").close()
+            os.remove(probe)
+            folder = os.path.join(root, key)
+            break
+        except OSError:
+            continue
+    if folder is None:
+        raise RuntimeError(f"tfmpc.envs.deviceenv: no writable cache directory among {roots}")
+    lib = os.path.join(folder, name)
+    src = os.path.join(folder, f"env.{os.getpid()}.hip")
     with open(src, "w") as fh:
         fh.write(text)
     tmp = lib + f".{os.getpid()}.tmp"
-    proc = subprocess.run([hipcc, *_FLAGS, "-I", _CSRC, src, "-o", tmp], capture_output=True, text=True)
+    proc = subprocess.run([hipcc, *_FLAGS, "-I", _CSRC, src, "-o", tmp], capture_output=True, text=True, env=_clean_env())
     if proc.returncode != 0:
         errors = "\n".join(l for l in proc.stderr.splitlines() if "warning" not in l)[:4000]      # (the first error is the informative one)
         raise RuntimeError(f"tfmpc.envs.deviceenv: the env's source does not compile:\n{errors}")
-    os.replace(tmp, lib)                       # (atomic: several processes may build the same env at once)
+    os.replace(src, os.path.join(folder, "env.hip"))
+    os.replace(tmp, lib)                       # (atomic: several processes may build the same env at once; each ends with a whole file)
     return lib
 
 

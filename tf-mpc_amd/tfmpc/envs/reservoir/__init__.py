@@ -28,14 +28,6 @@ class Reservoir(DiffEnv, GymEnv):
         self.downstream = _np(downstream)
         self.rain_shape, self.rain_scale = col(rain_shape), col(rain_scale)
         n = self.state_size
-        # `downstream` of every config the reference holds is a chain (tests/conftest.py:70-75, res4.config.json:13-18): said to the
-        # kernels through TfmpcEnv.coupling_shift (+1: i drains into i + 1, -1: into i - 1, 0: any matrix), which lets a large batch run
-        # the instantiation without coupling products (checked here on the host copy, and again on the device)
-        D = self.downstream
-        self.coupling_shift = 0
-        if D.shape == (n, n) and n > 1:
-            self.coupling_shift = 1 if np.array_equal(D, np.eye(n, k=1, dtype=np.float32)) else (
-                -1 if np.array_equal(D, np.eye(n, k=-1, dtype=np.float32)) else 0)
         self.obs_space = Box(0.0, self.max_res_cap, (n, 1))
         self.action_space = Box(0.0, 1.0, (n, 1))
 
@@ -46,6 +38,19 @@ class Reservoir(DiffEnv, GymEnv):
     @property
     def action_size(self):
         return self.state_size
+
+    @property
+    def coupling_shift(self):
+        """``downstream`` of every config the reference holds is a chain (tests/conftest.py:70-75, res4.config.json:13-18): said to the
+        kernels through TfmpcEnv.coupling_shift (+1: i drains into i + 1, -1: into i - 1, 0: any matrix), which lets a large batch run
+        the instantiation without coupling products.  Derived from the CURRENT matrix on every call (``downstream`` is a public attribute
+        and may be reassigned after construction); the kernel checks the promise again on the device (TFMPC_ST_ENV_FLAG)."""
+        D, n = np.asarray(self.downstream, dtype=np.float32), self.state_size
+        if D.shape != (n, n) or n <= 1:
+            return 0
+        if np.array_equal(D, np.eye(n, k=1, dtype=np.float32)):
+            return 1
+        return -1 if np.array_equal(D, np.eye(n, k=-1, dtype=np.float32)) else 0
 
     def _params(self):
         rain = (self.rain_shape * self.rain_scale).astype(np.float32)          # reservoir/__init__.py:100

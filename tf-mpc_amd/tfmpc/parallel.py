@@ -39,28 +39,34 @@ def check_shard_sizes(b, total, group=None):
                          f"(this rank: {int(b)} instances, the split gives it {hi - lo})")
 
 
-def gather_buffers(states, actions, costs, total, dst=0, group=None):
-    """The receive buffers of ``gather_trajectories(..., total=total)`` on rank ``dst`` (``None`` elsewhere): allocate
+def _row_floats(states, actions, costs, ints):
+    return states.shape[1:].numel() + actions.shape[1:].numel() + costs.shape[1:].numel() + len(ints)
+
+
+def gather_buffers(states, actions, costs, total, dst=0, group=None, iterations=None, status=None):
+    """The receive buffers of ``gather_results(..., total=total)`` on rank ``dst`` (``None`` elsewhere): allocate
     them when the job starts, where running out of memory is an ordinary start-up error, instead of in front of the
-    collective."""
+    collective.  Pass ``iterations`` / ``status`` iff the gather will carry them (one more float per row each)."""
     if not (dist.is_available() and dist.is_initialized()):
         return None
     world = dist.get_world_size(group)
     if dist.get_rank() != dst:
         return None
-    per = states.shape[1:].numel() + actions.shape[1:].numel() + costs.shape[1:].numel()
+    per = _row_floats(states, actions, costs, [t for t in (iterations, status) if t is not None])
     bmax = max(hi - lo for lo, hi in (shard_bounds(total, world, r) for r in range(world)))
     return [torch.empty((bmax, per), device=states.device, dtype=states.dtype) for _ in range(world)]
 
 
-def gather_trajectories(states, actions, costs, dst=0, group=None, total=None, recv=None):
-    """Gather per-rank result shards ``states[b,T+1,n,1]``, ``actions[b,T,m,1]``,
-    ``costs[b,T+1,...]`` on GLOBAL rank ``dst`` as ONE collective over a single packed
-    buffer.  Returns the concatenated tensors on ``dst`` and ``None`` elsewhere.
+def gather_results(states, actions, costs, iterations=None, status=None, dst=0, group=None, total=None, recv=None):
+    """Gather per-rank result shards ``states[b,T+1,n,1]``, ``actions[b,T,m,1]``, ``costs[b,T+1,...]`` and -- what
+    ``iLQR.solve`` returns beside the trajectory (ilqr.py:281-283) -- ``iterations[b]``, ``status[b]`` (int32) on GLOBAL
+    rank ``dst`` as ONE collective over a single packed fp32 buffer: the int32 columns ride in it BIT-CAST (a gather moves
+    bytes, no arithmetic touches them).  Returns ``(states, actions, costs, iterations, status)`` on ``dst`` (the last two
+    ``None`` when not given) and ``None`` elsewhere.  SURVEY.md 8(e)'s single RCCL gather.
 
     ``total`` = the global number of instances of a block-sharded batch (``shard`` / ``shard_bounds``): every rank
     then knows every shard's size, and the ONLY communication is one ``dist.gather`` of the packed rows (padded to
-    the largest shard, which is at most one row more than the smallest) -- SURVEY.md 8(e)'s single RCCL gather.
+    the largest shard, which is at most one row more than the smallest).
     ``recv`` = buffers from ``gather_buffers`` (else they are allocated here; an allocation failure then raises on
     that rank only).  A shard whose size is not the block split's raises ``ValueError`` on ITS rank before anything is
     sent -- the other ranks would then wait in the gather: ``check_shard_sizes`` at start-up makes that error collective.
@@ -68,33 +74,52 @@ def gather_trajectories(states, actions, costs, dst=0, group=None, total=None, r
     Without ``total`` the shards may be of any sizes: an 8-byte ``all_gather`` of the sizes and a 4-byte
     ``all_reduce`` by which the ranks agree that every buffer could be allocated precede the gather, so that an
     out-of-memory raises ``RuntimeError`` on EVERY rank instead of leaving the others inside the collective."""
+    ints = [t for t in (iterations, status) if t is not None]
+    for t in ints:
+        if t.dtype != torch.int32 or t.shape != (states.shape[0],):
+            raise ValueError("iterations / status: int32 [b], one entry per instance of this rank's shard")
+    if states.dtype != torch.float32 and ints:
+        raise ValueError("the int32 columns are bit-cast into an fp32 buffer: trajectories must be float32")
     if not (dist.is_available() and dist.is_initialized()):
-        return states, actions, costs
+        return states, actions, costs, iterations, status
     world = dist.get_world_size(group)
     is_dst = dist.get_rank() == dst                          # `dst` is a global rank, as dist.gather takes it
     b = states.shape[0]
     ns, na, nc = states.shape[1:].numel(), actions.shape[1:].numel(), costs.shape[1:].numel()   # valid for an empty shard too
-    per = ns + na + nc
+    per = ns + na + nc + len(ints)
 
     def pack(bmax):
         packed = torch.zeros((bmax, per), device=states.device, dtype=states.dtype)
-        packed[:b] = torch.cat([states.reshape(b, ns), actions.reshape(b, na), costs.reshape(b, nc)], dim=1)
+        cols = [states.reshape(b, ns), actions.reshape(b, na), costs.reshape(b, nc)]
+        cols += [t.to(states.device).contiguous().view(torch.float32).reshape(b, 1) for t in ints]      # same bits, fp32 label
+        packed[:b] = torch.cat(cols, dim=1)
         return packed
 
     def unpack(recv_, all_b):
         full = torch.cat([r[:nb] for r, nb in zip(recv_, all_b)], dim=0)
         B = full.shape[0]
-        return (full[:, :ns].reshape(B, *states.shape[1:]), full[:, ns:ns + na].reshape(B, *actions.shape[1:]),
-                full[:, ns + na:].reshape(B, *costs.shape[1:]))
+        out = [full[:, :ns].reshape(B, *states.shape[1:]), full[:, ns:ns + na].reshape(B, *actions.shape[1:]),
+               full[:, ns + na:ns + na + nc].reshape(B, *costs.shape[1:])]
+        col = ns + na + nc
+        for t in (iterations, status):
+            if t is None:
+                out.append(None)
+            else:
+                out.append(full[:, col].contiguous().view(torch.int32))
+                col += 1
+        return tuple(out)
 
     if total is not None:
         all_b = [hi - lo for lo, hi in (shard_bounds(total, world, r) for r in range(world))]
         mine = all_b[dist.get_rank(group)]
         if b != mine:                                        # a caller's error, raised before anything is sent
-            raise ValueError(f"gather_trajectories: this rank holds {b} instances, the block split of {total} gives it {mine}")
+            raise ValueError(f"gather_results: this rank holds {b} instances, the block split of {total} gives it {mine}")
         packed = pack(max(all_b))
         if is_dst and recv is None:
             recv = [torch.empty_like(packed) for _ in range(world)]
+        if is_dst and tuple(recv[0].shape) != tuple(packed.shape):
+            raise ValueError(f"gather_results: receive buffers are {tuple(recv[0].shape)}, the packed rows {tuple(packed.shape)} "
+                             "(gather_buffers must be told about iterations / status)")
         dist.gather(packed, recv if is_dst else None, dst=dst, group=group)          # the one collective
         return unpack(recv, all_b) if is_dst else None
 
@@ -111,11 +136,19 @@ def gather_trajectories(states, actions, costs, dst=0, group=None, total=None, r
     ok = torch.tensor([0 if error is not None else 1], device=states.device, dtype=torch.int32)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
     if int(ok.item()) == 0:
-        raise RuntimeError(f"gather_trajectories: buffer allocation failed on at least one rank ({error!r} here)")
+        raise RuntimeError(f"gather_results: buffer allocation failed on at least one rank ({error!r} here)")
     dist.gather(packed, recv, dst=dst, group=group)        # the one data-path collective
     return unpack(recv, all_b) if is_dst else None
 
 
-def gather_bytes_per_rank(states, actions, costs):
+def gather_trajectories(states, actions, costs, dst=0, group=None, total=None, recv=None):
+    """``gather_results`` for the trajectory alone (what ``LQR.solve`` returns, lqr.py:163-166): ``(states, actions, costs)`` on
+    ``dst``, ``None`` elsewhere, the inputs themselves without a process group."""
+    res = gather_results(states, actions, costs, dst=dst, group=group, total=total, recv=recv)
+    return None if res is None else res[:3]
+
+
+def gather_bytes_per_rank(states, actions, costs, iterations=None, status=None):
     """Payload one rank contributes to the gather (the packed fp32 rows)."""
-    return int(states.numel() + actions.numel() + costs.numel()) * states.element_size()
+    extra = sum(int(t.numel()) for t in (iterations, status) if t is not None)
+    return (int(states.numel() + actions.numel() + costs.numel()) + extra) * states.element_size()

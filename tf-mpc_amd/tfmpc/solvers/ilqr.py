@@ -379,15 +379,18 @@ class iLQR:
             if not batched:
                 x0, batched, B = x0.expand(eb, n).contiguous(), True, eb
         u = u.expand(B, T, m).contiguous()
-        states = torch.empty((B, T + 1, n), device=dev)
-        actions = torch.empty((B, T, m), device=dev)
-        costs = torch.empty((B, T + 1), device=dev)
+        env, keep = self.env.c_env()
+        # an env that makes a structural promise to the kernels (TfmpcEnv.coupling_shift) may be refused on the device
+        # (TFMPC_ST_ENV_FLAG: nothing computed): its outputs then read as zeros, never as uninitialised memory
+        alloc = torch.zeros if env.coupling_shift != 0 else torch.empty
+        states = alloc((B, T + 1, n), device=dev)
+        actions = alloc((B, T, m), device=dev)
+        costs = alloc((B, T + 1), device=dev)
         iterations = torch.zeros((B,), dtype=torch.int32, device=dev)
         status = torch.zeros((B,), dtype=torch.int32, device=dev)
         ws_bytes = int(lib.tfmpc_ilqr_workspace_bytes(B, n, m, T))
         if workspace is None or workspace.numel() * workspace.element_size() < ws_bytes:
             workspace = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
-        env, keep = self.env.c_env()
         cfg = self._c_config()
         trace = trace_len = None
         if trace_rows > 0:
@@ -407,8 +410,16 @@ class iLQR:
         return out
 
     # -- ilqr.py:214-283 ---------------------------------------------------------------------
-    def solve(self, x0, T, show_progress=True, u_init=None, seed=None, trace=False):
-        """``(Trajectory, iteration)`` as the reference returns them (ilqr.py:281-283).  ``trace=True`` also records what
+    def solve(self, x0, T, show_progress=True, u_init=None, seed=None, trace=False, gather=False, total=None):
+        """``(Trajectory, iteration)`` as the reference returns them (ilqr.py:281-283).
+
+        ``gather=True`` under an initialised ``torch.distributed`` process group (one process per GPU, ``x0`` / ``u_init`` = THIS rank's
+        block of the batch, ``tfmpc.parallel.shard``): the ranks solve their shards with no communication and ONE gather at the end
+        (``tfmpc.parallel.gather_results``; with ``total`` = the global batch size it is literally one collective) brings
+        ``(Trajectory[B_global], iterations[B_global])`` to rank 0 -- every other rank returns ``(None, None)``; the gathered
+        ``status[B_global]`` is left in ``self.last_status``.  Without a process group ``gather`` changes nothing.
+
+        ``trace=True`` also records what
         the reference logs while it solves (ilqr.py:243-279: per pass ``J_hat``, ``g_norm``, the step size the line
         search ended on, its ``J`` and ``residual``, ``mu`` / ``delta``) into ``self.last_trace`` -- a list of dicts
         per instance (``tfmpc.solvers.ilqr.trace_records``); with ``show_progress`` the progress bar's postfix
@@ -417,6 +428,9 @@ class iLQR:
         if trace:       # an iteration makes at most max_attempts rejected passes; almost all make one or two
             rows = int(self.max_iterations) + int(self.max_attempts) + 1
         out = self.solve_device(x0, T, u_init=u_init, seed=seed, trace_rows=rows)
+        if int(getattr(self.env.c_env()[0], "coupling_shift", 0)) != 0 and bool((out["status"] & _hip.ST_ENV_FLAG).any()):
+            raise ValueError("the env's TfmpcEnv.coupling_shift promises a chain that its `downstream` matrix is not "
+                             "(TFMPC_ST_ENV_FLAG): nothing was computed")
         if trace:
             self.last_trace = trace_records(out["trace"], out["trace_len"])
             if show_progress and not out["batched"]:
@@ -424,6 +438,18 @@ class iLQR:
                 for r in self.last_trace[0]:
                     res = "" if r["residual"] is None else f", residual={r['residual']:.4f}"
                     print(f"[iLQR] iteration {r['iteration']}: J={r['J_hat']:.4f}, g_norm={r['g_norm']:.4f}{res}", file=sys.stderr)
+        if gather:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                from tfmpc import parallel
+                if not out["batched"]:
+                    raise ValueError("gather=True shards a BATCH of instances over the ranks: x0 must carry the batch axis")
+                res = parallel.gather_results(out["states"], out["actions"], out["costs"], iterations=out["iterations"],
+                                              status=out["status"], total=total)
+                if res is None:
+                    return None, None
+                states, actions, costs, iterations, self.last_status = res
+                return trajectory.Trajectory(states, actions, costs), iterations.cpu().numpy()
         if out["batched"]:
             return trajectory.Trajectory(out["states"], out["actions"], out["costs"]), out["iterations"].cpu().numpy()
         traj = trajectory.Trajectory(out["states"][0], out["actions"][0], out["costs"][0])
