@@ -199,15 +199,18 @@ def ilqr_api_rate(n, m, T, B, reps=5):
         torch.cuda.synchronize()
         return out, (time.perf_counter() - t0) / reps_
 
-    def api_line(w):
+    def api_line(w, reuse=True):
         out, dt = run(workloads.solver_of(w), w, reps)
         its = float((out["iterations"].double() + 1).sum())
         flop = its * T * 45.0e3 + max(its - B, 0.0) * T * 2.2e3
         tf = flop / dt / 1e12
+        # EXECUTED flop (round 6): with gain reuse only the first backward pass of an instance is a full one (45.0 kflop a step); every
+        # later pass is the vector recursion -- F~^T V_x (2 x 24 x 16), k = -Q_uu^-1 Q_u (2 x 64), K^T Q_u (2 x 128), 40 adds = 1 192 flop
+        ex = (B * T * 45.0e3 + max(its - B, 0.0) * T * (1192.0 + 2.2e3)) if reuse else flop
         return {"iterations_per_s": its / dt, "ms_per_batch": dt * 1e3, "mean_iterations": its / B,
                 "flagged_instances": int((out["status"] != 0).sum()), "workload": w["text"], "workload_version": w["version"],
                 "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
-                             "algorithmic_flop": flop}}
+                             "algorithmic_flop": flop, "executed_flop": ex, "frac_executed": ex / dt / 1e12 / PEAK_F32_TFLOPS}}
 
     # the workloads are defined in tests/workloads.py, the module the decision-trace parity tests draw them from
     # (tests/test_ilqr_lq_trace_gpu.py); `workload_version` says which definition a number belongs to
@@ -217,10 +220,19 @@ def ilqr_api_rate(n, m, T, B, reps=5):
         res["cpu_baseline"] = ilqr_cpu_baseline("lq", [workloads.instance_cfg(w_warm, b) for b in range(8)], w_warm["x0"], w_warm["u0"], T, 100, 8, w_warm["version"])
     res["roofline"]["traffic"] = pmc_traffic("ilqr_lq_mfma_kernel", 65536, B)
     res["roofline"]["executed"] = pmc_executed("ilqr_lq_mfma_kernel")
-    res["roofline"]["kernel"] = "ilqr_lq_mfma_kernel (profiles/r04_ilqr_api_kernel_stats.csv: tools/ilqr_api_once.py under rocprofv3)"
+    res["roofline"]["kernel"] = "ilqr_lq_mfma_kernel<true, true> (profiles/r06_ilqr_api_kernel_stats.csv: tools/ilqr_api_once.py under rocprofv3)"
+    res["gain_reuse"] = ("default since round 6: the env is time-invariant LQ and every pass runs at mu = 0, so K_t, V_xx(t), Q_uu(t) do not depend on the "
+                         "trajectory -- from the second backward pass on the kernel keeps K_t and Q_uu^-1 of the first and runs the vector recursion for "
+                         "k_t, V_x alone (ilqr_lq_mfma.hip, REUSE).  `frac` divides the ALGORITHMIC flop (every pass counted as the full 45.0 kflop a step, "
+                         "as the reference executes it) by the time; `frac_executed` counts what the kernel executed.  TFMPC_ILQR_LQ_REUSE=0 is the full "
+                         "pass in every iteration: `full_pass_every_iteration`")
+    with _hip.option("TFMPC_ILQR_LQ_REUSE", "0"):
+        full = api_line(w_warm, reuse=False)
+    res["full_pass_every_iteration"] = {"ms_per_batch": full["ms_per_batch"], "frac": full["roofline"]["frac"], "mean_iterations": full["mean_iterations"]}
     # the same problems from zero actions: the first rollout runs open loop through an unstable system, several step sizes are tried
     cold = api_line(workloads.ilqr_api_cold(B, n, m, T))
     cold["roofline"].update(note="rollouts counted as iterations - B: a lower bound here (the line search backtracks)", traffic=None)
+    cold["roofline"]["frac_executed"] = None          # (the rollout count is a bound, so the executed count would be one too)
     res["cold_start"] = cold
     # CONTROL LIMITS: box-QP at every backward step, regularisation loop in the kernel.  On the well-conditioned generator
     # (tests/problems.py:make_lqr_batch_fast, eigenvalues of C in [1, 2]; zero start actions) as in rounds 1-3: with
@@ -666,7 +678,8 @@ def summarise_extras(extra):
     r3 = lambda v: None if v is None else float(f"{v:.3g}")
     oc = extra.get("other_configs", {}) if isinstance(extra, dict) else {}
     api = extra.get("ilqr_api", {}) if isinstance(extra, dict) else {}
-    out = {"ilqr_api_warm": [r3(get(api, "ms_per_batch")), r3(get(api, "roofline", "frac"))],
+    out = {"ilqr_api_warm": [r3(get(api, "ms_per_batch")), r3(get(api, "roofline", "frac")), r3(get(api, "roofline", "frac_executed"))],
+           "ilqr_api_warm_full_pass_every_iteration": [r3(get(api, "full_pass_every_iteration", "ms_per_batch")), r3(get(api, "full_pass_every_iteration", "frac"))],
            "ilqr_api_cold": [r3(get(api, "cold_start", "ms_per_batch")), r3(get(api, "cold_start", "roofline", "frac"))],
            "control_limited_ms": r3(get(api, "control_limited", "ms_per_batch")),
            "control_limited_stable_ms": r3(get(api, "control_limited", "stable_open_loop_variant", "ms_per_batch")),
@@ -675,7 +688,7 @@ def summarise_extras(extra):
            "bf16_sweep": get(extra, "bf16_storage_sweep") if isinstance(extra, dict) and "error" not in (extra.get("bf16_storage_sweep") or {}) else None,
            "torchenv_kit_s": r3((get(extra, "torchenv_generic_env", "iterations_per_s") or 0) / 1e3),
            "deviceenv_Mit_s": r3((get(extra, "deviceenv_user_env", "iterations_per_s") or 0) / 1e6),
-           "format": "[ms per batch, roofline frac (, algorithmic flop rate / fp32 peak)]"}
+           "format": "[ms per batch, roofline frac (, algorithmic flop rate / fp32 peak; ilqr_api_warm: executed flop rate / fp32 peak)]"}
     for key, short in (("cfg5_hvac_ilqr_n32", "cfg5_hvac"), ("cfg5_reservoir_ilqr_n32", "cfg5_reservoir"), ("hvac6_reference_config_ilqr", "hvac6"),
                        ("res4_reference_config_ilqr", "res4"), ("cfg5_literal_dims_ilqr_lq_n32_m16", "literal_dims"), ("lqr_n32_m16", "lqr_n32_m16")):
         v = [r3(get(oc, key, "ms_per_batch")), r3(get(oc, key, "roofline", "frac"))]

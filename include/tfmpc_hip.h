@@ -60,7 +60,10 @@ int tfmpc_version(void);
  * reservoirs, every config the reference holds -- instead of moving rows; same bits, for A/B timing and tests), TFMPC_BOX_HELPERS (off | number of
  * helper teams, default 8: a control-limited batch of more than 4 096 instances without heavy ones in the launcher's sample lends five helper
  * blocks to each of its longest-running instances, which roll out the step sizes of a line search side by side -- same bits) and
- * TFMPC_BOX_HELP_AFTER (passes before an instance may claim a team, default 8) are read ONCE per process, at the first use of the library; afterwards only
+ * TFMPC_BOX_HELP_AFTER (passes before an instance may claim a team, default 8), TFMPC_ILQR_LQ_REUSE (0: the matrix-core iLQR kernel of the
+ * unbounded LQ env runs the full backward pass in every iteration, as ilqr.py:94-172 does; default: from the second pass on it keeps K_t and
+ * Q_uu(t)^-1 -- which for a time-invariant LQ env at mu = 0 do not depend on the trajectory, so the recomputed ones would be the same bits -- and
+ * runs only the vector recursion for k_t, V_x: results agree to fp32 rounding) are read ONCE per process, at the first use of the library; afterwards only
  * this call changes them (value NULL or "" = back to the dispatcher's own choice).  Returns TFMPC_ERR_ARG
  * for an unknown name.  Process-wide; not meant to be flipped while other threads launch. */
 int tfmpc_set_option(const char *name, const char *value);

@@ -141,3 +141,58 @@ def test_large_tile_solve_matches_wave_kernel_oracle_and_lqr(force_kernel, n, m,
         budget = 5 * max(np.abs(x32 - x).max(), 1e-5 * np.abs(x).max())
         assert np.abs(mf["states"][b, ..., 0].cpu().numpy() - x).max() <= budget
         assert abs(float(tot_i[b]) - cs.sum()) <= 2e-3 * np.abs(cs).sum()
+
+
+@pytest.mark.parametrize("n,m,T", [(16, 8, 50), (12, 6, 20), (9, 3, 16)])
+def test_gain_reusing_later_passes_agree_with_full_passes(n, m, T):
+    """Round 6 (TFMPC_ILQR_LQ_REUSE): for a time-invariant LQ env at mu = 0 the matrices of the backward pass (Q_xx, Q_ux, Q_uu -> K_t, V_xx)
+    do not depend on the trajectory, so from the second pass on the kernel keeps K_t and Q_uu^-1 of the first and runs the vector recursion
+    (ilqr.py:122-123,152-156) alone.  Against the same kernel with the full pass in every iteration (=0, what ilqr.py:94-172 does): the same
+    decisions, and numbers that agree like two fp32 programs with different summation order.  An unreachable atol makes every instance run all
+    its iterations, i.e. five gain-reusing passes in a row, each followed by a line search on ITS k_t."""
+    B = 96
+    F, f, C, c, x0 = _problem(B, n, m, seed=7 * n + m)
+    u0 = (0.1 * np.random.default_rng(2).normal(size=(B, T, m, 1))).astype(np.float32)
+    for kwargs, min_passes in ((dict(), 2), (dict(atol=1e-12, max_iterations=6), 6)):
+        solver = iLQR(LQEnv(F, f, C, c), **kwargs)
+        rows = 8
+        out = {}
+        for mode in (None, "0"):
+            with _hip.option("TFMPC_ILQR_LQ_REUSE", mode):
+                out[mode] = solver.solve_device(x0[..., None], T, u_init=u0, trace_rows=rows)
+            torch.cuda.synchronize()
+            assert int(out[mode]["status"].abs().sum()) == 0
+            assert solver.last_kernel.startswith("lq_mfma")
+        re, full = out[None], out["0"]
+        assert float((re["iterations"] == full["iterations"]).float().mean()) >= 0.97
+        assert int(re["trace_len"].min()) >= min_passes
+        same = (re["iterations"] == full["iterations"])
+        for key in ("states", "actions", "costs"):
+            diff = (re[key] - full[key]).abs().reshape(B, -1).amax(dim=1)
+            scale = full[key].abs().reshape(B, -1).amax(dim=1).clamp_min(1e-6)
+            rel = (diff / scale)[same].cpu().numpy()
+            assert np.median(rel) <= 1e-5 and rel.max() <= 5e-3, (key, np.median(rel), rel.max())
+        # the first pass is the same code in both builds: its trace row (J_hat, g_norm, step size, J, residual) is the same bits -- except
+        # for an instance that ONE of the two hands to the wave kernel (a line search that rejects every step at the noise floor of the
+        # unreachable atol): that kernel re-solves it from the start and rewrites its rows
+        first_same = (re["trace"][:, 0].nan_to_num(-7.0) == full["trace"][:, 0].nan_to_num(-7.0)).all(dim=1)
+        assert float(first_same.float().mean()) >= (1.0 if not kwargs else 0.9)
+        # later passes: g_norm (computed from the vector recursion's k_t) agrees to rounding relative to the first pass's scale
+        from tfmpc.solvers.ilqr import TRACE_COLUMNS
+        gcol = TRACE_COLUMNS.index("g_norm")
+        g0 = full["trace"][:, 0, gcol]
+        for r in range(1, min_passes):
+            ok = same & (re["trace_len"] > r) & (full["trace_len"] > r)
+            dg = (re["trace"][:, r, gcol] - full["trace"][:, r, gcol]).abs()[ok]
+            assert float((dg / g0[ok]).max()) <= 1e-4, (r, float((dg / g0[ok]).max()))
+    # and against the fp64 restatement of ilqr.py, like every other kernel
+    solver = iLQR(LQEnv(F, f, C, c))
+    res = solver.solve_device(x0[..., None], T, u_init=u0)
+    for b in (1, B - 2):
+        o = ilqr_ref.ILQRRef(envs_ref.LQEnv(F[b], f[b], C[b], c[b]))
+        x, u, cs, it = o.solve(x0[b], T, u_init=u0[b])
+        assert it == int(res["iterations"][b])
+        o32 = ilqr_ref.ILQRRef(envs_ref.LQEnv(F[b], f[b], C[b], c[b], dtype=np.float32), dtype=np.float32)
+        x32, _, _, _ = o32.solve(x0[b], T, u_init=u0[b])
+        budget = 5 * max(np.abs(x32 - x).max(), 1e-5 * np.abs(x).max())
+        assert np.abs(res["states"][b, ..., 0].cpu().numpy() - x).max() <= budget

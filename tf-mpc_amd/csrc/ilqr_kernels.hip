@@ -195,7 +195,7 @@ int tfmpc_ilqr_forward_f32(const TfmpcEnv *env, int B, int T, const float *x, co
 // from a 256-byte boundary, the line-search scratch of the 2-D lane-group kernel and the wave-major trajectory buffers of
 // the 16-instances-per-wave HVAC / Reservoir kernel.  Offsets in bytes from a 256-byte aligned base.
 struct IlqrWsLayout {
-    size_t K, k, x, u, c, lane, wave, total;
+    size_t K, k, x, u, c, lane, wave, minv, total;
     IlqrWsLayout(int B, int n, int m, int T)
     {
         const size_t f = sizeof(float);
@@ -206,7 +206,8 @@ struct IlqrWsLayout {
         c = u + (size_t)B * T * m * f;
         lane = round256(c + (size_t)B * (T + 1) * f);
         wave = lane + round256(ilqr_lane_extra_workspace_bytes(B, n, m, T));
-        total = wave + ilqr_adjoint_mfma_workspace_bytes(B, n, m, T);
+        minv = round256(wave + ilqr_adjoint_mfma_workspace_bytes(B, n, m, T));
+        total = minv + ilqr_lq_mfma_reuse_workspace_bytes(B, n, m, T);       // -Q_uu^-1 of the LQ env's first pass (ilqr_lq_mfma.hip, REUSE)
     }
     static size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
 };
@@ -301,6 +302,7 @@ int tfmpc_ilqr_solve_trace_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, 
         if (!forced_wave && !cfg->storage_bf16 && ilqr_lq_mfma_supported(*env, T)) {
             IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk, a.wsu};
             la.trace = tr;
+            la.wsMinv = lay.total > lay.minv ? reinterpret_cast<float *>(base + lay.minv) : nullptr;
             if ((rc = ilqr_lq_mfma_launch(la, st)) != TFMPC_OK) return rc;
             a.only_flagged = 1;
             g_last_ilqr_kernel = "lq_mfma (matrix cores) + wave kernel for flagged instances";

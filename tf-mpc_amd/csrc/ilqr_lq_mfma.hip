@@ -63,14 +63,23 @@ constexpr int kZld = TFMPC_LQ_ZLD;
 
 __device__ __forceinline__ float sgn(float y) { return (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f); }
 
-#ifdef TFMPC_LQ_EU        // A/B builds: ask the compiler for that many waves per SIMD (register budget 512 / TFMPC_LQ_EU)
-#define TFMPC_LQ_OCCUPANCY __attribute__((amdgpu_waves_per_eu(TFMPC_LQ_EU, TFMPC_LQ_EU)))
-#else
-#define TFMPC_LQ_OCCUPANCY
+// The LDS slice (13.6 KB at T = 50) lets three waves onto a SIMD: the register budget is stated as that (168), so that no variant of the
+// kernel drifts past it unnoticed (round 6: the gain rings took the full-pass-every-iteration form to 175).  -DTFMPC_LQ_EU=n for A/B builds.
+#ifndef TFMPC_LQ_EU
+#define TFMPC_LQ_EU 3
 #endif
+#define TFMPC_LQ_OCCUPANCY __attribute__((amdgpu_waves_per_eu(TFMPC_LQ_EU, TFMPC_LQ_EU)))
 // EXACT: n == 16 and m == 8 (the BASELINE shape) as compile-time constants -- the padding guards of the shape-generic form fold
 // away and the gains move as 8-byte pieces (round 4; same arithmetic, same bits).
-template <bool EXACT>
+// REUSE (round 6): the env is time-invariant and LINEAR-QUADRATIC, and this kernel runs every pass at mu = 0 -- so Q_xx, Q_ux, Q_uu, hence K_t
+// and V_xx(t), do not depend on the nominal trajectory: every backward pass after the first recomputes the same matrices, bit for bit.  With
+// REUSE the first pass also leaves -Q_uu(t)^-1 in the workspace (eight spare lanes of the LDL^T solve carry identity columns: no extra
+// instructions but the selects), and every later pass runs only the VECTOR recursion of ilqr.py:122-123,152-156,
+//     Q_x = l_x + F_x^T V_x,  Q_u = l_u + F_u^T V_x,  k = -Q_uu^-1 Q_u,  V_x' = Q_x + Q_xu k = Q_x + K^T Q_u,
+// as wave-wide fp32 FMA mat-vecs (about a rollout's work instead of a sweep's).  Same K_t bits; k_t, V_x agree with the full pass to fp32
+// rounding (another summation order; k through the explicit inverse instead of the triangular solves).  TFMPC_ILQR_LQ_REUSE=0 keeps the
+// full pass every iteration (the reference recomputes everything, ilqr.py:94-172).
+template <bool EXACT, bool REUSE>
 __global__ __launch_bounds__(kWave) TFMPC_LQ_OCCUPANCY void ilqr_lq_mfma_kernel(IlqrLqArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -95,6 +104,7 @@ __global__ __launch_bounds__(kWave) TFMPC_LQ_OCCUPANCY void ilqr_lq_mfma_kernel(
     float *Kg = a.wsK + (size_t)b * T * m * n;
     float *kg = a.wsk + (size_t)b * T * m;
     float *qg = a.wsq + (size_t)b * T * m;
+    float *Mg = REUSE ? a.wsMinv + (size_t)b * T * 64 : nullptr;      // -Q_uu(t)^-1, [T][8][8] (padded actions: -1 on the diagonal)
 
     // padded-index accessors (x index in [0,16), u index in [0,8), z index in [0,24))
     auto Fxx = [&](int row, int xi) { return (row < n && xi < n) ? Fg[row * d + xi] : 0.0f; };
@@ -106,20 +116,31 @@ __global__ __launch_bounds__(kWave) TFMPC_LQ_OCCUPANCY void ilqr_lq_mfma_kernel(
     };
     auto cz = [&](int zr) { const int r = zmap(zr); return r >= 0 ? cg[r] : 0.0f; };
 
-    // ---- operands resident in registers for the whole solve ------------------------------
-    float Fb0[4], Fb1[4];
+    // ---- operands of the sweep: resident in registers for the whole solve -- or, with REUSE, for the one pass that uses them (they are
+    // then loaded inside the first iteration, so that nothing of them is live while the later passes and the line searches run) --------
     f32x4 Cd00, Cd01t, Cd11;
+    ConstFrag Fc0, Fc1;          // bf16x3 fragments of F~ for the two big products of the sweep (mfma_bf16x3.h)
+    auto load_sweep_operands = [&]() {
+        float Fb0[4], Fb1[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int k = 4 * q + r, ku = N + k;
-        Fb0[r] = Fxx(k, i);
-        Fb1[r] = (i < M) ? Fxu(k, i) : 0.0f;                     // no f column: the affine slot carries V_x
-        Cd00[r] = Cs(k, i);
-        Cd01t[r] = (k < M) ? Cs(N + k, i) : 0.0f;                // rows 0..7: C_ux; (q == 2, r == 0) <- l_x(t)[i] per step
-        float c11 = 0.0f;
-        if (ku < D && i < M) c11 = (k >= m && i == k) ? 1.0f : Cs(ku, N + i);
-        Cd11[r] = c11;                                           // lanes i == 8, q < 2 <- l_u(t) per step
-    }
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * q + r, ku = N + k;
+            Fb0[r] = Fxx(k, i);
+            Fb1[r] = (i < M) ? Fxu(k, i) : 0.0f;                     // no f column: the affine slot carries V_x
+            Cd00[r] = Cs(k, i);
+            Cd01t[r] = (k < M) ? Cs(N + k, i) : 0.0f;                // rows 0..7: C_ux; (q == 2, r == 0) <- l_x(t)[i] per step
+            float c11 = 0.0f;
+            if (ku < D && i < M) c11 = (k >= m && i == k) ? 1.0f : Cs(ku, N + i);
+            Cd11[r] = c11;                                           // lanes i == 8, q < 2 <- l_u(t) per step
+        }
+        Fc0 = const_frag(f32x4{Fb0[0], Fb0[1], Fb0[2], Fb0[3]});
+        Fc1 = const_frag(f32x4{Fb1[0], Fb1[1], Fb1[2], Fb1[3]});
+    };
+#ifdef TFMPC_AB_OPERANDS_FIRST
+    load_sweep_operands();
+#else
+    if (!REUSE) load_sweep_operands();
+#endif
     const int fi = lane >> 2, fc = lane & 3;       // F rows for x' = F z + f
     const int ka = lane >> 3, jc = lane & 7;       // K rows for du = K dx
     float Fr[6];
@@ -141,12 +162,26 @@ __global__ __launch_bounds__(kWave) TFMPC_LQ_OCCUPANCY void ilqr_lq_mfma_kernel(
         cq0[r] = cz(4 * q + r);
         cq1[r] = (q < 2) ? cz(N + 4 * q + r) : 0.0f;
     }
-    // bf16x3 fragments of F~ for the two big products of the sweep (mfma_bf16x3.h)
-    const ConstFrag Fc0 = const_frag(f32x4{Fb0[0], Fb0[1], Fb0[2], Fb0[3]});
-    const ConstFrag Fc1 = const_frag(f32x4{Fb1[0], Fb1[1], Fb1[2], Fb1[3]});
     for (int idx = lane; idx < kDyn; idx += kWave) lds[idx] = 0.0f;
     const int t01_src = (i == M) ? kQx + 4 * q : kZero;
     const int g1_src = (i == M) ? kKs + (N + M) * 8 + q : kZero + q;
+    // elimination input of this lane: column lane & 31 of [Q_ux | Q_uu | Q_u | 0..].  REUSE: lanes 48..55 (otherwise copies of the Q_uu
+    // columns) read IDENTITY columns instead and so come out of the LDL^T solve holding -Q_uu^-1; column j sits in the four pad floats of rows
+    // 2j (its rows 0..3) and 2j + 1 (rows 4..7) of the V_xx transpose staging, which the transposes never write
+#ifdef TFMPC_AB_NO_ID_LANES
+    const bool id_lane = false;
+#else
+    const bool id_lane = REUSE && (lane & 0x38) == 48;
+#endif
+    const int m2_lo = id_lane ? kVt + (2 * (lane & 7)) * kVtLd + 16 : kMs + (lane & 31) * 8;
+    const int m2_hi = id_lane ? kVt + (2 * (lane & 7) + 1) * kVtLd + 16 : kMs + (lane & 31) * 8 + 4;
+    static_assert(kVtLd == 20, "identity columns live in the pad floats 16..19 of the transpose staging rows");
+    __builtin_assume((m2_lo & 3) == 0 && (m2_hi & 3) == 0);       // 16-byte aligned either way: one ds_read_b128 each
+    if (REUSE && lane < 16) {
+        const int j = lane >> 1, half = lane & 1;                 // row 2j + half holds rows 4 half .. 4 half + 3 of e_j
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[kVt + lane * kVtLd + 16 + r] = (4 * half + r == j) ? 1.0f : 0.0f;
+    }
 
     // C Z on the matrix cores over rows [0, rows) of Z, 16 timesteps per tile.
     //   GRAD: L[t] = C_s z_t + c (cost gradient, diffenv.py:40-42);  else cost[t] = 1/2 z^T C z + c^T z
@@ -211,7 +246,7 @@ __global__ __launch_bounds__(kWave) TFMPC_LQ_OCCUPANCY void ilqr_lq_mfma_kernel(
         xn += dpp<kDppXor2>(xn);
         xn += f_i;
         if (fc == 0) nom[(t + 1) * kZld + fi] = xn;
-        __syncthreads();
+        lds_sync();
     }
     cz_pass(nom, Tp, cnom, false);
     __syncthreads();
@@ -219,14 +254,15 @@ __global__ __launch_bounds__(kWave) TFMPC_LQ_OCCUPANCY void ilqr_lq_mfma_kernel(
     int status = 0, iteration = 0;
     bool converged = false, retry = false;
     float delta = 1.0f;                                                // :216 (mu stays 0 in this kernel; delta is only logged)
-    for (iteration = 0; iteration < cfg.max_iterations; ++iteration) {
-        // ---- derivatives (ilqr.py:234): l_z(t) for the whole nominal trajectory -------------
-        float *Lz = cand;
-        cz_pass(nom, Tp, Lz, true);
-        __syncthreads();
-        const float J_hat = sum_costs(cnom);                       // ilqr.py:104,164
-
-        // ---- backward (ilqr.py:94-172 with mu = 0) -------------------------------------------
+    // One iteration = derivatives, backward pass, line search (ilqr.py:234-279), written as three pieces so that with REUSE the first
+    // iteration (full pass) stands OUTSIDE the loop of the later ones (vector recursion): the sweep's operands and temporaries are then
+    // dead while the later passes and their line searches run, and the kernel keeps the sweep's own register budget.
+    float *Lz = nullptr;
+    float J_hat = 0.0f;
+    auto sweep_pass = [&]() -> bool {            // false: Q_uu not positive definite (needs mu > 0: retry in the wave kernel)
+#ifndef TFMPC_AB_OPERANDS_FIRST
+        if (REUSE) load_sweep_operands();
+#endif
         f32x4 Vd = Cd00, vd = {0.f, 0.f, 0.f, 0.f};
         if (i == M) vd = *reinterpret_cast<const f32x4 *>(&Lz[T * kZld + 4 * q]);     // V_x = l_x^f
         int min_pivot_bits = 0x3f800000;
@@ -255,12 +291,11 @@ __global__ __launch_bounds__(kWave) TFMPC_LQ_OCCUPANCY void ilqr_lq_mfma_kernel(
             } else if (q == 2) {
                 lds[kQx + i] = T01t[0];                            // Q_x[i]               :122
             }
-            __syncthreads();
+            lds_sync();
             f32x2 M2[4];
             {
-                const int c = lane & 31;
-                const f32x4 lo = *reinterpret_cast<const f32x4 *>(&lds[kMs + c * 8]);
-                const f32x4 hi = *reinterpret_cast<const f32x4 *>(&lds[kMs + c * 8 + 4]);
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(&lds[m2_lo]);
+                const f32x4 hi = *reinterpret_cast<const f32x4 *>(&lds[m2_hi]);
                 M2[0] = f32x2{lo[0], lo[1]}; M2[1] = f32x2{lo[2], lo[3]};
                 M2[2] = f32x2{hi[0], hi[1]}; M2[3] = f32x2{hi[2], hi[3]};
             }
@@ -275,8 +310,17 @@ __global__ __launch_bounds__(kWave) TFMPC_LQ_OCCUPANCY void ilqr_lq_mfma_kernel(
                 for (int r = 0; r < 4; ++r) { lo[r] = Mr[r]; hi[r] = Mr[4 + r]; }
                 *reinterpret_cast<f32x4 *>(&lds[kKs + lane * 8]) = lo;
                 *reinterpret_cast<f32x4 *>(&lds[kKs + lane * 8 + 4]) = hi;
+#ifndef TFMPC_AB_NO_MINV_STORE
+            } else if (REUSE && (lane & 0x38) == 48) {      // column j = lane - 48 of the symmetric -Q_uu^-1 is its row j
+                f32x4 lo, hi;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { lo[r] = Mr[r]; hi[r] = Mr[4 + r]; }
+                float *row = Mg + (size_t)t * 64 + (lane & 7) * 8;
+                *reinterpret_cast<f32x4 *>(row) = lo;
+                *reinterpret_cast<f32x4 *>(row + 4) = hi;
+#endif
             }
-            __syncthreads();
+            lds_sync();
             // V_xx' = Q_xx + Q_xu K, V_x' = Q_x + Q_xu k                              :149-161
             // (Q_xu = Q_ux^T; vacc accumulates V_x' on Q_x in lanes i == 8, the other lanes read
             // always-zero pad columns so the next V_x is 0 there)
@@ -291,7 +335,7 @@ __global__ __launch_bounds__(kWave) TFMPC_LQ_OCCUPANCY void ilqr_lq_mfma_kernel(
             }
             // V_xx <- (V_xx + V_xx^T) / 2                                             :158-162
             *reinterpret_cast<f32x4 *>(&lds[kVt + i * kVtLd + 4 * q]) = T00;
-            __syncthreads();
+            lds_sync();
 #pragma unroll
             for (int r = 0; r < 4; ++r) Vd[r] = 0.5f * (T00[r] + lds[kVt + (4 * q + r) * kVtLd + i]);
             vd = vacc;
@@ -305,9 +349,89 @@ __global__ __launch_bounds__(kWave) TFMPC_LQ_OCCUPANCY void ilqr_lq_mfma_kernel(
                 }
                 if (lane < m) kg[(size_t)t * m + lane] = lds[kKs + 24 * 8 + lane];
             }
-            __syncthreads();
+            lds_sync();
         }
-        if (min_pivot_bits <= 0) { status |= TFMPC_ST_NOT_PD; retry = true; break; }   // needs mu > 0
+        __syncthreads();                                   // the gains (global memory) are read by other lanes from here on
+        if (min_pivot_bits <= 0) { status |= TFMPC_ST_NOT_PD; retry = true; return false; }   // needs mu > 0
+        return true;
+    };
+    auto vector_pass = [&]() {
+            // ---- the vector recursion alone: K_t and -Q_uu(t)^-1 of the first pass are this pass's too (see REUSE above) ----------
+            constexpr int kVx = kMs, kQu = kMs + 16;           // V_x(16) | Q_u(8) staging (the elimination buffers are idle from here on)
+            const int zi = lane >> 1, hf = lane & 1;           // lanes < 48: row zi of F~^T = [F_x^T; F_u^T], contraction half hf
+            float Ft[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = 8 * hf + j;
+                Ft[j] = (lane < 48) ? (zi < N ? Fxx(row, zi) : Fxu(row, zi - N)) : 0.0f;
+            }
+            // lanes < 32: K_t[4 hf + j][zi] (the transposed gains: V_x' = Q_x + K^T Q_u); every lane: (-Q_uu^-1)[ka][jc]
+            auto load_step = [&](int t, float (&Kt)[4], float &Mi) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ua = 4 * hf + j;
+                    if (EXACT) Kt[j] = (lane < 32) ? Kg[(size_t)t * (M * N) + ua * N + zi] : 0.0f;
+                    else Kt[j] = (lane < 32 && ua < m && zi < n) ? Kg[(size_t)t * m * n + ua * n + zi] : 0.0f;
+                }
+                Mi = Mg[(size_t)t * 64 + lane];
+            };
+            if (lane < N) lds[kVx + lane] = Lz[T * kZld + lane];                          // V_x = l_x^f            :113
+            // The gains come back from the Infinity Cache / HBM (the K slab of the resident waves is far beyond the L2): a register ring
+            // kDepth steps deep, statically indexed through the unrolled inner loop (no copies at the back edge, which the compiler would
+            // make wait for the load just issued) -- the wait in front of a step counts the younger loads and lets them fly.
+            constexpr int kDepth = EXACT ? 4 : 2;          // (the shape-generic form pays for every guarded address: a shallower ring keeps it at three waves per SIMD)
+            float KtR[kDepth][4], MiR[kDepth];
+#pragma unroll
+            for (int d = 0; d < kDepth; ++d) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) KtR[d][j] = 0.0f;
+                MiR[d] = 0.0f;
+                load_step(T - 1 - d >= 0 ? T - 1 - d : 0, KtR[d], MiR[d]);
+            }
+            __syncthreads();
+            for (int tb = T - 1; tb >= 0; tb -= kDepth) {
+#pragma unroll
+                for (int d = 0; d < kDepth; ++d) {
+                    const int t = tb - d;
+                    if (t < 0) break;
+                    float Kt[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Kt[j] = KtR[d][j];
+                    const float Mi = MiR[d];
+                    load_step(t - kDepth >= 0 ? t - kDepth : 0, KtR[d], MiR[d]);   // UNCONDITIONAL (a clamped, redundant load at the end):
+                                                                                   // behind a branch the compiler could no longer count
+                                                                                   // the loads in flight and would wait for all of them
+                    const f32x4 va = *reinterpret_cast<const f32x4 *>(&lds[kVx + 8 * hf]);
+                    const f32x4 vb = *reinterpret_cast<const f32x4 *>(&lds[kVx + 8 * hf + 4]);
+                    float y = Ft[0] * va[0];
+#pragma unroll
+                    for (int j = 1; j < 4; ++j) y = fmaf(Ft[j], va[j], y);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y = fmaf(Ft[4 + j], vb[j], y);
+                    y += dpp<kDppXor1>(y);                                                    // (F~^T V_x)[zi]
+                    const float Qz = ((lane < 48) ? Lz[t * kZld + zi] : 0.0f) + y;           // Q_x[zi] (zi < 16) | Q_u[zi - 16]   :122-123
+                    if (lane >= 32 && lane < 48 && hf == 0) lds[kQu + zi - N] = Qz;
+                    lds_sync();
+                    float kk = Mi * lds[kQu + jc];                                            // k = -Q_uu^-1 Q_u        :357-362
+                    kk += dpp<kDppXor1>(kk);
+                    kk += dpp<kDppXor2>(kk);
+                    kk += dpp<kDppHalfMirror>(kk);
+                    const f32x4 qu = *reinterpret_cast<const f32x4 *>(&lds[kQu + 4 * hf]);
+                    float w = Kt[0] * qu[0];
+#pragma unroll
+                    for (int j = 1; j < 4; ++j) w = fmaf(Kt[j], qu[j], w);
+                    w += dpp<kDppXor1>(w);                                                    // (K^T Q_u)[zi] = (Q_xu k)[zi]
+                    if (lane < 32 && hf == 0) lds[kVx + zi] = Qz + w;                         // V_x' = Q_x + Q_xu k     :152-156
+                    if (jc == 0 && ka < m) {
+                        kg[(size_t)t * m + ka] = kk;
+                        qg[(size_t)t * m + ka] = lds[kQu + ka];
+                    }
+                    lds_sync();
+                }
+            }
+            __syncthreads();                               // k_t, Q_u(t) (global memory) are read by other lanes below
+    };
+    auto finish_pass = [&]() -> bool {           // true: the solve of this instance ends here (converged, or handed to the wave kernel)
         // dV1 = sum k^T Q_u (:166), dV2 = 1/2 sum k^T Q_uu k = -dV1/2 at mu = 0 (:167),
         // g_norm = mean_t max_a |k| / (|u_hat| + 1) (:243)
         float dV1, g_norm;
@@ -336,7 +460,7 @@ __global__ __launch_bounds__(kWave) TFMPC_LQ_OCCUPANCY void ilqr_lq_mfma_kernel(
         if (g_norm < cfg.atol) {                                   // :243-248
             if (lane == 0) trace_write(a.trace, b, iteration, iteration, 0.0f, delta, J_hat, g_norm, -1, 0.0f, 0.0f, -1, -1.0f);
             converged = true;
-            break;
+            return true;
         }
 
         // ---- forward / line search (ilqr.py:317-355, :174-212) -----------------------------------
@@ -362,37 +486,48 @@ __global__ __launch_bounds__(kWave) TFMPC_LQ_OCCUPANCY void ilqr_lq_mfma_kernel(
                 gy = (row && 2 * jc + 1 < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] : 0.0f;
                 gk = row ? kg[(size_t)t * m + ka] : 0.0f;
             };
-            float Kxn = 0.0f, Kyn = 0.0f, kkn = 0.0f;
-            load_gain(0, Kxn, Kyn, kkn);
-            __syncthreads();
-            for (int t = 0; t < T; ++t) {
-                const float *zh = nom + t * kZld;
-                float *zt = cand + t * kZld;
-                const float Kx = Kxn, Ky = Kyn, kk = kkn;
-                if (t + 1 < T) load_gain(t + 1, Kxn, Kyn, kkn);
-                const float2 xv = *reinterpret_cast<const float2 *>(&zt[2 * jc]);
-                const float2 xh = *reinterpret_cast<const float2 *>(&zh[2 * jc]);
-                float du = fmaf(Kx, xv.x - xh.x, Ky * (xv.y - xh.y));              // K (x - x_hat)  :193-194
-                du += dpp<kDppXor1>(du);
-                du += dpp<kDppXor2>(du);
-                du += dpp<kDppHalfMirror>(du);
-                du = fmaf(alpha, kk, du);
-                rmax = fmaxf(rmax, fabsf(du));                                     // :206
-                if (jc == 0) zt[N + ka] = zh[N + ka] + du;                         // unbounded: clip is the identity
-                __syncthreads();
-                float xn = 0.0f;
-                const float2 *zp = reinterpret_cast<const float2 *>(&zt[6 * fc]);
+            // (register ring kDepth steps deep, statically indexed: see the gain-reusing pass)
+            constexpr int kDepth = EXACT ? 4 : 2;          // (the shape-generic form pays for every guarded address: a shallower ring keeps it at three waves per SIMD)
+            float gxR[kDepth], gyR[kDepth], gkR[kDepth];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float2 z2 = zp[j];
-                    xn = fmaf(Fr[2 * j], z2.x, xn);
-                    xn = fmaf(Fr[2 * j + 1], z2.y, xn);
+            for (int d = 0; d < kDepth; ++d) {
+                gxR[d] = gyR[d] = gkR[d] = 0.0f;
+                load_gain(d < T ? d : T - 1, gxR[d], gyR[d], gkR[d]);
+            }
+            __syncthreads();
+            for (int tb = 0; tb < T; tb += kDepth) {
+#pragma unroll
+                for (int d = 0; d < kDepth; ++d) {
+                    const int t = tb + d;
+                    if (t >= T) break;
+                    const float *zh = nom + t * kZld;
+                    float *zt = cand + t * kZld;
+                    const float Kx = gxR[d], Ky = gyR[d], kk = gkR[d];
+                    load_gain(t + kDepth < T ? t + kDepth : T - 1, gxR[d], gyR[d], gkR[d]);      // unconditional: see the gain-reusing pass
+                    const float2 xv = *reinterpret_cast<const float2 *>(&zt[2 * jc]);
+                    const float2 xh = *reinterpret_cast<const float2 *>(&zh[2 * jc]);
+                    float du = fmaf(Kx, xv.x - xh.x, Ky * (xv.y - xh.y));              // K (x - x_hat)  :193-194
+                    du += dpp<kDppXor1>(du);
+                    du += dpp<kDppXor2>(du);
+                    du += dpp<kDppHalfMirror>(du);
+                    du = fmaf(alpha, kk, du);
+                    rmax = fmaxf(rmax, fabsf(du));                                     // :206
+                    if (jc == 0) zt[N + ka] = zh[N + ka] + du;                         // unbounded: clip is the identity
+                    lds_sync();
+                    float xn = 0.0f;
+                    const float2 *zp = reinterpret_cast<const float2 *>(&zt[6 * fc]);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float2 z2 = zp[j];
+                        xn = fmaf(Fr[2 * j], z2.x, xn);
+                        xn = fmaf(Fr[2 * j + 1], z2.y, xn);
+                    }
+                    xn += dpp<kDppXor1>(xn);
+                    xn += dpp<kDppXor2>(xn);
+                    xn += f_i;
+                    if (fc == 0) zt[kZld + fi] = xn;
+                    lds_sync();
                 }
-                xn += dpp<kDppXor1>(xn);
-                xn += dpp<kDppXor2>(xn);
-                xn += f_i;
-                if (fc == 0) zt[kZld + fi] = xn;
-                __syncthreads();
             }
             residual = wave_max(rmax);
             cz_pass(cand, Tp, ccand, false);
@@ -412,9 +547,36 @@ __global__ __launch_bounds__(kWave) TFMPC_LQ_OCCUPANCY void ilqr_lq_mfma_kernel(
             float *tz = nom; nom = cand; cand = tz;
             float *tcst = cnom; cnom = ccand; ccand = tcst;
         }
-        if (small_step) { converged = true; break; }
-        if (!accept) { retry = true; break; }                                      // would raise mu (:267-270)
+        if (small_step) { converged = true; return true; }
+        if (!accept) { retry = true; return true; }                                      // would raise mu (:267-270)
         delta = fminf(1.0f / cfg.delta_0, delta / cfg.delta_0);                    // accepted with mu = 0: delta shrinks, mu stays 0 (:259-266)
+        return false;
+    };
+    auto derivatives = [&]() {
+        // ---- derivatives (ilqr.py:234): l_z(t) for the whole nominal trajectory -------------
+        Lz = cand;
+        cz_pass(nom, Tp, Lz, true);
+        __syncthreads();
+        J_hat = sum_costs(cnom);                       // ilqr.py:104,164
+
+    };
+    if (REUSE) {
+        derivatives();
+        bool stop = !sweep_pass();
+        if (!stop) stop = finish_pass();
+        if (!stop) {
+            for (iteration = 1; iteration < cfg.max_iterations; ++iteration) {
+                derivatives();
+                vector_pass();
+                if (finish_pass()) break;
+            }
+        }
+    } else {
+        for (iteration = 0; iteration < cfg.max_iterations; ++iteration) {
+            derivatives();
+            if (!sweep_pass()) break;
+            if (finish_pass()) break;
+        }
     }
     if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
     (void)converged;
@@ -456,9 +618,20 @@ int ilqr_lq_mfma_launch(const IlqrLqArgs &a, hipStream_t stream)
     // the workspace slabs are 256-byte aligned and an instance's K slab is T * 128 floats: the 8-byte pieces of the exact form are aligned
     // (TFMPC_ILQR_KERNEL=lq_generic keeps the shape-generic form: A/B timing, tests)
     const bool exact = a.env.n == N && a.env.m == M && (reinterpret_cast<uintptr_t>(a.wsK) & 7u) == 0 && !option_is(kOptIlqrKernel, "lq_generic");
-    if (exact) hipLaunchKernelGGL(ilqr_lq_mfma_kernel<true>, dim3(a.B), dim3(kWave), lds, stream, a);
-    else hipLaunchKernelGGL(ilqr_lq_mfma_kernel<false>, dim3(a.B), dim3(kWave), lds, stream, a);
+    // later passes run the vector recursion only (see REUSE above the kernel) unless TFMPC_ILQR_LQ_REUSE=0 or the caller gave no slab for -Q_uu^-1
+    const bool reuse = a.wsMinv != nullptr && (reinterpret_cast<uintptr_t>(a.wsMinv) & 15u) == 0 && !option_is(kOptIlqrLqReuse, "0");
+    const dim3 grid(a.B), block(kWave);
+    if (exact && reuse) hipLaunchKernelGGL((ilqr_lq_mfma_kernel<true, true>), grid, block, lds, stream, a);
+    else if (exact) hipLaunchKernelGGL((ilqr_lq_mfma_kernel<true, false>), grid, block, lds, stream, a);
+    else if (reuse) hipLaunchKernelGGL((ilqr_lq_mfma_kernel<false, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((ilqr_lq_mfma_kernel<false, false>), grid, block, lds, stream, a);
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
+}
+
+size_t ilqr_lq_mfma_reuse_workspace_bytes(int B, int n, int m, int T)
+{
+    if (!(n <= N && m <= M && n + m > 6) || T < 1) return 0;      // the shapes ilqr_lq_mfma_supported admits
+    return (size_t)B * T * 64 * sizeof(float);
 }
 
 }  // namespace tfmpc

@@ -82,6 +82,11 @@ constexpr int kVtLd = 20;        // V' transpose staging [16 cols][kVtLd] inside
 #endif
 constexpr int kTC = TFMPC_LQR_TC;         // timesteps per rollout chunk (T = 50 fits one chunk of 52)
 constexpr int kLdsFloats = kZs + (kTC + 1) * kZld + 6;
+#ifndef TFMPC_LQR_RING
+#define TFMPC_LQR_RING 4
+#endif
+constexpr int kRing = TFMPC_LQR_RING;     // rollout: gains in flight, in steps (the chunk length is a multiple of it: slots keep their phase across chunks)
+static_assert(kTC % kRing == 0, "a chunk must hold whole turns of the gain ring");
 
 // DPP lane exchanges inside a row of 16 lanes (no LDS traffic, folded into the VALU op)
 template <int CTRL>
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(kWave) TFMPC_LQR_OCCUPANCY void lqr_mfma16x8_kernel
             } else if (q == 2) {
                 lds[kQx + i] = T01t[0];                                                          // q_x[i]
             }
-            __syncthreads();
+            lds_sync();
             // rows (2k, 2k+1) share a register pair so that one v_pk_fma_f32 updates both
             f32x2 M2[4];
             {
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(kWave) TFMPC_LQR_OCCUPANCY void lqr_mfma16x8_kernel
                 *reinterpret_cast<f32x4 *>(&lds[kKs + lane * 8]) = lo;
                 *reinterpret_cast<f32x4 *>(&lds[kKs + lane * 8 + 4]) = hi;
             }
-            __syncthreads();
+            lds_sync();
             // 4. V' = Q_xx + Q_xu K ; v' = q_x + Q_xu k (column 24)            lqr.py:97-105
             //    contraction over the 8 actions as 2 k-steps: a = 4s + q
             //    vacc accumulates v' on q_x in column 24 (lanes i == 8); every other lane reads its
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(kWave) TFMPC_LQR_OCCUPANCY void lqr_mfma16x8_kernel
             {
                 float *vt = &lds[kZs];                    // rollout buffer, idle during the sweep
                 *reinterpret_cast<f32x4 *>(&vt[i * kVtLd + 4 * q]) = T00;
-                __syncthreads();
+                lds_sync();
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Vd[r] = 0.5f * (T00[r] + vt[(4 * q + r) * kVtLd + i]);
             }
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(kWave) TFMPC_LQR_OCCUPANCY void lqr_mfma16x8_kernel
                 }
                 if (OUT16 && a.cst16 && lane == 0) a.cst16[(size_t)b * T + t] = lqr_to_bf16(cst);
             }
-            __syncthreads();
+            lds_sync();
         }
         if (min_pivot_bits <= 0) status |= (min_pivot_bits == 0) ? TFMPC_ST_SINGULAR : TFMPC_ST_NOT_PD;
         if (VALUE && !(cst == cst)) status |= TFMPC_ST_NAN;
@@ -412,9 +417,16 @@ __global__ __launch_bounds__(kWave) TFMPC_LQR_OCCUPANCY void lqr_mfma16x8_kernel
                 kv = row ? kg[(size_t)t * m + ka] : 0.0f;
             }
         };
-        float2 Kn = {0.f, 0.f};
-        float kn = 0.0f;
-        if (T > 0) load_gain(0, Kn, kn);
+        // Register ring kRing steps deep, statically indexed through the unrolled inner loop below (round 6): a rotation through copies
+        // at the loop's back edge makes the compiler wait for the load it has just issued -- one memory round trip per step.
+        float2 KR[kRing];
+        float kR[kRing];
+#pragma unroll
+        for (int d = 0; d < kRing; ++d) {
+            KR[d] = float2{0.f, 0.f};
+            kR[d] = 0.0f;
+            if (T > 0) load_gain(d < T ? d : T - 1, KR[d], kR[d]);
+        }
         __syncthreads();
 
         // costs of rows [0, rows) of the chunk buffer: 1/2 z^T C z + c^T z  (lqr.py:41-47)
@@ -444,34 +456,41 @@ __global__ __launch_bounds__(kWave) TFMPC_LQR_OCCUPANCY void lqr_mfma16x8_kernel
 
         for (int t0 = 0; t0 < T; t0 += kTC) {
             const int tc = (T - t0 < kTC) ? (T - t0) : kTC;
-            for (int tt = 0; tt < tc; ++tt) {
-                const int t = t0 + tt;
-                float *zt = zs + tt * kZld;
-                const float2 Kc = Kn;
-                const float kc = kn;
-                if (t + 1 < T) load_gain(t + 1, Kn, kn);      // prefetch the next step's gains
-                // u = K x + k                                              lqr.py:143
-                const float2 xv = *reinterpret_cast<const float2 *>(&zt[2 * jc]);
-                float u = fmaf(Kc.x, xv.x, Kc.y * xv.y);
-                u += dpp<kDppXor1>(u);
-                u += dpp<kDppXor2>(u);
-                u += dpp<kDppHalfMirror>(u);
-                u += kc;
-                zt[N + ka] = u;                      // all eight lanes of the row hold the same sum
-                __syncthreads();
-                // x' = F z + f                                              lqr.py:36-39
-                float xn = f_part;
-                const float2 *zp = reinterpret_cast<const float2 *>(&zt[6 * fc]);
+            for (int tb = 0; tb < tc; tb += kRing) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float2 z2 = zp[j];
-                    xn = fmaf(Fr[2 * j], z2.x, xn);
-                    xn = fmaf(Fr[2 * j + 1], z2.y, xn);
+                for (int d = 0; d < kRing; ++d) {
+                    const int tt = tb + d;
+                    if (tt >= tc) break;
+                    const int t = t0 + tt;
+                    float *zt = zs + tt * kZld;
+                    const float2 Kc = KR[d];
+                    const float kc = kR[d];
+                    // this slot's next step -- UNCONDITIONAL (clamped: the last turns reload the final step): behind a branch the compiler
+                    // can no longer count the loads in flight and waits for all of them
+                    load_gain(t + kRing < T ? t + kRing : T - 1, KR[d], kR[d]);
+                    // u = K x + k                                              lqr.py:143
+                    const float2 xv = *reinterpret_cast<const float2 *>(&zt[2 * jc]);
+                    float u = fmaf(Kc.x, xv.x, Kc.y * xv.y);
+                    u += dpp<kDppXor1>(u);
+                    u += dpp<kDppXor2>(u);
+                    u += dpp<kDppHalfMirror>(u);
+                    u += kc;
+                    zt[N + ka] = u;                      // all eight lanes of the row hold the same sum
+                    lds_sync();
+                    // x' = F z + f                                              lqr.py:36-39
+                    float xn = f_part;
+                    const float2 *zp = reinterpret_cast<const float2 *>(&zt[6 * fc]);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float2 z2 = zp[j];
+                        xn = fmaf(Fr[2 * j], z2.x, xn);
+                        xn = fmaf(Fr[2 * j + 1], z2.y, xn);
+                    }
+                    xn += dpp<kDppXor1>(xn);
+                    xn += dpp<kDppXor2>(xn);
+                    zt[kZld + fi] = xn;                  // likewise: the four lanes of row fi agree
+                    lds_sync();
                 }
-                xn += dpp<kDppXor1>(xn);
-                xn += dpp<kDppXor2>(xn);
-                zt[kZld + fi] = xn;                  // likewise: the four lanes of row fi agree
-                __syncthreads();
             }
             // chunk epilogue: stage costs on the matrix cores, bulk coalesced stores
             chunk_costs(tc, cs + t0);
@@ -486,15 +505,15 @@ __global__ __launch_bounds__(kWave) TFMPC_LQR_OCCUPANCY void lqr_mfma16x8_kernel
                 for (int idx = lane; idx < tc * m; idx += kWave)
                     us[(size_t)t0 * m + idx] = zs[(idx / m) * kZld + N + idx % m];
             }
-            __syncthreads();
+            lds_sync();
             if (lane < N) zs[lane] = zs[tc * kZld + lane];      // carry x into row 0 of the next chunk
-            __syncthreads();
+            lds_sync();
         }
         // final cost 1/2 x^T C_xx x + c_x^T x == stage cost with u = 0      lqr.py:49-57
         if (lane < M) zs[N + lane] = 0.0f;
-        __syncthreads();
+        lds_sync();
         chunk_costs(1, cs + T);
-        __syncthreads();
+        lds_sync();
         if (lane == 0) {
             const float fcost = cs[T];
             if (!(fcost == fcost)) status |= TFMPC_ST_NAN;

@@ -18,6 +18,24 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 // Fence between cross-lane producer/consumer phases of one wave.
 __device__ __forceinline__ void wsync() { __syncthreads(); }
 
+// The same ordering point for phases that talk through LDS ONLY (round 6).  __syncthreads() is a fence over EVERY address space: in a
+// one-wave workgroup it compiles to s_waitcnt vmcnt(0) lgkmcnt(0), i.e. it also waits for every global load and store in flight -- inside a
+// time loop that parks the wave on the round trip of the gains it has just PREFETCHED for the next step, or on the acknowledgement of the
+// gains it has just stored, once per barrier.  A fence restricted to the local address space keeps the LDS order (s_waitcnt lgkmcnt(0);
+// a wave's LDS instructions execute in issue order) and lets the compiler count the global accesses instead (s_waitcnt vmcnt(N) where a
+// loaded value is used).  Global data written by one lane and read by another still needs wsync() between the two phases.
+// -DTFMPC_FULL_SYNC restores __syncthreads() everywhere (A/B builds).
+__device__ __forceinline__ void lds_sync()
+{
+#ifdef TFMPC_FULL_SYNC
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#endif
+}
+
 // Full-wave reductions on the vector unit's DPP cross-lane paths (no LDS traffic: `__shfl_xor`
 // compiles to ds_bpermute_b32 on gfx950, six dependent LDS-crossbar round trips per reduction).
 // Four butterfly steps inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 fold the four
