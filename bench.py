@@ -368,7 +368,22 @@ def deviceenv_rate(B=16384, T=50):
         user.env._library().force_wave_kernel(False)
     dt_w, its_w = timed(builtin, "wave")
     dt_g, its_g = timed(builtin)
-    return {"iterations_per_s": its_u / dt_u, "ms_per_batch": dt_u * 1e3, "mean_iterations": its_u / B, "batch": B, "horizon": T,
+    # ... and the same env written as PLAIN TORCH FUNCTIONS (tests/torch_envs.py), translated to device source by TorchEnv.to_device_env()
+    # (tfmpc/envs/fxsource.py, round 6): what a user of the reference has is Python methods
+    from_python = {}
+    try:
+        import torch_envs
+        t0 = time.perf_counter()
+        py = iLQR(torch_envs.navigation(cfg, "cuda").to_device_env())
+        py.env._library()
+        ready_py = time.perf_counter() - t0
+        dt_p, its_p = timed(py)
+        from_python = {"iterations_per_s": its_p / dt_p, "ms_per_batch": dt_p * 1e3, "mean_iterations": its_p / B, "trace_translate_compile_s": ready_py,
+                       "ratio_to_hand_written_device_source": dt_p / dt_u, "kernel": py.last_kernel,
+                       "workload": "Navigation as three plain torch functions -> TorchEnv(...).to_device_env() (make_fx trace -> device templates)"}
+    except Exception as exc:                                  # noqa: BLE001
+        from_python = {"error": repr(exc)}
+    return {"from_python_functions": from_python, "iterations_per_s": its_u / dt_u, "ms_per_batch": dt_u * 1e3, "mean_iterations": its_u / B, "batch": B, "horizon": T,
             "library_ready_s": ready, "kernel": kernel, "user_env_on_the_generic_wave_kernel_ms": dt_uw * 1e3,
             "same_env_builtin_generic_wave_kernel_ms": dt_w * 1e3, "same_env_builtin_lane_group_kernel_ms": dt_g * 1e3,
             "ratio_to_builtin_kernel": dt_u / dt_g,
@@ -688,6 +703,7 @@ def summarise_extras(extra):
            "bf16_sweep": get(extra, "bf16_storage_sweep") if isinstance(extra, dict) and "error" not in (extra.get("bf16_storage_sweep") or {}) else None,
            "torchenv_kit_s": r3((get(extra, "torchenv_generic_env", "iterations_per_s") or 0) / 1e3),
            "deviceenv_Mit_s": r3((get(extra, "deviceenv_user_env", "iterations_per_s") or 0) / 1e6),
+           "deviceenv_from_python_Mit_s": r3((get(extra, "deviceenv_user_env", "from_python_functions", "iterations_per_s") or 0) / 1e6),
            "format": "[ms per batch, roofline frac (, algorithmic flop rate / fp32 peak; ilqr_api_warm: executed flop rate / fp32 peak)]"}
     for key, short in (("cfg5_hvac_ilqr_n32", "cfg5_hvac"), ("cfg5_reservoir_ilqr_n32", "cfg5_reservoir"), ("hvac6_reference_config_ilqr", "hvac6"),
                        ("res4_reference_config_ilqr", "res4"), ("cfg5_literal_dims_ilqr_lq_n32_m16", "literal_dims"), ("lqr_n32_m16", "lqr_n32_m16")):

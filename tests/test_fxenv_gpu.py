@@ -1,0 +1,233 @@
+"""Python env -> DeviceEnv source, automatically (round 6): ``TorchEnv.to_device_env()`` traces the user's torch
+functions and emits the three device templates (tfmpc/envs/fxsource.py).  The reference differentiates whatever Python transition / cost it is
+handed (/root/reference/tfmpc/envs/diffenv.py:13-101); here Navigation, Reservoir and HVAC WRITTEN AS PLAIN TORCH FUNCTIONS (tests/torch_envs.py)
+are translated and held against the built-in kernels (closed forms, csrc/envs.h), torch.func autodiff of the very same functions, and the fp64
+restatement -- all 13 derivative tensors, rollouts, whole solves."""
+
+import numpy as np
+import pytest
+import torch
+
+import problems
+import torch_envs
+from tfmpc import _hip
+from tfmpc.envs import deviceenv, fxsource
+from tfmpc.envs.hvac import HVAC
+from tfmpc.envs.navigation import Navigation
+from tfmpc.envs.reservoir import Reservoir
+from tfmpc.envs.torchenv import TorchEnv
+from tfmpc.solvers.ilqr import iLQR
+
+needs_hipcc = pytest.mark.skipif(deviceenv.hipcc_path() is None, reason="a DeviceEnv is compiled with hipcc when it is first used")
+
+
+def _np(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+# ---- the translator alone (no GPU) -------------------------------------------------------------------------------------------------------------
+
+def test_translation_of_the_three_envs_and_where_their_constants_go():
+    nav = torch_envs.navigation(problems.NAV_CONFIG).to_device_env()
+    assert nav.state_size == 2 and nav.action_size == 2 and nav.params.shape == (8,)           # 2 centres x 2, 2 decays, goal (stored once)
+    assert "sqrt(" in nav.source and "exp(" in nav.source and "x_next[1]" in nav.source
+    res = torch_envs.reservoir(problems.RES4_CONFIG).to_device_env()
+    assert "sin(" in res.source and "abs(" in res.source and "max(0.0f" in res.source           # relu -> max(0, y): the tie goes to the constant
+    assert res.action_space.is_bounded()
+    hv = torch_envs.hvac(problems.hvac_config(6)).to_device_env()
+    # a zero of the adjacency mask is structure: the pairs of rooms that do not touch cost no statement
+    dense = torch_envs.hvac(dict(problems.hvac_config(6), adj=(~np.eye(6, dtype=bool)).tolist())).to_device_env()
+    assert hv.source.count("\n") < dense.source.count("\n")
+
+
+def test_unsupported_operations_and_python_branches_are_refused_with_a_clear_error():
+    good = lambda x: (x ** 2).sum()
+    with pytest.raises(fxsource.UnsupportedOperation, match="erf"):
+        TorchEnv(lambda x, u: torch.erf(x) + u, lambda x, u: good(x), good, 2, 2).to_device_env()
+    def branchy(x, u):
+        if x[0] > 0:                                # a Python branch on the state: a trace would keep one side only
+            return x + u
+        return x - u
+    with pytest.raises(fxsource.UnsupportedOperation, match="torch.where"):
+        TorchEnv(branchy, lambda x, u: good(x), good, 2, 2).to_device_env()
+    with pytest.raises(ValueError, match="expected 2 values"):
+        TorchEnv(lambda x, u: torch.cat([x, u]), lambda x, u: good(x), good, 2, 2).to_device_env()
+    with pytest.raises(ValueError, match="expected a scalar"):
+        TorchEnv(lambda x, u: x + u, lambda x, u: x * u, good, 2, 2).to_device_env()
+
+
+def test_in_place_writes_through_views_and_the_other_vocabulary():
+    """`out[i] = ...` on a fresh tensor, slices, cat / stack, where / clamp / maximum, matmul with a constant, a detach: everything lands in the
+    straight-line program (checked by evaluating the SAME function in torch and a tiny interpreter of the emitted statements)."""
+    W = torch.tensor([[0.5, -1.0, 0.0], [2.0, 0.0, 1.5], [0.0, 0.25, -0.75]])
+
+    def transition(x, u):
+        out = torch.zeros(3)
+        out[0] = x[0] + torch.tanh(u[0])
+        out[1:] = (W @ x)[1:] * torch.sigmoid(u[1])
+        out = torch.where(out > 1.0, 1.0 + 0.1 * (out - 1.0), out)
+        return torch.clamp(out, -5.0, 5.0) + torch.stack([x[2], x[0], x[1]]) * 0.1
+
+    def cost(x, u):
+        z = torch.cat([x, u])
+        return torch.maximum(z, torch.zeros(5)).sum() + (z ** 3).mean() + torch.sqrt(1.0 + (x * x.detach()).sum())
+
+    src, params = fxsource.translate(transition, cost, lambda x: torch.abs(x).sum(), 3, 2)
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        x, u = rng.normal(size=3).astype(np.float32), rng.normal(size=2).astype(np.float32)
+        got = _evaluate(src, "transition", params, x, u)
+        want = transition(torch.as_tensor(x), torch.as_tensor(u)).numpy()
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-6), (got, want)
+        assert np.isclose(_evaluate(src, "cost", params, x, u), float(cost(torch.as_tensor(x), torch.as_tensor(u))), rtol=1e-5)
+        assert np.isclose(_evaluate(src, "final_cost", params, x, None), float(np.abs(x).sum()), rtol=1e-6)
+
+
+def _evaluate(source, name, p, x, u):
+    """Runs the emitted statements of one function as Python (they are one assignment each, in C syntax that is also Python's but for the
+    ternary, the float suffix and a few names)."""
+    import math, re
+    body = source[source.index(f" {name}(const float *p"):]
+    body = body[body.index("{") + 1:body.index("\n}")]
+    env = {"p": p, "x": x, "u": u, "x_next": [0.0] * len(x), "sqrt": math.sqrt, "sqrtf": math.sqrt, "exp": math.exp, "expf": math.exp,
+           "log": math.log, "sin": math.sin, "cos": math.cos, "tanh": math.tanh, "abs": abs, "fabsf": abs, "max": lambda a, b: a if a >= b else b,
+           "min": lambda a, b: a if a <= b else b, "fmaxf": max, "fminf": min, "pow": pow, "powf": pow, "S": float, "true": True, "false": False}
+    env["tfmpc"] = type("ns", (), {"ad": type("ad", (), {"prim": staticmethod(float)})})
+    result = None
+    for line in body.strip().split("\n"):
+        line = line.strip().rstrip(";")
+        line = re.sub(r"(\d+\.\d+(?:e-?\d+)?)f", r"\1", line).replace("tfmpc::ad::prim", "float").replace("&&", " and ").replace("||", " or ")
+        line = re.sub(r"\(!(\w+)\)", r"(not \1)", line)
+        m = re.match(r"\((\w+) \? (.+) : (.+)\)$", line.split(" = ", 1)[1]) if " = " in line else None
+        if line.startswith("return "):
+            result = eval(line[7:], env)
+        elif line.startswith("const "):
+            _, _, rest = line.split(" ", 2)
+            var, expr = rest.split(" = ", 1)
+            if m:
+                expr = f"({m.group(2)}) if {m.group(1)} else ({m.group(3)})"
+            env[var] = np.float32(eval(expr, env)) if not isinstance(eval(expr, env), (bool, np.bool_)) else bool(eval(expr, env))
+        else:
+            var, expr = line.split(" = ", 1)
+            exec(f"{var} = {expr}", env)
+    return np.asarray(env["x_next"], dtype=np.float64) if name == "transition" else float(result)
+
+
+@needs_hipcc
+def test_the_generated_source_compiles_without_a_gpu():
+    import ctypes
+    env = torch_envs.reservoir(problems.RES4_CONFIG).to_device_env()
+    path = deviceenv.build(env.source, 4, 4, env.n_zones)
+    lib = ctypes.CDLL(path)
+    assert lib.tfmpc_userenv_state_size() == 4 and lib.tfmpc_userenv_action_size() == 4
+
+
+# ---- on the device ---------------------------------------------------------------------------------------------------------------------------------
+
+def _case(which):
+    if which == "navigation":
+        cfg = problems.NAV_CONFIG
+        return cfg, Navigation.load(cfg), torch_envs.navigation(cfg, "cuda"), (0.0, 10.0), (-1.0, 1.0)
+    if which.startswith("reservoir"):
+        n = int(which[9:])
+        cfg = dict(problems.RES4_CONFIG) if n == 4 else dict(problems.reservoir_config(n, seed=5))
+        return cfg, Reservoir.load(dict(cfg)), torch_envs.reservoir(cfg, "cuda"), (20.0, 95.0), (0.0, 1.0)
+    n = int(which[4:])
+    cfg = problems.hvac_config(n, seed=5)
+    return cfg, HVAC.load(cfg), torch_envs.hvac(cfg, "cuda"), (5.0, 35.0), (0.0, 1.0)
+
+
+@pytest.mark.gpu
+@needs_hipcc
+@pytest.mark.parametrize("which", ["navigation", "reservoir4", "reservoir7", "hvac6"])
+def test_all_thirteen_derivative_tensors_of_the_translated_env(which):
+    cfg, builtin, python_env, xr, ur = _case(which)
+    device_env = python_env.to_device_env()
+    n, m = device_env.state_size, device_env.action_size
+    rng = np.random.default_rng(3)
+    B, T = 12, 9
+    x = rng.uniform(*xr, size=(B, T + 1, n, 1)).astype(np.float32)
+    u = rng.uniform(*ur, size=(B, T, m, 1)).astype(np.float32)
+    got = iLQR(device_env).derivatives(x, u)
+    ref = iLQR(builtin).derivatives(x, u)
+    torch.cuda.synchronize()
+    names = [f"{t}.{f}" for t, tup in zip("tcf", got) for f in tup._fields]
+    for name, a, b in zip(names, [v for tup in got for v in tup], [v for tup in ref for v in tup]):
+        a, b = _np(a), _np(b)
+        assert a.shape == b.shape, name
+        scale = max(np.abs(b).max(), 1.0)
+        assert np.abs(a - b).max() <= 2e-5 * scale, (which, name, np.abs(a - b).max(), scale)
+    # ... and torch.func autodiff of the very functions that were translated (what TorchEnv itself computes)
+    tm = python_env.get_linear_transition(x[:, :-1], u)
+    cm = python_env.get_quadratic_cost(x[:, :-1], u)
+    for name, a, b in zip(names, list(got[0]) + list(got[1]), list(tm) + list(cm)):
+        a, b = _np(a), _np(b).reshape(_np(a).shape)
+        assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1.0), (which, name)
+    # single steps through the DiffEnv protocol
+    xn_u, xn_b = device_env.transition(x[:, 0], u[:, 0], batch=True), builtin.transition(x[:, 0], u[:, 0], batch=True)
+    assert np.abs(_np(xn_u) - _np(xn_b)).max() <= 2e-5 * max(np.abs(_np(xn_b)).max(), 1.0)
+    cu, cb = _np(device_env.cost(x[:, 0], u[:, 0], batch=True)), _np(builtin.cost(x[:, 0], u[:, 0], batch=True))
+    assert np.abs(cu - cb).max() <= 1e-5 * np.abs(cb).max() + 1e-5
+
+
+@pytest.mark.gpu
+@needs_hipcc
+def test_navigation_from_python_solves_like_the_builtin_kernel():
+    cfg, builtin, python_env, _, _ = _case("navigation")
+    device_env = python_env.to_device_env()
+    rng = np.random.default_rng(4)
+    B, T = 256, 50
+    x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
+    u0 = np.stack([problems.scalar_uniform_actions(T, [-1, -1], [1, 1], rng) for _ in range(B)]).astype(np.float32)
+    s_user, s_builtin = iLQR(device_env), iLQR(builtin)
+    out = s_user.solve_device(x0, T, u_init=u0)
+    ref = s_builtin.solve_device(x0, T, u_init=u0)
+    torch.cuda.synchronize()
+    assert s_user.last_kernel.startswith("lane_group") and "user env" in s_user.last_kernel
+    same = (out["iterations"] == ref["iterations"]).cpu().numpy()
+    assert same.mean() >= 0.9, same.mean()
+    cu, cb = _np(out["costs"]).sum(1), _np(ref["costs"]).sum(1)
+    assert np.abs(cu - cb)[same].max() <= 2e-3 * np.abs(cb).max()
+    assert np.median(np.abs(cu - cb) / np.abs(cb)) <= 1e-5
+    assert int((out["status"] & ~_hip.ST_NOT_PD).abs().sum()) == 0
+    # the host-driven TorchEnv solve of the same functions lands on the same costs (a handful of instances: it is the slow path)
+    tj, _ = iLQR(python_env).solve(x0[:8], T, show_progress=False, u_init=u0[:8])
+    assert np.median(np.abs(tj.costs.sum(1) - cu[:8]) / np.abs(cu[:8])) <= 1e-3
+
+
+@pytest.mark.gpu
+@needs_hipcc
+@pytest.mark.parametrize("which", ["reservoir4", "hvac6"])
+def test_piecewise_linear_envs_from_python_take_the_same_first_iterations(which):
+    """res4 / hvac6 (the reference's own configs) from Python: the cost's second derivatives are exactly zero through the translated max / abs
+    too, so the backward pass takes the bang-bang branch; three iterations against the built-in wave kernel."""
+    from oracle import envs_ref, ilqr_ref
+    cfg, builtin, python_env, xr, _ = _case(which)
+    device_env = python_env.to_device_env()
+    n = device_env.state_size
+    rng = np.random.default_rng(8)
+    B, T = 24, 30
+    x0 = rng.uniform(xr[0] + 0.3 * (xr[1] - xr[0]), xr[1] - 0.2 * (xr[1] - xr[0]), size=(B, n, 1)).astype(np.float32)
+    u0 = iLQR(builtin).random_actions(T, B, seed=2)
+    cm = iLQR(device_env).derivatives(iLQR(device_env).start(x0, T, u_init=u0)[0], u0)[1]
+    for name in ("l_xx", "l_uu", "l_ux", "l_xu"):
+        assert float(getattr(cm, name).abs().max()) == 0.0, name
+    with _hip.option("TFMPC_ILQR_KERNEL", "wave"):
+        ref = iLQR(builtin, max_iterations=3).solve_device(x0, T, u_init=u0)
+    out = iLQR(device_env, max_iterations=3).solve_device(x0, T, u_init=u0)
+    torch.cuda.synchronize()
+    cu, cb = _np(out["costs"]).sum(1), _np(ref["costs"]).sum(1)
+    assert int(out["status"].abs().sum()) == 0
+    assert np.median(np.abs(cu - cb) / np.abs(cb)) <= 1e-3
+    assert np.all((_np(out["actions"]) >= -1e-6) & (_np(out["actions"]) <= 1 + 1e-6))
+    # ... and the FIRST iteration against the fp64 restatement of ilqr.py on the restated env (bang-bang iterates of two arithmetics part
+    # ways after a few iterations -- a selector at a rounding-level Q_u -- so later iterations are compared with the built-in kernel only)
+    oenv = (envs_ref.Reservoir if which.startswith("reservoir") else envs_ref.HVAC)(**cfg)
+    one = iLQR(device_env, max_iterations=1).solve_device(x0, T, u_init=u0)
+    torch.cuda.synchronize()
+    # (without the final cost: at the LAST step Q_u = x_i (V_x[i+1] - V_x[i]) is an exact zero wherever two neighbouring reservoirs sit on the
+    # same linear piece of the cost -- the selector `Q_u >= 0` then reads the sign of a rounding error, and the last action, hence x_T, is a tie)
+    for b in (0, 5):
+        xs, us, cs, it = ilqr_ref.ILQRRef(oenv, max_iterations=1).solve(x0[b].astype(np.float64), T, u_init=_np(torch.as_tensor(u0[b])))
+        got = _np(one["costs"][b])[:-1].sum()
+        assert abs(cs[:-1].sum() - got) <= 5e-3 * abs(cs[:-1].sum()), (b, cs[:-1].sum(), got)

@@ -1,0 +1,89 @@
+"""Three of the reference's envs written as PLAIN torch functions of one instance (x[n], u[m]) -- what a user of the reference has: Python
+methods, not device templates (/root/reference/tfmpc/envs/navigation/__init__.py:34-74, reservoir/__init__.py:47-105,
+hvac/__init__.py:69-149, restated on torch with the vector shapes of tfmpc.envs.torchenv.TorchEnv).  tests/test_fxenv_gpu.py hands them to
+TorchEnv(...).to_device_env() and holds the result against the built-in kernels and the oracle; bench.py's `deviceenv_from_python` line times
+the Navigation one.  Written with the ordinary torch vocabulary on purpose (broadcasting, matmul, boolean masks, relu / abs / where)."""
+
+import numpy as np
+import torch
+
+from tfmpc.envs.torchenv import TorchEnv
+
+
+def _t(a, device):
+    return torch.as_tensor(np.asarray(a, dtype=np.float32), device=device)
+
+
+def navigation(cfg, device="cpu"):
+    goal = _t(cfg["goal"], device).reshape(-1)
+    centers = _t(cfg["deceleration"]["center"], device).reshape(-1, 2)
+    decay = _t(cfg["deceleration"]["decay"], device).reshape(-1)
+
+    def transition(x, u):
+        dist = torch.linalg.norm(x[None, :] - centers, dim=-1)                  # distance to every zone centre
+        lam = torch.prod(2.0 / (1.0 + torch.exp(-decay * dist)) - 1.0)          # joint deceleration factor
+        return x + lam * u
+
+    def cost(x, u):
+        return torch.sum((x - goal) ** 2)
+
+    def final_cost(x):
+        return torch.sum((x - goal) ** 2)
+
+    return TorchEnv(transition, cost, final_cost, 2, 2, np.asarray(cfg["low"]).reshape(2, 1), np.asarray(cfg["high"]).reshape(2, 1), device=device)
+
+
+def reservoir(cfg, device="cpu"):
+    col = lambda k: _t(cfg[k], device).reshape(-1)
+    cap, lo, hi = col("max_res_cap"), col("lower_bound"), col("upper_bound")
+    low_pen, high_pen, sp_pen = -col("low_penalty"), -col("high_penalty"), -col("set_point_penalty")      # (the configs hold them negative)
+    rain = col("rain_shape") * col("rain_scale")                                                           # mean rainfall (cec=True)
+    downstream = _t(cfg["downstream"], device)
+    n = cap.numel()
+
+    def transition(x, u):
+        outflow = u * x
+        inflow = downstream.T @ outflow
+        vaporated = 0.5 * torch.sin(x / cap) * x
+        return x + rain + inflow - vaporated - outflow
+
+    def cost(x, u):
+        mid = (lo + hi) / 2
+        penalty = low_pen * torch.relu(lo - x) + high_pen * torch.relu(x - hi) + sp_pen * torch.abs(mid - x)
+        return penalty.sum()
+
+    return TorchEnv(transition, cost, lambda x: cost(x, None), n, n, 0.0, 1.0, device=device)
+
+
+def hvac(cfg, device="cpu"):
+    CAP_AIR, COST_AIR, TEMP_AIR, TIME_DELTA, PENALTY, SET_POINT_PENALTY = 1.006, 1.0, 40.0, 1.0, 20000.0, 10.0
+    col = lambda k: _t(cfg[k], device).reshape(-1)
+    t_out, t_hall, lo, hi = col("temp_outside"), col("temp_hall"), col("temp_lower_bound"), col("temp_upper_bound")
+    r_out, r_hall, cap, air_max = col("R_outside"), col("R_hall"), col("capacity"), col("air_max")
+    r_wall = _t(cfg["R_wall"], device)
+    adj = torch.as_tensor(np.asarray(cfg["adj"], dtype=bool), device=device)
+    adj = (adj | adj.T).float()
+    adj_out = torch.as_tensor(np.asarray(cfg["adj_outside"], dtype=bool), device=device).reshape(-1).float()
+    adj_hall = torch.as_tensor(np.asarray(cfg["adj_hall"], dtype=bool), device=device).reshape(-1).float()
+    n = lo.numel()
+
+    def transition(x, u):
+        air = u * air_max
+        heating = air * CAP_AIR * (TEMP_AIR - x)
+        between = torch.sum(-adj / r_wall * (x[:, None] - x[None, :]), dim=-1)      # heat exchanged with the adjacent rooms
+        outside = adj_out / r_out * (t_out - x)
+        hall = adj_hall / r_hall * (t_hall - x)
+        return x + TIME_DELTA / cap * (heating + between + outside + hall)
+
+    def penalties(x):
+        out_of_bounds = PENALTY * (torch.relu(lo - x) + torch.relu(x - hi))
+        set_point = SET_POINT_PENALTY * torch.abs((lo + hi) / 2 - x)
+        return out_of_bounds + set_point
+
+    def cost(x, u):
+        return torch.sum(COST_AIR * (u * air_max) + penalties(x))
+
+    def final_cost(x):
+        return torch.sum(penalties(x))
+
+    return TorchEnv(transition, cost, final_cost, n, n, 0.0, 1.0, device=device)

@@ -37,6 +37,31 @@ class TorchEnv:
             self.device = _hip.default_device()
         return self.device
 
+    def to_device_env(self, trace_device=None):
+        """The SAME env at hot-path speed: the three torch functions are traced (``torch.fx`` ``make_fx``) and translated into the device
+        templates of a ``tfmpc.envs.deviceenv.DeviceEnv`` (``envs/fxsource.py``: what is supported, the subgradient conventions, and the
+        error an unsupported operation or data-dependent Python control flow raises), compiled with hipcc at first use into the fused
+        wave-per-instance kernels -- derivatives by dual numbers on the device instead of ``torch.func`` on the host.  Tensor constants the
+        functions close over become the env's ``params``.  ``trace_device``: where the example inputs of the trace live (default: CPU, and
+        the GPU if the functions' constants turn out to live there)."""
+        from tfmpc.envs import fxsource
+        from tfmpc.envs.deviceenv import DeviceEnv
+        devices = [trace_device] if trace_device is not None else ["cpu", self._device()]
+        error = None
+        for dev in devices:
+            try:
+                source, params = fxsource.translate(self._f, self._l, self._lf, self.state_size, self.action_size, device=dev)
+                break
+            except RuntimeError as exc:                       # constants on another device than the example inputs
+                if "device" not in str(exc):
+                    raise
+                error = exc
+        else:
+            raise error
+        env = DeviceEnv(source, self.state_size, self.action_size, params=params, low=self.action_space.low, high=self.action_space.high)
+        env.device = self.device
+        return env
+
     def env_batch_size(self):
         return None
 

@@ -428,7 +428,8 @@ class iLQR:
         if trace:       # an iteration makes at most max_attempts rejected passes; almost all make one or two
             rows = int(self.max_iterations) + int(self.max_attempts) + 1
         out = self.solve_device(x0, T, u_init=u_init, seed=seed, trace_rows=rows)
-        if int(getattr(self.env.c_env()[0], "coupling_shift", 0)) != 0 and bool((out["status"] & _hip.ST_ENV_FLAG).any()):
+        promised = hasattr(self.env, "c_env") and int(self.env.c_env()[0].coupling_shift) != 0       # (generic torch envs have no C struct)
+        if promised and bool((out["status"] & _hip.ST_ENV_FLAG).any()):
             raise ValueError("the env's TfmpcEnv.coupling_shift promises a chain that its `downstream` matrix is not "
                              "(TFMPC_ST_ENV_FLAG): nothing was computed")
         if trace:
