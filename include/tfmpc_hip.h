@@ -331,6 +331,22 @@ int tfmpc_ilqr_solve_trace_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, 
                                float *trace, int trace_rows, int32_t *trace_len,
                                void *workspace, size_t workspace_bytes, void *stream);
 
+/* tfmpc_ilqr_solve_trace_f32 that ALSO exports what the box-QP of every backward step ended on (version >= 300; test and
+ * diagnosis instrument: ilqr.py:364-385 computes K_t from the free set optimization.py:35-72 returns, so two fp32 programs that
+ * end a QP on different free sets differ DISCRETELY -- other rows of K_t are zero -- and no tolerance on numbers can compare them):
+ * clamp_mask[B][trace_rows][T], bit a of entry (b, pass, t) set = action a was CLAMPED in the last factorised free set of that
+ * step's QP (row a of K_t is zero); qp_iterations[B][trace_rows][T] = iterations of the projected-Newton loop
+ * (optimization.py:24; 0 = the step ran no QP).  Both NULL: identical to tfmpc_ilqr_solve_trace_f32; both need `trace`.
+ * Written by the control-limited matrix-core kernel (LQ env, n <= 16, m <= 8, bounded actions); other kernels leave the two
+ * buffers untouched -- pre-fill them with 0xFF to tell. */
+int tfmpc_ilqr_solve_trace_qp_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B, int T,
+                                  const float *x0, const float *u_init,
+                                  float *states, float *actions, float *costs,
+                                  int32_t *iterations, int32_t *status,
+                                  float *trace, int trace_rows, int32_t *trace_len,
+                                  uint8_t *clamp_mask, uint8_t *qp_iterations,
+                                  void *workspace, size_t workspace_bytes, void *stream);
+
 /* projected_newton_qp (tfmpc/utils/optimization.py:6-101): B independent box QPs
  * min 1/2 x^T H x + q^T x, low <= x <= high.  H[B][m][m], q/low/high/x0[B][m];
  * outputs x[B][m], free[B][m] (1.0 / 0.0), status[B]. */

@@ -124,6 +124,7 @@ class ILQRRef:
 
             if bounded:                                               # :136-143
                 if np.count_nonzero(V_xx) > 0:
+                    self._step = t                                    # (test hooks below: which step the controller is for)
                     K_t, k_t = self._get_constrained_controller(actions[t], Q_uu_reg, Q_ux_reg, Q_u)
                 else:
                     K_t = np.zeros((m, n), dtype=dt)
@@ -268,6 +269,20 @@ class ILQRRef:
         m, n = self.env.action_size, self.env.state_size
         K = np.zeros((m, n), dtype=dt)
         fr = free[:, 0]
+        t = getattr(self, "_step", None)
+        if getattr(self, "own_free", None) is not None and t is not None:      # test hook: the free set this restatement's QP ended on
+            self.own_free[t] = fr.copy()
+        forced = getattr(self, "forced_free", None)
+        if forced is not None and t is not None:
+            # TEST HOOK (tests/teacher_forced.py): K_t on ANOTHER program's free set -- the feedback gains of ilqr.py:375-385 are a
+            # discrete function of which actions the QP left free, so two fp32 programs are compared on the same set; k_t stays this
+            # restatement's own QP solution (the minimiser is unique: the programs agree on it to the QP's tolerance)
+            fr = np.asarray(forced[t], dtype=bool)
+            if np.count_nonzero(fr) > 0:
+                try:
+                    Hfree = np.linalg.cholesky(np.asarray(Q_uu[np.ix_(fr, fr)], dtype=dt)).astype(dt)
+                except np.linalg.LinAlgError:
+                    raise CholeskyFailure("box-QP (forced free set): H_ff not positive definite")
         if np.count_nonzero(fr) > 0:                                  # :377-383
             K[fr] = -_cholesky_solve(Hfree, Q_ux[fr])
         return K, k

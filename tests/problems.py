@@ -43,10 +43,19 @@ def make_lqr_batch_fast(B, n, m, seed=0):
     c = rng.normal(size=(B, d))
     A = rng.uniform(size=(B, d, d))
     # make_spd_matrix: A = rand(d,d); U,_,Vt = svd(A^T A); X = U (1 + diag(rand(d))) Vt
-    AtA = np.einsum("bki,bkj->bij", A, A)
-    U, _, Vt = np.linalg.svd(AtA)
     s = 1.0 + rng.uniform(size=(B, d))
-    C = np.einsum("bik,bk,bkj->bij", U, s, Vt)
+    if B >= 4096:
+        # the same matrices through the symmetric eigendecomposition (A^T A is symmetric positive definite: its left singular vectors ARE its
+        # eigenvectors, descending order = eigh's order reversed), batched and threaded by torch: 5 s instead of a minute at B = 32 768;
+        # agrees with the SVD form to fp64 rounding
+        import torch
+        At = torch.from_numpy(A)
+        _, V = torch.linalg.eigh(At.transpose(1, 2) @ At)
+        V = V.flip(-1)
+        C = ((V * torch.from_numpy(s)[:, None, :]) @ V.transpose(1, 2)).numpy()
+    else:
+        U, _, Vt = np.linalg.svd(np.matmul(np.swapaxes(A, 1, 2), A))
+        C = np.matmul(U * s[:, None, :], Vt)
     C = 0.5 * (C + np.swapaxes(C, 1, 2))
     x0 = rng.normal(size=(B, n))
     return F, f, C, c, x0

@@ -44,7 +44,7 @@ def _bumped(o, mu, delta, level):
     return mu
 
 
-def one_pass(o, x_hat, u_hat, mu, delta, dev_level, dev_alpha_index, dev_k=None):
+def one_pass(o, x_hat, u_hat, mu, delta, dev_level, dev_alpha_index, dev_k=None, dev_free=None):
     """One pass through the body of ilqr.py:238-270 from (x_hat[T+1,n,1], u_hat[T,m,1], mu, delta).
 
     -> dict(free=dict(level, converged_g, alpha_index, accepted, small_step, margin, later_failures[, k, selector_margin]) | None,
@@ -56,7 +56,12 @@ def one_pass(o, x_hat, u_hat, mu, delta, dev_level, dev_alpha_index, dev_k=None)
     `dev_k[T,m,1]` (bang-bang envs, ilqr.py:140-141 -- HVAC / Reservoir): the open-loop step the DEVICE's selector
     built (k_i = low - u or high - u by the sign of Q_u,i; read off the actions it moved).  The selector has exact ties on
     Reservoir in every sweep, so the line search and the rollout are restated on the device's direction (K = 0, dV1 = k_dev . Q_u,
-    dV2 = 0) while `free["k"]` / `free["selector_margin"]` report the restatement's own selector entry by entry."""
+    dV2 = 0) while `free["k"]` / `free["selector_margin"]` report the restatement's own selector entry by entry.
+
+    `dev_free[T,m]` (bool; control-limited envs, round 6): the free set the DEVICE's box-QP ended on at every step of this pass
+    (`clamp_mask` of tfmpc_ilqr_solve_trace_qp_f32).  The `forced` numbers are then computed with K_t on THAT set (ilqr.py:375-385: solve the
+    free-set Newton system, K_clamped = 0; k_t stays the restatement's own QP solution) -- the discrete part of the backward pass is taken from
+    the device, so the numbers can be compared without an excuse clause; `free["own_free"]` is the set the restatement's own QP ended on."""
     from oracle import ilqr_ref
     dt = o.dtype
     T = u_hat.shape[0]
@@ -69,6 +74,7 @@ def one_pass(o, x_hat, u_hat, mu, delta, dev_level, dev_alpha_index, dev_k=None)
         bang[t] = (np.asarray(Q_u, dtype=np.float64).reshape(-1), np.asarray(terms, dtype=np.float64).reshape(-1))
 
     o.on_bang_bang = on_bang_bang
+    o.forced_free, o.own_free = None, {}
     free = None
     with trace_oracle._PivotLog(value_tests=True) as pivots:
         try:
@@ -87,6 +93,8 @@ def one_pass(o, x_hat, u_hat, mu, delta, dev_level, dev_alpha_index, dev_k=None)
             pivot, failures, qp_sign = pivots.take()
             later_failures = failures - level             # factorisations that failed INSIDE a box-QP after its first (optimization.py:47-51)
             free = dict(level=int(level), alpha_index=None, accepted=None, small_step=None, later_failures=int(later_failures))
+            if len(o.own_free) == T:
+                free["own_free"] = np.stack([o.own_free[t] for t in range(T)])
             # discrete decisions INSIDE the backward pass: positive definite or not, which side of a bound a clamp test fell, and the
             # box-QP's own comparisons of objective values (Armijo, "no more improvement"): a pass whose smallest such margin is
             # under 1 can end on another free set -- other rows of K zero -- in another fp32 program
@@ -131,9 +139,13 @@ def one_pass(o, x_hat, u_hat, mu, delta, dev_level, dev_alpha_index, dev_k=None)
         except (ilqr_ref.CholeskyFailure, FloatingPointError):
             free = None
     forced = None
+    o.own_free = None
     try:
-        if free is None or free["level"] != dev_level:
+        same_sets = dev_free is None or (free is not None and "own_free" in free and np.array_equal(free["own_free"], np.asarray(dev_free, dtype=bool)))
+        if free is None or free["level"] != dev_level or not same_sets:
+            o.forced_free = None if dev_free is None else np.asarray(dev_free, dtype=bool)
             K, k, J_hat, dV1, dV2 = o.backward(T, u_hat, *models, dt(_bumped(o, mu, delta, dev_level)))
+            o.forced_free = None
         forced = dict(J_hat=float(J_hat), g_norm=gn(k), J=None, residual=None, x=None, u=None, c=None)
         if dev_alpha_index is not None:
             x, u, c, J, residual = o.forward(x_hat, u_hat, K, k, dt(ALPHAS[dev_alpha_index]))
@@ -142,11 +154,13 @@ def one_pass(o, x_hat, u_hat, mu, delta, dev_level, dev_alpha_index, dev_k=None)
     except ilqr_ref.CholeskyFailure:
         forced = None
     o.on_bang_bang = None
+    o.forced_free = None
     return dict(free=free, forced=forced)
 
 
 def _job(args):
-    kind, cfg, x_hat, u_hat, mu, delta, dev_level, dev_alpha_index, dev_k, dtypes = args
+    kind, cfg, x_hat, u_hat, mu, delta, dev_level, dev_alpha_index, dev_k, dtypes = args[:10]
+    dev_free = args[10] if len(args) > 10 else None
     import torch
     torch.set_num_threads(1)
     from oracle import ilqr_ref
@@ -162,12 +176,12 @@ def _job(args):
                 c = {k: jig(v) for k, v in cfg.items()}
         o = ilqr_ref.ILQRRef(trace_oracle.make_env(kind, c, dtype), dtype=dtype)
         with np.errstate(all="ignore"):
-            out[name] = one_pass(o, xh, uh, mu, delta, dev_level, dev_alpha_index, dev_k)
+            out[name] = one_pass(o, xh, uh, mu, delta, dev_level, dev_alpha_index, dev_k, dev_free)
     return out
 
 
 def run_passes(jobs, workers=None):
-    """jobs: list of (kind, cfg, x_hat[T+1,n,1], u_hat[T,m,1], mu, delta, dev_level, dev_alpha_index, dev_k | None, dtype names)
+    """jobs: list of (kind, cfg, x_hat[T+1,n,1], u_hat[T,m,1], mu, delta, dev_level, dev_alpha_index, dev_k | None, dtype names[, dev_free[T,m] | None])
     -> list of dicts {dtype name: one_pass(...)}."""
     import concurrent.futures
     import multiprocessing
@@ -191,13 +205,14 @@ def sample_passes(n_passes, cap):
     return sorted(keep)
 
 
-def compare_pass(d, nxt, r32, r64, r32p=None, atol=5e-3, traj_floor=2e-6):
+def compare_pass(d, nxt, r32, r64, r32p=None, atol=5e-3, traj_floor=2e-6, forced_sets=False):
     """One device pass `d` (a trace_records row) + the trajectory `nxt` = (x[T+1,n], u[T,m], c[T+1]) the device held afterwards (or
     None if the pass changed nothing) against the restatement's results of the same pass.
 
     -> (decision verdict, number verdict, detail):  decision: "same" | "tie" | "mismatch";  numbers: "ok" | "loose" | "mismatch" |
     "excused" (out of tolerance, but the pass holds a near-tie inside its backward pass) | "unposed" (the restatement cannot factorise
-    at the device's level, or fp32 / fp64 overflow)."""
+    at the device's level, or fp32 / fp64 overflow).  `forced_sets`: the restatement's numbers were computed on the DEVICE's box-QP free
+    sets (one_pass(dev_free=...)): what a near-tie could change discretely has been taken from the device, so nothing is excused."""
     f32, f64 = r32["free"], r64["free"]
     dev_dec = dict(level=d["level"], converged_g=d["accepted"] is None, alpha_index=d["alpha_index"], accepted=d["accepted"],
                    small_step=None if d["residual"] is None else bool(d["residual"] < atol))
@@ -243,7 +258,7 @@ def compare_pass(d, nxt, r32, r64, r32p=None, atol=5e-3, traj_floor=2e-6):
     # may legitimately have ended a box-QP on another free set: other rows of K_t are zero from that step on, and no tolerance on the
     # numbers downstream can hold.  Such a pass is "excused" -- counted, and capped in number by the caller.
     # (the fp32 runs' margins count: the fp64 run meets the same comparisons far from ITS rounding level)
-    if numbers != "ok" and (f32 is None or f32["internal_margin"] < 1.0 or (r32p is not None and (r32p["free"] is None or r32p["free"]["internal_margin"] < 1.0))):
+    if not forced_sets and numbers != "ok" and (f32 is None or f32["internal_margin"] < 1.0 or (r32p is not None and (r32p["free"] is None or r32p["free"]["internal_margin"] < 1.0))):
         numbers = "excused"
     if numbers != "ok":
         detail = (detail + "; " if detail else "") + f"{what} ({worst:.1f} x tolerance)"

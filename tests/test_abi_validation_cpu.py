@@ -74,7 +74,9 @@ def test_ilqr_entry_points_reject_bad_arguments(lib):
     assert lib.tfmpc_ilqr_solve_f32(byref(good), byref(cfg), 4, 5, d, d, d, d, d, NULL, d, d, 1 << 20, NULL) == ERR_ARG   # iterations
     # five slabs per instance (K, k, candidate x, u, costs), rounded up to 256 bytes ...
     slabs = lambda B, n, m, T: -(-B * (T * m * n + T * m + (T + 1) * n + T * m + (T + 1)) * 4 // 256) * 256
-    assert lib.tfmpc_ilqr_workspace_bytes(4, 3, 5, 5) == slabs(4, 3, 5, 5)
+    # ... plus, for the shapes the matrix-core LQ kernel takes (n <= 16, m <= 8, n + m > 6), -Q_uu(t)^-1 of its first backward pass: 64 floats
+    # per instance and time step, which the later, gain-reusing passes read (round 6)
+    assert lib.tfmpc_ilqr_workspace_bytes(4, 3, 5, 5) == slabs(4, 3, 5, 5) + 4 * 5 * 64 * 4
     # ... plus, for n == m <= 32, the wave-major trajectory buffers of the 16-per-wave costate kernel: per wave two
     # buffers of (T + 1) + T tiles of 64 lanes x 4 rows and (T + 1) x 64 stage costs, T x 64 selector bytes, one time step's
     # worth of "nowhere" for the counted unconditional stores, 8 x 7 checkpoint tile sets of the multi-wave groups and, with one tile,

@@ -137,8 +137,9 @@ def test_cfg5_literal_dims_as_ilqr_on_the_lq_env():
     lq = LQR(F[idx], f[idx], C[idx], c[idx]).solve_device(x0[idx], T)
     tot_i, tot_l = costs[torch.as_tensor(idx, device="cuda")].sum(dim=1), lq["costs"][:, :, 0, 0].sum(dim=1)
     assert float(((tot_i - tot_l).abs() / lq["costs"].abs().sum(dim=(1, 2, 3))).max()) <= 2e-3
-    # fp64 oracle (and the fp32 restatement for the budget) on two instances
-    for b in (0, B - 1):
+    # fp64 oracle (and the fp32 restatement for the budget) on one instance (TFMPC_SLOW=1: two -- each costs ~10 s of restatement at this shape)
+    import os
+    for b in ((0, B - 1) if os.environ.get("TFMPC_SLOW") == "1" else (B - 1,)):
         o = ilqr_ref.ILQRRef(envs_ref.LQEnv(F[b], f[b], C[b], c[b]))
         x, u, cs, it = o.solve(x0[b], T, u_init=np.zeros((T, m, 1)))
         o32 = ilqr_ref.ILQRRef(envs_ref.LQEnv(F[b], f[b], C[b], c[b], dtype=np.float32), dtype=np.float32)

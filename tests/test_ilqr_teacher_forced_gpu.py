@@ -73,8 +73,10 @@ def _nominals(make_solver, x0, u0, T, k_max, rows, full):
     return N
 
 
-def _run(kind, cfgs, dev, N, final, caps, low=None, high=None, traj_floor=2e-6, label="", second_opinion=True):
-    """dev[i]: trace rows of instance i; N[k][j][i]: nominals; caps[i]: passes sampled of instance i.  -> statistics (Counter), details."""
+def _run(kind, cfgs, dev, N, final, caps, low=None, high=None, traj_floor=2e-6, label="", second_opinion=True, masks=None, m=None):
+    """dev[i]: trace rows of instance i; N[k][j][i]: nominals; caps[i]: passes sampled of instance i.  -> statistics (Counter), details.
+    masks[i][p][t] (uint8, control-limited): the device's clamp mask of pass p, step t -- the restatement's numbers are then computed on the
+    device's free sets and nothing is excused (tests/teacher_forced.py)."""
     jobs, where = [], []
     for i, rows in enumerate(dev):
         for p in tf.sample_passes(len(rows), caps[i]):
@@ -90,22 +92,27 @@ def _run(kind, cfgs, dev, N, final, caps, low=None, high=None, traj_floor=2e-6, 
             if kind in ("reservoir", "hvac") and nxt is not None:           # the device's bang-bang step, read off the actions it moved
                 du = nxt[1] - N[it][1][i]
                 dev_k = (np.where(du > 0, high - N[it][1][i], low - N[it][1][i]) * (du != 0))[..., None]
+            dev_free = None
+            if masks is not None:
+                mk = np.asarray(masks[i][p], dtype=np.uint8)
+                assert not np.any(mk == 0xFF) or m == 8, "a step of this pass has no recorded mask"
+                dev_free = ((mk[:, None] >> np.arange(m)[None, :]) & 1) == 0                    # [T, m]: bit a set = clamped
             jobs.append((kind, cfgs[i] if isinstance(cfgs, list) else cfgs, x_hat, u_hat, d["mu"], d["delta"], d["level"], d["alpha_index"], dev_k,
-                         ("float32", "float64")))
+                         ("float32", "float64"), dev_free))
             where.append((i, p, d, nxt))
     res = tf.run_passes(jobs)
     stats, details, again = collections.Counter(), [], []
     verdicts = []
     for j, ((i, p, d, nxt), r) in enumerate(zip(where, res)):
-        v = tf.compare_pass(d, nxt, r["float32"], r["float64"], traj_floor=traj_floor)
+        v = tf.compare_pass(d, nxt, r["float32"], r["float64"], traj_floor=traj_floor, forced_sets=masks is not None)
         verdicts.append(v)
         if second_opinion and (v[0] == "mismatch" or v[1] in ("loose", "mismatch", "excused")):
             again.append(j)
     if again:                # second opinion: the fp32 restatement on inputs moved by one ulp measures the rounding noise of THAT pass
-        res_p = tf.run_passes([jobs[j][:-1] + (("float32p",),) for j in again])
+        res_p = tf.run_passes([jobs[j][:9] + (("float32p",),) + jobs[j][10:] for j in again])
         for j, rp in zip(again, res_p):
             i, p, d, nxt = where[j]
-            verdicts[j] = tf.compare_pass(d, nxt, res[j]["float32"], res[j]["float64"], rp["float32p"], traj_floor=traj_floor)
+            verdicts[j] = tf.compare_pass(d, nxt, res[j]["float32"], res[j]["float64"], rp["float32p"], traj_floor=traj_floor, forced_sets=masks is not None)
     for (i, p, d, nxt), r, v in zip(where, res, verdicts):
         stats["passes"] += 1
         stats["decision " + v[0]] += 1
@@ -116,6 +123,15 @@ def _run(kind, cfgs, dev, N, final, caps, low=None, high=None, traj_floor=2e-6, 
             stats["passes with a near-tie inside the backward pass (fp32 restatement)"] += 1
         if r["float32"]["free"] is not None and r["float32"]["free"]["level"] > 0:
             stats["passes with Cholesky retries (fp32 restatement)"] += 1
+        if masks is not None and r["float32"]["free"] is not None and "own_free" in r["float32"]["free"]:
+            own = r["float32"]["free"]["own_free"]
+            mine = ((np.asarray(masks[i][p], dtype=np.uint8)[:, None] >> np.arange(m)[None, :]) & 1) == 0
+            if r["float32"]["free"]["level"] == d["level"] and not np.array_equal(own, mine):
+                stats["passes whose box-QP free sets differ between device and fp32 restatement (same level)"] += 1
+                steps = np.flatnonzero((own != mine).any(axis=1))
+                if v[1] != "ok" or len(details) < 4:
+                    details.append((i, p, ("free sets", f"{len(steps)} steps differ, first t={int(steps[-1])}: device free "
+                                           f"{np.flatnonzero(mine[steps[-1]]).tolist()}, restatement {np.flatnonzero(own[steps[-1]]).tolist()}", "")))
         if v[2]:
             details.append((i, p, v))
     print(f"\n{label}: {dict(stats)}")
@@ -124,8 +140,17 @@ def _run(kind, cfgs, dev, N, final, caps, low=None, high=None, traj_floor=2e-6, 
     return stats, details, where, res, verdicts
 
 
-@pytest.mark.gpu
-def test_control_limited_workload_every_pass_teacher_forced():
+def _control_limited(n_order, n_group, cap_light, cap_heavy, every_pass_of=0, log=None, dump=None, replay=None, workers=None):
+    """The control-limited workload, teacher-forced: `n_order` instances in order + `n_group` of each heavy kind; `cap_*` passes sampled per
+    instance (tests/teacher_forced.py:sample_passes), EVERY pass of the first `every_pass_of` instances of the two heavy groups.
+    `dump` (GPU side) writes everything the restatement needs -- the device's traces, clamp masks, nominal trajectories, the instances'
+    problem data -- to a file and stops; `replay` (no GPU) reads such a file and does the comparison (tools/teacher_forced_heavy.py: the
+    every-pass run of the heavy instances is minutes of restatement on CPU cores the GPU box does not have to hold a GPU for)."""
+    if replay is not None:
+        import pickle
+        with open(replay, "rb") as fh:
+            saved = pickle.load(fh)
+        return _control_limited_compare(log=log, workers=workers, **saved)
     w = workloads.control_limited(65536)
     rows = 170
     solver = workloads.solver_of(w)
@@ -135,45 +160,88 @@ def test_control_limited_workload_every_pass_teacher_forced():
     retried = np.flatnonzero((st & _hip.ST_NOT_PD) != 0)
     capped = np.flatnonzero((st & _hip.ST_MAX_ATTEMPTS) != 0)
     family = np.flatnonzero((it == 99) & ((st & _hip.ST_MAX_ATTEMPTS) == 0) & ((st & _hip.ST_NOT_PD) != 0))
-    light = retried[np.argsort(it[retried], kind="stable")][:16]
-    groups = collections.OrderedDict([("in order", np.arange(80)), ("Cholesky retries, few iterations", light),
-                                      ("100-iteration family", family[:16]), ("attempt cap", capped[:16])])
-    assert all(len(g) >= 16 for g in groups.values())
+    light = retried[np.argsort(it[retried], kind="stable")][:n_group]
+    groups = collections.OrderedDict([("in order", np.arange(n_order)), ("Cholesky retries, few iterations", light),
+                                      ("100-iteration family", family[:n_group]), ("attempt cap", capped[:n_group])])
+    assert all(len(g) >= min(n_group, 4) for g in groups.values())
     pick = []
     for g in groups.values():
         pick += [int(b) for b in g if int(b) not in pick]
-    assert len(pick) >= 120
-    heavy = set(int(b) for b in family[:16]) | set(int(b) for b in capped[:16])
-    # the picked instances as a batch of their own: same bits per instance as in the 65 536 batch (the kernel owns one instance per wave)
+    heavy = set(int(b) for b in family[:n_group]) | set(int(b) for b in capped[:n_group])
+    whole = set(int(b) for b in family[:every_pass_of]) | set(int(b) for b in capped[:every_pass_of])
+    # the picked instances as a batch of their own: same bits per instance as in the 65 536 batch (the kernel owns one instance per wave);
+    # this launch also records the box-QP clamp masks (tfmpc_ilqr_solve_trace_qp_f32)
     sub = dict(w, F=w["F"][pick], f=w["f"][pick], C=w["C"][pick], c=w["c"][pick], x0=w["x0"][pick].contiguous(), u0=w["u0"][pick].contiguous())
     make = lambda **kw: workloads.solver_of(sub, **kw)
-    sub_full = make().solve_device(sub["x0"], sub["T"], u_init=sub["u0"], trace_rows=rows)
+    sub_full = make().solve_device(sub["x0"], sub["T"], u_init=sub["u0"], trace_rows=rows, qp_masks=True)
     torch.cuda.synchronize()
     for key in ("states", "actions", "costs", "iterations", "status", "trace_len"):
         assert torch.equal(sub_full[key], full[key][pick]), key
     assert torch.equal(torch.nan_to_num(sub_full["trace"]), torch.nan_to_num(full["trace"][pick]))
     dev = trace_records(sub_full["trace"], sub_full["trace_len"])
+    masks, qp_it = _np(sub_full["clamp_mask"]), _np(sub_full["qp_iterations"])
+    m = int(sub["F"].shape[-1] - sub["F"].shape[-2])
+    for i, r in enumerate(dev):                         # every pass the device made has a mask at every step, and a QP that iterated
+        assert not np.any(qp_it[i, :len(r)] == 0xFF) and int(qp_it[i, :len(r)].min()) >= 1 and int(qp_it[i, :len(r)].max()) <= 100
+        assert np.all(masks[i, :len(r)] < (1 << m))
     k_max = int(max(r[-1]["iteration"] for r in dev)) + 1
     N = _nominals(make, sub["x0"], sub["u0"], sub["T"], min(k_max, 100), rows, sub_full)
     final = (_np(sub_full["states"])[..., 0].astype(np.float64), _np(sub_full["actions"])[..., 0].astype(np.float64), _np(sub_full["costs"]).astype(np.float64))
     cfgs = [workloads.instance_cfg(w, b) for b in pick]
-    caps = [12 if b in heavy else 24 for b in pick]
+    caps = [10 ** 6 if b in whole else (cap_heavy if b in heavy else cap_light) for b in pick]
     # traj_floor: the box-QP stops when an iteration improves its objective by less than 1e-8 of its value (optimization.py:13,27-29), which
     # pins its minimiser to ~1e-4 only; two fp32 programs can end an iterate apart (tests/test_ilqr_lq_trace_gpu.py)
-    stats, details, where, res, verdicts = _run("lq", cfgs, dev, N, final, caps, traj_floor=5e-4, label="control-limited, teacher-forced")
+    saved = dict(cfgs=cfgs, dev=dev, N=N, final=final, caps=caps, masks=masks, m=m, pick=pick,
+                 groups=collections.OrderedDict((k, [int(b) for b in v]) for k, v in groups.items()))
+    if dump is not None:
+        import pickle
+        with open(dump, "wb") as fh:
+            pickle.dump(saved, fh)
+        return None
+    return _control_limited_compare(log=log, workers=workers, **saved)
+
+
+def _control_limited_compare(cfgs, dev, N, final, caps, masks, m, pick, groups, log=None, workers=None):
+    if workers:
+        tf.run_passes.__defaults__ = (workers,)
+    stats, details, where, res, verdicts = _run("lq", cfgs, dev, N, final, caps, traj_floor=5e-4, label="control-limited, teacher-forced on the device's free sets",
+                                                masks=masks, m=m)
     pos = {b: i for i, b in enumerate(pick)}
+    lines = [f"control-limited, teacher-forced on the device's box-QP free sets: {dict(stats)}"]
     for name, members in groups.items():
         idx = set(pos[int(b)] for b in members)
         sel = [v for (i, p, d, nxt), v in zip(where, verdicts) if i in idx]
         c = collections.Counter([("decision " + v[0]) for v in sel] + [("numbers " + v[1]) for v in sel])
-        print(f"  {name}: {len(sel)} passes sampled of {sum(len(dev[i]) for i in idx)}: {dict(c)}")
+        lines.append(f"  {name}: {len(sel)} passes compared of {sum(len(dev[i]) for i in idx)}: {dict(c)}")
+    lines += [f"    {det}" for det in details[:40]]
+    print("\n".join(lines[1:]))
+    if log:
+        with open(log, "w") as fh:
+            fh.write("\n".join(lines) + "\n")
     assert stats["decision mismatch"] == 0, details[:5]
     assert stats["numbers mismatch"] == 0, details[:5]
+    assert stats["numbers excused"] == 0                                    # nothing to excuse: the discrete part came from the device
     assert stats["numbers loose"] <= max(2, stats["passes"] // 100), details[:5]
-    assert stats["numbers excused"] <= 0.04 * stats["passes"], dict(stats)  # out of tolerance behind a near-tie inside the backward pass (measured: 2.4 %)
-    posed = stats["numbers ok"] + stats["numbers loose"]
-    assert posed >= 0.9 * stats["passes"], dict(stats)                      # >= 90 % of the sampled passes compared number by number
+    assert stats["numbers ok"] + stats["numbers loose"] >= 0.97 * stats["passes"], dict(stats)      # (the rest: "unposed" in fp32)
     assert stats["decision same"] >= 0.5 * stats["passes"], dict(stats)
+    return stats
+
+
+@pytest.mark.gpu
+def test_control_limited_workload_teacher_forced_on_the_devices_free_sets():
+    """The default run: a tenth of the full sampling below (GPU-suite wall time; the restatement costs seconds per pass on the heavy
+    instances) -- 32 instances in order, 4 of each heavy kind."""
+    _control_limited(n_order=32, n_group=4, cap_light=12, cap_heavy=6)
+
+
+@pytest.mark.gpu
+@pytest.mark.slow
+def test_control_limited_workload_every_pass_teacher_forced():
+    """TFMPC_SLOW=1: 80 instances in order, 16 of each heavy kind, EVERY pass of four instances of the 100-iteration family and of four at the
+    attempt cap; the statistics go to gpurun_out/ (copied to profiles/ by hand)."""
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    _control_limited(n_order=80, n_group=16, cap_light=24, cap_heavy=12, every_pass_of=4, log="gpurun_out/r06_teacher_forced_control_limited.txt")
 
 
 @pytest.mark.gpu

@@ -38,5 +38,5 @@ def test_bench_through_the_launcher_and_rccl_with_one_rank():
     assert g["backend"] == "nccl" and g["world_size"] == 1
     assert g["checked"] is True                                  # what rank 0 gathered IS its own shard, bit for bit
     assert line["gathered_states_shape"] == [4096, 51, 16, 1]
-    assert g["bytes_per_rank"] == 4096 * 1267 * 4
+    assert g["bytes_per_rank"] == 4096 * (1267 + 1) * 4              # states + actions + costs per instance, + its status (bit-cast int32)
     assert "gather_error" not in line

@@ -237,6 +237,16 @@ int tfmpc_ilqr_solve_trace_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, 
                                int32_t *status, float *trace, int trace_rows, int32_t *trace_len, void *workspace,
                                size_t workspace_bytes, void *stream)
 {
+    return tfmpc_ilqr_solve_trace_qp_f32(env, cfg, B, T, x0, u_init, states, actions, costs, iterations, status, trace, trace_rows,
+                                         trace_len, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+int tfmpc_ilqr_solve_trace_qp_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, int B, int T, const float *x0,
+                                  const float *u_init, float *states, float *actions, float *costs, int32_t *iterations,
+                                  int32_t *status, float *trace, int trace_rows, int32_t *trace_len, uint8_t *clamp_mask,
+                                  uint8_t *qp_iterations, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if ((clamp_mask != nullptr) != (qp_iterations != nullptr) || (clamp_mask && !trace)) return TFMPC_ERR_ARG;
     int rc = check_env(env);
     if (rc != TFMPC_OK) return rc;
     if (!cfg || B < 0 || T < 0 || cfg->n_alphas < 1 || cfg->n_alphas > TFMPC_MAX_ALPHAS || cfg->max_iterations < 1)
@@ -249,7 +259,7 @@ int tfmpc_ilqr_solve_trace_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cfg, 
     if (!workspace || workspace_bytes < lay.total || (reinterpret_cast<uintptr_t>(workspace) & 255u)) return TFMPC_ERR_WORKSPACE;
     char *const base = static_cast<char *>(workspace);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const TraceArgs tr{trace, trace_len, trace ? trace_rows : 0};
+    const TraceArgs tr{trace, trace_len, trace ? trace_rows : 0, clamp_mask, qp_iterations};
     const bool traced = trace != nullptr;
     if (traced && hipMemsetAsync(trace_len, 0, (size_t)B * sizeof(int32_t), st) != hipSuccess) return TFMPC_ERR_LAUNCH;
     SolveArgs a{};

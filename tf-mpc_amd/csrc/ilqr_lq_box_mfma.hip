@@ -391,8 +391,11 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
     const bool qp_col_a = c32 < N, qp_col_h = c32 >= N && c32 < N + M, qp_col_g = c32 == N + M;     // Q~_ux | H | g~ columns of the QP system
     float step_round0 = 1.0f;            // 0.6^(lane >> 3), formed by repeated products like the sequential backtracking loop's
     for (int e = 0; e < (lane >> 3); ++e) step_round0 *= 0.6f;
+    unsigned qp_fmask = 0xFFu;           // free set of the last factorisation of the last box-QP (the one its K belongs to) ...
+    int qp_count = 0;                    // ... and that QP's iterations: what a traced solve exports per pass and time step
     auto boxqp8 = [&](const float (&Hrow)[8], const float (&Mreg)[8], float q_r, float lo_r, float hi_r, float &x_r,
                       float (&Kcol)[8]) -> int {
+        qp_count = 0;
         const float rtol = 1e-8f, step_dec = 0.6f, min_step = 1e-22f, armijo = 0.1f, eps = 1e-6f;       // :13-17
         float xs[8];
         auto bcast = [&](float v) {
@@ -418,12 +421,14 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
 #ifdef TFMPC_BOX_PROBE
             const unsigned long long th0 = __builtin_amdgcn_s_memtime();
 #endif
+            ++qp_count;
             old_value = value;
             float g = q_r;                                                                               // :34
 #pragma unroll
             for (int j = 0; j < 8; ++j) g = fmaf(Hrow[j], xs[j], g);
             const bool clamped = (fabsf(x_r - lo_r) < eps && g > 0.0f) || (fabsf(hi_r - x_r) < eps && g < 0.0f);   // :121-127
             const unsigned fmask = (unsigned)(__ballot(!clamped) & 0xFFull);                             // free rows, wave-uniform
+            qp_fmask = fmask;
             const float gn = sum8(clamped ? 0.0f : g * g);
             float gc = q_r;                                                                              // :65 grad_clamped
 #pragma unroll
@@ -525,6 +530,7 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
 #ifdef TFMPC_BOX_PROBE
     int probe_steps = 0;                 // time steps the current sweep has run
 #endif
+    int trace_row = 0;                   // the pass the next sweep belongs to (= passes made so far): set by the solve loop
     auto backward = [&](const float *Lz, float mu) -> StepResult {
         StepResult res{0.0f, 0.0f, 0.0f, 0.0f, false, 0};
 #ifdef TFMPC_BOX_PROBE
@@ -607,6 +613,13 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
                 k_r = (Qu_r >= 0.0f) ? (low_r - uh_r) : (high_r - uh_r);                               // :140-141
 #pragma unroll
                 for (int e = 0; e < 8; ++e) Kcol[e] = 0.0f;
+            }
+            if (a.trace.clamp && lane == 0 && trace_row < a.trace.max_rows) {
+                // which rows of K_t the box-QP left at zero, and how long it iterated (a step without QP: all free / all clamped, 0 iterations)
+                const size_t at = ((size_t)b * a.trace.max_rows + trace_row) * T + t;
+                const bool qp = bounded && vxx_nonzero;
+                a.trace.clamp[at] = (uint8_t)(qp ? (~qp_fmask & ((1u << m) - 1u)) : (bounded ? ((1u << m) - 1u) : 0u));
+                a.trace.qp_it[at] = (uint8_t)(qp ? qp_count : 0);
             }
             // K~ to LDS: columns 0..15 = K, column 24 = k
             if (lane < N) {
@@ -880,6 +893,7 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
             // regularisation path (as many ended better as worse).  The default stays the reference's linear probe.
             StepResult r;
             bool grads_ready = false;
+            trace_row = iteration + attempts;
             auto attempt = [&](int level) {
                 float mu_l = mu, delta_l = delta;
                 for (int j = 0; j < level; ++j) {

@@ -13,6 +13,10 @@ struct TraceArgs {
     float *rows;          // [B][max_rows][TFMPC_TRACE_COLS], or nullptr: no trace
     int32_t *len;         // [B]: passes made
     int max_rows;
+    // tfmpc_ilqr_solve_trace_qp_f32 only (else nullptr): per pass and time step, what the box-QP of the controller ended on
+    // (ilqr.py:364-385, optimization.py:35-72) -- written by the control-limited matrix-core kernel
+    uint8_t *clamp;       // [B][max_rows][T]: bit a set = action a CLAMPED in the last factorised free set (row a of K_t is zero)
+    uint8_t *qp_it;       // [B][max_rows][T]: iterations of the projected-Newton loop (optimization.py:24), 0 = no QP at this step
 };
 
 // called by ONE lane of the instance, once per pass, with row = the number of passes before this one

@@ -49,6 +49,7 @@ ENV_LQ, ENV_NAVLQR, ENV_NAVIGATION, ENV_HVAC, ENV_RESERVOIR, ENV_USER = range(6)
 ENV_MAX_PARAMS = 10
 MAX_ALPHAS = 16
 TRACE_COLS = 11          # TFMPC_TRACE_COLS
+MIN_VERSION = 300        # tfmpc_version() this binding was written against (include/tfmpc_hip.h)
 
 
 class TfmpcEnv(ctypes.Structure):
@@ -77,6 +78,7 @@ _SIGNATURES.update({
     "tfmpc_ilqr_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "tfmpc_ilqr_solve_f32": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "tfmpc_ilqr_solve_trace_f32": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _P]),
+    "tfmpc_ilqr_solve_trace_qp_f32": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _P]),
     "tfmpc_boxqp_f32": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 })
 
@@ -103,6 +105,9 @@ def load():
                                    "package (rebuild it: make -C tf-mpc_amd/csrc)") from None
             fn.restype = res
             fn.argtypes = args
+        if lib.tfmpc_version() < MIN_VERSION:          # (layouts this package assumes -- TRACE_COLS, TfmpcEnv, status bits)
+            raise RuntimeError(f"tfmpc: {_LIB_PATH} is ABI version {lib.tfmpc_version()}, this package needs >= {MIN_VERSION} "
+                               "(rebuild it: make -C tf-mpc_amd/csrc)")
         _lib = lib
     return _lib
 

@@ -351,14 +351,18 @@ class iLQR:
         return states, actions, costs, J, residual
 
     # -- fused solve, device tensors in/out -----------------------------------------------------
-    def solve_device(self, x0, T, u_init=None, seed=None, workspace=None, trace_rows=0):
+    def solve_device(self, x0, T, u_init=None, seed=None, workspace=None, trace_rows=0, qp_masks=False):
         """ONE kernel launch for B whole iLQR solves.  Returns a dict of device tensors:
         ``states[B,T+1,n,1]``, ``actions[B,T,m,1]``, ``costs[B,T+1]``, ``iterations[B]``
         (the reference's returned loop index) and ``status[B]``.  Never synchronises.
 
         ``trace_rows > 0``: also the decision trace of every instance -- ``trace[B, trace_rows, TRACE_COLS]`` (one row
         per backward pass + line search, columns ``TRACE_COLUMNS``; rows never written are NaN) and ``trace_len[B]``
-        (passes made): what the reference logs per pass of ilqr.py:238-279 (``tfmpc_ilqr_solve_trace_f32``)."""
+        (passes made): what the reference logs per pass of ilqr.py:238-279 (``tfmpc_ilqr_solve_trace_f32``).
+
+        ``qp_masks=True`` (with ``trace_rows``; ``tfmpc_ilqr_solve_trace_qp_f32``): also ``clamp_mask[B, trace_rows, T]`` (uint8: bit a set =
+        action a clamped in the last factorised free set of that step's box-QP, i.e. row a of ``K_t`` is zero, ilqr.py:375-385) and
+        ``qp_iterations[B, trace_rows, T]`` -- written by the control-limited matrix-core kernel; entries no kernel wrote stay 0xFF."""
         lib = self._library()
         T = int(T)
         n, m = self.env.state_size, self.env.action_size
@@ -396,10 +400,24 @@ class iLQR:
         if trace_rows > 0:
             trace = torch.full((B, int(trace_rows), _hip.TRACE_COLS), float("nan"), dtype=torch.float32, device=dev)
             trace_len = torch.zeros((B,), dtype=torch.int32, device=dev)
-        rc = lib.tfmpc_ilqr_solve_trace_f32(ctypes.byref(env), ctypes.byref(cfg), B, T, _hip.ptr(x0), _hip.ptr(u),
-                                            _hip.ptr(states), _hip.ptr(actions), _hip.ptr(costs), _hip.ptr(iterations),
-                                            _hip.ptr(status), _hip.ptr(trace), int(trace_rows), _hip.ptr(trace_len),
-                                            _hip.ptr(workspace), workspace.numel() * workspace.element_size(), _hip.stream())
+        clamp = qp_it = None
+        if qp_masks:
+            if trace is None:
+                raise ValueError("qp_masks needs trace_rows > 0 (the masks are indexed by pass like the trace rows)")
+            if not hasattr(lib, "tfmpc_ilqr_solve_trace_qp_f32") or getattr(lib, "path", None):
+                raise NotImplementedError("qp_masks: served by the main library's control-limited LQ kernel only")
+            clamp = torch.full((B, int(trace_rows), T), 0xFF, dtype=torch.uint8, device=dev)
+            qp_it = torch.full((B, int(trace_rows), T), 0xFF, dtype=torch.uint8, device=dev)
+            rc = lib.tfmpc_ilqr_solve_trace_qp_f32(ctypes.byref(env), ctypes.byref(cfg), B, T, _hip.ptr(x0), _hip.ptr(u),
+                                                   _hip.ptr(states), _hip.ptr(actions), _hip.ptr(costs), _hip.ptr(iterations),
+                                                   _hip.ptr(status), _hip.ptr(trace), int(trace_rows), _hip.ptr(trace_len),
+                                                   _hip.ptr(clamp), _hip.ptr(qp_it),
+                                                   _hip.ptr(workspace), workspace.numel() * workspace.element_size(), _hip.stream())
+        else:
+            rc = lib.tfmpc_ilqr_solve_trace_f32(ctypes.byref(env), ctypes.byref(cfg), B, T, _hip.ptr(x0), _hip.ptr(u),
+                                                _hip.ptr(states), _hip.ptr(actions), _hip.ptr(costs), _hip.ptr(iterations),
+                                                _hip.ptr(status), _hip.ptr(trace), int(trace_rows), _hip.ptr(trace_len),
+                                                _hip.ptr(workspace), workspace.numel() * workspace.element_size(), _hip.stream())
         _hip.check(rc, "tfmpc_ilqr_solve_trace_f32")
         self.last_status = status
         self.last_kernel = lib.tfmpc_ilqr_last_kernel_name().decode()      # which kernel family solved it (a traced solve can take another)
@@ -407,6 +425,8 @@ class iLQR:
                    status=status, batched=batched, workspace=workspace)
         if trace is not None:
             out.update(trace=trace, trace_len=trace_len)
+        if clamp is not None:
+            out.update(clamp_mask=clamp, qp_iterations=qp_it)
         return out
 
     # -- ilqr.py:214-283 ---------------------------------------------------------------------
