@@ -232,7 +232,9 @@ def compare_pass(d, nxt, r32, r64, r32p=None, atol=5e-3, traj_floor=2e-6, forced
     worst, what = 0.0, ""
     # floors: two fp32 programs that sum ~50 costs in different orders differ by a few 1e-6 of the sum even when the restatement's own
     # error happens to be tiny; g_norm / residual are compared with atol, so they are held to 0.1 % of their size or of atol
-    quantities = [("J_hat", 2e-5, 1e-6), ("g_norm", 1e-3, 1e-3 * atol)] + ([("J", 2e-5, 1e-6), ("residual", 1e-3, 1e-3 * atol)] if d["alpha_index"] is not None else [])
+    # (J sums the costs of the CANDIDATE trajectory, which is itself only pinned to `traj_floor` of its size -- on the control-limited workload
+    # the box-QP's own stopping rule, optimization.py:27-29, leaves k_t that loose -- so J is held to the larger of the two relative bounds)
+    quantities = [("J_hat", 2e-5, 1e-6), ("g_norm", 1e-3, 1e-3 * atol)] + ([("J", max(2e-5, traj_floor), 1e-6), ("residual", 1e-3, 1e-3 * atol)] if d["alpha_index"] is not None else [])
     for key, rtol, floor in quantities:
         ref = g64[key]
         if ref is None or not np.isfinite(ref) or not np.isfinite(g32[key]):
