@@ -65,8 +65,8 @@ def lqr_bytes_per_solve(n, m, T):
 
 
 # which kernel source a profiled kernel lives in (its PMC summary is only quoted while that file is unchanged)
-KERNEL_SOURCES = {"mfma": ["lqr_mfma16x8.hip", "wave_ldlt8.h", "mfma_bf16x3.h"], "ilqr_group_solve": ["ilqr_lane.hip", "ilqr_lane_kernels.h", "envs.h"],
-                  "ilqr_adjoint_mfma": ["ilqr_adjoint_mfma.hip", "trig.h"], "ilqr_lq_mfma_kernel": ["ilqr_lq_mfma.hip", "wave_ldlt8.h"],
+KERNEL_SOURCES = {"mfma": ["lqr_mfma16x8.hip", "wave_ldlt8.h", "mfma_bf16x3.h", "wave_ops.h"], "ilqr_group_solve": ["ilqr_lane.hip", "ilqr_lane_kernels.h", "envs.h"],
+                  "ilqr_adjoint_mfma": ["ilqr_adjoint_mfma.hip", "trig.h"], "ilqr_lq_mfma_kernel": ["ilqr_lq_mfma.hip", "wave_ldlt8.h", "wave_ops.h"],
                   "ilqr_lq_box_mfma": ["ilqr_lq_box_mfma.hip", "wave_ldlt8.h"], "ilqr_lq_mfma32": ["ilqr_lq_mfma32.hip", "wave_ldlt.h"],
                   "lqr_mfma32x16": ["lqr_mfma32x16.hip", "wave_ldlt.h"]}
 
@@ -101,19 +101,67 @@ def measured_traffic(kernel, batch):
     return per_instance * batch, f"profiles/{os.path.basename(best_path)} (kernel sources unchanged since)"
 
 
-def pmc_traffic(kernel_substring, per_launch_units, units):
+def _pmc_files(file_tag=None):
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True)
+    return [p for p in paths if file_tag is None or file_tag in os.path.basename(p)]
+
+
+def profile_duration(kernel_substring, file_tag=None):
+    """The duration of the kernel's launches in the newest committed profile taken on its current sources (tools/pmc_workload.sh: the same
+    workload as the bench line, >= 40 untimed + 10 timed launches; average of the timed dispatches) -- or None."""
+    for path in _pmc_files(file_tag):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        for name, k in d.get("kernel_stats", {}).items():
+            if kernel_substring in name and "timed_avg_ms" in k:
+                key = max((q for q in KERNEL_SOURCES if q in kernel_substring or kernel_substring in q), key=len, default=None)
+                if not _summary_is_current(d, key):
+                    return None
+                tool = next((w["ms_per_launch"] for w in d.get("workloads", [])), None) if len(d.get("workloads", [])) == 1 else None
+                return {"kernel_timed_avg_ms": k["timed_avg_ms"], "span_ms_per_launch": k.get("timed_span_ms_per_launch"), "calls": k["calls"],
+                        "tool_ms_per_launch": tool, "source": "profiles/" + os.path.basename(path)}
+    return None
+
+
+def attach_profile(line, kernel_substring, file_tag=None):
+    """Side by side: this line's ms per launch and the committed rocprofv3 duration of the same workload's kernel.  A profile whose duration
+    differs from the line by more than 5 % is NOT quoted: `traffic` and `executed` of the line are withdrawn."""
+    prof = profile_duration(kernel_substring, file_tag)
+    if prof is None or not isinstance(line, dict) or "ms_per_batch" not in line:
+        return line
+    ref = prof["span_ms_per_launch"] or prof["kernel_timed_avg_ms"]
+    prof["line_over_profile"] = line["ms_per_batch"] / ref
+    prof["reproduces_within_5_percent"] = bool(abs(prof["line_over_profile"] - 1.0) <= 0.05)
+    line["profile"] = prof
+    if not prof["reproduces_within_5_percent"]:
+        if isinstance(line.get("roofline"), dict):
+            line["roofline"]["traffic"] = None
+            line["roofline"]["traffic_withdrawn"] = "the committed profile's duration differs from this line by more than 5 %"
+        for key in ("executed",):
+            if key in line:
+                line[key] = None
+    return line
+
+
+def pmc_traffic(kernel_substring, per_launch_units, units, file_tag=None):
     """HBM bytes of one launch of a secondary kernel, from the newest committed PMC summary of that kernel
     (profiles/r*_pmc.json, written by tools/pmc_kernel.sh: separate --pmc passes, FETCH_SIZE x2 + WRITE_SIZE as
     MI355X_MICROARCH.md prescribes), scaled to `units` work units (the summary was taken at `per_launch_units`).
     None when the newest summary was taken on other sources of that kernel (tools/source_stamp.py)."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+    for path in _pmc_files(file_tag):
         try:
             d = json.load(open(path))
         except Exception:
             continue
         for name, c in d.get("counters_per_launch", {}).items():
             if kernel_substring in name and "hbm_bytes_per_launch" in c:
+                if per_launch_units is None:              # (tools/pmc_workload.sh summaries say what one profiled launch processed)
+                    per_launch_units = next((w.get("units_per_launch") for w in d.get("workloads", []) if w.get("units_per_launch")), None)
+                    if per_launch_units is None:
+                        return None
                 # the LONGEST key that matches ("mfma" alone is the headline kernel and is part of every other name)
                 key = max((k for k in KERNEL_SOURCES if k in kernel_substring or kernel_substring in k), key=len, default=None)
                 if not _summary_is_current(d, key):
@@ -122,13 +170,12 @@ def pmc_traffic(kernel_substring, per_launch_units, units):
     return None
 
 
-def pmc_executed(kernel_substring):
+def pmc_executed(kernel_substring, file_tag=None):
     """What the kernel EXECUTED per launch, from the newest committed PMC summary taken on its current sources (else None): share of the
     SIMD cycles the vector unit / the matrix unit was busy (SQ_ACTIVE_INST_VALU x 4, SQ_VALU_MFMA_BUSY_CYCLES over 1 024 SIMDs x
     GRBM_GUI_ACTIVE / 8) and a wave's share of its residence spent in s_waitcnt -- the issue-side yardstick of the kernels whose
     algorithmic-byte or dense-flop fractions say nothing about headroom (latency- / issue-bound formulations)."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+    for path in _pmc_files(file_tag):
         try:
             d = json.load(open(path))
         except Exception:
@@ -174,7 +221,7 @@ def roofline_hbm(alg_bytes, seconds, traffic):
             "algorithmic_bytes": alg_bytes, "traffic": traffic}
 
 
-def ilqr_api_rate(n, m, T, B, reps=5):
+def ilqr_api_rate(n, m, T, B, reps=10):
     """Secondary number (not `value`), first-class since round 3: BASELINE.json's headline shape driven through
     tfmpc.solvers.ilqr.iLQR.solve on the LQ env (whole iteration loops in one launch, matrix-core kernel).
     Problems: the reference's make_lqr distribution (tests/problems.py:make_lqr_batch_spd: C by make_spd_matrix's formula,
@@ -192,6 +239,9 @@ def ilqr_api_rate(n, m, T, B, reps=5):
     def run(solver, w, reps_):
         x0, u0 = w["x0"], w["u0"]
         out = solver.solve_device(x0, T, u_init=u0)
+        if reps_ > 1:                                # (a few untimed launches: the first ones after host-side problem generation find the GPU at
+            for _ in range(4):                       # idle clocks -- round 6: one warm-up launch read 3.98 ms where forty read 3.45)
+                out = solver.solve_device(x0, T, u_init=u0, workspace=out["workspace"])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps_):
@@ -218,8 +268,11 @@ def ilqr_api_rate(n, m, T, B, reps=5):
     res = api_line(w_warm)
     if CPU_BASELINES:
         res["cpu_baseline"] = ilqr_cpu_baseline("lq", [workloads.instance_cfg(w_warm, b) for b in range(8)], w_warm["x0"], w_warm["u0"], T, 100, 8, w_warm["version"])
-    res["roofline"]["traffic"] = pmc_traffic("ilqr_lq_mfma_kernel", 65536, B)
-    res["roofline"]["executed"] = pmc_executed("ilqr_lq_mfma_kernel")
+    res["roofline"]["traffic"] = pmc_traffic("ilqr_lq_mfma_kernel", None, float((res["mean_iterations"]) * B), file_tag="ilqr_api_pmc")
+    res["roofline"]["traffic_note"] = "HBM bytes of the whole launch (PMC); the counters are scaled by iterations"
+    res["executed"] = pmc_executed("ilqr_lq_mfma_kernel", file_tag="ilqr_api_pmc")
+    res["roofline"]["executed"] = res["executed"]
+    attach_profile(res, "ilqr_lq_mfma_kernel", file_tag="ilqr_api_pmc")
     res["roofline"]["kernel"] = "ilqr_lq_mfma_kernel<true, true> (profiles/r06_ilqr_api_kernel_stats.csv: tools/ilqr_api_once.py under rocprofv3)"
     res["gain_reuse"] = ("default since round 6: the env is time-invariant LQ and every pass runs at mu = 0, so K_t, V_xx(t), Q_uu(t) do not depend on the "
                          "trajectory -- from the second backward pass on the kernel keeps K_t and Q_uu^-1 of the first and runs the vector recursion for "
@@ -253,7 +306,8 @@ def ilqr_api_rate(n, m, T, B, reps=5):
     wl_run, wl = wl, workloads.control_limited_stable(B, n, m, T)
     stable = limited("linear probe 0, 1, 2, ... (ilqr.py:285-315; the default)")
     stable["workload"], stable["workload_version"] = wl["text"], wl["version"]
-    stable["executed"] = pmc_executed("ilqr_lq_box_mfma_kernel<false, 0, true>")      # (the main launch -- the instantiation with helper teams --, not the sample probe)
+    stable["executed"] = pmc_executed("ilqr_lq_box_mfma_kernel<false, 0, true>", file_tag="box_stable")      # (the main launch -- the instantiation with helper teams --, not the sample probe)
+    attach_profile(stable, "ilqr_lq_box_mfma_kernel<false, 0, true>", file_tag="box_stable")
     stable["helper_teams"] = ("8 teams x 5 helper blocks of the same launch roll out the step sizes of the longest instances' line searches side by side "
                               "(DESIGN.md 3.6; same bits: tests/test_ilqr_lq_box_mfma_gpu.py); TFMPC_BOX_HELPERS=off is the launch without them")
     with _hip.option("TFMPC_BOX_HELPERS", "off"):
@@ -328,6 +382,37 @@ def torchenv_rate(B=1024, T=40):
             "workload": "Navigation (nav.config.json) as torch functions through TorchEnv: host-driven loop, <= 10 iterations",
             "note": "the rollout and derivative blocks of the loop are replayed as hipGraphs (iLQR(env, graphs=True)); "
                     "the built-in envs run fused"}
+
+
+def mpc_rate(B=16384, T=20):
+    """Secondary number: batched receding-horizon MPC episodes (agents/mpc.py:10-15, runners/__init__.py:14-43 of the
+    reference, one episode per instance): T control steps, each = one fused iLQR re-solve over the remaining horizon + one env step with
+    its noise model.  Wall time per control step, cold restart (the reference's: random actions every step) and warm start (the previous
+    solution shifted by one step) -- tools/mpc_rates.py prints the full table."""
+    import problems
+    from tfmpc import agents, runners
+    from tfmpc.envs.navigation import Navigation
+    from tfmpc.envs.reservoir import Reservoir
+    from tfmpc.solvers.ilqr import iLQR
+    out = {"batch": B, "control_steps": T, "workload": "B episodes of T control steps, eager loop, one fused iLQR launch per control step"}
+    for name, env, x0 in (("navigation", Navigation.load(problems.NAV_CONFIG), np.random.default_rng(1).uniform(0, 10, size=(B, 2, 1)).astype(np.float32)),
+                          ("res4", Reservoir.load(dict(problems.RES4_CONFIG)), np.tile(np.array(problems.RES4_X0, dtype=np.float32)[None], (B, 1, 1)))):
+        for warm in (False, True):
+            agent = agents.MPC(iLQR(env), T, warm_start=warm, seed=3)
+            runner = runners.Runner(env, agent)
+            env.seed(3)
+            for _ in range(2):                                # (the second episode batch is the timed one)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                with runner(x0, T) as r:
+                    traj = r.run()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            out[f"{name}_{'warm' if warm else 'cold'}_start"] = {
+                "ms_per_control_step": dt / T * 1e3, "ms_per_episode_batch": dt * 1e3,
+                "mean_ilqr_iterations_per_resolve": float(np.mean([np.mean(i) for i in agent.iterations])),
+                "mean_total_cost": float(np.mean(traj.total_cost))}
+    return out
 
 
 def deviceenv_rate(B=16384, T=50):
@@ -427,24 +512,28 @@ def other_config_rates():
                 "flagged_instances": int((out["status"] != 0).sum()), "batch": int(x0.shape[0]), "horizon": T,
                 "launches_timed": reps}       # (back to back on one stream, one synchronize behind the last: the contract's K steps)
         if alg_bytes is not None:
-            line["roofline"] = roofline_hbm(alg_bytes * its, dt, pmc_traffic(pmc[0], pmc[1], its) if pmc else None)
+            line["roofline"] = roofline_hbm(alg_bytes * its, dt, pmc_traffic(pmc[0], pmc[1], its, file_tag=pmc[2]) if pmc else None)
             line["roofline"]["algorithmic_bytes_per_iteration"] = alg_bytes
+        if pmc:
+            attach_profile(line, pmc[0], file_tag=pmc[2])
         return line
 
     res = {}
-    rng = np.random.default_rng(4)
-    F, f, C, c, x0n, goal = problems.make_navlin_batch(4096, 5.0)
-    lqr = make_lqr_linear_navigation(goal[..., None], 5.0)
-    x0n_d = torch.as_tensor(np.ascontiguousarray(x0n[..., None], dtype=np.float32), device="cuda")      # (resident before the timed region)
+    w2 = workloads.cfg2()
+    lqr, x0n_d = w2["lqr"], w2["x0"]                                                     # (resident before the timed region)
     _, dt = timed(lambda ws: lqr.solve_device(x0n_d, 50, workspace=ws), 20)
-    res["cfg2_navlin_lqr"] = {"ms_per_batch": dt * 1e3, "solves_per_s": 4096 / dt, "batch": 4096, "horizon": 50}
+    # cfg2: n = m = 2, T = 50, F and C shared by the batch: read x0, goal 16 B, write x, u, c 253 floats = 1 012 B per solve
+    res["cfg2_navlin_lqr"] = {"ms_per_batch": dt * 1e3, "solves_per_s": 4096 / dt, "batch": 4096, "horizon": 50, "launches_timed": 20,
+                              "kernel": _hip_kernel_name(2, 2, 50),
+                              "roofline": dict(roofline_hbm(1028 * 4096, dt, pmc_traffic("lqr_lane", None, 4096, file_tag="cfg2")), algorithmic_bytes_per_solve=1028,
+                                               note="4 096 solves are 64 wavefronts of a lane-per-instance kernel on a 1 024-SIMD chip: the launch is one wave's "
+                                                    "dependent T = 50 recursion (latency), not bandwidth")}
+    attach_profile(res["cfg2_navlin_lqr"], "lqr_lane", file_tag="cfg2")
     # cfg4: n = m = 2, T = 50 -> read x, u 808 B + write x, u, c 1 012 B per iteration
-    solver = iLQR(Navigation.load(problems.NAV_CONFIG))
-    Bn = 16384
-    x0 = torch.as_tensor(rng.uniform(0, 10, size=(Bn, 2, 1)).astype(np.float32), device="cuda")      # (resident before the timed region)
-    u0 = solver.random_actions(50, Bn, seed=4)
-    res["cfg4_navigation_ilqr"] = ilqr_line(solver, x0, 50, u0, 5, alg_bytes=1820, pmc=("ilqr_group_solve", 142719))
-    ex4 = pmc_executed("ilqr_group_solve")
+    w4 = workloads.cfg4()
+    solver, x0, u0, Bn = w4["solver"], w4["x0"], w4["u0"], 16384                       # (resident before the timed region)
+    res["cfg4_navigation_ilqr"] = ilqr_line(solver, x0, 50, u0, 5, alg_bytes=1820, pmc=("ilqr_group_solve", None, "cfg4_pmc"))
+    ex4 = pmc_executed("ilqr_group_solve", file_tag="cfg4_pmc")
     if ex4 is not None:
         # HBM is the wrong yardstick for this kernel (30 GB/s of 8 TB/s): it is bound by the issue and latency of its own instruction stream.
         # Issue side: the rate the same instruction stream would reach with the vector unit busy every cycle.
@@ -461,21 +550,21 @@ def other_config_rates():
     # Sustained rate: ONE launch of 8 x 16 384 instances.  The group kernel is persistent since round 4 (ilqr_lane.hip: the grid is
     # what the chip holds at once, a group whose instance has finished takes the next one from an atomic queue), so the rate that
     # round 3 needed eight batches in flight on eight host streams (and a throw-away stream pool) for comes out of a single launch.
-    x8 = torch.as_tensor(np.concatenate([np.random.default_rng(100 + i).uniform(0, 10, size=(Bn, 2, 1)) for i in range(8)]).astype(np.float32),
-                         device="cuda")
-    u8 = torch.cat([solver.random_actions(50, Bn, seed=100 + i) for i in range(8)])
-    big = ilqr_line(solver, x8, 50, u8, 3, alg_bytes=1820)
+    w8 = workloads.cfg4(batches=8)
+    x8, u8 = w8["x0"], w8["u0"]
+    big = ilqr_line(solver, x8, 50, u8, 3, alg_bytes=1820, pmc=("ilqr_group_solve", None, "cfg4_one_launch"))
+    big["executed"] = pmc_executed("ilqr_group_solve", file_tag="cfg4_one_launch")
     res["cfg4_navigation_ilqr"]["one_launch_of_8x16384_instances"] = big
     res["cfg4_navigation_ilqr"]["one_launch_of_8x16384_instances"]["note"] = (
         "persistent lane groups + instance queue; round 3: 8 streams x 16 384 = 51.1 M it/s (profiles/r03_cfg4_sustained.json)")
-    del x8, u8
+    del x8, u8, w8
     # cfg5: n = m = 32, T = 100 -> read x, u 25.7 KB + write x, u, c 26.1 KB = 51.8 KB per iteration
     for kind, kernel_tag in (("hvac", "ilqr_adjoint_mfma_kernel<3, 2"), ("reservoir", "ilqr_adjoint_mfma_kernel<100, 2")):     # two-tile instantiations (Reservoir: the chain form, tag 100)
         n, T, B = 32, 100, 32768
         w5 = workloads.cfg5(kind, B, n, T)            # the same problems tests/test_ilqr_teacher_forced_gpu.py holds against the restatement
         env, x0, u0c = w5["env"], w5["x0"], w5["u0"]
         solver = iLQR(env, max_iterations=12)
-        line = ilqr_line(solver, x0, T, u0c, 8, alg_bytes=4 * (2 * (T + 1) * n + 2 * T * n + (T + 1)), pmc=(kernel_tag, 32768 * 12))
+        line = ilqr_line(solver, x0, T, u0c, 8, alg_bytes=4 * (2 * (T + 1) * n + 2 * T * n + (T + 1)), pmc=(kernel_tag, None, f"cfg5_{kind}"))
         # The flop side (round 4): rollouts per iteration MEASURED from the decision trace of the same solve (a traced launch returns
         # the same bits): a pass of the reference's line search makes alpha_index + 1 rollouts (ilqr.py:322-353).  Algorithmic flop
         # per iteration, SURVEY.md 8(d) dense count: costate sweep T x 4 n^2 + rollouts x T x (4 n^2 + env), env = 20 n flop per step
@@ -499,7 +588,15 @@ def other_config_rates():
                                       "note": "dense count of SURVEY.md 8(d) with the measured rollouts; the ridge is 157.3 TF / 8 TB/s = 19.7 flop/B"}
         del tr, rows
         line["workload_version"] = w5["version"]
-        line["executed"] = pmc_executed(kernel_tag)
+        line["executed"] = pmc_executed(kernel_tag, file_tag=f"cfg5_{kind}") if (line.get("profile") or {}).get("reproduces_within_5_percent", True) else None
+        # 43 - 57 algorithmic flop per algorithmic byte (ridge 19.7): this line sits on the COMPUTE side, and the units that compute here are the
+        # vector ALUs (closed-form Jacobians, row moves; the matrix cores carry only HVAC's coupling products) -- so the yardstick the line LEADS
+        # with is the share of SIMD cycles the vector unit is busy in the profiled launch; the HBM block comes second
+        line["roofline_hbm"] = line["roofline"]
+        if line["executed"]:
+            line["roofline"] = {"bound": "valu", "achieved": line["executed"]["valu_busy_frac"], "peak": 1.0, "unit": "share of SIMD cycles with the vector unit busy (PMC)",
+                                "frac": line["executed"]["valu_busy_frac"], "traffic": line["roofline_hbm"].get("traffic"),
+                                "mfma_busy_frac": line["executed"].get("mfma_busy_frac"), "source": line["executed"].get("source")}
         if CPU_BASELINES:
             line["cpu_baseline"] = ilqr_cpu_baseline(kind, w5["cfg"], x0, u0c, T, 12, 3, w5["version"])
         res[f"cfg5_{kind}_ilqr_n32"] = line
@@ -507,13 +604,12 @@ def other_config_rates():
     for name, env, x0r, kernel_tag in (("hvac6", HVAC.load(dict(problems.HVAC6_CONFIG)), problems.HVAC6_X0, "ilqr_adjoint_mfma_kernel<3, 1"),
                                        ("res4", Reservoir.load(dict(problems.RES4_CONFIG)), problems.RES4_X0, "ilqr_adjoint_mfma_kernel<4, 1")):
         B, T = 16384, 100
-        n = len(x0r)
-        x0 = torch.as_tensor((np.array(x0r, dtype=np.float32)[None] * rng.uniform(0.9, 1.1, size=(B, 1, 1))).astype(np.float32), device="cuda")   # (resident before the timed region, as the contract says: a host array is uploaded by every call, +0.08 ms on a 2 ms launch)
-        solver = iLQR(env, max_iterations=12)
+        ws_ = workloads.small_env(name, B, T)
+        n, x0, solver = ws_["n"], ws_["x0"], ws_["solver"]                              # (resident before the timed region)
         # PMC: profiles/r0x_small_env_pmc.json (tools/small_env_once.py, 16 384 instances x 12 iterations)
-        res[f"{name}_reference_config_ilqr"] = ilqr_line(solver, x0, T, solver.random_actions(T, B, seed=1), 10,      # (ten launches back to back: one sync's latency over 20 ms, not over 4)
+        res[f"{name}_reference_config_ilqr"] = ilqr_line(solver, x0, T, ws_["u0"], 10,      # (ten launches back to back: one sync's latency over 20 ms, not over 4)
                                                          alg_bytes=4 * (2 * (T + 1) * n + 2 * T * n + (T + 1)),
-                                                         pmc=(kernel_tag, 16384 * 12))
+                                                         pmc=(kernel_tag, None, name))
     # configs[4] at its literal dims (n = 32, m = 16, T = 100, B = 32 768) as iLQR on the generalised LQ env
     n, m, T, B = 32, 16, 100, 32768
     import workloads
@@ -532,20 +628,21 @@ def other_config_rates():
     line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
                         "algorithmic_flop": flop,
                         # PMC: profiles/r04_large_tile_pmc.json, taken at 8 192 instances x 2.02 iterations (tools/large_tile_once.py)
-                        "traffic": pmc_traffic("ilqr_lq_mfma32_kernel", 8192 * 2.02, its)}
+                        "traffic": pmc_traffic("ilqr_lq_mfma32_kernel", None, its, file_tag="literal_dims")}
+    attach_profile(line, "ilqr_lq_mfma32_kernel", file_tag="literal_dims")
     line["kernel"] = "ilqr_lq_mfma32_kernel (2 x 2 tiles of bf16x3, trajectories in HBM); round-2 start: wave kernel, 1 123 ms"
     res["cfg5_literal_dims_ilqr_lq_n32_m16"] = line
     del solver, x0d
-    F, f, C, c, x0 = problems.make_lqr_batch_fast(8192, 32, 16, seed=1)
-    big = LQR(0.5 * F, f, C, c)
-    x0d = big._prep_x0(x0)
+    w32 = workloads.lqr32()
+    big, x0d = w32["lqr"], w32["x0"]
     _, dt = timed(lambda ws: big.solve_device(x0d, 50, workspace=ws), 3)
     tf = lqr_flops_per_solve(32, 16, 50) * 8192 / dt / 1e12
     res["lqr_n32_m16"] = {"ms_per_batch": dt * 1e3, "solves_per_s": 8192 / dt, "batch": 8192, "horizon": 50,
                           "kernel": _hip_kernel_name(32, 16, 50),
                           "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                                        "frac": tf / PEAK_F32_TFLOPS, "algorithmic_flop_per_solve": lqr_flops_per_solve(32, 16, 50),
-                                       "traffic": pmc_traffic("lqr_mfma32x16_kernel", 8192, 8192)}}
+                                       "traffic": pmc_traffic("lqr_mfma32x16_kernel", None, 8192, file_tag="lqr32")}}
+    attach_profile(res["lqr_n32_m16"], "lqr_mfma32x16_kernel", file_tag="lqr32")
     return res
 
 
@@ -703,6 +800,8 @@ def summarise_extras(extra):
            "bf16_sweep": get(extra, "bf16_storage_sweep") if isinstance(extra, dict) and "error" not in (extra.get("bf16_storage_sweep") or {}) else None,
            "torchenv_kit_s": r3((get(extra, "torchenv_generic_env", "iterations_per_s") or 0) / 1e3),
            "deviceenv_Mit_s": r3((get(extra, "deviceenv_user_env", "iterations_per_s") or 0) / 1e6),
+           "mpc_ms_per_control_step_nav_cold_warm_res4_cold_warm": [r3(get(extra, "mpc", k, "ms_per_control_step")) for k in
+                                                                    ("navigation_cold_start", "navigation_warm_start", "res4_cold_start", "res4_warm_start")],
            "deviceenv_from_python_Mit_s": r3((get(extra, "deviceenv_user_env", "from_python_functions", "iterations_per_s") or 0) / 1e6),
            "format": "[ms per batch, roofline frac (, algorithmic flop rate / fp32 peak; ilqr_api_warm: executed flop rate / fp32 peak)]"}
     for key, short in (("cfg5_hvac_ilqr_n32", "cfg5_hvac"), ("cfg5_reservoir_ilqr_n32", "cfg5_reservoir"), ("hvac6_reference_config_ilqr", "hvac6"),
@@ -742,6 +841,10 @@ def extras_only(args):
             extra["torchenv_generic_env"] = torchenv_rate()
         except Exception as exc:                              # noqa: BLE001
             extra["torchenv_generic_env"] = {"error": repr(exc)}
+        try:
+            extra["mpc"] = mpc_rate()
+        except Exception as exc:                              # noqa: BLE001
+            extra["mpc"] = {"error": repr(exc)}
         try:
             extra["deviceenv_user_env"] = deviceenv_rate()
         except Exception as exc:                              # noqa: BLE001

@@ -108,3 +108,62 @@ def solver_of(w, **kwargs):
 def instance_cfg(w, b, u0_host=None):
     """One instance of a workload as the per-instance config ``tests/trace_oracle.py`` takes (kind ``"lq"``)."""
     return dict(F=w["F"][b], f=w["f"][b], C=w["C"][b], c=w["c"][b], low=w["low"], high=w["high"])
+
+
+# ---- the other lines of bench.py's `other_configs` (round 6: defined here too, so that tools/profile_workload.py -- the process rocprofv3
+# runs -- launches the very problems bench.py times; until round 5 they were built inline in bench.py) ------------------------------------------
+
+def headline(B, n=N, m=M, seed=1234):
+    """The headline LQR batch of rank 0 (bench.py main: tests/problems.py:make_lqr_batch_spd, seed 1234 + rank)."""
+    from tfmpc.solvers.lqr import LQR
+    F, f, C, c, x0 = problems.make_lqr_batch_spd(B, n, m, seed=seed)
+    return dict(version="headline/spd-r2", lqr=LQR(F, f, C, c), x0=torch.as_tensor(x0[..., None].astype(np.float32), device="cuda"), T=T)
+
+
+def cfg2():
+    """BASELINE configs[1]: navlin LQR, beta = 5, B = 4 096, T = 50 (tests/problems.py:make_navlin_batch)."""
+    from tfmpc.envs import make_lqr_linear_navigation
+    F, f, C, c, x0n, goal = problems.make_navlin_batch(4096, 5.0)
+    lqr = make_lqr_linear_navigation(goal[..., None], 5.0)
+    return dict(version="cfg2/navlin-r1", lqr=lqr, x0=torch.as_tensor(np.ascontiguousarray(x0n[..., None], dtype=np.float32), device="cuda"), T=50)
+
+
+def cfg4(batches=1):
+    """BASELINE configs[3]: Navigation iLQR, n = m = 2, T = 50; `batches` = 1: the config's 16 384 instances (x0 ~ U(0, 10)^2 from
+    default_rng(4), start actions seed 4); 8: ONE launch of 8 x 16 384 instances (seeds 100 .. 107)."""
+    from tfmpc.envs.navigation import Navigation
+    from tfmpc.solvers.ilqr import iLQR
+    solver = iLQR(Navigation.load(problems.NAV_CONFIG))
+    Bn = 16384
+    if batches == 1:
+        x0 = torch.as_tensor(np.random.default_rng(4).uniform(0, 10, size=(Bn, 2, 1)).astype(np.float32), device="cuda")
+        u0 = solver.random_actions(50, Bn, seed=4)
+    else:
+        x0 = torch.as_tensor(np.concatenate([np.random.default_rng(100 + i).uniform(0, 10, size=(Bn, 2, 1)) for i in range(batches)]).astype(np.float32), device="cuda")
+        u0 = torch.cat([solver.random_actions(50, Bn, seed=100 + i) for i in range(batches)])
+    return dict(version=f"cfg4/nav-r2x{batches}", solver=solver, x0=x0, u0=u0, T=50)
+
+
+def small_env(name, B=16384, horizon=100):
+    """The reference's own env configs (hvac6.config.json, res4.config.json) at B = 16 384, T = 100, <= 12 iterations: the config's initial
+    state times U(0.9, 1.1) per instance -- drawn from default_rng(4) AFTER cfg4's x0 (and, for res4, after hvac6's factors): the order
+    bench.py drew them in when these lines were built inline (rounds 2-5), kept so that the numbers stay comparable."""
+    from tfmpc.envs.hvac import HVAC
+    from tfmpc.envs.reservoir import Reservoir
+    from tfmpc.solvers.ilqr import iLQR
+    rng = np.random.default_rng(4)
+    rng.uniform(0, 10, size=(16384, 2, 1))
+    factors = {"hvac6": rng.uniform(0.9, 1.1, size=(B, 1, 1))}
+    factors["res4"] = rng.uniform(0.9, 1.1, size=(B, 1, 1))
+    env, x0r = (HVAC.load(dict(problems.HVAC6_CONFIG)), problems.HVAC6_X0) if name == "hvac6" else (Reservoir.load(dict(problems.RES4_CONFIG)), problems.RES4_X0)
+    x0 = torch.as_tensor((np.array(x0r, dtype=np.float32)[None] * factors[name]).astype(np.float32), device="cuda")
+    solver = iLQR(env, max_iterations=12)
+    return dict(version=f"small_env/{name}-r2", solver=solver, x0=x0, u0=solver.random_actions(horizon, B, seed=1), T=horizon, n=len(x0r))
+
+
+def lqr32():
+    """A dense LQR beyond the headline tile: n = 32, m = 16, T = 50, B = 8 192 (make_lqr_batch_fast seed 1, 0.5 F)."""
+    from tfmpc.solvers.lqr import LQR
+    F, f, C, c, x0 = problems.make_lqr_batch_fast(8192, 32, 16, seed=1)
+    lqr = LQR(0.5 * F, f, C, c)
+    return dict(version="lqr32/fast-r2", lqr=lqr, x0=lqr._prep_x0(x0), T=50)

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 cp gpurun_out/pmc_$R/summary.json profiles/${R}_mfma16x8_pmc_summary.json
 cp $(ls -t gpurun_out/pmc_$R/stats/*/*_kernel_stats.csv | head -1) profiles/${R}_mfma16x8_kernel_stats.csv
 grep "^{\"summary\"" gpurun_out/pmc_$R/stats.log | tail -1 > profiles/${R}_mfma16x8_bench_under_rocprof.json
-for tag in ilqr_api box box_stable cfg5 small_env large_tile cfg4; do
+for tag in ilqr_api ilqr_api_full box box_stable cfg5 cfg5_hvac cfg5_reservoir small_env hvac6 res4 large_tile lqr32 literal_dims cfg4 cfg4_one_launch cfg2; do
   d=gpurun_out/pmc_${R}_$tag
   [ -f $d/summary.json ] || continue
   cp $d/summary.json profiles/${R}_${tag}_pmc.json

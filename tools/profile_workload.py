@@ -1,6 +1,6 @@
 """One named group of bench.py's workloads, launched the way bench.py launches them, for rocprofv3 (round 6):
 
-    python tools/profile_workload.py <group>         groups: headline ilqr_api cfg5 small_env large_tile cfg4 box_stable box cfg2
+    python tools/profile_workload.py <group>         groups: headline ilqr_api ilqr_api_full cfg5_hvac cfg5_reservoir hvac6 res4 lqr32 literal_dims cfg4 cfg4_one_launch box_stable box cfg2
 
 Per workload of the group: PROFILE_WARM (default 40) untimed launches, then PROFILE_TIMED (default 10) launches inside ONE pair of events --
 bench.py's protocol -- and one JSON line {"workload", "ms_per_launch", "warm", "timed", "iterations"}.  tools/pmc_workload.sh reads those lines
@@ -17,7 +17,7 @@ from tfmpc.solvers.lqr import LQR
 WARM, TIMED = int(os.environ.get("PROFILE_WARM", 40)), int(os.environ.get("PROFILE_TIMED", 10))
 
 
-def run(name, launch, warm=None, timed=None, note=None):
+def run(name, launch, warm=None, timed=None, note=None, units=None):
     warm, timed = WARM if warm is None else warm, TIMED if timed is None else timed
     out = launch(None)
     for _ in range(max(warm - 1, 0)):
@@ -33,6 +33,7 @@ def run(name, launch, warm=None, timed=None, note=None):
     if isinstance(out, dict) and "iterations" in out:
         line["iterations"] = float((out["iterations"].double() + 1).sum())
         line["flagged"] = int((out["status"] != 0).sum())
+    line["units_per_launch"] = units if units is not None else line.get("iterations")       # what bench.py scales the counters by
     if note:
         line["note"] = note
     print("PROFILE_WORKLOAD " + json.dumps(line), flush=True)
@@ -42,55 +43,62 @@ def ilqr_launcher(solver, x0, u0, T):
     return lambda out: solver.solve_device(x0, T, u_init=u0, workspace=None if out is None else out["workspace"])
 
 
+def lqr_launcher(w):
+    return lambda out: w["lqr"].solve_device(w["x0"], w["T"], workspace=None if out is None else out["workspace"])
+
+
 def group_headline():
-    B, n, m, T = 65536, 16, 8, 50
-    F, f, C, c, x0 = problems.make_lqr_batch_spd(B, n, m, seed=0)           # bench.py's headline generator
-    lqr = LQR(F, f, C, c)
-    x0d = torch.as_tensor(x0[..., None].astype(np.float32), device="cuda")
-    run("headline_lqr_n16_m8_T50_B65536", lambda out: lqr.solve_device(x0d, T, workspace=None if out is None else out["workspace"]))
+    run("headline_lqr_n16_m8_T50_B65536", lqr_launcher(workloads.headline(65536)), units=65536)
 
 
 def group_ilqr_api():
     w = workloads.ilqr_api_warm(65536, 16, 8, 50)
     run("ilqr_api_warm", ilqr_launcher(workloads.solver_of(w), w["x0"], w["u0"], w["T"]))
+
+
+def group_ilqr_api_full():
+    w = workloads.ilqr_api_warm(65536, 16, 8, 50)
     with _hip.option("TFMPC_ILQR_LQ_REUSE", "0"):
-        run("ilqr_api_warm_full_pass_every_iteration", ilqr_launcher(workloads.solver_of(w), w["x0"], w["u0"], w["T"]), warm=10, timed=5)
+        run("ilqr_api_warm_full_pass_every_iteration", ilqr_launcher(workloads.solver_of(w), w["x0"], w["u0"], w["T"]))
 
 
-def group_cfg5():
-    for kind in ("hvac", "reservoir"):
-        w = workloads.cfg5(kind, 32768)
-        run(f"cfg5_{kind}", ilqr_launcher(iLQR(w["env"], max_iterations=12), w["x0"], w["u0"], w["T"]))
+def _cfg5(kind):
+    w = workloads.cfg5(kind, 32768)
+    run(f"cfg5_{kind}", ilqr_launcher(iLQR(w["env"], max_iterations=12), w["x0"], w["u0"], w["T"]))
 
 
-def group_small_env():
-    from tfmpc.envs.hvac import HVAC
-    from tfmpc.envs.reservoir import Reservoir
-    B, T = 16384, 100
-    for name, env, x0r in (("hvac6", HVAC.load(dict(problems.HVAC6_CONFIG)), problems.HVAC6_X0), ("res4", Reservoir.load(dict(problems.RES4_CONFIG)), problems.RES4_X0)):
-        x0 = torch.as_tensor(np.tile(np.array(x0r, dtype=np.float32)[None], (B, 1, 1)), device="cuda")
-        s = iLQR(env, max_iterations=12)
-        run(name, ilqr_launcher(s, x0, s.random_actions(T, B, seed=1), T))
+def group_cfg5_hvac(): _cfg5("hvac")
+def group_cfg5_reservoir(): _cfg5("reservoir")
 
 
-def group_large_tile():
-    n, m, B = 32, 16, 8192
-    F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=1)
-    lqr = LQR(F * 0.5, f, C, c)
-    x0d = lqr._prep_x0(x0)
-    run("lqr_n32_m16_T50_B8192", lambda out: lqr.solve_device(x0d, 50, workspace=None if out is None else out["workspace"]))
+def _small(name):
+    w = workloads.small_env(name)
+    run(name, ilqr_launcher(w["solver"], w["x0"], w["u0"], w["T"]))
+
+
+def group_hvac6(): _small("hvac6")
+def group_res4(): _small("res4")
+
+
+def group_lqr32():
+    run("lqr_n32_m16_T50_B8192", lqr_launcher(workloads.lqr32()), units=8192)
+
+
+def group_literal_dims():
     w = workloads.literal_dims(32768)
-    run("literal_dims_ilqr_lq_n32_m16_T100_B32768", ilqr_launcher(workloads.solver_of(w), w["x0"], w["u0"], w["T"]), warm=10, timed=5)
+    run("literal_dims_ilqr_lq_n32_m16_T100_B32768", ilqr_launcher(workloads.solver_of(w), w["x0"], w["u0"], w["T"]), warm=min(WARM, 12), timed=min(TIMED, 6),
+        note="37 ms per launch: 12 + 6 launches")
 
 
 def group_cfg4():
-    from tfmpc.envs.navigation import Navigation
-    T = 50
-    solver = iLQR(Navigation.load(problems.NAV_CONFIG))
-    for B in (16384, 131072):
-        x0 = torch.as_tensor(np.concatenate([np.random.default_rng(4 if B == 16384 else 100 + i).uniform(0, 10, size=(16384, 2, 1)) for i in range(B // 16384)]).astype(np.float32), device="cuda")
-        u0 = torch.cat([solver.random_actions(T, 16384, seed=4 if B == 16384 else 100 + i) for i in range(B // 16384)])
-        run(f"cfg4_navigation_B{B}", ilqr_launcher(solver, x0, u0, T), warm=min(WARM, 20), note="one launch; the kernel is persistent: grid = resident groups")
+    w = workloads.cfg4()
+    run("cfg4_navigation_B16384", ilqr_launcher(w["solver"], w["x0"], w["u0"], w["T"]))
+
+
+def group_cfg4_one_launch():
+    w = workloads.cfg4(batches=8)
+    run("cfg4_navigation_one_launch_of_8x16384", ilqr_launcher(w["solver"], w["x0"], w["u0"], w["T"]), warm=min(WARM, 12), timed=min(TIMED, 6),
+        note="the persistent group kernel: grid = resident groups; 12 + 6 launches")
 
 
 def group_box_stable():
@@ -105,12 +113,7 @@ def group_box():
 
 
 def group_cfg2():
-    B, T = 4096, 50
-    for beta in (5.0, 0.0):
-        F, f, C, c, x0 = problems.make_navlin_batch(B, beta)
-        lqr = LQR(F, f, C, c)
-        x0d = lqr._prep_x0(x0)
-        run(f"cfg2_navlin_beta{beta:g}", lambda out: lqr.solve_device(x0d, T, workspace=None if out is None else out["workspace"]))
+    run("cfg2_navlin_beta5", lqr_launcher(workloads.cfg2()), units=4096)
 
 
 if __name__ == "__main__":
