@@ -236,8 +236,9 @@ def _control_limited_compare(cfgs, dev, N, final, caps, masks, m, pick, groups, 
 @pytest.mark.gpu
 def test_control_limited_workload_teacher_forced_on_the_devices_free_sets():
     """The default run: a tenth of the full sampling below (GPU-suite wall time; the restatement costs seconds per pass on the heavy
-    instances) -- 32 instances in order, 4 of each heavy kind."""
-    _control_limited(n_order=32, n_group=4, cap_light=12, cap_heavy=6)
+    instances) -- 40 instances in order (among them #1 and #38, whose passes 1 and 4 round 5 had to EXCUSE at 476 x and 665 x the tolerance:
+    on the device's free sets they are inside it), 4 of each heavy kind."""
+    _control_limited(n_order=40, n_group=4, cap_light=12, cap_heavy=6)
 
 
 @pytest.mark.gpu
