@@ -143,7 +143,7 @@ def test_large_tile_solve_matches_wave_kernel_oracle_and_lqr(force_kernel, n, m,
         assert abs(float(tot_i[b]) - cs.sum()) <= 2e-3 * np.abs(cs).sum()
 
 
-@pytest.mark.parametrize("n,m,T", [(16, 8, 50), (12, 6, 20), (9, 3, 16)])
+@pytest.mark.parametrize("n,m,T", [(16, 8, 50), (12, 6, 20), (9, 3, 16), (32, 16, 40), (24, 12, 20), (20, 5, 16)])
 def test_gain_reusing_later_passes_agree_with_full_passes(n, m, T):
     """Round 6 (TFMPC_ILQR_LQ_REUSE): for a time-invariant LQ env at mu = 0 the matrices of the backward pass (Q_xx, Q_ux, Q_uu -> K_t, V_xx)
     do not depend on the trajectory, so from the second pass on the kernel keeps K_t and Q_uu^-1 of the first and runs the vector recursion
@@ -151,7 +151,11 @@ def test_gain_reusing_later_passes_agree_with_full_passes(n, m, T):
     decisions, and numbers that agree like two fp32 programs with different summation order.  An unreachable atol makes every instance run all
     its iterations, i.e. five gain-reusing passes in a row, each followed by a line search on ITS k_t."""
     B = 96
-    F, f, C, c, x0 = _problem(B, n, m, seed=7 * n + m)
+    if n > 16:                       # the large-tile twin (ilqr_lq_mfma32.hip: -Q_uu^-1 through fifteen identity columns + the last pivot's reciprocal)
+        F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=7 * n + m)
+        F, x0 = F * (0.9 / np.sqrt(n)), x0.astype(np.float32)
+    else:
+        F, f, C, c, x0 = _problem(B, n, m, seed=7 * n + m)
     u0 = (0.1 * np.random.default_rng(2).normal(size=(B, T, m, 1))).astype(np.float32)
     for kwargs, min_passes in ((dict(), 2), (dict(atol=1e-12, max_iterations=6), 6)):
         solver = iLQR(LQEnv(F, f, C, c), **kwargs)

@@ -207,7 +207,8 @@ struct IlqrWsLayout {
         lane = round256(c + (size_t)B * (T + 1) * f);
         wave = lane + round256(ilqr_lane_extra_workspace_bytes(B, n, m, T));
         minv = round256(wave + ilqr_adjoint_mfma_workspace_bytes(B, n, m, T));
-        total = minv + ilqr_lq_mfma_reuse_workspace_bytes(B, n, m, T);       // -Q_uu^-1 of the LQ env's first pass (ilqr_lq_mfma.hip, REUSE)
+        total = minv + ilqr_lq_mfma_reuse_workspace_bytes(B, n, m, T)        // -Q_uu^-1 of the LQ env's first pass (ilqr_lq_mfma.hip, REUSE) ...
+                     + ilqr_lq_mfma32_reuse_workspace_bytes(B, n, m, T);     // ... or of its large-tile twin (the two shape ranges are disjoint)
     }
     static size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
 };
@@ -305,6 +306,7 @@ int tfmpc_ilqr_solve_trace_qp_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cf
             IlqrLqArgs la{*env, *cfg, B, T, x0, u_init, states, actions, costs, iterations, status, a.wsK, a.wsk, a.wsu,
                           a.wsx, a.wsu, a.wsc};
             la.trace = tr;
+            la.wsMinv = lay.total > lay.minv ? reinterpret_cast<float *>(base + lay.minv) : nullptr;
             if ((rc = ilqr_lq_mfma32_launch(la, st)) != TFMPC_OK) return rc;
             a.only_flagged = 1;
             g_last_ilqr_kernel = "lq_mfma32 (matrix cores, 2 x 2 tiles) + wave kernel for flagged instances";

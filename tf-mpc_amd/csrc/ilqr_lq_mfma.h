@@ -31,7 +31,7 @@ struct IlqrLqArgs {
     int helper_teams, help_after;   // (set by the launcher) teams of helper blocks; passes an instance makes before it may claim one
     const int32_t *gate;         // (set by the launcher) MODE 0 runs only if (*gate != 0) == (gate_value != 0); null: always
     int gate_value;
-    float *wsMinv;               // ilqr_lq_mfma.hip: -Q_uu(t)^-1 [B][T][8][8] for the gain-reusing later passes, or null: full pass every time
+    float *wsMinv;               // ilqr_lq_mfma.hip / ilqr_lq_mfma32.hip: -Q_uu(t)^-1 [B][T][8][8] / [B][T][16][16] for the gain-reusing later passes, or null: full pass every time
 };
 
 // Control-limited twin (ilqr_lq_box_mfma.hip): bounded actions or any finite bound; the whole state machine
@@ -45,6 +45,7 @@ int ilqr_lq_mfma32_launch(const IlqrLqArgs &a, hipStream_t stream);
 
 size_t ilqr_lq_mfma_lds_bytes(int T);
 size_t ilqr_lq_mfma_reuse_workspace_bytes(int B, int n, int m, int T);     // the -Q_uu^-1 slab (0 for shapes the kernel does not take)
+size_t ilqr_lq_mfma32_reuse_workspace_bytes(int B, int n, int m, int T);   // likewise for the large-tile twin ([T][16][16])
 bool ilqr_lq_mfma_supported(const TfmpcEnv &env, int T);
 int ilqr_lq_mfma_launch(const IlqrLqArgs &a, hipStream_t stream);
 

@@ -16,6 +16,7 @@
 
 #include "ilqr_lq_mfma.h"
 #include "mfma_bf16x3.h"
+#include "options.h"
 #include "wave_ldlt.h"
 #include "wave_ops.h"
 
@@ -61,6 +62,13 @@ constexpr int kZld = 52;
 constexpr int kTC = 48;
 constexpr int kLdsFloats = (kSweepFloats > (kTC + 1) * kZld ? kSweepFloats : (kTC + 1) * kZld) + 8;
 
+// REUSE (round 6): as in ilqr_lq_mfma.hip -- the env is time-invariant LQ and every pass runs at mu = 0, so K_t, V_xx(t), Q_uu(t) do not depend on the
+// trajectory.  The first backward pass also leaves -Q_uu(t)^-1 in the workspace: lanes 49 .. 63 of the 16-pivot LDL^T solve (beyond the 32 + 16 + 1
+// columns of [Q_ux | Q_uu | Q_u]: zero columns until now) read the identity columns e_0 .. e_14 and come out holding columns 0 .. 14 of the inverse;
+// its last row is their sixteenth entries by symmetry, and its (15, 15) entry is -1 / d_15, the folded reciprocal of the last pivot (wave_ldlt.h).
+// Every later pass runs the VECTOR recursion of ilqr.py:122-123,152-156 alone -- Q_x = l_x + F_x^T V_x, Q_u = l_u + F_u^T V_x, k = -Q_uu^-1 Q_u,
+// V_x' = Q_x + K^T Q_u -- as wave-wide fp32 mat-vecs with K_t, Q_uu^-1, l_z(t) from four-deep register rings.  TFMPC_ILQR_LQ_REUSE=0: full pass always.
+template <bool REUSE>
 __global__ __launch_bounds__(kWave, 2) void ilqr_lq_mfma32_kernel(IlqrLqArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
@@ -76,6 +84,7 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_mfma32_kernel(IlqrLqArgs a)
     const float *cg = a.env.p[3] + (size_t)b * a.env.stride[3];
     float *Kg = a.wsK + (size_t)b * T * m * n;
     float *kg = a.wsk + (size_t)b * T * m;
+    float *Mg = REUSE ? a.wsMinv + (size_t)b * T * (M * M) : nullptr;      // -Q_uu(t)^-1, [T][16][16] (padded actions: -1 on the diagonal)
     // trajectory buffers: [0] the output arrays, [1] the workspace; the nominal one is [flip]
     float *const xb[2] = {a.states + (size_t)b * Tp * n, a.wsx + (size_t)b * Tp * n};
     float *const ub[2] = {a.actions + (size_t)b * T * m, a.wsu + (size_t)b * T * m};
@@ -91,28 +100,32 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_mfma32_kernel(IlqrLqArgs a)
     };
     auto cz = [&](int zr) { const int r = zmap(zr); return r >= 0 ? cg[r] : 0.0f; };
 
-    // ---- operands resident for the whole solve: bf16x3 fragments of F~ = [F_x | F_u] (no f column: the affine slot carries V_x)
+    // ---- operands of the sweep: bf16x3 fragments of F~ = [F_x | F_u] (no f column: the affine slot carries V_x) and the tiles of C_s.
+    // Resident for the whole solve -- or, with REUSE, loaded inside the one pass that uses them (84 registers that are dead afterwards)
     ConstFrag Fc[2][3];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int ct = 0; ct < 3; ++ct) {
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = Fz(16 * kt + 4 * q + r, 16 * ct + i);
-            Fc[kt][ct] = const_frag(v);
-        }
     f32x4 Cxx[2][2], Cux[2], Cuu;
+    auto load_sweep_operands = [&]() {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int a_ = 0; a_ < 2; ++a_)
+            for (int ct = 0; ct < 3; ++ct) {
+                f32x4 v;
 #pragma unroll
-            for (int b_ = 0; b_ < 2; ++b_) Cxx[a_][b_][r] = Cs(16 * a_ + 4 * q + r, 16 * b_ + i);
+                for (int r = 0; r < 4; ++r) v[r] = Fz(16 * kt + 4 * q + r, 16 * ct + i);
+                Fc[kt][ct] = const_frag(v);
+            }
 #pragma unroll
-        for (int b_ = 0; b_ < 2; ++b_) Cux[b_][r] = Cs(N + 4 * q + r, 16 * b_ + i);
-        Cuu[r] = Cs(N + 4 * q + r, N + i);
-    }
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+                for (int b_ = 0; b_ < 2; ++b_) Cxx[a_][b_][r] = Cs(16 * a_ + 4 * q + r, 16 * b_ + i);
+#pragma unroll
+            for (int b_ = 0; b_ < 2; ++b_) Cux[b_][r] = Cs(N + 4 * q + r, 16 * b_ + i);
+            Cuu[r] = Cs(N + 4 * q + r, N + i);
+        }
+    };
+    if (!REUSE) load_sweep_operands();
     const int kv_src = (i == 0) ? kkv + q : kZeros + q;
 
     // ---- C Z on the f32 matrix cores over the trajectory (xs, us), 16 timesteps per tile; row T carries u = 0.
@@ -221,46 +234,59 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_mfma32_kernel(IlqrLqArgs a)
                 kv = row ? kg[(size_t)t * m + ka] : 0.0f;
             }
         };
-        float Kn[8], xn8[8], kn = 0.0f, un = 0.0f;
+        // inputs of the coming steps in a register ring, statically indexed through the unrolled inner loop and refilled unconditionally (wave_ops.h,
+        // "two rules of the time loops"): four steps deep where the registers are there (REUSE: the sweep's operands are dead by now), else one
+        constexpr int kRing = REUSE ? 4 : 1;
+        static_assert(kTC % kRing == 0, "a chunk holds whole turns of the ring");
+        float KR[kRing][8], xR[kRing][8], kR[kRing], uR[kRing];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { Kn[j] = 0.0f; xn8[j] = 0.0f; }
-        if (T > 0) load_step(0, Kn, xn8, kn, un);
+        for (int d = 0; d < kRing; ++d) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { KR[d][j] = 0.0f; xR[d][j] = 0.0f; }
+            kR[d] = 0.0f; uR[d] = 0.0f;
+            if (T > 0) load_step(d < T ? d : T - 1, KR[d], xR[d], kR[d], uR[d]);
+        }
         float rmax = 0.0f;
         __syncthreads();
         for (int t0 = 0; t0 < T; t0 += kTC) {
             const int tc = (T - t0 < kTC) ? (T - t0) : kTC;
-            for (int tt = 0; tt < tc; ++tt) {
-                const int t = t0 + tt;
-                float *zt = zs + tt * kZld;
-                float Kc[8], xc[8];
+            for (int tb = 0; tb < tc; tb += kRing) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { Kc[j] = Kn[j]; xc[j] = xn8[j]; }
-                const float kc = kn, uc = un;
-                if (t + 1 < T) load_step(t + 1, Kn, xn8, kn, un);
-                float u = uc;
-                if (search) {
-                    const f32x4 xlo = *reinterpret_cast<const f32x4 *>(&zt[8 * jc]), xhi = *reinterpret_cast<const f32x4 *>(&zt[8 * jc + 4]);
-                    float du = 0.0f;
+                for (int d = 0; d < kRing; ++d) {
+                    const int tt = tb + d;
+                    if (tt >= tc) break;
+                    const int t = t0 + tt;
+                    float *zt = zs + tt * kZld;
+                    float Kc[8], xc[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { du = fmaf(Kc[j], xlo[j] - xc[j], du); du = fmaf(Kc[4 + j], xhi[j] - xc[4 + j], du); }   // K (x - x_hat)
-                    du += dpp<kDppXor1>(du);
-                    du += dpp<kDppXor2>(du);
-                    du = fmaf(alpha, kc, du);
-                    rmax = fmaxf(rmax, fabsf(du));                                     // :206
-                    u = uc + du;
+                    for (int j = 0; j < 8; ++j) { Kc[j] = KR[d][j]; xc[j] = xR[d][j]; }
+                    const float kc = kR[d], uc = uR[d];
+                    load_step(t + kRing < T ? t + kRing : T - 1, KR[d], xR[d], kR[d], uR[d]);
+                    float u = uc;
+                    if (search) {
+                        const f32x4 xlo = *reinterpret_cast<const f32x4 *>(&zt[8 * jc]), xhi = *reinterpret_cast<const f32x4 *>(&zt[8 * jc + 4]);
+                        float du = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { du = fmaf(Kc[j], xlo[j] - xc[j], du); du = fmaf(Kc[4 + j], xhi[j] - xc[4 + j], du); }   // K (x - x_hat)
+                        du += dpp<kDppXor1>(du);
+                        du += dpp<kDppXor2>(du);
+                        du = fmaf(alpha, kc, du);
+                        rmax = fmaxf(rmax, fabsf(du));                                     // :206
+                        u = uc + du;
+                    }
+                    zt[N + ka] = u;                      // the four lanes of the row hold the same value
+                    lds_sync();
+                    float xn = f_part;                   // x' = F z + f
+#pragma unroll
+                    for (int j4 = 0; j4 < 6; ++j4) {
+                        const f32x4 z4 = *reinterpret_cast<const f32x4 *>(&zt[24 * fc + 4 * j4]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) xn = fmaf(Fr[4 * j4 + j], z4[j], xn);
+                    }
+                    xn += dpp<kDppXor1>(xn);
+                    zt[kZld + fi] = xn;
+                    lds_sync();
                 }
-                zt[N + ka] = u;                      // the four lanes of the row hold the same value
-                __syncthreads();
-                float xn = f_part;                   // x' = F z + f
-#pragma unroll
-                for (int j4 = 0; j4 < 6; ++j4) {
-                    const f32x4 z4 = *reinterpret_cast<const f32x4 *>(&zt[24 * fc + 4 * j4]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) xn = fmaf(Fr[4 * j4 + j], z4[j], xn);
-                }
-                xn += dpp<kDppXor1>(xn);
-                zt[kZld + fi] = xn;
-                __syncthreads();
             }
             for (int idx = lane; idx < tc * n; idx += kWave) xs[(size_t)(t0 + 1) * n + idx] = zs[(1 + idx / n) * kZld + idx % n];
             for (int idx = lane; idx < tc * m; idx += kWave) us[(size_t)t0 * m + idx] = zs[(idx / m) * kZld + N + idx % m];
@@ -280,15 +306,23 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_mfma32_kernel(IlqrLqArgs a)
     int status = 0, iteration = 0;
     bool converged = false, retry = false;
     float delta = 1.0f;                                                // :216 (mu stays 0 in this kernel; delta is only logged)
-    for (iteration = 0; iteration < cfg.max_iterations; ++iteration) {
-        float *const xhat = xb[flip], *const uhat = ub[flip];
-        float *const xc = xb[flip ^ 1], *const uc = ub[flip ^ 1], *const cc = cb[flip ^ 1];
+    // One iteration = derivatives, backward pass, line search (ilqr.py:234-279) as pieces, so that with REUSE the first iteration (full pass) stands
+    // outside the loop of the later ones (vector recursion) and the sweep's 84 operand registers are dead while those run.
+    float dV1 = 0.0f, gsum = 0.0f;
+    float *xhat = nullptr, *uhat = nullptr, *xc = nullptr, *uc = nullptr, *cc = nullptr, *Lx = nullptr, *Lu = nullptr;
+    auto derivatives = [&]() {
+        xhat = xb[flip]; uhat = ub[flip];
+        xc = xb[flip ^ 1]; uc = ub[flip ^ 1]; cc = cb[flip ^ 1];
+        Lx = xc; Lu = uc;
         // ---- derivatives (ilqr.py:234): l_z(t) of the nominal trajectory, parked in the candidate buffers ---------------
-        float *const Lx = xc, *const Lu = uc;
         cz_pass(xhat, uhat, true, Lx, Lu, nullptr);
         for (int idx = lane; idx < kSweepFloats; idx += kWave) lds[idx] = 0.0f;
+        if (REUSE && lane < M - 1) lds[kMs + lane * kMld + N + M + 1 + lane] = 1.0f;      // e_0 .. e_14 in the columns of lanes 49 .. 63 (same wave: after the zeroing)
         __syncthreads();
 
+    };
+    auto sweep_pass = [&]() -> bool {            // false: Q_uu not positive definite (needs mu > 0: the wave kernel re-solves the instance)
+        if (REUSE) load_sweep_operands();
         // ---- backward (ilqr.py:94-172 with mu = 0): the sweep of lqr_mfma32x16.hip ----------------------------------------
         f32x4 Vd[2][2], vd[2];
 #pragma unroll
@@ -308,7 +342,7 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_mfma32_kernel(IlqrLqArgs a)
         vd[0] = load_col(Lx + (size_t)T * n, n, 0);                            // V_x = l_x^f
         vd[1] = load_col(Lx + (size_t)T * n, n, 16);
         int min_pivot_bits = 0x3f800000;
-        float dV1 = 0.0f, gsum = 0.0f;
+        dV1 = 0.0f; gsum = 0.0f;
         f32x4 lxn[2], lun;                                                       // l_x(t), l_u(t) one step ahead
         if (T > 0) {
             lxn[0] = load_col(Lx + (size_t)(T - 1) * n, n, 0);
@@ -398,7 +432,16 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_mfma32_kernel(IlqrLqArgs a)
                 quc[2 * e + 1] = M2[e][1];
             }
             float Mr[M];
-            ldlt_solve_neg<M, N>(M2, Mr, min_pivot_bits);                           // [K | k] = -Q_uu^-1 [Q_ux | Q_u]  :357-362
+            float ninv_last = 0.0f;
+            ldlt_solve_neg<M, N>(M2, Mr, min_pivot_bits, REUSE ? &ninv_last : nullptr);   // [K | k] = -Q_uu^-1 [Q_ux | Q_u]  :357-362
+            if (REUSE && lane > N + M) {                  // lanes 49 .. 63: column j = lane - 49 of -Q_uu^-1 = its row j; their 16th entries = row 15
+                float *Mt = Mg + (size_t)t * (M * M);
+                const int j = lane - (N + M + 1);
+#pragma unroll
+                for (int e = 0; e < M; e += 4) *reinterpret_cast<f32x4 *>(&Mt[j * M + e]) = f32x4{Mr[e], Mr[e + 1], Mr[e + 2], Mr[e + 3]};
+                Mt[(M - 1) * M + j] = Mr[M - 1];
+                if (lane == 63) Mt[M * M - 1] = ninv_last;
+            }
             {   // dV1 += k^T Q_u (:166), g_norm term max_a |k_a| / (|u_hat_a| + 1) (:243): lane 48 holds k and Q_u
                 float p1 = 0.0f, gm = 0.0f;
 #pragma unroll
@@ -466,7 +509,113 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_mfma32_kernel(IlqrLqArgs a)
             }
             __syncthreads();
         }
-        if (min_pivot_bits <= 0) { status |= TFMPC_ST_NOT_PD; retry = true; break; }   // needs mu > 0
+        if (min_pivot_bits <= 0) { status |= TFMPC_ST_NOT_PD; retry = true; return false; }   // needs mu > 0
+        return true;
+    };
+    auto vector_pass = [&]() {
+        // ---- the vector recursion alone (REUSE, iterations >= 1): K_t and -Q_uu(t)^-1 of the first pass are this pass's too -----------------------
+        constexpr int kVx = kMs, kQx = kMs + 32, kQu = kMs + 64;      // V_x(32) | Q_x(32) | Q_u(16) staging (the elimination buffers are idle)
+        const int lo = opaque(lane);
+        const int o = lo >> 2, part = lo & 3;              // layout A: 16 outputs x 4 contraction parts (F~^T V_x in three rounds; Q_uu^-1 Q_u)
+        const int o2 = lo >> 1, half = lo & 1;             // layout B: 32 outputs x 2 halves (K^T Q_u)
+        float Ft[3][8];                                    // F~[8 part + j][16 r + o]
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Ft[r][j] = Fz(8 * part + j, 16 * r + o);
+        const bool exact = n == N && m == M && ((reinterpret_cast<uintptr_t>(Lx) | reinterpret_cast<uintptr_t>(Kg)) & 15u) == 0;
+        // per-step inputs from HBM: l_z(t) in layout A (three per lane), four entries of row o of -Q_uu^-1, eight of column o2 of K_t
+        auto load_step = [&](int t, float (&lz)[3], f32x4 &Mi, float (&Kt)[8]) {
+            if (exact) {
+                const float *Lxt = Lx + (size_t)t * N, *Lut = Lu + (size_t)t * M, *Kr = Kg + (size_t)t * (M * N);
+                lz[0] = Lxt[o]; lz[1] = Lxt[16 + o]; lz[2] = Lut[o];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Kt[j] = Kr[(8 * half + j) * N + o2];
+            } else {
+                lz[0] = o < n ? Lx[(size_t)t * n + o] : 0.0f;
+                lz[1] = 16 + o < n ? Lx[(size_t)t * n + 16 + o] : 0.0f;
+                lz[2] = o < m ? Lu[(size_t)t * m + o] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Kt[j] = (8 * half + j < m && o2 < n) ? Kg[(size_t)t * m * n + (8 * half + j) * n + o2] : 0.0f;
+            }
+            Mi = *reinterpret_cast<const f32x4 *>(Mg + (size_t)t * (M * M) + 4 * lo);
+        };
+        // V_x = l_x^f                                                                    :113
+        if (lane < N) lds[kVx + lane] = lane < n ? Lx[(size_t)T * n + lane] : 0.0f;
+        constexpr int kDepth = 4;
+        float lzR[kDepth][3], KtR[kDepth][8];
+        f32x4 MiR[kDepth];
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) load_step(T - 1 - d >= 0 ? T - 1 - d : 0, lzR[d], MiR[d], KtR[d]);
+        float p1 = 0.0f;
+        __syncthreads();
+        for (int tb = T - 1; tb >= 0; tb -= kDepth) {
+#pragma unroll
+            for (int d = 0; d < kDepth; ++d) {
+                const int t = tb - d;
+                if (t < 0) break;
+                float lz[3], Kt[8];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) lz[j] = lzR[d][j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Kt[j] = KtR[d][j];
+                const f32x4 Mi = MiR[d];
+                load_step(t - kDepth >= 0 ? t - kDepth : 0, lzR[d], MiR[d], KtR[d]);       // unconditional: the compiler can count the loads in flight
+                const f32x4 va = *reinterpret_cast<const f32x4 *>(&lds[kVx + 8 * part]), vb = *reinterpret_cast<const f32x4 *>(&lds[kVx + 8 * part + 4]);
+                float y[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    float acc = Ft[r][0] * va[0];
+#pragma unroll
+                    for (int j = 1; j < 4; ++j) acc = fmaf(Ft[r][j], va[j], acc);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc = fmaf(Ft[r][4 + j], vb[j], acc);
+                    acc += dpp<kDppXor1>(acc);
+                    acc += dpp<kDppXor2>(acc);
+                    y[r] = lz[r] + acc;                                                  // Q_x[o], Q_x[16 + o], Q_u[o]      :122-123
+                }
+                if (part == 0) { lds[kQx + o] = y[0]; lds[kQx + 16 + o] = y[1]; lds[kQu + o] = y[2]; }
+                lds_sync();
+                const f32x4 qa = *reinterpret_cast<const f32x4 *>(&lds[kQu + 4 * part]);
+                float kk = Mi[0] * qa[0];                                                // k = -Q_uu^-1 Q_u                   :357-362
+#pragma unroll
+                for (int j = 1; j < 4; ++j) kk = fmaf(Mi[j], qa[j], kk);
+                kk += dpp<kDppXor1>(kk);
+                kk += dpp<kDppXor2>(kk);
+                const f32x4 q0 = *reinterpret_cast<const f32x4 *>(&lds[kQu + 8 * half]), q1 = *reinterpret_cast<const f32x4 *>(&lds[kQu + 8 * half + 4]);
+                float w = Kt[0] * q0[0];
+#pragma unroll
+                for (int j = 1; j < 4; ++j) w = fmaf(Kt[j], q0[j], w);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w = fmaf(Kt[4 + j], q1[j], w);
+                w += dpp<kDppXor1>(w);                                                   // (K^T Q_u)[o2] = (Q_xu k)[o2]
+                const float vnew = lds[kQx + o2] + w;                                    // V_x' = Q_x + Q_xu k                :152-156
+                if (part == 0) {
+                    p1 = fmaf(kk, y[2], p1);                                             // dV1 += k^T Q_u                     :166
+                    if (o < m) kg[(size_t)t * m + o] = kk;
+                }
+                lds_sync();                                                              // (every lane has read Q_x before V_x is replaced)
+                if (half == 0) lds[kVx + o2] = vnew;
+                lds_sync();
+            }
+        }
+        __syncthreads();                                   // k_t (global memory) is read by other lanes below
+        dV1 = wave_sum(p1);
+        // g_norm term: mean_t max_a |k_a| / (|u_hat_a| + 1) (:243), sixteen lanes per time step (hardware reciprocal as in the full pass)
+        float gs = 0.0f;
+        for (int base = 0; base < T * M; base += kWave) {
+            const int idx = base + lane, t = idx >> 4, ua = idx & 15;
+            float ratio = 0.0f;
+            if (idx < T * M && ua < m) ratio = fabsf(kg[(size_t)t * m + ua]) * __builtin_amdgcn_rcpf(fabsf(uhat[(size_t)t * m + ua]) + 1.0f);
+            ratio = fmaxf(ratio, dpp<kDppXor1>(ratio));
+            ratio = fmaxf(ratio, dpp<kDppXor2>(ratio));
+            ratio = fmaxf(ratio, dpp<0x141>(ratio));                                     // row_half_mirror
+            ratio = fmaxf(ratio, dpp<0x140>(ratio));                                     // row_mirror: every lane of the row holds the row's maximum
+            if (ua == 0 && idx < T * M) gs += ratio;
+        }
+        gsum = wave_sum(gs);
+    };
+    auto finish_pass = [&]() -> bool {           // true: the solve of this instance ends here (converged, or handed to the wave kernel)
         const float dV2 = -0.5f * dV1;                                                 // :167 at mu = 0
         const float g_norm = T > 0 ? gsum / (float)T : 0.0f;
         // decision trace (what ilqr.py:243-279 logs per pass): mu = 0 in every pass of this kernel, so row = iteration; an
@@ -474,7 +623,7 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_mfma32_kernel(IlqrLqArgs a)
         if (g_norm < cfg.atol) {                                                       // :243-248
             if (lane == 0) trace_write(a.trace, b, iteration, iteration, 0.0f, delta, J_hat, g_norm, -1, 0.0f, 0.0f, -1, -1.0f);
             converged = true;
-            break;
+            return true;
         }
 
         // ---- forward / line search (ilqr.py:317-355) -------------------------------------------------------------------
@@ -496,9 +645,28 @@ __global__ __launch_bounds__(kWave, 2) void ilqr_lq_mfma32_kernel(IlqrLqArgs a)
             trace_write(a.trace, b, iteration, iteration, 0.0f, delta, J_hat, g_norm, ai_last,
                         ai_last >= 0 ? cfg.alphas[ai_last] : 0.0f, J, accept ? 1 : 0, residual);
         if (small_step || accept) { flip ^= 1; J_hat = J; }                        // the candidate becomes the nominal
-        if (small_step) { converged = true; break; }
-        if (!accept) { retry = true; break; }                                      // would raise mu (:267-270)
+        if (small_step) { converged = true; return true; }
+        if (!accept) { retry = true; return true; }                                      // would raise mu (:267-270)
         delta = fminf(1.0f / cfg.delta_0, delta / cfg.delta_0);                    // :259-266 at mu = 0
+        return false;
+    };
+    if (REUSE) {
+        derivatives();
+        bool stop = !sweep_pass();
+        if (!stop) stop = finish_pass();
+        if (!stop) {
+            for (iteration = 1; iteration < cfg.max_iterations; ++iteration) {
+                derivatives();
+                vector_pass();
+                if (finish_pass()) break;
+            }
+        }
+    } else {
+        for (iteration = 0; iteration < cfg.max_iterations; ++iteration) {
+            derivatives();
+            if (!sweep_pass()) break;
+            if (finish_pass()) break;
+        }
     }
     if (iteration >= cfg.max_iterations) iteration = cfg.max_iterations - 1;
     (void)converged;
@@ -526,9 +694,17 @@ bool ilqr_lq_mfma32_supported(const TfmpcEnv &env, int T)
            !(env.n <= 16 && env.m <= 8) && env.n + env.m >= 12 && T >= 1;
 }
 
+size_t ilqr_lq_mfma32_reuse_workspace_bytes(int B, int n, int m, int T)
+{
+    if (!(n <= N && m <= M && !(n <= 16 && m <= 8) && n + m >= 12) || T < 1) return 0;      // the shapes ilqr_lq_mfma32_supported admits
+    return (size_t)B * T * (M * M) * sizeof(float);
+}
+
 int ilqr_lq_mfma32_launch(const IlqrLqArgs &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(ilqr_lq_mfma32_kernel, dim3(a.B), dim3(kWave), 0, stream, a);
+    const bool reuse = a.wsMinv != nullptr && (reinterpret_cast<uintptr_t>(a.wsMinv) & 15u) == 0 && !option_is(kOptIlqrLqReuse, "0");
+    if (reuse) hipLaunchKernelGGL(ilqr_lq_mfma32_kernel<true>, dim3(a.B), dim3(kWave), 0, stream, a);
+    else hipLaunchKernelGGL(ilqr_lq_mfma32_kernel<false>, dim3(a.B), dim3(kWave), 0, stream, a);
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
 }
 

@@ -18,8 +18,11 @@ namespace tfmpc {
 // -row_p / d_p (Nkeep) instead of keeping them live.  Rows (2k, 2k+1) share a register pair (v_pk_fma_f32).
 // min_pivot_bits tracks the smallest pivot as float bits: <= 0 at the end <=> Q_uu was not positive definite.
 // CAUTION: ignoring the lower triangle is only consistent while the caller keeps the value matrix exactly symmetric.
+// `last_ninv` (optional): receives -1 / d_{R-1}, the reciprocal of the LAST pivot with its sign folded in -- which is the (R-1, R-1) entry of
+// -Q_uu^-1 (for an LDL^T with unit lower L the last diagonal entry of the inverse is 1 / d_last): the one entry the gain-reusing iLQR kernel
+// cannot read off its fifteen identity columns (ilqr_lq_mfma32.hip).
 template <int R, int KQ>
-__device__ __forceinline__ void ldlt_solve_neg(f32x2 (&M2)[R / 2], float (&X)[R], int &min_pivot_bits)
+__device__ __forceinline__ void ldlt_solve_neg(f32x2 (&M2)[R / 2], float (&X)[R], int &min_pivot_bits, float *last_ninv = nullptr)
 {
     static_assert(R % 2 == 0, "rows come in register pairs");
     f32x2 N2[R / 2];
@@ -32,6 +35,7 @@ __device__ __forceinline__ void ldlt_solve_neg(f32x2 (&M2)[R / 2], float (&X)[R]
         asm("s_min_i32 %0, %0, %1" : "+s"(min_pivot_bits) : "s"(pvb) : "scc");
         const float ninv = __builtin_amdgcn_rcpf(-__builtin_bit_cast(float, pvb));
         const float Mn = Mp * ninv;                      // -row_p / d_p
+        if (last_ninv && p == R - 1) *last_ninv = ninv;
         N2[pp][ps] = Mn;
         Nkeep[p] = Mn;
         float nl[R];                                     // -L[s][p], s > p
