@@ -1048,6 +1048,9 @@ def main():
             flop_s = flops / (f32_ms * 1e-3) / 1e12
             line["strict_f32_variant"] = {"option": "TFMPC_LQR_MFMA=f32 (v_mfma_f32_16x16x4_f32 instead of bf16x3)",
                                           "kernel_ms": f32_ms, "achieved": flop_s, "frac": flop_s / PEAK_F32_TFLOPS}
+            # inside `roofline` too, so that a reader who keeps only that block keeps the like-for-like figure
+            line["roofline"]["frac_strict_f32"] = flop_s / PEAK_F32_TFLOPS
+            line["roofline"]["kernel_ms_strict_f32"] = f32_ms
         if gathered is not None:
             line["gathered_states_shape"] = list(gathered[0].shape)
         if gather_ms is not None:

@@ -531,6 +531,7 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
     int probe_steps = 0;                 // time steps the current sweep has run
 #endif
     int trace_row = 0;                   // the pass the next sweep belongs to (= passes made so far): set by the solve loop
+    constexpr int kGainRing = 4;         // rollouts: steps of gains in flight
     auto backward = [&](const float *Lz, float mu) -> StepResult {
         StepResult res{0.0f, 0.0f, 0.0f, 0.0f, false, 0};
 #ifdef TFMPC_BOX_PROBE
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
             } else if (q == 2) {
                 lds[kQx + i] = T01t[0];                            // Q_x[i]               :122
             }
-            __syncthreads();
+            lds_sync();
             // this lane's column of [Q_ux | Q_uu | Q_u] and its regularised twin; its row of H and of Q_uu; Q_u[r8], u_hat[r8]
             float Mcol[8], Mreg[8], Hrow0[8], Hrow[8];
             {
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
                 *reinterpret_cast<f32x4 *>(&lds[kKs + lane * 8 + 4]) = f32x4{Kcol[4], Kcol[5], Kcol[6], Kcol[7]};
             }
             if (lane < M) lds[kKs + (N + M) * 8 + lane] = k_r;
-            __syncthreads();
+            lds_sync();
             // dV1 += k^T Q_u, dV2 += 1/2 k^T Q_uu k (:164-167), g_norm term (:243)
             {
                 const f32x4 k03 = *reinterpret_cast<const f32x4 *>(&lds[kKs + (N + M) * 8]);
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
                 *reinterpret_cast<f32x4 *>(&lds[kPs + i * 8 + 4 * q]) = Pt + T01t;
                 if (i == M) *reinterpret_cast<f32x4 *>(&lds[kPs + (N + M) * 8 + 4 * q]) = pt + T11;
             }
-            __syncthreads();
+            lds_sync();
             // V_xx' = Q_xx + Q_xu K + K^T S ; V_x' = Q_x + Q_xu k + K^T sp                :149-161
             f32x4 vacc = *reinterpret_cast<const f32x4 *>(&lds[t01_src]);
 #pragma unroll
@@ -672,7 +673,7 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
                 vacc = mfma(g0, s1, vacc);
             }
             *reinterpret_cast<f32x4 *>(&lds[kVt + i * kVtLd + 4 * q]) = T00;
-            __syncthreads();
+            lds_sync();
 #pragma unroll
             for (int r = 0; r < 4; ++r) Vd[r] = 0.5f * (T00[r] + lds[kVt + (4 * q + r) * kVtLd + i]);      // :162
             vd = vacc;
@@ -682,8 +683,9 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
                 if (ka < m && 2 * jc + 1 < n) Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] = ky;
                 if (lane < m) kg[(size_t)t * m + lane] = lds[kKs + (N + M) * 8 + lane];
             }
-            __syncthreads();
+            lds_sync();
         }
+        __syncthreads();                                   // the gains (global memory) are read by other lanes from here on
         res.g_norm = T > 0 ? gsum / (float)T : 0.0f;
         return res;
     };
@@ -699,27 +701,39 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
             gy = (row && 2 * jc + 1 < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] : 0.0f;
             gk = row ? kg[(size_t)t * m + ka] : 0.0f;
         };
-        float Kxn = 0.0f, Kyn = 0.0f, kkn = 0.0f;
-        load_gain(0, Kxn, Kyn, kkn);
+        // gains through a register ring kGainRing steps deep, statically indexed through the unrolled inner loop, refilled unconditionally (wave_ops.h:
+        // "two rules of the time loops"); the step's phases are ordered by the LDS-only fence -- for the instances that set this kernel's launch
+        // time (one wave alone on its SIMD, 100+ dependent passes) a memory round trip per step was most of a step
+        float gxR[kGainRing], gyR[kGainRing], gkR[kGainRing];
+#pragma unroll
+        for (int d = 0; d < kGainRing; ++d) {
+            gxR[d] = gyR[d] = gkR[d] = 0.0f;
+            if (T > 0) load_gain(d < T ? d : T - 1, gxR[d], gyR[d], gkR[d]);
+        }
         __syncthreads();
-        for (int t = 0; t < T; ++t) {
-            const float *zh = nom + t * kZld;
-            float *zt = cand + t * kZld;
-            const float Kx = Kxn, Ky = Kyn, kk = kkn;
-            if (t + 1 < T) load_gain(t + 1, Kxn, Kyn, kkn);
-            const float2 xv = *reinterpret_cast<const float2 *>(&zt[2 * jc]);
-            const float2 xh = *reinterpret_cast<const float2 *>(&zh[2 * jc]);
-            float du = fmaf(Kx, xv.x - xh.x, Ky * (xv.y - xh.y));              // K (x - x_hat)  :193-194
-            du += dpp<kDppXor1>(du);
-            du += dpp<kDppXor2>(du);
-            du += dpp<kDppHalfMirror>(du);
-            du = fmaf(alpha, kk, du);
-            rmax = fmaxf(rmax, fabsf(du));                                     // :206 (before the clip)
-            if (jc == 0) zt[N + ka] = fminf(fmaxf(zh[N + ka] + du, low_k), high_k);      // :196-197
-            __syncthreads();
-            const float xn = next_state(zt);
-            if (fc == 0) zt[kZld + fi] = xn;
-            __syncthreads();
+        for (int tb = 0; tb < T; tb += kGainRing) {
+#pragma unroll
+            for (int d = 0; d < kGainRing; ++d) {
+                const int t = tb + d;
+                if (t >= T) break;
+                const float *zh = nom + t * kZld;
+                float *zt = cand + t * kZld;
+                const float Kx = gxR[d], Ky = gyR[d], kk = gkR[d];
+                load_gain(t + kGainRing < T ? t + kGainRing : T - 1, gxR[d], gyR[d], gkR[d]);
+                const float2 xv = *reinterpret_cast<const float2 *>(&zt[2 * jc]);
+                const float2 xh = *reinterpret_cast<const float2 *>(&zh[2 * jc]);
+                float du = fmaf(Kx, xv.x - xh.x, Ky * (xv.y - xh.y));              // K (x - x_hat)  :193-194
+                du += dpp<kDppXor1>(du);
+                du += dpp<kDppXor2>(du);
+                du += dpp<kDppHalfMirror>(du);
+                du = fmaf(alpha, kk, du);
+                rmax = fmaxf(rmax, fabsf(du));                                     // :206 (before the clip)
+                if (jc == 0) zt[N + ka] = fminf(fmaxf(zh[N + ka] + du, low_k), high_k);      // :196-197
+                lds_sync();
+                const float xn = next_state(zt);
+                if (fc == 0) zt[kZld + fi] = xn;
+                lds_sync();
+            }
         }
         residual = wave_max(rmax);
         cz_pass(cand, Tp, ccand, false);
@@ -740,38 +754,47 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
             gy = (row && 2 * jc + 1 < n) ? Kg[(size_t)t * m * n + ka * n + 2 * jc + 1] : 0.0f;
             gk = row ? kg[(size_t)t * m + ka] : 0.0f;
         };
-        float Kxn = 0.0f, Kyn = 0.0f, kkn = 0.0f;
-        load_gain(0, Kxn, Kyn, kkn);
+        float gxR[kGainRing], gyR[kGainRing], gkR[kGainRing];            // (ring + LDS-only fence: see `forward`)
+#pragma unroll
+        for (int d = 0; d < kGainRing; ++d) {
+            gxR[d] = gyR[d] = gkR[d] = 0.0f;
+            if (T > 0) load_gain(d < T ? d : T - 1, gxR[d], gyR[d], gkR[d]);
+        }
         __syncthreads();
-        for (int t = 0; t < T; ++t) {
-            const float *zh = nom + t * kZld;
-            float *ztA = cand + t * kZld, *ztB = cand2 + t * kZld;
-            const float Kx = Kxn, Ky = Kyn, kk = kkn;
-            if (t + 1 < T) load_gain(t + 1, Kxn, Kyn, kkn);
-            const float2 xh = *reinterpret_cast<const float2 *>(&zh[2 * jc]);
-            const float2 xvA = *reinterpret_cast<const float2 *>(&ztA[2 * jc]);
-            const float2 xvB = *reinterpret_cast<const float2 *>(&ztB[2 * jc]);
-            float duA = fmaf(Kx, xvA.x - xh.x, Ky * (xvA.y - xh.y));           // K (x - x_hat)  :193-194
-            float duB = fmaf(Kx, xvB.x - xh.x, Ky * (xvB.y - xh.y));
-            duA += dpp<kDppXor1>(duA);
-            duB += dpp<kDppXor1>(duB);
-            duA += dpp<kDppXor2>(duA);
-            duB += dpp<kDppXor2>(duB);
-            duA += dpp<kDppHalfMirror>(duA);
-            duB += dpp<kDppHalfMirror>(duB);
-            duA = fmaf(alphaA, kk, duA);
-            duB = fmaf(alphaB, kk, duB);
-            rmaxA = fmaxf(rmaxA, fabsf(duA));                                  // :206 (before the clip)
-            rmaxB = fmaxf(rmaxB, fabsf(duB));
-            if (jc == 0) {
-                const float uh = zh[N + ka];
-                ztA[N + ka] = fminf(fmaxf(uh + duA, low_k), high_k);           // :196-197
-                ztB[N + ka] = fminf(fmaxf(uh + duB, low_k), high_k);
+        for (int tb = 0; tb < T; tb += kGainRing) {
+#pragma unroll
+            for (int d = 0; d < kGainRing; ++d) {
+                const int t = tb + d;
+                if (t >= T) break;
+                const float *zh = nom + t * kZld;
+                float *ztA = cand + t * kZld, *ztB = cand2 + t * kZld;
+                const float Kx = gxR[d], Ky = gyR[d], kk = gkR[d];
+                load_gain(t + kGainRing < T ? t + kGainRing : T - 1, gxR[d], gyR[d], gkR[d]);
+                const float2 xh = *reinterpret_cast<const float2 *>(&zh[2 * jc]);
+                const float2 xvA = *reinterpret_cast<const float2 *>(&ztA[2 * jc]);
+                const float2 xvB = *reinterpret_cast<const float2 *>(&ztB[2 * jc]);
+                float duA = fmaf(Kx, xvA.x - xh.x, Ky * (xvA.y - xh.y));           // K (x - x_hat)  :193-194
+                float duB = fmaf(Kx, xvB.x - xh.x, Ky * (xvB.y - xh.y));
+                duA += dpp<kDppXor1>(duA);
+                duB += dpp<kDppXor1>(duB);
+                duA += dpp<kDppXor2>(duA);
+                duB += dpp<kDppXor2>(duB);
+                duA += dpp<kDppHalfMirror>(duA);
+                duB += dpp<kDppHalfMirror>(duB);
+                duA = fmaf(alphaA, kk, duA);
+                duB = fmaf(alphaB, kk, duB);
+                rmaxA = fmaxf(rmaxA, fabsf(duA));                                  // :206 (before the clip)
+                rmaxB = fmaxf(rmaxB, fabsf(duB));
+                if (jc == 0) {
+                    const float uh = zh[N + ka];
+                    ztA[N + ka] = fminf(fmaxf(uh + duA, low_k), high_k);           // :196-197
+                    ztB[N + ka] = fminf(fmaxf(uh + duB, low_k), high_k);
+                }
+                lds_sync();
+                const float xnA = next_state(ztA), xnB = next_state(ztB);
+                if (fc == 0) { ztA[kZld + fi] = xnA; ztB[kZld + fi] = xnB; }
+                lds_sync();
             }
-            __syncthreads();
-            const float xnA = next_state(ztA), xnB = next_state(ztB);
-            if (fc == 0) { ztA[kZld + fi] = xnA; ztB[kZld + fi] = xnB; }
-            __syncthreads();
         }
         resA = wave_max(rmaxA);
         resB = wave_max(rmaxB);
