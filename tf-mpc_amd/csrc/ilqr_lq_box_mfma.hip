@@ -1209,6 +1209,29 @@ int ilqr_lq_box_mfma_launch(const IlqrLqArgs &a, hipStream_t stream)
         const uintptr_t p0 = reinterpret_cast<uintptr_t>(a.board), p1 = (p0 + 255) & ~(uintptr_t)255;
         if (a.board_bytes < (p1 - p0) + box_board_bytes(teams, a.T)) teams = 0;
         if (teams) {
+            // Helpers spin on the board until every owner has finished, so they must never be able to hold the chip: ASKED of the runtime at launch
+            // time (round 6; until then argued in a comment) -- the helper blocks may take at most an eighth of the blocks this kernel can have
+            // resident at once (occupancy x CUs), else there are fewer teams, or none.  (Owners only ever wait for helpers that have checked in
+            // on the board, and those waits are bounded: what this check adds is that owners always find room to run beside spinning helpers.)
+            static thread_local int cached_device = -1;
+            static thread_local size_t cached_lds = 0;
+            static thread_local long cached_capacity = 0;           // (asked once per device and LDS size: the property query is not free)
+            int device = 0;
+            if (hipGetDevice(&device) != hipSuccess) device = -2;
+            if (device != cached_device || lds != cached_lds) {
+                int per_cu = 0;
+                hipDeviceProp_t prop;
+                cached_capacity = 0;
+                if (device >= 0 && hipGetDeviceProperties(&prop, device) == hipSuccess &&
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ilqr_lq_box_mfma_kernel<false, 0, true>, kWave, lds) == hipSuccess)
+                    cached_capacity = (long)per_cu * prop.multiProcessorCount;
+                cached_device = device;
+                cached_lds = lds;
+            }
+            const long capacity = cached_capacity;
+            while (teams > 0 && (long)teams * kBoxHelpers * 8 > capacity) --teams;
+        }
+        if (teams) {
             run.board = reinterpret_cast<void *>(p1);
             run.helper_teams = teams;
             run.help_after = option_int(kOptBoxHelpAfter, kBoxHelpAfter);       // (TFMPC_BOX_HELP_AFTER: tests lower it to make every instance claim)
