@@ -54,6 +54,9 @@ def make_lqr_batch_fast(B, n, m, seed=0):
             _, V = np.linalg.eigh(np.matmul(np.ascontiguousarray(np.swapaxes(Ac, 1, 2)), Ac))
             V = V[:, :, ::-1]
             C[lo:lo + 2048] = np.matmul(V * s[lo:lo + 2048, None, :], np.ascontiguousarray(np.swapaxes(V, 1, 2)))
+    else:
+        U, _, Vt = np.linalg.svd(np.matmul(np.swapaxes(A, 1, 2), A))
+        C = np.matmul(U * s[:, None, :], Vt)
     C = 0.5 * (C + np.swapaxes(C, 1, 2))
     x0 = rng.normal(size=(B, n))
     return F, f, C, c, x0

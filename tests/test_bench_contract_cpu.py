@@ -102,12 +102,12 @@ def test_extra_summary_is_compact_and_survives_missing_entries():
     sys.path.insert(0, ROOT)
     import bench
     empty = bench.summarise_extras({"error": "the extras process exited with 3"})
-    assert empty["ilqr_api_warm"] == [None, None] and empty["cfg5_hvac"] == [None, None]
+    assert empty["ilqr_api_warm"] == [None, None, None] and empty["cfg5_hvac"] == [None, None]        # (ms, frac, executed-flop frac: round 6)
     full = bench.summarise_extras({
-        "ilqr_api": {"ms_per_batch": 5.4588, "roofline": {"frac": 0.35744}, "cold_start": {"ms_per_batch": 5.57, "roofline": {"frac": 0.357}},
+        "ilqr_api": {"ms_per_batch": 5.4588, "roofline": {"frac": 0.35744, "frac_executed": 0.2011}, "cold_start": {"ms_per_batch": 5.57, "roofline": {"frac": 0.357}},
                      "control_limited": {"ms_per_batch": 512.6, "stable_open_loop_variant": {"ms_per_batch": 88.86}}},
         "other_configs": {"cfg5_hvac_ilqr_n32": {"ms_per_batch": 13.147, "roofline": {"frac": 0.1938}, "algorithmic_flop_rate": {"frac": 0.4294}},
                           "cfg4_navigation_ilqr": {"ms_per_batch": 9.19, "one_launch_of_8x16384_instances": {"iterations_per_s": 56.14e6}}},
         "bf16_storage_sweep": {"error": "x"}})
-    assert full["ilqr_api_warm"] == [5.46, 0.357] and full["cfg5_hvac"] == [13.1, 0.194, 0.429] and full["cfg4_one_launch_8x16384_Mit_s"] == 56.1
+    assert full["ilqr_api_warm"] == [5.46, 0.357, 0.201] and full["cfg5_hvac"] == [13.1, 0.194, 0.429] and full["cfg4_one_launch_8x16384_Mit_s"] == 56.1
     assert full["bf16_sweep"] is None and len(json.dumps(full)) < 1200
