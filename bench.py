@@ -522,9 +522,9 @@ def other_config_rates():
     res = {}
     w2 = workloads.cfg2()
     lqr, x0n_d = w2["lqr"], w2["x0"]                                                     # (resident before the timed region)
-    _, dt = timed(lambda ws: lqr.solve_device(x0n_d, 50, workspace=ws), 20)
+    _, dt = timed(lambda ws: lqr.solve_device(x0n_d, 50, workspace=ws), 200)     # (0.05 ms per launch: 200 launches behind one synchronize)
     # cfg2: n = m = 2, T = 50, F and C shared by the batch: read x0, goal 16 B, write x, u, c 253 floats = 1 012 B per solve
-    res["cfg2_navlin_lqr"] = {"ms_per_batch": dt * 1e3, "solves_per_s": 4096 / dt, "batch": 4096, "horizon": 50, "launches_timed": 20,
+    res["cfg2_navlin_lqr"] = {"ms_per_batch": dt * 1e3, "solves_per_s": 4096 / dt, "batch": 4096, "horizon": 50, "launches_timed": 200,
                               "kernel": _hip_kernel_name(2, 2, 50),
                               "roofline": dict(roofline_hbm(1028 * 4096, dt, pmc_traffic("lqr_lane", None, 4096, file_tag="cfg2")), algorithmic_bytes_per_solve=1028,
                                                note="4 096 solves are 64 wavefronts of a lane-per-instance kernel on a 1 024-SIMD chip: the launch is one wave's "
@@ -636,7 +636,7 @@ def other_config_rates():
     del solver, x0d
     w32 = workloads.lqr32()
     big, x0d = w32["lqr"], w32["x0"]
-    _, dt = timed(lambda ws: big.solve_device(x0d, 50, workspace=ws), 3)
+    _, dt = timed(lambda ws: big.solve_device(x0d, 50, workspace=ws), 20)
     tf = lqr_flops_per_solve(32, 16, 50) * 8192 / dt / 1e12
     res["lqr_n32_m16"] = {"ms_per_batch": dt * 1e3, "solves_per_s": 8192 / dt, "batch": 8192, "horizon": 50,
                           "kernel": _hip_kernel_name(32, 16, 50),
