@@ -35,6 +35,11 @@ def test_translation_of_the_three_envs_and_where_their_constants_go():
     assert "sin(" in res.source and "abs(" in res.source and "max(0.0f" in res.source           # relu -> max(0, y): the tie goes to the constant
     assert res.action_space.is_bounded()
     hv = torch_envs.hvac(problems.hvac_config(6)).to_device_env()
+    # the translator PROVES piecewise-affine costs (sums, products with constants, relu / abs of such): those envs get the costate form of the kernels
+    assert res.zero_cost_hessian and hv.zero_cost_hessian and not nav.zero_cost_hessian
+    unbounded = torch_envs.reservoir(problems.RES4_CONFIG)
+    unbounded.action_space = type(unbounded.action_space)(-np.inf, np.inf, (4, 1))
+    assert not unbounded.to_device_env().zero_cost_hessian                      # (unbounded actions: ilqr.py:143 takes the Cholesky controller)
     # a zero of the adjacency mask is structure: the pairs of rooms that do not touch cost no statement
     dense = torch_envs.hvac(dict(problems.hvac_config(6), adj=(~np.eye(6, dtype=bool)).tolist())).to_device_env()
     assert hv.source.count("\n") < dense.source.count("\n")
@@ -231,3 +236,33 @@ def test_piecewise_linear_envs_from_python_take_the_same_first_iterations(which)
         xs, us, cs, it = ilqr_ref.ILQRRef(oenv, max_iterations=1).solve(x0[b].astype(np.float64), T, u_init=_np(torch.as_tensor(u0[b])))
         got = _np(one["costs"][b])[:-1].sum()
         assert abs(cs[:-1].sum() - got) <= 5e-3 * abs(cs[:-1].sum()), (b, cs[:-1].sum(), got)
+
+
+@pytest.mark.gpu
+@needs_hipcc
+@pytest.mark.parametrize("which", ["reservoir4", "hvac6"])
+def test_costate_form_of_a_user_env_equals_its_dense_form(which):
+    """A user env whose cost the translator proved piecewise affine runs the COSTATE form of the fused kernel (one first-order dual evaluation per
+    direction instead of second-order linearisation + dense backward pass; every step size of a line search at once, one per lane).  Against the very
+    same device source compiled WITHOUT the promise (dense form: dual-number Hessians, which come out exactly zero, box-QP branch never taken): the
+    reference's backward pass takes the bang-bang branch either way (ilqr.py:137-141), so decisions and trajectories agree like two fp32 programs."""
+    from tfmpc.envs.deviceenv import DeviceEnv
+    cfg, builtin, python_env, xr, _ = _case(which)
+    fast = python_env.to_device_env()
+    assert fast.zero_cost_hessian
+    dense = DeviceEnv(fast.source, fast.state_size, fast.action_size, params=fast.params, low=0.0, high=1.0, zero_cost_hessian=False)
+    n = fast.state_size
+    rng = np.random.default_rng(11)
+    B, T = 64, 40
+    x0 = rng.uniform(xr[0] + 0.3 * (xr[1] - xr[0]), xr[1] - 0.2 * (xr[1] - xr[0]), size=(B, n, 1)).astype(np.float32)
+    u0 = iLQR(builtin).random_actions(T, B, seed=3)
+    a = iLQR(fast, max_iterations=6).solve_device(x0, T, u_init=u0, trace_rows=20)
+    b = iLQR(dense, max_iterations=6).solve_device(x0, T, u_init=u0, trace_rows=20)
+    torch.cuda.synchronize()
+    assert int(a["status"].abs().sum()) == 0 and int(b["status"].abs().sum()) == 0
+    # first pass: same nominal trajectory, same gradients up to the summation order -> same step size on (nearly) every instance, same cost
+    first_alpha = (a["trace"][:, 0, 5] == b["trace"][:, 0, 5]).float().mean()
+    assert float(first_alpha) >= 0.9
+    ca, cb = _np(a["costs"]).sum(1), _np(b["costs"]).sum(1)
+    assert np.median(np.abs(ca - cb) / np.abs(cb)) <= 1e-3
+    assert np.all((_np(a["actions"]) >= -1e-6) & (_np(a["actions"]) <= 1 + 1e-6))

@@ -402,8 +402,26 @@ __device__ inline BackwardResult backward_pass_adjoint(IlqrSmem &s, const EnvLds
             for (int a = lane; a < m; a += kWave) s.uh[a] = uhat[(size_t)t * m + a];
         }
         wsync();
-        const float l = Env<KIND>::cost(e, s.xh, s.uh);
+        float l = 0.0f;
         float p1 = 0.0f, gmax = 0.0f;
+        if constexpr (KIND == TFMPC_ENV_USER) {
+            // a user env (user_env.h): direction i of z = [x; u] in lane i, Q_z[i] by ONE first-order dual evaluation of the user's transition and cost
+            for (int base = 0; base < n + m; base += kWave) {
+                const int i = base + lane;
+                float acc;
+                l = Env<KIND>::adjoint_direction(e, s.xh, s.uh, s.Vx, i, acc);
+                if (i < n) {
+                    s.Qx[i] = acc;
+                } else if (i < n + m) {
+                    const int a = i - n;
+                    const float kt = (acc >= 0.0f) ? (e.low[a] - s.uh[a]) : (e.high[a] - s.uh[a]);       // ilqr.py:140-141
+                    kg[(size_t)t * m + a] = stq(s, kt);
+                    p1 = fmaf(kt, acc, p1);
+                    gmax = fmaxf(gmax, fabsf(kt) / (fabsf(s.uh[a]) + 1.0f));
+                }
+            }
+        } else {
+        l = Env<KIND>::cost(e, s.xh, s.uh);
         for (int i = lane; i < n + m; i += kWave) {
             if (i < n) {
                 s.Qx[i] = Env<KIND>::adjoint_qx(e, s.xh, s.uh, s.Vx, Env<KIND>::cost_grad_x_i(e, s.xh, i), i);
@@ -415,6 +433,7 @@ __device__ inline BackwardResult backward_pass_adjoint(IlqrSmem &s, const EnvLds
                 p1 = fmaf(kt, acc, p1);
                 gmax = fmaxf(gmax, fabsf(kt) / (fabsf(s.uh[a]) + 1.0f));
             }
+        }
         }
         r.J += l;
         r.dV1 += wave_sum(p1);

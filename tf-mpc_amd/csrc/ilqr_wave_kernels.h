@@ -218,6 +218,7 @@ __global__ __launch_bounds__(kWave) void ilqr_solve_kernel(TfmpcEnv env, TfmpcIl
     float mu = 0.0f, delta = 1.0f;                                        // :215-216
     int status = 0, attempts = 0, iteration = 0;
     bool converged = false, give_up = false;
+    int last_index = 0;                      // (user envs on the costate path: the step size the previous line search accepted)
     const bool bounded = env.bounded != 0;
     EnvProvider<KIND> prov{s, e, xhat, uhat, T};
 
@@ -250,7 +251,24 @@ __global__ __launch_bounds__(kWave) void ilqr_solve_kernel(TfmpcEnv env, TfmpcIl
             bool accept = false;
             float residual = 0.0f, J = 0.0f;
             int ai_last = -1;
-            for (int ai = 0; ai < cfg.n_alphas; ++ai) {
+            bool searched = false;
+            if constexpr (kAdjoint && KIND == TFMPC_ENV_USER) {
+                // a user env on the costate path: every step size at once, one per lane (user_env.h: speculative_search); the candidate of the
+                // guessed step size is stored on the way, any other chosen one is rolled out again below -- the same arithmetic per step size
+                if (!cfg.storage_bf16 && cfg.n_alphas <= kWave) {
+                    int chosen = 0;
+                    Env<KIND>::speculative_search(e, cfg, T, xhat, uhat, kg, r.J, r.dV1, last_index < cfg.n_alphas ? last_index : 0, xc, uc, cc, chosen, accept, J, residual);
+                    wsync();
+                    if (chosen != (last_index < cfg.n_alphas ? last_index : 0)) {
+                        forward_pass<KIND, false>(s, e, T, cfg.alphas[chosen], xhat, uhat, Kg, kg, xc, uc, cc, J, residual);
+                        wsync();
+                    }
+                    ai_last = chosen;
+                    if (accept) last_index = chosen;
+                    searched = true;
+                }
+            }
+            for (int ai = 0; !searched && ai < cfg.n_alphas; ++ai) {
                 const float alpha = cfg.alphas[ai];
                 ai_last = ai;
                 forward_pass<KIND, !kAdjoint>(s, e, T, alpha, xhat, uhat, Kg, kg, xc, uc, cc, J, residual);

@@ -141,9 +141,95 @@ using D2 = Dual<Dual<float>>;
 namespace tfmpc {
 
 // The instance's parameter floats are p[0] (TfmpcEnv::n_zones of them: envs.h:env_param_len), copied to LDS like every env's.
+#ifndef TFMPC_USER_ZERO_HESSIAN
+#define TFMPC_USER_ZERO_HESSIAN 0
+#endif
 template <> struct Env<TFMPC_ENV_USER> {
-    static constexpr bool kPiecewiseLinearCost = false;
+    // TFMPC_USER_ZERO_HESSIAN (stated by the Python side: tfmpc.envs.deviceenv.DeviceEnv(zero_cost_hessian=True), or proved by the translator of
+    // TorchEnv.to_device_env): every second derivative of cost / final_cost is identically zero and the actions are bounded -- V_xx stays exactly 0,
+    // the backward pass of ilqr.py:94-172 only ever takes its bang-bang branch (:137-141), and the fused solve kernel runs the COSTATE
+    // form: `adjoint_direction` / `final_grad` below (one first-order dual evaluation per direction) and `speculative_search`.
+    static constexpr bool kPiecewiseLinearCost = TFMPC_USER_ZERO_HESSIAN != 0;
     static constexpr int N = TFMPC_USER_N, M = TFMPC_USER_M, D = N + M;
+
+    // direction j of z = [x; u]: Q_z[j] = dl/dz_j + sum_i df_i/dz_j V_x[i] (ilqr.py:122-123), ONE first-order dual evaluation of transition and cost
+    // in this lane; returns the stage cost (every lane: the same value)
+    static __device__ float adjoint_direction(const EnvLds &e, const float *x, const float *u, const float *Vx, int j, float &qz)
+    {
+        using ad::D1;
+        D1 xs[N], us[M], out[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) xs[i] = D1(x[i], i == j ? 1.0f : 0.0f);
+#pragma unroll
+        for (int a = 0; a < M; ++a) us[a] = D1(u[a], N + a == j ? 1.0f : 0.0f);
+        tfmpc_user::transition<D1>(e.p[0], xs, us, out);
+        const D1 c = tfmpc_user::cost<D1>(e.p[0], xs, us);
+        float acc = c.d;
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc = fmaf(out[i].d, Vx[i], acc);
+        qz = acc;
+        return c.v;
+    }
+    // V_x = l_x^f (ilqr.py:101), lane j < N its entry j; returns the final cost
+    static __device__ float final_grad(const EnvLds &e, const float *x, float *Vx)
+    {
+        using ad::D1;
+        float value = 0.0f;
+        for (int base = 0; base < N; base += kWave) {
+            const int j = base + lane_id();
+            D1 xs[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) xs[i] = D1(x[i], i == j ? 1.0f : 0.0f);
+            const D1 c = tfmpc_user::final_cost<D1>(e.p[0], xs);
+            if (j < N) Vx[j] = c.d;
+            value = c.v;
+        }
+        return value;
+    }
+    // The line search of ilqr.py:317-355 with K == 0, EVERY step size at once, one per lane: the user's transition / cost are scalar programs that each
+    // lane of a wave evaluates anyway (wave-uniform in the sequential rollout), so lane s rolls out step size s for the price of one rollout.  Lane `guess`
+    // (the step size the previous pass accepted) stores its candidate as it goes; the reference's rule -- the FIRST step size with z >= c1, else the last
+    // one, rejected (:322-353) -- is a ballot.  `chosen` != `guess`: the caller rolls the chosen one out again (forward_pass, same arithmetic: same bits).
+    static __device__ void speculative_search(const EnvLds &e, const TfmpcIlqrConfig &cfg, int T, const float *xhat, const float *uhat, const float *kg,
+                                              float J_hat, float dV1, int guess, float *xc, float *uc, float *cc, int &chosen, bool &accept, float &J_out,
+                                              float &residual_out)
+    {
+        const int lane = lane_id();
+        const int mine = lane < cfg.n_alphas ? lane : cfg.n_alphas - 1;
+        const float alpha = cfg.alphas[mine];
+        const bool keep = lane == guess;
+        const float *p = e.p[0];
+        float x[N], xn[N], u[M];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { x[i] = xhat[i]; if (keep) xc[i] = x[i]; }
+        float J = 0.0f, rmax = 0.0f;
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int a = 0; a < M; ++a) {
+                const float du = alpha * kg[(size_t)t * M + a];                                          // :193-194 (K == 0)
+                u[a] = fminf(fmaxf(uhat[(size_t)t * M + a] + du, e.low[a]), e.high[a]);                  // :196-197
+                rmax = fmaxf(rmax, fabsf(du));                                                            // :206
+                if (keep) uc[(size_t)t * M + a] = u[a];
+            }
+            const float c = tfmpc_user::cost<float>(p, x, u);                                            // :198
+            tfmpc_user::transition<float>(p, x, u, xn);                                                  // :199
+            J += c;                                                                                      // :205
+            if (keep) cc[t] = c;
+#pragma unroll
+            for (int i = 0; i < N; ++i) { x[i] = xn[i]; if (keep) xc[(size_t)(t + 1) * N + i] = xn[i]; }
+        }
+        const float fc = tfmpc_user::final_cost<float>(p, x);                                            // :208-210
+        if (keep) cc[T] = fc;
+        J += fc;
+        const float delta_J = -alpha * (dV1 + alpha * 0.0f);                                             // :339 (dV2 == 0)
+        const float dcost = J_hat - J;
+        const float z = (delta_J > 0.0f) ? dcost / delta_J : ((dcost > 0.0f) ? 1.0f : ((dcost < 0.0f) ? -1.0f : 0.0f));   // :342-346
+        const unsigned long long pass = __ballot(lane < cfg.n_alphas && z >= cfg.c1);
+        accept = pass != 0ull;
+        chosen = accept ? __builtin_ctzll(pass) : cfg.n_alphas - 1;
+        J_out = __shfl(J, chosen, kWave);
+        residual_out = __shfl(rmax, chosen, kWave);
+    }
 
     template <class S>
     static __device__ __forceinline__ void seed_point(const float *x, const float *u, S (&xs)[N], S (&us)[M])

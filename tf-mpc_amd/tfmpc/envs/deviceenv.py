@@ -47,13 +47,13 @@ def hipcc_path():
     return None
 
 
-def translation_unit(source, state_size, action_size, param_count=0):
+def translation_unit(source, state_size, action_size, param_count=0, zero_hessian=False):
     """``param_count``: the env's parameter floats per instance, if known (a small parameter vector is then held in registers by the 2 x 2
     lane-group kernel instead of being read through the pointer at every use, csrc/user_env.h)."""
     with open(os.path.join(_CSRC, "user_env_kernels.hip.in")) as fh:
         text = fh.read()
     return (text.replace("@STATE_SIZE@", str(int(state_size))).replace("@ACTION_SIZE@", str(int(action_size)))
-            .replace("@PARAM_COUNT@", str(int(param_count)))
+            .replace("@PARAM_COUNT@", str(int(param_count))).replace("@ZERO_HESSIAN@", "1" if zero_hessian else "0")
             .replace("@SOURCE@", source))       # (the headers are found through -I: the text, hence the cache key, does not depend on where the tree lives)
 
 
@@ -95,11 +95,11 @@ def _cache_roots():
     return [_CACHE, user, os.path.join(tempfile.gettempdir(), f"tfmpc-userenv-{os.getuid()}")]
 
 
-def build(source, state_size, action_size, param_count=0):
+def build(source, state_size, action_size, param_count=0, zero_hessian=False):
     """Compile (or find in the cache) the companion library of a user env; returns its path.  Works without a GPU.
     A process that is being PROFILED should find the library prebuilt (``__graft_entry__.build`` does that for the repo's own sources):
     the compiler is started with the profiler's variables removed, but a profiled run is not the place to compile."""
-    text = translation_unit(source, state_size, action_size, param_count)
+    text = translation_unit(source, state_size, action_size, param_count, zero_hessian)
     stamp = _stamp(text)
     hipcc = hipcc_path()
     name = "libtfmpc_userenv.so"
@@ -175,7 +175,13 @@ class _UserLibrary:
 class DeviceEnv(DiffEnv):
     kind = _hip.ENV_USER
 
-    def __init__(self, source, state_size, action_size, params=(), low=None, high=None):
+    def __init__(self, source, state_size, action_size, params=(), low=None, high=None, zero_cost_hessian=False):
+        """``zero_cost_hessian=True``: a PROMISE that every second derivative of ``cost`` and ``final_cost`` is identically zero (piecewise-linear
+        costs like the reference's HVAC / Reservoir).  With bounded actions the reference's backward pass then only ever takes its bang-bang
+        branch (``ilqr.py:137-141``: ``V_xx`` stays exactly 0), and the companion library is built on the COSTATE form of the
+        kernels: one first-order dual evaluation of ``transition`` and ``cost`` per direction and time step instead of the second-order
+        linearisation + the dense backward pass, and every step size of a line search rolled out at once, one per lane.
+        ``TorchEnv.to_device_env()`` sets it from what its translator proved about the cost; a false promise gives wrong gains."""
         self.source = str(source)
         self._n, self._m = int(state_size), int(action_size)
         self.params = np.asarray(params, dtype=np.float32)
@@ -185,6 +191,7 @@ class DeviceEnv(DiffEnv):
         lo = -np.inf if low is None else low
         hi = np.inf if high is None else high
         self.action_space = Box(lo, hi, (self._m, 1))
+        self.zero_cost_hessian = bool(zero_cost_hessian) and self.action_space.is_bounded()      # (unbounded: ilqr.py:143 takes the Cholesky controller)
         self._lib = None
 
     @property
@@ -200,7 +207,7 @@ class DeviceEnv(DiffEnv):
 
     def _library(self):
         if self._lib is None:
-            path = build(self.source, self._n, self._m, self.n_zones)
+            path = build(self.source, self._n, self._m, self.n_zones, self.zero_cost_hessian)
             if path not in _loaded:
                 _loaded[path] = _UserLibrary(path)
             self._lib = _loaded[path]

@@ -37,10 +37,13 @@ class UnsupportedOperation(NotImplementedError):
 class _E:
     """One scalar of the unrolled program: a C++ expression (a variable name, ``p[k]``, ``x[i]`` or a literal) and its kind --
     'S' (the templated scalar: depends on the inputs), 'f' (float: constants and parameters), 'b' (bool), 'i' (int literal)."""
-    __slots__ = ("code", "kind", "val")
+    __slots__ = ("code", "kind", "val", "lin")
 
-    def __init__(self, code, kind, val=None):
-        self.code, self.kind, self.val = code, kind, val
+    def __init__(self, code, kind, val=None, lin=True):
+        # lin (kind 'S' only): the value is PIECEWISE AFFINE in (x, u) -- sums, products with constants, abs / max / min / where of such --
+        # so every second derivative the dual numbers would compute for it is exactly zero (what the translator reports as
+        # `cost_is_piecewise_linear`: the reference's backward pass then only ever takes its bang-bang branch, ilqr.py:137-141)
+        self.code, self.kind, self.val, self.lin = code, kind, val, lin
 
     def __repr__(self):
         return f"<{self.kind}:{self.code}>"
@@ -96,12 +99,12 @@ class _Program:
         self.lines = []
         self.count = 0
 
-    def new(self, kind, expr):
+    def new(self, kind, expr, lin=True):
         name = f"v{self.count}"
         self.count += 1
         ctype = {"S": "S", "f": "float", "b": "bool"}[kind]
         self.lines.append(f"    const {ctype} {name} = {expr};")
-        return _E(name, kind)
+        return _E(name, kind, lin=lin if kind == "S" else True)
 
 
 def _arr(elems, shape=None):
@@ -171,7 +174,13 @@ class _Translator:
         if op == "/" and b.val == 1.0:
             return a
         kind = "S" if "S" in (a.kind, b.kind) else "f"
-        return self.prog.new(kind, f"{a.code} {op} {b.code}")
+        if op in "+-":
+            lin = a.lin and b.lin
+        elif op == "*":
+            lin = (a.lin and b.lin) and not (a.kind == "S" and b.kind == "S")       # a constant times a piecewise-affine value
+        else:
+            lin = a.lin and b.kind != "S"                                            # ... divided by a constant
+        return self.prog.new(kind, f"{a.code} {op} {b.code}", lin)
 
     def add(self, a, b): return self._binary(a, b, "+", lambda x, y: x + y)
     def sub(self, a, b): return self._binary(a, b, "-", lambda x, y: x - y)
@@ -185,15 +194,16 @@ class _Translator:
                 return _lit(fold(a.val))
             except (ValueError, OverflowError, ZeroDivisionError):
                 pass
+        lin = a.lin and (fn == "abs" or a.kind != "S")     # |y| keeps a value piecewise affine; sqrt, exp, ... do not
         if a.kind == "f":                                   # plain float: the C names (no overload resolution between float and dual forms)
             fn = {"sqrt": "sqrtf", "exp": "expf", "log": "logf", "sin": "sinf", "cos": "cosf", "tanh": "tanhf", "abs": "fabsf"}.get(fn, fn)
-        return self.prog.new(a.kind, f"{fn}({a.code})")
+        return self.prog.new(a.kind, f"{fn}({a.code})", lin)
 
     def neg(self, a):
         a = self._num(self._as_e(a))
         if a.val is not None:
             return _lit(-a.val)
-        return self.prog.new(a.kind, f"-{a.code}")
+        return self.prog.new(a.kind, f"-{a.code}", a.lin)
 
     def fmax(self, a, b, fn="max"):
         a, b = self._num(self._as_e(a)), self._num(self._as_e(b))
@@ -201,7 +211,7 @@ class _Translator:
             return _lit(max(a.val, b.val) if fn == "max" else min(a.val, b.val))
         if a.kind == "f" and b.kind == "f":
             return self.prog.new("f", f"{'fmaxf' if fn == 'max' else 'fminf'}({a.code}, {b.code})")
-        return self.prog.new("S", f"{fn}({a.code}, {b.code})")        # a tie goes to the first argument (user_env.h)
+        return self.prog.new("S", f"{fn}({a.code}, {b.code})", a.lin and b.lin)        # a tie goes to the first argument (user_env.h)
 
     def pow(self, a, b):
         a, b = self._num(self._as_e(a)), self._num(self._as_e(b))
@@ -228,7 +238,7 @@ class _Translator:
             raise UnsupportedOperation("pow with an exponent that depends on the state or action (write it as exp(e * log(b)))")
         if a.kind == "f":
             return self.prog.new("f", f"powf({a.code}, {b.code})")
-        return self.prog.new("S", f"pow({a.code}, {b.code})")
+        return self.prog.new("S", f"pow({a.code}, {b.code})", False)
 
     def compare(self, a, b, op):
         a, b = self._num(self._as_e(a)), self._num(self._as_e(b))
@@ -252,7 +262,7 @@ class _Translator:
             return a if c.val else b
         kind = "S" if "S" in (a.kind, b.kind) else "f"
         wrap = lambda e: f"S({e.code})" if (kind == "S" and e.kind != "S") else e.code
-        return self.prog.new(kind, f"({c.code} ? {wrap(a)} : {wrap(b)})")
+        return self.prog.new(kind, f"({c.code} ? {wrap(a)} : {wrap(b)})", a.lin and b.lin)
 
     def stop_gradient(self, a):
         a = self._num(self._as_e(a))
@@ -686,6 +696,14 @@ def _trace(fn, example):
 
 def translate(transition_fn, cost_fn, final_cost_fn, state_size, action_size, device="cpu"):
     """-> ``(source, params)``: the three device templates of a ``DeviceEnv`` and its parameter vector (float32 ``[P]``)."""
+    source, params, _ = translate_ex(transition_fn, cost_fn, final_cost_fn, state_size, action_size, device)
+    return source, params
+
+
+def translate_ex(transition_fn, cost_fn, final_cost_fn, state_size, action_size, device="cpu"):
+    """``translate`` + what the translator learned on the way: ``info["cost_is_piecewise_linear"]`` -- stage and final cost are piecewise
+    affine in (x, u) (every operation on the way from the inputs to the cost keeps second derivatives at exactly zero), as the reference's
+    HVAC and Reservoir costs are."""
     n, m = int(state_size), int(action_size)
     gen = torch.Generator().manual_seed(0)
     x = (0.25 + torch.rand(n, generator=gen)).to(device)
@@ -694,6 +712,7 @@ def translate(transition_fn, cost_fn, final_cost_fn, state_size, action_size, de
     xe = _arr([_E(f"x[{i}]", "S") for i in range(n)])
     ue = _arr([_E(f"u[{a}]", "S") for a in range(m)])
     pieces = []
+    cost_lin = True
     for name, fn, example, inputs in (("transition", transition_fn, (x, u), (xe, ue)), ("cost", cost_fn, (x, u), (xe, ue)),
                                       ("final_cost", final_cost_fn, (x,), (xe,))):
         with torch.no_grad():
@@ -716,7 +735,8 @@ def translate(transition_fn, cost_fn, final_cost_fn, state_size, action_size, de
             if out.size != 1:
                 raise ValueError(f"{name} returns {tuple(out.shape)}, expected a scalar")
             e = tr._num(out.reshape(-1)[0])
+            cost_lin = cost_lin and (e.kind != "S" or e.lin)
             sig = ("template <class S> __device__ S cost(const float *p, const S *x, const S *u)" if name == "cost"
                    else "template <class S> __device__ S final_cost(const float *p, const S *x)")
             pieces.append(sig + "\n{\n" + "\n".join(tr.prog.lines + [f"    return S({e.code});"]) + "\n}\n")
-    return "\n".join(pieces), params.array()
+    return "\n".join(pieces), params.array(), {"cost_is_piecewise_linear": bool(cost_lin)}

@@ -50,7 +50,7 @@ class TorchEnv:
         error = None
         for dev in devices:
             try:
-                source, params = fxsource.translate(self._f, self._l, self._lf, self.state_size, self.action_size, device=dev)
+                source, params, info = fxsource.translate_ex(self._f, self._l, self._lf, self.state_size, self.action_size, device=dev)
                 break
             except RuntimeError as exc:                       # constants on another device than the example inputs
                 if "device" not in str(exc):
@@ -58,7 +58,10 @@ class TorchEnv:
                 error = exc
         else:
             raise error
-        env = DeviceEnv(source, self.state_size, self.action_size, params=params, low=self.action_space.low, high=self.action_space.high)
+        # a cost the translator found piecewise affine (all second derivatives exactly zero): with bounded actions the reference's backward pass
+        # only ever takes its bang-bang branch (ilqr.py:137-141) -- the companion library is then built on the costate form of the kernels
+        env = DeviceEnv(source, self.state_size, self.action_size, params=params, low=self.action_space.low, high=self.action_space.high,
+                        zero_cost_hessian=info["cost_is_piecewise_linear"])
         env.device = self.device
         return env
 
