@@ -88,6 +88,33 @@ def test_in_place_writes_through_views_and_the_other_vocabulary():
         assert np.isclose(_evaluate(src, "final_cost", params, x, None), float(np.abs(x).sum()), rtol=1e-6)
 
 
+def test_activation_and_statistics_vocabulary():
+    """softplus / elu / leaky_relu / silu / logsigmoid / log1p / expm1 / lerp / addcmul / var / std / dist: what a learned-dynamics env is made of."""
+    import torch.nn.functional as Fn
+    W = torch.tensor([[0.3, -0.2, 0.1], [0.0, 0.5, -0.4], [0.2, 0.0, 0.7]])
+
+    def transition(x, u):
+        h = Fn.softplus(W @ x) + Fn.elu(x) * 0.1 + Fn.leaky_relu(x, 0.2) + torch.log1p(x.abs()) - torch.expm1(-x.abs()) * 0.05
+        return torch.lerp(x, h, 0.5) + Fn.silu(torch.cat([u, u[:1]]))
+
+    def cost(x, u):
+        return torch.var(x) + torch.std(torch.cat([x, u])) + torch.addcmul(x, x, x, value=0.5).sum() + Fn.logsigmoid(u).sum()
+
+    final = lambda x: torch.dist(x, torch.ones(3))
+    src, params, info = fxsource.translate_ex(transition, cost, final, 3, 2)
+    assert not info["cost_is_piecewise_linear"]
+    rng = np.random.default_rng(1)
+    for _ in range(4):
+        x, u = rng.normal(size=3).astype(np.float32), rng.normal(size=2).astype(np.float32)
+        assert np.allclose(_evaluate(src, "transition", params, x, u), transition(torch.as_tensor(x), torch.as_tensor(u)).numpy(), rtol=2e-5, atol=1e-6)
+        assert np.isclose(_evaluate(src, "cost", params, x, u), float(cost(torch.as_tensor(x), torch.as_tensor(u))), rtol=2e-5)
+        assert np.isclose(_evaluate(src, "final_cost", params, x, None), float(final(torch.as_tensor(x))), rtol=2e-5)
+    # piecewise-affine analysis: sums, constants, relu / abs / maximum / where keep it; a product of two inputs or a smooth nonlinearity ends it
+    lin = lambda c: fxsource.translate_ex(lambda x, u: x + u, c, lambda x: x.abs().sum(), 2, 2)[2]["cost_is_piecewise_linear"]
+    assert lin(lambda x, u: (3.0 * torch.relu(x - 1.0) + torch.abs(u) / 2.0).sum() + torch.maximum(x, u).sum() + torch.where(x > 0, x, -2.0 * x).sum())
+    assert not lin(lambda x, u: (x * u).sum()) and not lin(lambda x, u: torch.sqrt(1.0 + x.abs()).sum()) and not lin(lambda x, u: (x ** 2).sum())
+
+
 def _evaluate(source, name, p, x, u):
     """Runs the emitted statements of one function as Python (they are one assignment each, in C syntax that is also Python's but for the
     ternary, the float suffix and a few names)."""

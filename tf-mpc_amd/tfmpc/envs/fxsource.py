@@ -16,7 +16,7 @@ built-in ones, its derivatives taken by the dual numbers of ``csrc/user_env.h``:
   baked in, so the terms it removes cost nothing); Python numbers become literals.
 
 Supported: elementwise arithmetic and comparisons, ``where`` / ``clamp`` / ``abs`` / ``maximum`` / ``minimum`` / ``relu`` / ``sign``, ``sqrt
-exp log sin cos tanh sigmoid pow reciprocal rsqrt square neg``, ``sum mean prod amax amin cumsum``, ``linalg.norm`` (1, 2, inf), ``dot mv mm
+exp log log1p expm1 sin cos tanh sigmoid silu softplus elu leaky_relu pow reciprocal rsqrt square neg addcmul lerp``, ``sum mean var std prod amax amin cumsum``, ``linalg.norm`` (1, 2, inf), ``dot mv mm
 matmul addmm``, indexing / slicing / ``cat`` / ``stack`` / ``reshape`` / ``transpose`` / ``expand`` / ``unbind`` / ``split``, constant
 creation (``zeros ones full arange tensor``), ``detach``, dtype casts, and the in-place forms of the above on views (``out[i] = ...``).
 Subgradient conventions are TensorFlow's, as in the built-in envs: ``|y|' = sign(y)`` (0 at 0), a tie of
@@ -275,6 +275,8 @@ class _Translator:
         """Any graph value as an object array of _E."""
         if isinstance(v, np.ndarray) and v.dtype == object:
             return v
+        if isinstance(v, _E):
+            return _full((), v)
         if isinstance(v, np.ndarray):                     # integer / bool constants
             out = np.empty(v.size, dtype=object)
             flat = v.reshape(-1)
@@ -435,6 +437,43 @@ class _Translator:
     def op_sigmoid(self, a):
         return self._map1(a, lambda e: self.div(_lit(1.0), self.add(_lit(1.0), self._unary(self.neg(e), "exp", math.exp))))
     def op_relu(self, a): return self._map1(a, lambda e: self.fmax(_lit(0.0), e))          # relu'(0) = 0: the tie goes to the constant
+    def op_log1p(self, a): return self._map1(a, lambda e: self._unary(self.add(_lit(1.0), e), "log", math.log))
+    def op_expm1(self, a): return self._map1(a, lambda e: self.sub(self._unary(e, "exp", math.exp), _lit(1.0)))
+    def op_silu(self, a):
+        return self._map1(a, lambda e: self.div(e, self.add(_lit(1.0), self._unary(self.neg(e), "exp", math.exp))))
+    def op_leaky_relu(self, a, negative_slope=0.01):
+        return self._map1(a, lambda e: self.select(self.compare(e, _lit(0.0), ">"), e, self.mul(e, _lit(negative_slope))))
+    def op_elu(self, a, alpha=1.0, scale=1.0, input_scale=1.0):
+        def one(e):
+            neg = self.mul(_lit(alpha), self.sub(self._unary(self.mul(e, _lit(input_scale)), "exp", math.exp), _lit(1.0)))
+            return self.mul(_lit(scale), self.select(self.compare(e, _lit(0.0), ">"), e, neg))
+        return self._map1(a, one)
+    def op_softplus(self, a, beta=1.0, threshold=20.0):
+        def one(e):
+            bx = self.mul(e, _lit(beta))
+            soft = self.div(self._unary(self.add(_lit(1.0), self._unary(bx, "exp", math.exp)), "log", math.log), _lit(beta))
+            return self.select(self.compare(bx, _lit(threshold), ">"), e, soft)          # torch's own switch to the identity above the threshold
+        return self._map1(a, one)
+    def op_log_sigmoid(self, a): return self._map1(self.op_softplus(self._map1(a, self.neg)), self.neg)
+    def op_log_sigmoid_forward(self, a):           # (the ATen form returns (output, buffer))
+        out = self.op_log_sigmoid(a)
+        return out, out
+    def op_addcmul(self, a, t1, t2, value=1): return self.op_add(a, self._map2(self.op_mul(t1, t2), value, self.mul))
+    def op_addcdiv(self, a, t1, t2, value=1): return self.op_add(a, self._map2(self.op_div(t1, t2), value, self.mul))
+    def op_lerp(self, a, b, w): return self.op_add(a, self.op_mul(w, self.op_sub(b, a)))
+    def op_frobenius_norm(self, a, dim=None, keepdim=False): return self.op_linalg_vector_norm(a, 2, dim, keepdim)
+    def op_dist(self, a, b, p=2): return self.op_linalg_vector_norm(self.op_sub(a, b), p)
+    def op_var(self, a, dim=None, correction=1, keepdim=False, unbiased=None):
+        a = self._t(a)
+        if unbiased is not None:
+            correction = 1 if unbiased else 0
+        mean = self.op_mean(a, dim, True)
+        sq = self._map1(self.op_sub(a, mean), lambda e: self.mul(e, e))
+        total = self._reduce(sq, dim, keepdim, self.add)
+        count = a.size // max(total.size, 1)
+        return self._map1(total, lambda e: self.mul(e, _lit(1.0 / max(count - correction, 1))))
+    def op_std(self, a, dim=None, correction=1, keepdim=False, unbiased=None):
+        return self._map1(self.op_var(a, dim, correction, keepdim, unbiased), lambda e: self._unary(e, "sqrt", math.sqrt))
     def op_maximum(self, a, b): return self._map2(a, b, lambda x, y: self.fmax(x, y, "max"))
     def op_minimum(self, a, b): return self._map2(a, b, lambda x, y: self.fmax(x, y, "min"))
     op_fmax, op_fmin = op_maximum, op_minimum
