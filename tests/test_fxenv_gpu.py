@@ -30,11 +30,14 @@ def _np(t):
 def test_translation_of_the_three_envs_and_where_their_constants_go():
     nav = torch_envs.navigation(problems.NAV_CONFIG).to_device_env()
     assert nav.state_size == 2 and nav.action_size == 2 and nav.params.shape == (8,)           # 2 centres x 2, 2 decays, goal (stored once)
+    assert "    const float v" not in nav.source and "(-p[" in nav.source                            # (the negated decays: a sign on the operand, no statement)
     assert "sqrt(" in nav.source and "exp(" in nav.source and "x_next[1]" in nav.source
     res = torch_envs.reservoir(problems.RES4_CONFIG).to_device_env()
     assert "sin(" in res.source and "abs(" in res.source and "max(0.0f" in res.source           # relu -> max(0, y): the tie goes to the constant
     assert res.action_space.is_bounded()
     hv = torch_envs.hvac(problems.hvac_config(6)).to_device_env()
+    # arithmetic BETWEEN constants (adj / R_wall, dt / capacity, (lo + hi) / 2 ...) is done at translation time and lands in derived parameter slots
+    assert "    const float v" not in hv.source and hv.params.shape[0] > 6 * 11 + 36
     # the translator PROVES piecewise-affine costs (sums, products with constants, relu / abs of such): those envs get the costate form of the kernels
     assert res.zero_cost_hessian and hv.zero_cost_hessian and not nav.zero_cost_hessian
     unbounded = torch_envs.reservoir(problems.RES4_CONFIG)

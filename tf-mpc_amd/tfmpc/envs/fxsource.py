@@ -68,6 +68,11 @@ def _lit(v):
     return _E(f"({code})" if v32 < 0 else code, "f", v32)
 
 
+def _is_param(e):
+    """An element that is read from the parameter vector (its numeric value known at translation time), as opposed to a literal."""
+    return e.code.startswith("p[") or e.code.startswith("(-p[")
+
+
 class ParamTable:
     """The env's parameter floats: every tensor constant of the three functions, each stored once."""
 
@@ -86,9 +91,19 @@ class ParamTable:
         flat = a.reshape(-1)
         for k in range(a.size):
             # an exact zero of a constant is STRUCTURE (an adjacency matrix, a mask): it is baked in as the literal, so that the products it
-            # kills cost no statement and no derivative code; every other entry is read from the parameter vector
-            out[k] = _lit(0.0) if flat[k] == 0.0 else _E(f"p[{base + k}]", "f")
+            # kills cost no statement and no derivative code; every other entry is read from the parameter vector (`val`: its value, so that
+            # arithmetic BETWEEN constants is done here, once, and lands in a derived parameter slot -- see `derived`)
+            out[k] = _lit(0.0) if flat[k] == 0.0 else _E(f"p[{base + k}]", "f", float(flat[k]))
         return out.reshape(a.shape)
+
+    def derived(self, value):
+        """A constant computed from other constants at translation time (adj / R_wall, dt / capacity, (lo + hi) / 2 ...): one more parameter slot
+        instead of a float division in every evaluation of the env on the device."""
+        v = float(np.float32(value))
+        if v == 0.0 or not math.isfinite(v):
+            return _lit(v)
+        self.values.append(v)
+        return _E(f"p[{len(self.values) - 1}]", "f", v)
 
     def array(self):
         return np.asarray(self.values, dtype=np.float32)
@@ -153,7 +168,8 @@ class _Translator:
         a, b = self._num(self._as_e(a)), self._num(self._as_e(b))
         if a.val is not None and b.val is not None:
             try:
-                return _lit(fold(a.val, b.val))
+                value = fold(a.val, b.val)
+                return _lit(value) if not (_is_param(a) or _is_param(b)) else self.params.derived(value)
             except (ZeroDivisionError, OverflowError, ValueError):
                 pass
         # identities that keep the program (and the derivative code) small
@@ -191,7 +207,7 @@ class _Translator:
         a = self._num(self._as_e(a))
         if a.val is not None and fold is not None:
             try:
-                return _lit(fold(a.val))
+                return _lit(fold(a.val)) if not _is_param(a) else self.params.derived(fold(a.val))
             except (ValueError, OverflowError, ZeroDivisionError):
                 pass
         lin = a.lin and (fn == "abs" or a.kind != "S")     # |y| keeps a value piecewise affine; sqrt, exp, ... do not
@@ -201,14 +217,15 @@ class _Translator:
 
     def neg(self, a):
         a = self._num(self._as_e(a))
-        if a.val is not None:
-            return _lit(-a.val)
+        if a.val is not None:                               # (a negated parameter is the parameter with a sign: no slot, no statement -- the ISA negates operands for free)
+            return _lit(-a.val) if not _is_param(a) else _E(a.code[2:-1] if a.code.startswith("(-") else f"(-{a.code})", "f", -a.val)
         return self.prog.new(a.kind, f"-{a.code}", a.lin)
 
     def fmax(self, a, b, fn="max"):
         a, b = self._num(self._as_e(a)), self._num(self._as_e(b))
         if a.val is not None and b.val is not None:
-            return _lit(max(a.val, b.val) if fn == "max" else min(a.val, b.val))
+            value = max(a.val, b.val) if fn == "max" else min(a.val, b.val)
+            return _lit(value) if not (_is_param(a) or _is_param(b)) else self.params.derived(value)
         if a.kind == "f" and b.kind == "f":
             return self.prog.new("f", f"{'fmaxf' if fn == 'max' else 'fminf'}({a.code}, {b.code})")
         return self.prog.new("S", f"{fn}({a.code}, {b.code})", a.lin and b.lin)        # a tie goes to the first argument (user_env.h)
@@ -219,7 +236,7 @@ class _Translator:
             p = b.val
             if a.val is not None:
                 try:
-                    return _lit(a.val ** p)
+                    return _lit(a.val ** p) if not (_is_param(a) or _is_param(b)) else self.params.derived(a.val ** p)
                 except (ValueError, OverflowError, ZeroDivisionError):
                     pass
             if p == 1.0:
