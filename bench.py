@@ -466,8 +466,32 @@ def deviceenv_rate(B=16384, T=50):
         from_python = {"iterations_per_s": its_p / dt_p, "ms_per_batch": dt_p * 1e3, "mean_iterations": its_p / B, "trace_translate_compile_s": ready_py,
                        "ratio_to_hand_written_device_source": dt_p / dt_u, "kernel": py.last_kernel,
                        "workload": "Navigation as three plain torch functions -> TorchEnv(...).to_device_env() (make_fx trace -> device templates)"}
+        # ... and the reference's own res4 / hvac6 configs written in plain torch: costs the translator PROVES piecewise linear -> the costate form of
+        # the fused kernel, every step size of a line search at once (B = 16 384, T = 100, <= 12 iterations; beside the built-in env on the same
+        # generic wave kernel, TFMPC_ILQR_KERNEL=wave, and on its specialised sixteen-per-wave kernel)
+        import workloads
+        small = {}
+        for name, make, cfg_ in (("res4", torch_envs.reservoir, problems.RES4_CONFIG), ("hvac6", torch_envs.hvac, problems.HVAC6_CONFIG)):
+            ws_ = workloads.small_env(name)
+
+            def timed_small(solver, option=None):
+                with _hip.option("TFMPC_ILQR_KERNEL", option):
+                    out = solver.solve_device(ws_["x0"], ws_["T"], u_init=ws_["u0"])
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        out = solver.solve_device(ws_["x0"], ws_["T"], u_init=ws_["u0"], workspace=out["workspace"])
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t0) / 3, float((out["iterations"].double() + 1).sum())
+            env_py = make(dict(cfg_), "cuda").to_device_env()
+            dt_s, its_s = timed_small(iLQR(env_py, max_iterations=12))
+            dt_w, _ = timed_small(ws_["solver"], "wave")
+            dt_d, _ = timed_small(ws_["solver"])
+            small[name] = {"ms_per_batch": dt_s * 1e3, "iterations_per_s": its_s / dt_s, "cost_proved_piecewise_linear": bool(env_py.zero_cost_hessian),
+                           "builtin_env_same_generic_wave_kernel_ms": dt_w * 1e3, "builtin_env_specialised_kernel_ms": dt_d * 1e3}
+        from_python["piecewise_linear_envs_B16384_T100"] = small
     except Exception as exc:                                  # noqa: BLE001
-        from_python = {"error": repr(exc)}
+        from_python = dict(from_python, error=repr(exc))
     return {"from_python_functions": from_python, "iterations_per_s": its_u / dt_u, "ms_per_batch": dt_u * 1e3, "mean_iterations": its_u / B, "batch": B, "horizon": T,
             "library_ready_s": ready, "kernel": kernel, "user_env_on_the_generic_wave_kernel_ms": dt_uw * 1e3,
             "same_env_builtin_generic_wave_kernel_ms": dt_w * 1e3, "same_env_builtin_lane_group_kernel_ms": dt_g * 1e3,
@@ -804,6 +828,7 @@ def summarise_extras(extra):
            "mpc_ms_per_control_step_nav_cold_warm_res4_cold_warm": [r3(get(extra, "mpc", k, "ms_per_control_step")) for k in
                                                                     ("navigation_cold_start", "navigation_warm_start", "res4_cold_start", "res4_warm_start")],
            "deviceenv_from_python_Mit_s": r3((get(extra, "deviceenv_user_env", "from_python_functions", "iterations_per_s") or 0) / 1e6),
+           "res4_hvac6_from_python_ms": [r3(get(extra, "deviceenv_user_env", "from_python_functions", "piecewise_linear_envs_B16384_T100", k, "ms_per_batch")) for k in ("res4", "hvac6")],
            "format": "[ms per batch, roofline frac (, algorithmic flop rate / fp32 peak; ilqr_api_warm: executed flop rate / fp32 peak)]"}
     for key, short in (("cfg5_hvac_ilqr_n32", "cfg5_hvac"), ("cfg5_reservoir_ilqr_n32", "cfg5_reservoir"), ("hvac6_reference_config_ilqr", "hvac6"),
                        ("res4_reference_config_ilqr", "res4"), ("cfg5_literal_dims_ilqr_lq_n32_m16", "literal_dims"), ("lqr_n32_m16", "lqr_n32_m16")):
