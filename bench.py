@@ -367,7 +367,7 @@ def torchenv_rate(B=1024, T=40):
 
     env = TorchEnv(transition, cost, lambda x: torch.sum((x - goal) ** 2), 2, 2,
                    low=np.array(cfg["low"], dtype=np.float32).reshape(-1, 1), high=np.array(cfg["high"], dtype=np.float32).reshape(-1, 1))
-    solver = iLQR(env, max_iterations=10)
+    solver = iLQR(env, max_iterations=10, compile_env=False)     # (the HOST-driven loop: what an env the translator cannot take still gets)
     rng = np.random.default_rng(4)
     x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
     u0 = solver.random_actions(T, B, seed=4)

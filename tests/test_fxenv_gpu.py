@@ -226,7 +226,9 @@ def test_navigation_from_python_solves_like_the_builtin_kernel():
     assert np.median(np.abs(cu - cb) / np.abs(cb)) <= 1e-5
     assert int((out["status"] & ~_hip.ST_NOT_PD).abs().sum()) == 0
     # the host-driven TorchEnv solve of the same functions lands on the same costs (a handful of instances: it is the slow path)
-    tj, _ = iLQR(python_env).solve(x0[:8], T, show_progress=False, u_init=u0[:8])
+    host = iLQR(python_env, compile_env=False)
+    assert host.python_env is None and iLQR(python_env).python_env is python_env        # (the default translates; compile_env=False keeps the host loop)
+    tj, _ = host.solve(x0[:8], T, show_progress=False, u_init=u0[:8])
     assert np.median(np.abs(tj.costs.sum(1) - cu[:8]) / np.abs(cu[:8])) <= 1e-3
 
 
@@ -296,3 +298,30 @@ def test_costate_form_of_a_user_env_equals_its_dense_form(which):
     ca, cb = _np(a["costs"]).sum(1), _np(b["costs"]).sum(1)
     assert np.median(np.abs(ca - cb) / np.abs(cb)) <= 1e-3
     assert np.all((_np(a["actions"]) >= -1e-6) & (_np(a["actions"]) <= 1 + 1e-6))
+
+
+@pytest.mark.gpu
+@needs_hipcc
+def test_ilqr_takes_the_device_path_for_a_python_env_by_itself_and_falls_back_when_it_cannot():
+    """`iLQR(TorchEnv(...))`: the functions are translated and compiled when possible -- the reference user changes nothing -- and an env the translator
+    cannot take (here: torch.erf) runs the host-driven loop, with the reason kept."""
+    cfg, builtin, python_env, _, _ = _case("navigation")
+    solver = iLQR(python_env)
+    assert solver.python_env is python_env and solver.compile_error is None and solver.env.kind == _hip.ENV_USER
+    rng = np.random.default_rng(5)
+    B, T = 64, 30
+    x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
+    u0 = iLQR(builtin).random_actions(T, B, seed=2)
+    traj, its = solver.solve(x0, T, show_progress=False, u_init=u0)
+    ref, its_ref = iLQR(builtin).solve(x0, T, show_progress=False, u_init=u0)
+    assert solver.last_kernel.startswith("lane_group") and (its == its_ref).mean() >= 0.9
+    assert np.median(np.abs(traj.costs.sum(1) - ref.costs.sum(1)) / np.abs(ref.costs.sum(1))) <= 1e-5
+    g = torch.as_tensor(np.array(cfg["goal"], dtype=np.float32).reshape(-1), device="cuda")
+    odd = TorchEnv(lambda x, u: x + torch.erf(u), lambda x, u: ((x - g) ** 2).sum(), lambda x: ((x - g) ** 2).sum(), 2, 2, -1.0, 1.0)
+    fallback = iLQR(odd, max_iterations=3)
+    assert fallback.python_env is None and isinstance(fallback.compile_error, fxsource.UnsupportedOperation) and fallback.env is odd
+    out = fallback.solve_device(x0[:4], 10, u_init=u0[:4, :10])
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out["costs"]).all())
+    with pytest.raises(fxsource.UnsupportedOperation):
+        iLQR(odd, compile_env=True)

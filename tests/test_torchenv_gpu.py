@@ -16,6 +16,16 @@ from tfmpc.solvers.ilqr import iLQR
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _host_driven_loop():
+    """This file covers the HOST-driven loop of a generic env (torch.func derivatives, HIP backward pass, torch rollouts): since round 6 iLQR would
+    translate these functions to device source instead (tests/test_fxenv_gpu.py covers that), so the automatic translation is switched off here."""
+    before = TorchEnv.auto_compile
+    TorchEnv.auto_compile = False
+    yield
+    TorchEnv.auto_compile = before
+
+
 def _navlqr_torch(goal, beta, low=None, high=None):
     g = torch.as_tensor(goal, dtype=torch.float32, device="cuda").reshape(-1)
     return TorchEnv(lambda x, u: x + u,

@@ -7,8 +7,12 @@ restores the reference's generality: the model is given as three torch functions
 instance (``x[n], u[m] -> x'[n]``, ``-> scalar``, ``x[n] -> scalar``) and the linear/quadratic
 models come from ``torch.func`` (``vmap`` over batch and time of ``jacrev`` / ``jacfwd``), on the
 GPU.  ``iLQR`` then runs the reference's loop with the Riccati backward pass in the HIP kernel
-(``tfmpc_ilqr_backward_f32``, materialised models) and the rollouts as batched torch ops --
-the env code is the user's Python, so it cannot live inside a hand-written kernel.
+(``tfmpc_ilqr_backward_f32``, materialised models) and the rollouts as batched torch ops.
+
+Round 6: that host-driven loop is the FALLBACK.  ``iLQR(TorchEnv(...))`` first tries ``to_device_env()`` -- the functions
+traced and translated into device source (``envs/fxsource.py``), compiled into the fused kernels, two orders of magnitude
+faster -- and only an env the translator cannot take (an unsupported operation, a Python branch on the state, no hipcc)
+stays here (``iLQR(...).compile_error`` says why; ``TorchEnv(..., auto_compile=False)`` / ``iLQR(env, compile_env=False)`` ask for it).
 """
 
 import numpy as np
@@ -21,9 +25,12 @@ from tfmpc.envs.diffenv import Box, CostApprox, FinalCostApprox, TransitionAppro
 
 class TorchEnv:
     kind = None          # not one of the device-resident env kinds
+    auto_compile = True  # iLQR(env) translates the functions to device source when it can (to_device_env); False keeps the host-driven loop
 
     def __init__(self, transition_fn, cost_fn, final_cost_fn, state_size, action_size, low=None, high=None,
-                 device=None):
+                 device=None, auto_compile=None):
+        if auto_compile is not None:
+            self.auto_compile = bool(auto_compile)
         self._f, self._l, self._lf = transition_fn, cost_fn, final_cost_fn
         self.state_size, self.action_size = int(state_size), int(action_size)
         low = -np.inf if low is None else low

@@ -125,6 +125,23 @@ def _f32(a, device):
 class iLQR:
 
     def __init__(self, env, **kwargs):
+        # build-only: an env given as PLAIN TORCH FUNCTIONS (tfmpc.envs.torchenv.TorchEnv) is translated to device source and compiled into the fused
+        # kernels when that is possible (TorchEnv.to_device_env: two orders of magnitude over the host-driven loop below) -- compile_env="auto"
+        # (default): try, and fall back to the host-driven loop when the functions use an operation the translator does not know, branch in Python on
+        # the state, or no hipcc is there (the reason is kept in `self.compile_error`); True: raise instead of falling back; False: host-driven loop.
+        self.python_env, self.compile_error = None, None
+        compile_env = kwargs.get("compile_env", "auto")
+        if compile_env == "auto" and not getattr(env, "auto_compile", True):       # (TorchEnv(..., auto_compile=False): this env stays on the host-driven loop)
+            compile_env = False
+        if compile_env and hasattr(env, "to_device_env") and getattr(env, "kind", 0) is None:
+            try:
+                device_env = env.to_device_env()
+                device_env._library()                       # (compiles, or finds the library in the cache)
+                self.python_env, env = env, device_env
+            except Exception as exc:                        # noqa: BLE001 -- whatever stops the translation: the host-driven loop serves the env
+                if compile_env is True:
+                    raise
+                self.compile_error = exc
         self.env = env
 
         # solve

@@ -18,7 +18,7 @@ def transition(x, u):
     return x + lam * u
 def cost(x, u):
     return torch.sum((x - goal) ** 2)
-env = TorchEnv(transition, cost, lambda x: torch.sum((x - goal) ** 2), 2, 2,
+env = TorchEnv(transition, cost, lambda x: torch.sum((x - goal) ** 2), 2, 2, auto_compile=False,
                low=np.array(cfg["low"], dtype=np.float32).reshape(-1, 1), high=np.array(cfg["high"], dtype=np.float32).reshape(-1, 1))
 rng = np.random.default_rng(4)
 x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
