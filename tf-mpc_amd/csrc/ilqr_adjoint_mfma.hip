@@ -88,34 +88,39 @@ __device__ __forceinline__ void wave_sync()
 // assembly the compiler knows nothing about: it cannot merge, copy or hoist them, and it inserts no vmcnt(0) of its
 // own in front of LDS reads (which it does, once per loop trip, for the __builtin_amdgcn_global_load_lds form).  Its
 // own waits stay correct: an extra outstanding load can only make a compiler-placed vmcnt(N) wait longer.  M0 (the
-// LDS base of the DMA) is saved and restored around each issue.
+// LDS base of the DMA) is set in front of each issue (round 6; rounds 3 - 5 saved and restored it around each).
 #define TFMPC_LDS __attribute__((address_space(3)))
 __device__ __forceinline__ unsigned lds_addr_of(const void *p) { return (unsigned)(uintptr_t)(const TFMPC_LDS void *)p; }
+#ifdef TFMPC_AB_M0_SAVE                 // A/B builds: round 3 - 5's form, M0 saved and restored around every issue (two more scalar slots per DMA)
+#define TFMPC_DMA_ASM(BODY) unsigned keep; asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t" BODY "\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(lds) : "memory")
+#else
+// M0 is overwritten, not saved and restored (round 6): nothing else in these kernels lives in it -- gfx950's ds_* instructions do not read M0, and the
+// compiler, for which M0 is a reserved register it does not allocate (it rejects it on a clobber list), emits no other use; tools/check_ring_waits.py
+// holds the device assembly to that (every mention of m0 is one of these writes).  A lone wave pays ~4 cycles for each of the two copies --
+// 4 DMAs a sweep step, 2 a rollout step.
+#define TFMPC_DMA_ASM(BODY) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t" BODY : : "v"(g), "s"(lds) : "memory")
+#endif
+#ifdef TFMPC_AB_M0_SAVE
+#define TFMPC_DMA_G "%1"
+#else
+#define TFMPC_DMA_G "%0"
+#endif
 __device__ __forceinline__ void dma16(const void *g, unsigned lds)          // 16 bytes per lane -> lds + 16 lane
 {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+    TFMPC_DMA_ASM("global_load_lds_dwordx4 " TFMPC_DMA_G ", off");
 }
 __device__ __forceinline__ void dma4(const void *g, unsigned lds)           // 4 bytes per lane -> lds + 4 lane
 {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+    TFMPC_DMA_ASM("global_load_lds_dword " TFMPC_DMA_G ", off");
 }
 __device__ __forceinline__ void dma1(const void *g, unsigned lds)           // 1 byte per lane -> the low byte of lds + 4 lane
 {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+    TFMPC_DMA_ASM("global_load_lds_ubyte " TFMPC_DMA_G ", off");
 }
 // three 16-byte pieces per lane, 1 KB apart in memory AND in LDS (the instruction offset moves both addresses): one M0 set-up
 __device__ __forceinline__ void dma16x3(const void *g, unsigned lds)
 {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+    TFMPC_DMA_ASM("global_load_lds_dwordx4 " TFMPC_DMA_G ", off\n\tglobal_load_lds_dwordx4 " TFMPC_DMA_G ", off offset:1024\n\tglobal_load_lds_dwordx4 " TFMPC_DMA_G ", off offset:2048");
 }
 // bit E of `bits` ? a : b in two instructions that touch no condition register (compare + select is four issue slots with its hazard no-ops)
 template <int E>
@@ -1150,7 +1155,56 @@ template <int NT, bool LEAN, bool ROWREGS> struct EnvM<kEnvReservoirChain, NT, L
         return __all(ok);
     }
 };
+// Round 6: the same promise in ONE tile (the reference's own res4 config, 64 instances per wave: n = 16 / PK, so that an instance's rows fill
+// its lane quarters and no padding row can receive a neighbour's value -- no leak mask; reservoir i drains into i + 1, coupling_shift = +1, which is what
+// every config the reference holds is).  The run-time form (MatOp<1>::shift, shift_apply1) pays for its generality on every step of a kernel whose time
+// IS one wave's instruction count: a wave-uniform branch around the matrix instructions, the matrix path's seven hazard no-ops in the block both paths
+// join, eight selects (direction, leak) -- ~17 of a step's ~150 - 200 issue slots.  Here the direction is a constant of the phase (forward = down,
+// backward = up), PK = 4 moves registers only, and the products do not exist.  Same values moved, same `acc + moved` adds: the same bits.
+struct MatShift1 { int dir; };
+template <int PK>
+__device__ __forceinline__ void shift_apply1_const(int dir, const float (&z)[4], float (&acc)[4])
+{
+    constexpr int QS = 4 / PK;                       // lane quarters per instance
+    const bool down = dir < 0;                       // (a compile-time constant wherever this is inlined: load_forward / load_backward set literals)
+    float t = 0.0f;
+    if constexpr (QS > 1) {
+        const int lane = lane_id(), q = lane >> 4;
+        float z_first = z[0], z_last = z[3];
+        asm volatile("" : "+v"(z_first), "+v"(z_last));       // (see shift_apply1)
+        t = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((down ? lane - 16 : lane + 16) & 63) << 2,
+                                                                   __builtin_bit_cast(int, down ? z_last : z_first)));
+        t = (q % QS == (down ? 0 : QS - 1)) ? 0.0f : t;
+    }
+    if (down) { acc[0] += t; acc[1] += z[0]; acc[2] += z[1]; acc[3] += z[2]; }
+    else { acc[0] += z[1]; acc[1] += z[2]; acc[2] += z[3]; acc[3] += t; }
+}
+template <int PK> struct MatShift1Of : MatShift1 {};
+template <int PK>
+__device__ __forceinline__ void mat_apply(const MatShift1Of<PK> &A, const float (&z)[4], float (&acc)[4]) { shift_apply1_const<PK>(A.dir, z, acc); }
+template <int PK> __device__ __forceinline__ void force_dense(MatShift1Of<PK> &, bool) {}
+template <bool LEAN, bool ROWREGS, int PK> struct EnvChain1 : EnvM<TFMPC_ENV_RESERVOIR, 1, LEAN, ROWREGS> {
+    using Operand = MatShift1Of<PK>;
+    static constexpr bool kChain = true;
+    template <int PK_>
+    __device__ __forceinline__ void load_forward(const TfmpcEnv &, int, int, Operand &A, u32x4 *) const { A.dir = -1; }     // D^T: row R receives z[R - 1]
+    template <int PK_>
+    __device__ __forceinline__ void load_backward(const TfmpcEnv &, int, int, Operand &A, u32x4 *) const { A.dir = 1; }     // D without its diagonal: V_x[R + 1]
+    // is `downstream` the chain i -> i + 1 on exactly n = 16 / PK reservoirs?  (every lane tests all entries: n <= 16, at most 256 loads once per kernel... n = 4: 16)
+    __device__ __forceinline__ static bool promise_holds(const TfmpcEnv &g, int)
+    {
+        const float *D = g.p[7];
+        const int n = g.n;
+        bool ok = g.coupling_shift == 1 && n == 16 / PK;
+        if (ok)
+            for (int R = 0; R < n; ++R)
+                for (int C = 0; C < n; ++C) ok = ok && D[R * n + C] == ((C == R + 1) ? 1.0f : 0.0f);      // (a zero diagonal too)
+        return __all(ok);
+    }
+};
+constexpr int kEnvReservoirChain1 = 101;             // internal tag: EnvChain1 (the PK is the kernel's)
 template <int KIND, int NT, bool LEAN> struct EnvTraits { static constexpr bool kChain = false; };
+template <bool LEAN> struct EnvTraits<kEnvReservoirChain1, 1, LEAN> { static constexpr bool kChain = true; };
 template <int NT, bool LEAN> struct EnvTraits<kEnvReservoirChain, NT, LEAN> { static constexpr bool kChain = true; };
 
 #ifdef TFMPC_CFG5_TRACE
@@ -1206,6 +1260,14 @@ __host__ __device__ constexpr size_t adjoint_mfma_wave_bytes(int NT, int T)
 // the element-wise state per wave) without wasting half of every matrix instruction, and the measurement says no:
 // at 128 registers the costate sweep spills ~120-330 registers (31.8 / 41.6 ms), at the register count it wants
 // two groups no longer fit a SIMD.
+// issue priority of this wave among the waves of its SIMD (s_setprio takes an immediate)
+__device__ __forceinline__ void set_priority(int p)
+{
+    if (p >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
 template <int NW>
 __device__ __forceinline__ void group_sync()
 {
@@ -1255,10 +1317,29 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
 #else
     constexpr bool kRowRegs = NT == 1 && NW >= 4 && !BF16;              // the env's constant rows and the action bounds in registers (see EnvM)
 #endif
-    using Env = EnvM<KIND, NT, (NW > 1), kRowRegs>;
+    using Env = typename std::conditional<KIND == kEnvReservoirChain1, EnvChain1<(NW > 1), kRowRegs, PK>, EnvM<KIND == kEnvReservoirChain1 ? TFMPC_ENV_RESERVOIR : KIND, NT, (NW > 1), kRowRegs>>::type;
     __shared__ u32x4 op_rest_all[NW][NT == 2 && !kChain ? 4 * kWave : 1];  // MatOp<2, true>: the non-leading parts of the operand, per wave
     __shared__ float x_sweep[NW > 1 ? 4 : 1][kWave];           // wave 0 -> the others: J_hat, dV1, g_norm, max |k|
     __shared__ float x_pass[2][NW][2][kWave];                  // [pass parity][wave][J | cut short][lane]
+    // Round 6, groups of four / eight waves: a chain GIVES UP once it cannot matter.  The search takes, per column, the FIRST step size (in the
+    // reference's order, ilqr.py:323-353) whose rollout is accepted; wave w rolls out position w of the pass.  So when every wave below w has finished
+    // and every trying column was accepted by one of them, position w decides nothing -- and on a chip where the chains of a pass share SIMDs in pairs
+    // (a res4 pass: positions 0 - 4 take 17 - 83 k cycles, 5 - 7 next to a partner 103 - 110 k, and the group waits for the slowest) the pass is over
+    // when the positions that CAN matter are (three of res4's first five iterations accept by position 2 in every column of a group).  Each wave posts,
+    // when its rollout ends, which trying columns it accepts (`give_acc`, a lane mask) and then its bit in `give_posted`; a chain polls that word every
+    // fourth step (one LDS read) and stops -- reporting "cut short", as the cost-based early exit does -- when the bits below it are all set and their
+    // masks cover the trying columns.  No wave ever WAITS on another here (a poll that fails changes nothing), and what a given-up chain would have
+    // reported is read by no column: the results are the same bits.  The chains of the earlier positions are given issue priority (s_setprio) over
+    // their SIMD partners, so that the ones that can matter finish first.  Slots alternate with the pass parity; a wave clears its bit of the
+    // OTHER slot when it posts (nobody reads that slot between the two barriers around this pass).
+#ifdef TFMPC_AB_NO_GIVE_UP             // A/B builds
+    constexpr bool kGiveUp = false;
+#else
+    constexpr bool kGiveUp = NW >= 4 && !BF16;
+#endif
+    __shared__ unsigned long long give_acc[2][kGiveUp ? NW : 1];
+    __shared__ unsigned give_posted[2];
+    if (kGiveUp && threadIdx.x < 2) give_posted[threadIdx.x] = 0u;      // (visible to the group behind the barrier below)
     u32x4 *const op_rest = op_rest_all[wv];
     // the LDS-DMA input ring of this wave (fp32 containers): [slot][x tiles | u tiles][lane] 16-byte pieces, the stage
     // cost and the selector byte of a slot.  Depth 3 with two tiles keeps 8 groups per CU inside the 160 KB.
@@ -1275,7 +1356,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
 #ifdef TFMPC_NO_SWEEP_COEFFICIENTS     // A/B builds
     constexpr bool kSweepCoefficients = false;
 #else
-    constexpr bool kSweepCoefficients = KIND == TFMPC_ENV_RESERVOIR && NT == 1 && NW >= 4 && kLdsRing;
+    constexpr bool kSweepCoefficients = (KIND == TFMPC_ENV_RESERVOIR || KIND == kEnvReservoirChain1) && NT == 1 && NW >= 4 && kLdsRing;
 #endif
 #ifndef TFMPC_CHAIN_RING
 #define TFMPC_CHAIN_RING 3
@@ -1394,7 +1475,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
     auto rollout = [&](auto search, auto store, auto n_alpha, const float (&alpha)[decltype(n_alpha)::value], auto uh,
                        bool keep, TT *xs, TT *us, TT *cs, float (&J_out)[decltype(n_alpha)::value],
                        bool trying = false, float reject_above = 0.0f, bool may_stop = false, bool *stopped_out = nullptr,
-                       float *ck_out = nullptr, int t_lo = 0, int t_hi_ = -1, const float *ck_in = nullptr) {
+                       float *ck_out = nullptr, int t_lo = 0, int t_hi_ = -1, const float *ck_in = nullptr, int give_slot = -1) {
         // ck_out (line-search chains of a multi-wave group): the state at every segment boundary goes to the workspace, columns
         // that are trying only.  [t_lo, t_hi) + ck_in (stored rollout of a multi-wave group): ONE segment of the horizon, from
         // the accepted chain's checkpoint -- the state the one-piece rollout reaches there, bit for bit.
@@ -1500,7 +1581,39 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
 #ifdef TFMPC_CFG5_TRACE
         trace_fa[0] = trace_fa[1] = trace_fa[2] = trace_fa[3] = -1;
 #endif
+        // (give-up, see `kGiveUp`) the trying columns as a lane mask, and the bits of the waves below this one
+        unsigned long long trying_mask = 0;
+        if constexpr (kGiveUp && DEFER) trying_mask = __builtin_amdgcn_ballot_w64(trying);
+        unsigned give_seen = 0u;                             // (nothing posted yet)
+        int give_run = 0;                                    // waves 0 .. give_run - 1 have posted and are in give_cov
+        unsigned long long give_cov = 0;
         for (int t0 = t_lo; t0 < t_hi; t0 += kAheadRoll) {
+            if constexpr (kGiveUp && DEFER) {
+                if (give_slot >= 0 && wv > 0 && early_exit && may_stop && (t0 & 3) == 0) {                  // (wave-uniform)
+                    // (atomic accessors on the __shared__ objects themselves: ds_* instructions, in order within a wave; a volatile access through a cast
+                    // pointer would be a FLAT access -- another queue than the ds_or that posts the bit)
+                    // The word tested is the one READ AT THE POLL BEFORE (`give_seen`): the read issued now is used four steps on, so no step waits for the
+                    // LDS round trip (tested synchronously the poll cost ~300 cycles -- a tenth of a pass on the chains that matter); a give-up is decided
+                    // at most one poll late.  The masks are read when the bits are complete, hence after them.
+                    const unsigned posted = __builtin_amdgcn_readfirstlane(give_seen);
+                    give_seen = __hip_atomic_load(&give_posted[give_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    // the waves 0 .. L - 1 have all posted (L: the run of set bits from bit 0, capped at this wave): their masks, each read once
+                    int run = __builtin_ctz(~posted);
+                    run = run < wv ? run : wv;
+                    if (give_run < run) {
+                        for (; give_run < run; ++give_run) give_cov |= __hip_atomic_load(&give_acc[give_slot][give_run], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        // (wave-uniform: into scalar registers.  readfirstlane returns a SIGNED int -- widened without the cast it smears bit 31 over the upper half)
+                        give_cov = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(give_cov >> 32)) << 32) |
+                                   (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)give_cov);
+                    }
+                    const bool decided = give_run > 0 && (trying_mask & ~give_cov) == 0;      // every trying column is accepted by a position below this one
+#ifdef TFMPC_AB_GIVE_UP_DRY            // probe builds: the whole protocol without the stop
+                    if (decided) asm volatile("s_nop 0");
+#else
+                    if (decided) { stopped = true; break; }
+#endif
+                }
+            }
             if (SEARCH && early_exit && may_stop) {
                 bool open = false;                       // a trying column whose partial cost may still end at or below J_hat
 #pragma unroll
@@ -1851,7 +1964,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
 #ifndef TFMPC_GROUP4_ALPHAS
 #define TFMPC_GROUP4_ALPHAS (NT == 2 ? 2 : 1)
 #endif
-        constexpr int NA = NW == 1 ? EnvM<KIND, NT, false>::kSearchAlphas : (NW == 4 ? TFMPC_GROUP4_ALPHAS : 1);
+        constexpr int NA = NW == 1 ? Env::kSearchAlphas : (NW == 4 ? TFMPC_GROUP4_ALPHAS : 1);
         static_assert(NA * NW <= kMaxGroupWaves || NW == 1, "checkpoint tiles of a pass");
         static_assert(NW == 1 || NA <= 2, "the exchange buffer holds two values per wave");
         constexpr int NAP = NA * NW;                                          // ... per group and pass
@@ -1891,14 +2004,32 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                 if (storing)
                     rollout(std::true_type{}, std::integral_constant<bool, kStoreWhileSearching>{}, std::integral_constant<int, NA>{}, al,
                             uhat, trying_now, xc, uc, cc, J, trying_now, rJ, true, &stopped);
-                else
+                else {
+#ifndef TFMPC_AB_NO_PRIORITY
+                    // (see `kGiveUp`) SIMD partners are waves w and w + NW / 2 (of this group, or of the group that shares the CU): the earlier position first
+                    if constexpr (kGiveUp) set_priority(NW == 8 ? 3 - (wv >> 1) : 3 - wv);
+#endif
                     rollout(std::true_type{}, std::false_type{}, std::integral_constant<int, NA>{}, al,
                             uhat, false, xc, uc, cc, J, trying_now, rJ, true, &stopped,
-                            kSegments ? ckpt + (size_t)wv * NA * (kMaxGroupWaves - 1) * NT * kTileElems : nullptr);
+                            kSegments ? ckpt + (size_t)wv * NA * (kMaxGroupWaves - 1) * NT * kTileElems : nullptr, 0, -1, nullptr,
+                            kGiveUp ? parity : -1);
+                    if constexpr (kGiveUp) set_priority(0);
+                }
                 TFMPC_PHASE_END(2);
             } else {
 #pragma unroll
                 for (int k = 0; k < NA; ++k) J[k] = 0.0f;
+            }
+            if constexpr (kGiveUp) {                                           // (see `kGiveUp`; every wave posts, also one without a step size left)
+                bool mine_accepts = false;                                     // c1 == 0 (early_exit): z >= c1 <=> J_hat - J >= 0 on either branch of :342-346
+#pragma unroll
+                for (int k = 0; k < NA; ++k) mine_accepts = mine_accepts || (mine + k < cfg.n_alphas && (rJ - J[k]) >= 0.0f);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(trying_now && !stopped && mine_accepts);
+                if (lane == 0) {
+                    __hip_atomic_store(&give_acc[parity][wv], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_or(&give_posted[parity], 1u << wv, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_and(&give_posted[parity ^ 1], ~(1u << wv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
             if (NW > 1) {                                                      // the group's J(alpha) of this pass, in step-size order
 #pragma unroll
@@ -2020,8 +2151,8 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
 }  // namespace
 
 // ---- host side.  The instantiations are spread over NINE translation units (Makefile: this file compiled with
-// -DTFMPC_AM_PART=0..7 = (HVAC | Reservoir) x (two tiles | one tile with 1, 2, 4 instances per column), 18 kernels each, and part 8 = the
-// Reservoir-chain form, built in parallel); part 0 also carries the host functions.  Without the macro (tools/probes) everything is one unit.
+// -DTFMPC_AM_PART=0..7 = (HVAC | Reservoir) x (two tiles | one tile with 1, 2, 4 instances per column), 18 kernels each, and parts 8, 9 = the
+// Reservoir-chain forms (two tiles; one tile of four instances per column), built in parallel); part 0 also carries the host functions.  Without the macro (tools/probes) everything is one unit.
 #ifndef TFMPC_AM_PART
 #define TFMPC_AM_PART -1
 #endif
@@ -2095,7 +2226,7 @@ bool ilqr_adjoint_mfma_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg
     int ilqr_adjoint_mfma_launch_part##P(const TfmpcEnv &, const TfmpcIlqrConfig &, const AdjointSolveArgs &, hipStream_t, int, int, dim3, dim3);
 TFMPC_AM_PART_DECL(0) TFMPC_AM_PART_DECL(1) TFMPC_AM_PART_DECL(2) TFMPC_AM_PART_DECL(3)
 TFMPC_AM_PART_DECL(4) TFMPC_AM_PART_DECL(5) TFMPC_AM_PART_DECL(6) TFMPC_AM_PART_DECL(7)
-TFMPC_AM_PART_DECL(8)
+TFMPC_AM_PART_DECL(8) TFMPC_AM_PART_DECL(9)
 #if TFMPC_AM_PART < 0 || TFMPC_AM_PART == 8
 // the Reservoir chain (EnvM<kEnvReservoirChain>): one-wave groups, fp32 containers, two tiles -- the form a full cfg5 batch takes
 int ilqr_adjoint_mfma_launch_part8(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const AdjointSolveArgs &a, hipStream_t stream,
@@ -2104,6 +2235,18 @@ int ilqr_adjoint_mfma_launch_part8(const TfmpcEnv &env, const TfmpcIlqrConfig &c
     if (vw == 4) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<kEnvReservoirChain, 2, 4, 1, false, 1>), grid, block, 0, stream, env, cfg, a);
     else if (vw == 2) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<kEnvReservoirChain, 2, 2, 1, false, 1>), grid, block, 0, stream, env, cfg, a);
     else hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<kEnvReservoirChain, 2, 1, 1, false, 1>), grid, block, 0, stream, env, cfg, a);
+    return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
+}
+#endif
+#if TFMPC_AM_PART < 0 || TFMPC_AM_PART == 9
+// the Reservoir chain in ONE tile, four instances per column (EnvChain1; res4.config.json): 16-byte pieces, fp32 containers, every group size
+int ilqr_adjoint_mfma_launch_part9(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, const AdjointSolveArgs &a, hipStream_t stream,
+                                   int, int nw, dim3 grid, dim3 block)
+{
+    if (nw == 8) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<kEnvReservoirChain1, 1, 4, 4, false, 8>), grid, block, 0, stream, env, cfg, a);
+    else if (nw == 4) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<kEnvReservoirChain1, 1, 4, 4, false, 4>), grid, block, 0, stream, env, cfg, a);
+    else if (nw == 2) hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<kEnvReservoirChain1, 1, 4, 4, false, 2>), grid, block, 0, stream, env, cfg, a);
+    else hipLaunchKernelGGL((ilqr_adjoint_mfma_kernel<kEnvReservoirChain1, 1, 4, 4, false, 1>), grid, block, 0, stream, env, cfg, a);
     return hipGetLastError() == hipSuccess ? TFMPC_OK : TFMPC_ERR_LAUNCH;
 }
 #endif
@@ -2171,6 +2314,9 @@ int ilqr_adjoint_mfma_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, co
     if (part == 4 && nw == 1 && !cfg.storage_bf16 && (env.coupling_shift == 1 || env.coupling_shift == -1) && !a.dense_coupling &&
         !option_is(kOptCostateCoupling, "runtime"))
         part = 8;
+    // ... and in the form the reference's own res4 config takes (one tile, four instances per column, n = 4 exactly, i -> i + 1): EnvChain1
+    if (part == 7 && vw == 4 && env.n == 4 && !cfg.storage_bf16 && env.coupling_shift == 1 && !a.dense_coupling && !option_is(kOptCostateCoupling, "runtime"))
+        part = 9;
     switch (part) {
     case 0: return ilqr_adjoint_mfma_launch_part0(env, cfg, a, stream, vw, nw, grid, block);
     case 1: return ilqr_adjoint_mfma_launch_part1(env, cfg, a, stream, vw, nw, grid, block);
@@ -2180,6 +2326,7 @@ int ilqr_adjoint_mfma_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, co
     case 5: return ilqr_adjoint_mfma_launch_part5(env, cfg, a, stream, vw, nw, grid, block);
     case 6: return ilqr_adjoint_mfma_launch_part6(env, cfg, a, stream, vw, nw, grid, block);
     case 8: return ilqr_adjoint_mfma_launch_part8(env, cfg, a, stream, vw, nw, grid, block);
+    case 9: return ilqr_adjoint_mfma_launch_part9(env, cfg, a, stream, vw, nw, grid, block);
     default: return ilqr_adjoint_mfma_launch_part7(env, cfg, a, stream, vw, nw, grid, block);
     }
 }

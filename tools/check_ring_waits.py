@@ -9,7 +9,7 @@ assembly and checks every innermost loop that holds `global_load_lds_*` and a co
                    k * (DMA loads) < N <= k * (ALL vector-memory instructions in the loop body)   (one that counts the stores too),
     k = ring depth - 1 (depth 3 for the two-tile kernels, 4 otherwise)
 
-    python tools/check_ring_waits.py [part ...]        parts 0..7 (default: all); exit status 1 on a violation
+    python tools/check_ring_waits.py [part ...]        parts 0..9 (default: all); exit status 1 on a violation
 Importable: check_part(part) -> list of findings (tests/test_ring_waits_cpu.py runs the two cfg5 parts)."""
 import os, re, subprocess, sys, tempfile
 
@@ -62,6 +62,11 @@ def check_kernel(name, items):
             tgt = ins.split()[-1]
             if tgt in labels and labels[tgt] <= idx:
                 loops.append((labels[tgt], idx))
+    # round 6: the DMA helpers overwrite M0 without saving it -- sound only while nothing else in the kernel uses M0
+    for idx, ins in enumerate(instrs):
+        if re.search(r"\bm0\b", ins) and not (re.match(r"^s_mov_b32 m0, s\d+$", ins) and idx + 2 < len(instrs) and instrs[idx + 1].startswith("s_nop")
+                                               and instrs[idx + 2].startswith("global_load_lds")):
+            findings.append(f"{name[:60]}: `{ins}` uses M0 outside a DMA issue (the DMA helpers do not preserve it)")
     checked = 0
     for lo, hi in loops:
         if any(l2 != (lo, hi) and lo <= l2[0] and l2[1] <= hi for l2 in loops):
@@ -119,7 +124,7 @@ def check_part(part):
 
 
 if __name__ == "__main__":
-    parts = [int(p) for p in sys.argv[1:]] or list(range(8))
+    parts = [int(p) for p in sys.argv[1:]] or list(range(10))
     bad = 0
     for p in parts:
         findings, checked = check_part(p)
