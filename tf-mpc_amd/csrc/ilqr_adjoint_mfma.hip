@@ -173,6 +173,11 @@ __device__ __forceinline__ float col_sum(const float (&v)[4 * NT])
     if (NT == 2) t += tile_sum<PK>((v[4] + v[5]) + (v[6] + v[7]));
     return t;
 }
+// v_max_f32 as the instruction it is.  fmaxf() of a value the compiler cannot prove canonical (a loop-carried running maximum, the result of a lane
+// swap) is preceded by a quieting v_max x, x -- one more issue slot per operand on every step of kernels whose time is their instruction count.  The
+// instruction itself returns the same bits for every input but a signalling NaN (which no arithmetic here produces).  max_abs: max(a, |b|).
+__device__ __forceinline__ float max_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float max_abs(float a, float b) { float r; asm("v_max_f32 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
 template <int NT, int PK>
 __device__ __forceinline__ float col_max(const float (&v)[4 * NT])         // non-negative inputs
 {
@@ -182,11 +187,11 @@ __device__ __forceinline__ float col_max(const float (&v)[4 * NT])         // no
     if (PK == 4) return a;
     float b = a;
     swap16(a, b);
-    a = fmaxf(a, b);
+    a = max_raw(a, b);
     if (PK == 2) return a;
     b = a;
     swap32(a, b);
-    return fmaxf(a, b);
+    return max_raw(a, b);
 }
 
 // The trajectory pointers are picked per column (output array or workspace), which hides their address space from the
@@ -527,6 +532,11 @@ __device__ __forceinline__ void mat_apply(const MatOp<2, true> &A, const float (
 __device__ __forceinline__ void force_dense(MatOp<2, false> &, bool) {}
 __device__ __forceinline__ void force_dense(MatOp<2, true> &A, bool dense) { if (dense) A.shift = 0; }
 template <bool S> __device__ __forceinline__ void force_dense(MatOp<1, S> &A, bool dense) { A.shift = __builtin_amdgcn_readfirstlane(dense ? 0 : A.shift); }     // (wave-uniform: a scalar register)
+// "this operand is never a row move" as a compile-time fact (HVAC: its matrix carries -(row sum + outside + hall conductances) on the diagonal; were it a
+// 0/1 shift all the same, the products return the moved values bit for bit): the branch around the matrix instructions and the move's code are gone
+__device__ __forceinline__ void never_a_shift(MatOp<2, false> &) {}
+__device__ __forceinline__ void never_a_shift(MatOp<2, true> &A) { A.shift = 0; A.leak_mask = 0; }
+template <bool S> __device__ __forceinline__ void never_a_shift(MatOp<1, S> &A) { A.shift = 0; A.leak_mask = 0; }
 
 // A copy of a lane-dependent index the optimiser cannot see through: what is computed from it inside a loop stays
 // inside (hoisted out, the 16 operand addresses of each phase would stay live across the whole solve).
@@ -709,11 +719,13 @@ template <int NT, bool LEAN, bool ROWREGS> struct EnvM<TFMPC_ENV_HVAC, NT, LEAN,
     __device__ __forceinline__ void load_forward(const TfmpcEnv &g, int i, int q, Operand &A, u32x4 *rest) const
     {
         load_operand<PK>(g.n, i, q, [&](int R, int C) { return el(g, R, C); }, A, rest);
+        never_a_shift(A);
     }
     template <int PK>
     __device__ __forceinline__ void load_backward(const TfmpcEnv &g, int i, int q, Operand &A, u32x4 *rest) const
     {
         load_operand<PK>(g.n, i, q, [&](int R, int C) { return el(g, C, R); }, A, rest);
+        never_a_shift(A);
     }
     __device__ void load(const TfmpcEnv &g, int lane, int q, float *lds_)
     {
@@ -1914,7 +1926,8 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
                             sel |= (lowb0 ? (1u << e) : 0u) | (lowb1 ? (2u << e) : 0u);
                             unpr(p1, e, fma2(kt, pr(Qu, e), pr(p1, e)));
                             const f32x2 akt = abs2(kt);
-                            unpr(ka, e, max2(pr(ka, e), akt));
+                            ka[e] = max_abs(ka[e], kt.x);                                           // (max_raw's note: the running maximum of |k_t|)
+                            ka[e + 1] = max_abs(ka[e + 1], kt.y);
                             const f32x2 den = abs2(pr(uh, e)) + 1.0f;
                             // |k| / (|u| + 1) (:243-245) with the hardware reciprocal (1 ulp) instead of an IEEE division
                             // (8 per step were ~130 instructions): g_norm is only ever compared with atol
