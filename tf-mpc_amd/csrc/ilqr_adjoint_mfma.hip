@@ -1347,7 +1347,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
 #ifdef TFMPC_AB_NO_GIVE_UP             // A/B builds
     constexpr bool kGiveUp = false;
 #else
-    constexpr bool kGiveUp = NW >= 4 && !BF16;
+    constexpr bool kGiveUp = NW == 8 && !BF16;       // (four-wave groups: one chain per SIMD and group -- measured no gain on hvac6, and the poll is ~4 issue slots a step)
 #endif
     __shared__ unsigned long long give_acc[2][kGiveUp ? NW : 1];
     __shared__ unsigned give_posted[2];
@@ -1599,173 +1599,184 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
         unsigned give_seen = 0u;                             // (nothing posted yet)
         int give_run = 0;                                    // waves 0 .. give_run - 1 have posted and are in give_cov
         unsigned long long give_cov = 0;
-        for (int t0 = t_lo; t0 < t_hi; t0 += kAheadRoll) {
-            if constexpr (kGiveUp && DEFER) {
-                if (give_slot >= 0 && wv > 0 && early_exit && may_stop && (t0 & 3) == 0) {                  // (wave-uniform)
-                    // (atomic accessors on the __shared__ objects themselves: ds_* instructions, in order within a wave; a volatile access through a cast
-                    // pointer would be a FLAT access -- another queue than the ds_or that posts the bit)
-                    // The word tested is the one READ AT THE POLL BEFORE (`give_seen`): the read issued now is used four steps on, so no step waits for the
-                    // LDS round trip (tested synchronously the poll cost ~300 cycles -- a tenth of a pass on the chains that matter); a give-up is decided
-                    // at most one poll late.  The masks are read when the bits are complete, hence after them.
-                    const unsigned posted = __builtin_amdgcn_readfirstlane(give_seen);
-                    give_seen = __hip_atomic_load(&give_posted[give_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    // the waves 0 .. L - 1 have all posted (L: the run of set bits from bit 0, capped at this wave): their masks, each read once
-                    int run = __builtin_ctz(~posted);
-                    run = run < wv ? run : wv;
-                    if (give_run < run) {
-                        for (; give_run < run; ++give_run) give_cov |= __hip_atomic_load(&give_acc[give_slot][give_run], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        // (wave-uniform: into scalar registers.  readfirstlane returns a SIGNED int -- widened without the cast it smears bit 31 over the upper half)
-                        give_cov = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(give_cov >> 32)) << 32) |
-                                   (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)give_cov);
+        // The time loop, once per form of the deferred stage cost: `fused_cost` (HVAC with ordered comfort bounds) is a run-time fact, and tested inside
+        // the step it was two taken branches and three scalar instructions on every step of every chain (round 6: hoisted -- the loop exists twice
+        // where an env has a fused form at all, and the test runs once per rollout).
+        auto time_loop = [&](auto fused_c) {
+            for (int t0 = t_lo; t0 < t_hi; t0 += kAheadRoll) {
+                if constexpr (kGiveUp && DEFER) {
+                    if (give_slot >= 0 && wv > 0 && early_exit && may_stop && (t0 & 3) == 0) {                  // (wave-uniform)
+                        // (atomic accessors on the __shared__ objects themselves: ds_* instructions, in order within a wave; a volatile access through a cast
+                        // pointer would be a FLAT access -- another queue than the ds_or that posts the bit)
+                        // The word tested is the one READ AT THE POLL BEFORE (`give_seen`): the read issued now is used four steps on, so no step waits for the
+                        // LDS round trip (tested synchronously the poll cost ~300 cycles -- a tenth of a pass on the chains that matter); a give-up is decided
+                        // at most one poll late.  The masks are read when the bits are complete, hence after them.
+                        const unsigned posted = __builtin_amdgcn_readfirstlane(give_seen);
+                        give_seen = __hip_atomic_load(&give_posted[give_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        // the waves 0 .. L - 1 have all posted (L: the run of set bits from bit 0, capped at this wave): their masks, each read once
+                        int run = __builtin_ctz(~posted);
+                        run = run < wv ? run : wv;
+                        if (give_run < run) {
+                            for (; give_run < run; ++give_run) give_cov |= __hip_atomic_load(&give_acc[give_slot][give_run], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            // (wave-uniform: into scalar registers.  readfirstlane returns a SIGNED int -- widened without the cast it smears bit 31 over the upper half)
+                            give_cov = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(give_cov >> 32)) << 32) |
+                                       (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)give_cov);
+                        }
+                        const bool decided = give_run > 0 && (trying_mask & ~give_cov) == 0;      // every trying column is accepted by a position below this one
+    #ifdef TFMPC_AB_GIVE_UP_DRY            // probe builds: the whole protocol without the stop
+                        if (decided) asm volatile("s_nop 0");
+    #else
+                        if (decided) { stopped = true; break; }
+    #endif
                     }
-                    const bool decided = give_run > 0 && (trying_mask & ~give_cov) == 0;      // every trying column is accepted by a position below this one
-#ifdef TFMPC_AB_GIVE_UP_DRY            // probe builds: the whole protocol without the stop
-                    if (decided) asm volatile("s_nop 0");
-#else
-                    if (decided) { stopped = true; break; }
-#endif
                 }
-            }
-            if (SEARCH && early_exit && may_stop) {
-                bool open = false;                       // a trying column whose partial cost may still end at or below J_hat
-#pragma unroll
-                for (int k = 0; k < NA; ++k) open = open || (trying && !((DEFER ? partial(k) : J[k]) > reject_above));
-                if (__builtin_amdgcn_ballot_w64(open) == 0) { stopped = true; break; }      // (__any materialises an integer per lane first)
-            }
-#pragma unroll
-            for (int d = 0; d < kAheadRoll; ++d) {
-                const int t = t0 + d;
-                __builtin_amdgcn_sched_barrier(0);          // the unrolled steps are not interleaved (registers)
-                if (t < t_hi) {
-                    const int qo = opaque(ql);
-                    float u[NA][NV];
-                    const int dd = RING ? 0 : d;                // the register ring's slot of this unrolled step
-                    constexpr bool kEarlyProduct = NT == 1 && NW > 1 && Env::kProductOfStateOnly;      // (see EnvM<HVAC>::state_product; one-wave groups share their SIMD with two others and have no registers to park it in)
-                    float pre[NA][NV];
-                    if constexpr (kEarlyProduct) {
-#pragma unroll
-                        for (int k = 0; k < NA; ++k) env.state_product(A, x[k], qo, pre[k]);
-                    }
-                    if (NW > 1 && DEFER && ck_out && t == ck_next) {    // (wave-uniform; uncounted stores only make the ring's waits longer)
-#pragma unroll
-                        for (int k = 0; k < NA; ++k) stw<NT>(ck_out + ((size_t)k * (kMaxGroupWaves - 1) + ck_slot) * NT * kTileElems, 0, wl, trying, x[k]);
-                        ck_next += t_seg;
-                        ++ck_slot;
-                    }
-                    if constexpr (RING) {
-                        // step t + depth - 1 goes into the slot the previous step has just read; then the loads of THIS
-                        // step have landed once at most the (depth - 1) younger steps' are outstanding
-                        const int ahead = t + kRingDepth - 1;
-                        issue(pslot, ahead < t_hi ? ahead : t_hi - 1);
-                        // (a stored rollout also issues kStores stores per step, unconditionally: they are younger than the
-                        // loads waited for and stay in flight too -- counted without them, every step waited for the previous
-                        // step's stores to be acknowledged by the memory system, ~2 us: the stored rollout, one chain, took as
-                        // long as a search pass with two)
-                        // (the loads of THIS step were issued at the start of step t - (depth - 1), BEFORE that step's stores: the
-                        // stores of the last depth - 1 steps are younger and stay in flight; that many exist from step depth - 1 on)
-#ifdef TFMPC_PROBE_NO_RING_READS        // probe builds (timing only, wrong results): what the ring's wait and its LDS reads cost a step
-#pragma unroll
-                        for (int e = 0; e < NV; ++e) { ur[0][e] = 0.25f; opaque_f(ur[0][e]); }
-                        kb[0] = 5u + (unsigned)t;
-#else
-                        if (STORE && t - t_lo >= kRingDepth - 1) wait_vmem<(kRingDepth - 1) * (kLoads + 2 * NT + 1 + (kSweepCoefficients ? kCoefPieces : 0))>();
-                        else wait_vmem<(kRingDepth - 1) * kLoads>();
-#pragma unroll
-                        for (int b = 0; b < NT; ++b) {
-                            const f32x4 v = ring_v[slot][b][lane];
-                            ur[0][4 * b] = v[0]; ur[0][4 * b + 1] = v[1]; ur[0][4 * b + 2] = v[2]; ur[0][4 * b + 3] = v[3];
+                if (SEARCH && early_exit && may_stop) {
+                    bool open = false;                       // a trying column whose partial cost may still end at or below J_hat
+    #pragma unroll
+                    for (int k = 0; k < NA; ++k) open = open || (trying && !((DEFER ? partial(k) : J[k]) > reject_above));
+                    if (__builtin_amdgcn_ballot_w64(open) == 0) { stopped = true; break; }      // (__any materialises an integer per lane first)
+                }
+    #pragma unroll
+                for (int d = 0; d < kAheadRoll; ++d) {
+                    const int t = t0 + d;
+                    __builtin_amdgcn_sched_barrier(0);          // the unrolled steps are not interleaved (registers)
+                    if (t < t_hi) {
+                        const int qo = opaque(ql);
+                        float u[NA][NV];
+                        const int dd = RING ? 0 : d;                // the register ring's slot of this unrolled step
+                        constexpr bool kEarlyProduct = NT == 1 && NW > 1 && Env::kProductOfStateOnly;      // (see EnvM<HVAC>::state_product; one-wave groups share their SIMD with two others and have no registers to park it in)
+                        float pre[NA][NV];
+                        if constexpr (kEarlyProduct) {
+    #pragma unroll
+                            for (int k = 0; k < NA; ++k) env.state_product(A, x[k], qo, pre[k]);
                         }
-                        kb[0] = ring_k[slot][lane] & 0xFFu;
-#endif
-                        pslot = slot, slot = ring_next(slot);
-                    }
-                    if (SEARCH) {
-                        float alow[NV], ahigh[NV];
-                        bounds(qo, alow, ahigh);
-                        float bnd[NV];
-                        select_bits<NV>(kb[dd], alow, ahigh, bnd);              // the bound the sweep's selector bit names
-#pragma unroll
-                        for (int e = 0; e < NV; e += 2) {
-                            const f32x2 uh_e = pr(ur[dd], e);
-                            const f32x2 bound = pr(bnd, e);
-                            const f32x2 kt = bound - uh_e;                                                   // :140-141
-#pragma unroll
-                            for (int k = 0; k < NA; ++k) {
-                                const f32x2 un = uh_e + alpha[k] * kt;                                       // :193-194
-                                u[k][e] = __builtin_amdgcn_fmed3f(un.x, alow[e], ahigh[e]);                  // :196-197 (low <= high)
-                                u[k][e + 1] = __builtin_amdgcn_fmed3f(un.y, alow[e + 1], ahigh[e + 1]);
+                        if (NW > 1 && DEFER && ck_out && t == ck_next) {    // (wave-uniform; uncounted stores only make the ring's waits longer)
+    #pragma unroll
+                            for (int k = 0; k < NA; ++k) stw<NT>(ck_out + ((size_t)k * (kMaxGroupWaves - 1) + ck_slot) * NT * kTileElems, 0, wl, trying, x[k]);
+                            ck_next += t_seg;
+                            ++ck_slot;
+                        }
+                        if constexpr (RING) {
+                            // step t + depth - 1 goes into the slot the previous step has just read; then the loads of THIS
+                            // step have landed once at most the (depth - 1) younger steps' are outstanding
+                            const int ahead = t + kRingDepth - 1;
+                            issue(pslot, ahead < t_hi ? ahead : t_hi - 1);
+                            // (a stored rollout also issues kStores stores per step, unconditionally: they are younger than the
+                            // loads waited for and stay in flight too -- counted without them, every step waited for the previous
+                            // step's stores to be acknowledged by the memory system, ~2 us: the stored rollout, one chain, took as
+                            // long as a search pass with two)
+                            // (the loads of THIS step were issued at the start of step t - (depth - 1), BEFORE that step's stores: the
+                            // stores of the last depth - 1 steps are younger and stay in flight; that many exist from step depth - 1 on)
+    #ifdef TFMPC_PROBE_NO_RING_READS        // probe builds (timing only, wrong results): what the ring's wait and its LDS reads cost a step
+    #pragma unroll
+                            for (int e = 0; e < NV; ++e) { ur[0][e] = 0.25f; opaque_f(ur[0][e]); }
+                            kb[0] = 5u + (unsigned)t;
+    #else
+                            if (STORE && t - t_lo >= kRingDepth - 1) wait_vmem<(kRingDepth - 1) * (kLoads + 2 * NT + 1 + (kSweepCoefficients ? kCoefPieces : 0))>();
+                            else wait_vmem<(kRingDepth - 1) * kLoads>();
+    #pragma unroll
+                            for (int b = 0; b < NT; ++b) {
+                                const f32x4 v = ring_v[slot][b][lane];
+                                ur[0][4 * b] = v[0]; ur[0][4 * b + 1] = v[1]; ur[0][4 * b + 2] = v[2]; ur[0][4 * b + 3] = v[3];
                             }
+                            kb[0] = ring_k[slot][lane] & 0xFFu;
+    #endif
+                            pslot = slot, slot = ring_next(slot);
                         }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < NV; ++e) u[0][e] = ur[dd][e];
-                    }
-                    if constexpr (!RING) {
-                        // the refill is issued AFTER the slot's last use (a scheduling fence on either side)
-                        __builtin_amdgcn_sched_barrier(0);
-                        request(t + kAheadRoll < T ? t + kAheadRoll : T - 1, ur[dd], kb[dd]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll
-                    for (int k = 0; k < NA; ++k) {
-                        float xn[NV];
-                        if constexpr (DEFER) {
-                            if (fused_cost) {                                   // (wave-uniform)
-                                env.cost_accumulate(x[k], u[k], qo, jacc[k]);
+                        if (SEARCH) {
+                            float alow[NV], ahigh[NV];
+                            bounds(qo, alow, ahigh);
+                            float bnd[NV];
+                            select_bits<NV>(kb[dd], alow, ahigh, bnd);              // the bound the sweep's selector bit names
+    #pragma unroll
+                            for (int e = 0; e < NV; e += 2) {
+                                const f32x2 uh_e = pr(ur[dd], e);
+                                const f32x2 bound = pr(bnd, e);
+                                const f32x2 kt = bound - uh_e;                                                   // :140-141
+    #pragma unroll
+                                for (int k = 0; k < NA; ++k) {
+                                    const f32x2 un = uh_e + alpha[k] * kt;                                       // :193-194
+                                    u[k][e] = __builtin_amdgcn_fmed3f(un.x, alow[e], ahigh[e]);                  // :196-197 (low <= high)
+                                    u[k][e + 1] = __builtin_amdgcn_fmed3f(un.y, alow[e + 1], ahigh[e + 1]);
+                                }
+                            }
+                        } else {
+    #pragma unroll
+                            for (int e = 0; e < NV; ++e) u[0][e] = ur[dd][e];
+                        }
+                        if constexpr (!RING) {
+                            // the refill is issued AFTER the slot's last use (a scheduling fence on either side)
+                            __builtin_amdgcn_sched_barrier(0);
+                            request(t + kAheadRoll < T ? t + kAheadRoll : T - 1, ur[dd], kb[dd]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+    #pragma unroll
+                        for (int k = 0; k < NA; ++k) {
+                            float xn[NV];
+                            if constexpr (DEFER) {
+                                if constexpr (decltype(fused_c)::value) {            // (see `time_loop`)
+                                    env.cost_accumulate(x[k], u[k], qo, jacc[k]);
+                                } else {
+                                    float cp[NV];
+                                    env.stage_costs(x[k], u[k], qo, cp);
+    #pragma unroll
+                                    for (int e = 0; e < NV; e += 2) jacc[k][(e >> 1) & 1] += pr(cp, e);
+                                }
+                                if constexpr (kEarlyProduct) env.step_with(pre[k], x[k], u[k], xn);
+                                else env.step(A, x[k], u[k], qo, xn);
+    #ifdef TFMPC_CFG5_TRACE
+                                if (trace_fa[k] < 0 && partial(k) > reject_above) trace_fa[k] = t;
+    #endif
                             } else {
                                 float cp[NV];
                                 env.stage_costs(x[k], u[k], qo, cp);
-#pragma unroll
-                                for (int e = 0; e < NV; e += 2) jacc[k][(e >> 1) & 1] += pr(cp, e);
-                            }
-                            if constexpr (kEarlyProduct) env.step_with(pre[k], x[k], u[k], xn);
-                            else env.step(A, x[k], u[k], qo, xn);
-#ifdef TFMPC_CFG5_TRACE
-                            if (trace_fa[k] < 0 && partial(k) > reject_above) trace_fa[k] = t;
-#endif
-                        } else {
-                            float cp[NV];
-                            env.stage_costs(x[k], u[k], qo, cp);
-                            const float c = col_sum<NT, PK>(cp);
-                            float cA[NV], gx[NV];                               // (kSweepCoefficients: the next sweep's coefficients of step t)
-                            if constexpr (kSweepCoefficients) {                 // (Reservoir: no early product)
-                                if constexpr (STORE) env.step_with_coefficients(A, x[k], u[k], qo, xn, cA, gx);
-                                else env.step(A, x[k], u[k], qo, xn);
-                            } else {
-                                if constexpr (kEarlyProduct) env.step_with(pre[k], x[k], u[k], xn);
-                                else env.step(A, x[k], u[k], qo, xn);
-                            }
-                            J[k] += c;
-                            if (STORE) {
-                                if constexpr (RING) {
-                                    // every store is issued on every step (columns that do not keep the candidate write to
-                                    // the trash slot): kStores per step, which the ring's wait counts
-                                    stw<NT>(keep ? us : trash, keep ? t : 0, wl, true, u[k]);
-                                    stw<NT>(keep ? xs : trash, keep ? t + 1 : 0, wl, true, xn);
-                                    stc(keep ? cs + (size_t)t * kCostLd : trash + NT * kTileElems + ccol, c);
+                                const float c = col_sum<NT, PK>(cp);
+                                float cA[NV], gx[NV];                               // (kSweepCoefficients: the next sweep's coefficients of step t)
+                                if constexpr (kSweepCoefficients) {                 // (Reservoir: no early product)
+                                    if constexpr (STORE) env.step_with_coefficients(A, x[k], u[k], qo, xn, cA, gx);
+                                    else env.step(A, x[k], u[k], qo, xn);
                                 } else {
-                                    stw<NT>(us, t, wl, keep, u[k]);
-                                    stw<NT>(xs, t + 1, wl, keep, xn);
-                                    if (keep && ql == 0) stc(cs + (size_t)t * kCostLd, c);
+                                    if constexpr (kEarlyProduct) env.step_with(pre[k], x[k], u[k], xn);
+                                    else env.step(A, x[k], u[k], qo, xn);
                                 }
-                                if constexpr (kSweepCoefficients) {             // (see kSweepCoefficients)
-                                    f32x4 rd;
-#pragma unroll
-                                    for (int e = 0; e < NV; ++e) rd[e] = __builtin_amdgcn_rcpf(fabsf(u[k][e]) + 1.0f);      // (see the sweep: |k| / (|u| + 1))
-                                    f32x4 *const dst = reinterpret_cast<f32x4 *>(keep ? coef + (size_t)t * kCoefPieces * kTileElems : reinterpret_cast<float *>(trash)) + lane;
-                                    if (RING || keep) {                         // (the LDS-DMA ring counts its stores: issued on every step, as above)
-                                        gst(dst, f32x4{cA[0], cA[1], cA[2], cA[3]});
-                                        gst(keep ? dst + kWave : dst, f32x4{gx[0], gx[1], gx[2], gx[3]});
-                                        gst(keep ? dst + 2 * kWave : dst, rd);
+                                J[k] += c;
+                                if (STORE) {
+                                    if constexpr (RING) {
+                                        // every store is issued on every step (columns that do not keep the candidate write to
+                                        // the trash slot): kStores per step, which the ring's wait counts
+                                        stw<NT>(keep ? us : trash, keep ? t : 0, wl, true, u[k]);
+                                        stw<NT>(keep ? xs : trash, keep ? t + 1 : 0, wl, true, xn);
+                                        stc(keep ? cs + (size_t)t * kCostLd : trash + NT * kTileElems + ccol, c);
+                                    } else {
+                                        stw<NT>(us, t, wl, keep, u[k]);
+                                        stw<NT>(xs, t + 1, wl, keep, xn);
+                                        if (keep && ql == 0) stc(cs + (size_t)t * kCostLd, c);
+                                    }
+                                    if constexpr (kSweepCoefficients) {             // (see kSweepCoefficients)
+                                        f32x4 rd;
+    #pragma unroll
+                                        for (int e = 0; e < NV; ++e) rd[e] = __builtin_amdgcn_rcpf(fabsf(u[k][e]) + 1.0f);      // (see the sweep: |k| / (|u| + 1))
+                                        f32x4 *const dst = reinterpret_cast<f32x4 *>(keep ? coef + (size_t)t * kCoefPieces * kTileElems : reinterpret_cast<float *>(trash)) + lane;
+                                        if (RING || keep) {                         // (the LDS-DMA ring counts its stores: issued on every step, as above)
+                                            gst(dst, f32x4{cA[0], cA[1], cA[2], cA[3]});
+                                            gst(keep ? dst + kWave : dst, f32x4{gx[0], gx[1], gx[2], gx[3]});
+                                            gst(keep ? dst + 2 * kWave : dst, rd);
+                                        }
                                     }
                                 }
                             }
+    #pragma unroll
+                            for (int e = 0; e < NV; ++e) x[k][e] = xn[e];
                         }
-#pragma unroll
-                        for (int e = 0; e < NV; ++e) x[k][e] = xn[e];
                     }
                 }
             }
+        };
+        if constexpr (DEFER && Env::kFusedSearchCost) {
+            if (fused_cost) time_loop(std::true_type{});
+            else time_loop(std::false_type{});
+        } else {
+            time_loop(std::false_type{});
         }
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
