@@ -64,7 +64,7 @@ def check_kernel(name, items):
                 loops.append((labels[tgt], idx))
     # round 6: the DMA helpers overwrite M0 without saving it -- sound only while nothing else in the kernel uses M0
     for idx, ins in enumerate(instrs):
-        if re.search(r"\bm0\b", ins) and not (re.match(r"^s_mov_b32 m0, s\d+$", ins) and idx + 2 < len(instrs) and instrs[idx + 1].startswith("s_nop")
+        if re.search(r"\bm0\b", ins) and not (re.match(r"^s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi)$", ins) and idx + 2 < len(instrs) and instrs[idx + 1].startswith("s_nop")
                                                and instrs[idx + 2].startswith("global_load_lds")):
             findings.append(f"{name[:60]}: `{ins}` uses M0 outside a DMA issue (the DMA helpers do not preserve it)")
     checked = 0
