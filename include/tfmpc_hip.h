@@ -55,7 +55,9 @@ int tfmpc_version(void);
  * Reservoir kernel; default: the form that brings the launch to about two waves per SIMD) and TFMPC_ILQR_RETRY (bracket: the control-limited LQ kernel looks for the regularisation level
  * of a failed factorisation around the level of its previous pass instead of probing 0, 1, 2, ... as ilqr.py:285-315
  * does -- another regularisation path on ~0.5 % of the instances; unsorted: that kernel launches its blocks in instance order instead of
- * starting the instances whose first backward pass probes most levels first -- same results, for A/B timing) and TFMPC_COSTATE_COUPLING
+ * starting the instances whose first backward pass probes most levels first -- same results, for A/B timing; levels: a batch whose sample shows no
+ * such instance keeps instance order instead of starting its largest start costs first, as before round 6 -- same results; sorted: the whole batch is
+ * probed whatever the sample says) and TFMPC_COSTATE_COUPLING
  * (dense: the 16-per-wave Reservoir kernel multiplies by its `downstream` matrix also when that matrix is a shift -- a chain of
  * reservoirs, every config the reference holds -- instead of moving rows; same bits, for A/B timing and tests), TFMPC_BOX_HELPERS (off | number of
  * helper teams, default 8: a control-limited batch of more than 4 096 instances without heavy ones in the launcher's sample lends five helper

@@ -201,6 +201,33 @@ def test_heavy_first_block_order_changes_no_result():
     assert int(((outs[None]["status"] & _hip.ST_NOT_PD) != 0).sum()) > 0          # some instances did probe levels > 0
 
 
+def test_start_cost_block_order_changes_no_result():
+    """A batch WITHOUT heavy instances in the launcher's sample (0.18 F: the stable open loop) is started in the order of descending start cost J_0
+    (round 6: a pre-pass writes the keys, a counting sort on the device orders the blocks -- the longest instances of bench.py's stable batch are
+    among the largest J_0).  A launch ORDER only: every output and the decision trace equal the launch in instance order (TFMPC_ILQR_RETRY=levels:
+    the order of rounds 4 - 5 for such a batch; =unsorted: no probe at all) bit for bit, with and without helper teams."""
+    B, n, m, T, bound = 5003, 16, 8, 50, 0.5
+    F, f, C, c, x0 = _problem(B, n, m, seed=79, scale=0.18)
+    solver = iLQR(LQEnv(F, f, C, c, low=-bound, high=bound), max_iterations=20)
+    x0d = torch.as_tensor(x0[..., None], device="cuda")
+    u0 = torch.zeros(B, T, m, 1, device="cuda")
+    outs = {}
+    for mode, helpers in ((None, None), ("levels", None), ("unsorted", None), (None, "off")):
+        with _hip.option("TFMPC_ILQR_RETRY", mode), _hip.option("TFMPC_BOX_HELPERS", helpers):
+            o = solver.solve_device(x0d, T, u_init=u0, trace_rows=24)
+            torch.cuda.synchronize()
+            outs[(mode, helpers)] = {k: v.clone() for k, v in o.items() if torch.is_tensor(v) and k != "workspace"}
+    ref = outs[(None, None)]
+    for key, other in outs.items():
+        for name in ("states", "actions", "costs", "iterations", "status", "trace_len"):
+            assert torch.equal(ref[name], other[name]), (key, name)
+        assert torch.equal(torch.nan_to_num(ref["trace"], nan=-7.0), torch.nan_to_num(other["trace"], nan=-7.0)), key
+    # the order itself, read back from the launcher's scratch slab is not part of the ABI; what can be observed: the batch spread over several
+    # start costs (else the sort had nothing to do)
+    J0 = ref["trace"][:, 0, 3]
+    assert float(J0.max()) > 4.0 * float(J0.median())
+
+
 def _board_header(workspace, B, n, m, T):
     """The helper teams' board (ilqr_lq_box_mfma.hip: BoxBoardHeader) read back from the caller's workspace: it sits in the candidate-trajectory
     slab behind the gain slabs K[B][T][m][n], k[B][T][m], on the next 256-byte boundary."""

@@ -176,6 +176,17 @@ __device__ __forceinline__ void box_rollout_operands(const float *Fg, const floa
     cq1 = (q < 2) ? f32x4{cz(N + 4 * q), cz(N + 4 * q + 1), cz(N + 4 * q + 2), cz(N + 4 * q + 3)} : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 }
 
+// Sort key of the start-cost order (MODE 3, box_order_kernel): the top 12 bits of the float's order-preserving integer image -- sign, exponent, three
+// mantissa bits (steps of 9 %) --, larger cost = larger key; NaN sorts first.
+constexpr int kCostKeyBits = 12;
+__device__ __forceinline__ int box_cost_key(float J)
+{
+    unsigned u = __builtin_bit_cast(unsigned, J);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    if (!(J == J)) u = 0xFFFFFFFFu;
+    return (int)(u >> (32 - kCostKeyBits));
+}
+
 template <bool BRACKET, int MODE = 0, bool TEAMS = false>
 __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(IlqrLqArgs a)
 {
@@ -221,10 +232,10 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
         b = (MODE == 0 && a.order) ? a.order[owner_index] : (MODE == 2 ? owner_index * kProbeStride : owner_index);
     }
     if constexpr (MODE == 1) {
-        if (reinterpret_cast<const int32_t *>(a.wsq)[2 * (size_t)a.B] == 0) {         // (wave-uniform) nothing heavy in the sample: no sort
-            if (lane == 0) reinterpret_cast<int32_t *>(a.wsq)[b] = 0;
-            return;
-        }
+        if (reinterpret_cast<const int32_t *>(a.wsq)[2 * (size_t)a.B] == 0) return;   // (wave-uniform) nothing heavy in the sample: MODE 3 writes the keys
+    }
+    if constexpr (MODE == 3) {
+        if (reinterpret_cast<const int32_t *>(a.wsq)[2 * (size_t)a.B] != 0) return;   // (wave-uniform) heavy instances in the sample: MODE 1 writes the keys
     }
     const int i = lane & 15, q = lane >> 4;
     const int r8 = lane & 7;                       // QP: the row this lane owns
@@ -379,6 +390,11 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
         cz_pass(nom, Tp, cnom, false);
     }
     __syncthreads();
+    if constexpr (MODE == 3) {          // the start-cost pre-pass (see box_order_kernel): the sort key of this instance, nothing else
+        const float J0 = sum_costs(cnom);
+        if (lane == 0) reinterpret_cast<int32_t *>(a.wsq)[b] = box_cost_key(J0);
+        return;
+    }
 
     // ---- projected-Newton box-QP (optimization.py:6-101) of one timestep, in registers -----------------
     // In: Hrow (row r8 of the regularised H), Mreg (column c32 of the regularised [Q~_ux | H | .]), q_r, lo_r, hi_r.
@@ -945,6 +961,12 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
             int lo_fail = -1, hi_ok = 1 << 20, probe = (BRACKET && r_hint > 0) ? r_hint - 1 : 0, level = 0;
             for (;;) {
                 r = attempt(probe);
+                if constexpr (MODE == 2) {
+                    // the sample only asks "does the first backward pass need a regularisation level >= 1?" (box_decide_kernel): answered by the first
+                    // sweep -- finding the level itself made the sample pass as long as its slowest instance's climb (2.0 ms of a 54 ms launch)
+                    if (lane == 0) reinterpret_cast<int32_t *>(a.wsq)[b] = r.failed ? 1 : 0;
+                    return;
+                }
                 if (r.failed) lo_fail = probe > lo_fail ? probe : lo_fail;
                 else hi_ok = probe < hi_ok ? probe : hi_ok;
                 if (hi_ok == lo_fail + 1) {                                 // bracketed (hi_ok == 0: nothing below it)
@@ -961,7 +983,7 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
 #ifdef TFMPC_BOX_PROBE
             if (first_level < 0) first_level = level;
 #endif
-            if constexpr (MODE == 1 || MODE == 2) {
+            if constexpr (MODE == 1) {
                 if (lane == 0) reinterpret_cast<int32_t *>(a.wsq)[b] = give_up ? 41 : level;
                 return;
             }
@@ -1171,23 +1193,32 @@ __global__ __launch_bounds__(1024) void box_decide_kernel(const int32_t *level, 
     if (threadIdx.x == 0) *flag = heavy >= kProbeHeavy ? 1 : 0;
 }
 
-__global__ __launch_bounds__(1024) void box_order_kernel(const int32_t *level, int32_t *order, int B)
+__global__ __launch_bounds__(1024) void box_order_kernel(const int32_t *level, int32_t *order, int B, int by_cost_allowed)
 {
-    __shared__ int hist[64], base[64];
-    if (level[2 * (size_t)B] == 0) {                          // (uniform) nothing heavy in the sample: blocks in instance order
+    // Round 6: a batch WITHOUT heavy instances in the sample (the stable-open-loop variant of bench.py) used to run in instance order, and its launch
+    // lasted as long as its two longest instances happened to start late: 142 passes from 11.5 ms on, 100 from 29 ms on -- 60 ms for 34 ms of chip time.
+    // Which instances will be long is not known in advance, but the cost of the START trajectory tells most of it: the eight heaviest instances of that
+    // batch are all among the 5 300 largest J_0 of 65 536 (ranks 54, 5 295, 1 494, 216, 479, 560, 743, 136; `tools/probes/r6_box_predict.py` -- the first
+    // pass's step length would rank them within the first 500, but costs a sweep per instance, 10 ms; J_0 is the start rollout every block does
+    // anyway, ~1 ms as a pass of its own).  So such a batch is started in the order of DESCENDING start cost (MODE 3 writes the keys).  A heuristic of
+    // launch ORDER only: instances are independent, every result is the same bits in any order; at worst it is as good as the order it replaces.
+    __shared__ int hist[1 << kCostKeyBits], base[1 << kCostKeyBits];
+    const bool by_cost = level[2 * (size_t)B] == 0;           // (uniform) nothing heavy in the sample
+    if (by_cost && !by_cost_allowed) {                        // (TFMPC_ILQR_RETRY=levels: instance order, as before round 6)
         for (int b = threadIdx.x; b < B; b += 1024) order[b] = b;
         return;
     }
-    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    const int bins = by_cost ? (1 << kCostKeyBits) : 64;
+    for (int k = threadIdx.x; k < bins; k += 1024) hist[k] = 0;
     __syncthreads();
-    for (int b = threadIdx.x; b < B; b += 1024) atomicAdd(&hist[min(max(level[b], 0), 63)], 1);
+    for (int b = threadIdx.x; b < B; b += 1024) atomicAdd(&hist[min(max(level[b], 0), bins - 1)], 1);
     __syncthreads();
     if (threadIdx.x == 0) {
         int at = 0;
-        for (int l = 63; l >= 0; --l) { base[l] = at; at += hist[l]; }
+        for (int l = bins - 1; l >= 0; --l) { base[l] = at; at += hist[l]; }
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < B; b += 1024) order[atomicAdd(&base[min(max(level[b], 0), 63)], 1)] = b;
+    for (int b = threadIdx.x; b < B; b += 1024) order[atomicAdd(&base[min(max(level[b], 0), bins - 1)], 1)] = b;
 }
 
 }  // namespace
@@ -1248,8 +1279,11 @@ int ilqr_lq_box_mfma_launch(const IlqrLqArgs &a, hipStream_t stream)
             hipLaunchKernelGGL((ilqr_lq_box_mfma_kernel<false, 2>), dim3((a.B + kProbeStride - 1) / kProbeStride), dim3(kWave), lds, stream, a);
             hipLaunchKernelGGL(box_decide_kernel, dim3(1), dim3(1024), 0, stream, level, flag, a.B);
         }
+        // whole batch: the first-pass level (heavy instances in the sample) or the start cost (none) -- each pass leaves at once when it is the other's turn
+        const bool by_cost = !option_is(kOptIlqrRetry, "levels");
         hipLaunchKernelGGL((ilqr_lq_box_mfma_kernel<false, 1>), dim3(a.B), dim3(kWave), lds, stream, a);
-        hipLaunchKernelGGL(box_order_kernel, dim3(1), dim3(1024), 0, stream, level, order, a.B);
+        if (by_cost) hipLaunchKernelGGL((ilqr_lq_box_mfma_kernel<false, 3>), dim3(a.B), dim3(kWave), lds, stream, a);
+        hipLaunchKernelGGL(box_order_kernel, dim3(1), dim3(1024), 0, stream, level, order, a.B, by_cost ? 1 : 0);
         run.order = order;
     }
     if (bracket) {
