@@ -137,6 +137,35 @@ def test_four_groups_per_wave_equal_the_per_lane_kernel(force_kernel, kind, T):
         assert torch.equal(out[None][key], out["lane1"][key]), key
 
 
+@pytest.mark.parametrize("B", [300, 2300])
+def test_candidates_that_are_not_kept_are_rolled_out_again(force_kernel, B):
+    """Round 6: only the first TFMPC_GROUP_STORED (default 4) step sizes of a group's line search keep their candidate trajectory; a pass that adopts
+    another one rolls it out once more on the whole group.  With 1 or 2 kept almost every backtracking pass takes that path, with 16 none does (the
+    layout before round 6): every output and the decision trace equal the one-lane-per-instance kernel's / each other's bit for bit, in both the
+    one-group-per-wave form (B = 300) and the four-groups form with the instance queue (B = 2 300)."""
+    rng = np.random.default_rng(41)
+    T = 50
+    solver = iLQR(Navigation.load(problems.NAV_CONFIG))
+    x0 = rng.uniform(0, 10, size=(B, 2, 1)).astype(np.float32)
+    u0 = solver.random_actions(T, B, seed=9)
+    force_kernel("lane1")
+    ref = solver.solve_device(x0, T, u_init=u0)
+    torch.cuda.synchronize()
+    force_kernel(None)
+    traces, beyond = {}, 0
+    for stored in ("1", "2", None, "16"):
+        with _hip.option("TFMPC_GROUP_STORED", stored):
+            out = solver.solve_device(x0, T, u_init=u0, trace_rows=100)
+            torch.cuda.synchronize()
+        assert solver.last_kernel.startswith("lane_group")
+        for key in ("iterations", "status", "states", "actions", "costs"):
+            assert torch.equal(out[key], ref[key]), (stored, key)
+        traces[stored] = torch.nan_to_num(out["trace"], nan=-7.0).clone()
+        assert torch.equal(traces[stored], traces["1"]) and int(out["trace_len"].max()) <= 100
+    adopted = traces["1"][..., 5]                                     # alpha_index of every pass (-1 / -7: none)
+    assert int((adopted >= 1).sum()) > B and int((adopted >= 4).sum()) > 0       # the replay path was taken, also with the default
+
+
 def test_instance_queue_of_the_persistent_groups(force_kernel):
     """Round 4: the group kernel's grid is what the chip holds at once (~3 840 wavefronts = 15 360 groups) and a group whose
     instance has finished takes the next one from an atomic queue.  20 011 instances are more than one round of groups: every

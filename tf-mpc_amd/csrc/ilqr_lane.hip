@@ -139,6 +139,7 @@ int ilqr_lane_solve_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, int 
             // [queue counter: 256 bytes][scratch blocks]
             a.queue = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(extra) + 255) & ~(uintptr_t)255);
             a.scratch = reinterpret_cast<float *>(reinterpret_cast<char *>(a.queue) + kQueueBytes);
+            a.stored = group_stored_candidates(option_int(kOptGroupStored, 0));
             if (env.kind == TFMPC_ENV_NAVLQR) return group_launch<TFMPC_ENV_NAVLQR>(env, cfg, a, stream);
             if (env.kind == TFMPC_ENV_NAVIGATION) return group_launch<TFMPC_ENV_NAVIGATION>(env, cfg, a, stream);
             return TFMPC_ERR_UNSUPPORTED;

@@ -483,9 +483,14 @@ struct SolveArgsLane {
     int32_t *iterations, *status;
     float *wsK, *wsk, *wsx, *wsu, *wsc;
     float *scratch;          // group kernel only: one block of candidate trajectories per wavefront
+    int stored;              // group kernel only: how many step sizes of a group keep their candidate (ScratchSink)
     int *queue;              // group kernel only: the next instance nobody has taken yet (zeroed by the launcher)
     TraceArgs trace;         // group kernel only: the optional decision trace
 };
+// (TFMPC_GROUP_STORED, tests and A/B timing: 16 = every step size keeps its candidate, as before round 6; 1 = almost every backtracking pass replays;
+// what the default is about: ScratchSink)
+constexpr int kStoredCandidates = 4;
+inline int group_stored_candidates(int requested) { return requested < 1 ? kStoredCandidates : (requested > 16 ? 16 : requested); }
 
 template <int KIND, int N, int M, class Store, bool PRE = false>
 __device__ inline LaneBackward backward_lane(const LaneEnv<KIND, N, M> &env, int T, float mu, bool bounded,
@@ -884,16 +889,22 @@ struct GroupStore {
 };
 
 // Candidate trajectory of one lane's speculative rollout: rows [x_1 .. x_T | u_0 .. u_{T-1} | c_0 .. c_T] of the
-// wave's scratch, one column per lane (x_0 never changes).
+// group's scratch, one column per STORED step size (x_0 never changes).
+// Round 6: only the first `stored` step sizes of a group keep their candidates (default kStoredCandidates = 4: 99.8 % of cfg4's passes adopt
+// index 0 .. 3 -- 67 439 / 40 349 / 14 888 / 3 400 of 126 321, and the slowest instances, which set the launch time, index 3 --,
+// tools/probes/r6_cfg4_alpha_hist.py), in a block of the group's own: [row][stored] floats, 16 bytes a row.  Every lane used to write its column
+// of a [row][64 lanes] block -- 64 KB per wave and pass, of which the adoption read one column at 64-byte sector granularity: 4.35 GB of HBM traffic per
+// launch of 16 384 instances against 0.26 GB algorithmic (the round-5 verdict's item 8).  A pass that adopts a step size beyond the stored ones (0.2 %)
+// rolls THAT step size out once more on the whole group into column 0 -- the same function on the same inputs: the same bits -- and adopts it from there.
 template <int N, int M>
 struct ScratchSink {
-    float *col;                  // wave's scratch + lane
-    int T;
-    bool live;                   // lanes beyond the number of step sizes repeat the last one: nothing to keep
+    float *col;                  // group's scratch block + this lane's column
+    int T, stride;               // floats between rows (= stored columns)
+    bool live;                   // only the stored step sizes keep their candidate
     __host__ __device__ static int rows(int T) { return T * N + T * M + T + 1; }
-    __device__ void x(int t, int i, float v) const { if (live && t > 0) col[((t - 1) * N + i) * 64] = v; }
-    __device__ void u(int t, int a, float v) const { if (live) col[(T * N + t * M + a) * 64] = v; }
-    __device__ void c(int t, float v) const { if (live) col[(T * N + T * M + t) * 64] = v; }
+    __device__ void x(int t, int i, float v) const { if (live && t > 0) col[((t - 1) * N + i) * stride] = v; }
+    __device__ void u(int t, int a, float v) const { if (live) col[(T * N + t * M + a) * stride] = v; }
+    __device__ void c(int t, float v) const { if (live) col[(T * N + T * M + t) * stride] = v; }
 };
 
 // Round 4: PERSISTENT groups with an instance QUEUE.  A launch used to give every group exactly one instance, so a wave lasted as
@@ -929,11 +940,10 @@ __global__ __launch_bounds__(64, TFMPC_GROUP_LANE_EU) void ilqr_group_solve_kern
     const bool leader = gl == 0;
     const int my_alpha_idx = (gl < cfg.n_alphas) ? gl : cfg.n_alphas - 1;
     const float my_alpha = cfg.alphas[my_alpha_idx];
-    float *scratch = a.scratch + (size_t)blockIdx.x * ScratchSink<N, M>::rows(T) * 64;
-    // every lane of the group writes its column, also lanes 11 .. 15 (they repeat the last step size and their column is
-    // never adopted): the 16 lanes of a group are ONE 64-byte sector per scratch row -- 11 of 16 would be a partial-sector
-    // write (read-modify-write in the memory system)
-    const ScratchSink<N, M> sink{scratch + threadIdx.x, T, true};
+    // this group's block of the wave's scratch: [row][stored] (see ScratchSink); a.stored: 1 .. 16 (TFMPC_GROUP_STORED; the launcher's default 4)
+    const int stored = a.stored;
+    float *scratch = a.scratch + ((size_t)blockIdx.x * GROUPS + grp) * ScratchSink<N, M>::rows(T) * G;
+    const ScratchSink<N, M> sink{scratch + (gl < stored ? gl : 0), T, stored, gl < stored && gl < cfg.n_alphas};
     Store st{lane_lds + grp, T};
 
     // ---- per-group state of the machine --------------------------------------------------------------------------------
@@ -1042,15 +1052,22 @@ __global__ __launch_bounds__(64, TFMPC_GROUP_LANE_EU) void ilqr_group_solve_kern
                                             cfg.alphas[chosen], J_chosen, accept ? 1 : 0, res_chosen, level);
                 }
                 if (small_step || accept) {
-                    // adopt the chosen lane's candidate: its scratch column becomes the nominal trajectory
+                    // adopt the chosen step size's candidate: its scratch column becomes the nominal trajectory
                     TFMPC_PROBE_START();
+                    int column = chosen;
+                    if (chosen >= stored) {             // (group-uniform) not kept: once more, the whole group on that step size, lane 0 writes column 0
+                        float J_again, residual_again;
+                        const ScratchSink<N, M> again{scratch, T, stored, leader};
+                        forward_lane<KIND, N, M>(env, T, cfg.alphas[chosen], low, high, st, again, J_again, residual_again);
+                        column = 0;
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    const float *col = scratch + grp * G + chosen;
+                    const float *col = scratch + column;
                     const int rx = T * N, ru = T * M;
-                    for (int rr = gl; rr < rx; rr += G) st.at(N + rr) = col[rr * 64];
-                    for (int rr = gl; rr < ru; rr += G) st.at(st.uoff() + rr) = col[(rx + rr) * 64];
-                    for (int rr = gl; rr <= T; rr += G) chat[rr] = col[(rx + ru + rr) * 64];
+                    for (int rr = gl; rr < rx; rr += G) st.at(N + rr) = col[rr * stored];
+                    for (int rr = gl; rr < ru; rr += G) st.at(st.uoff() + rr) = col[(rx + rr) * stored];
+                    for (int rr = gl; rr <= T; rr += G) chat[rr] = col[(rx + ru + rr) * stored];
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     TFMPC_PROBE(6);
                 }
