@@ -1630,7 +1630,15 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
     #endif
                     }
                 }
-                if (SEARCH && early_exit && may_stop) {
+                // (tested every FOURTH step: the column sums behind `partial` are two lane swaps and their hazard no-ops per chain -- ~10 issue slots a
+                // step of hvac6's chains when tested every second step; a chain that is over stops at most two steps later, which changes nothing
+                // but the partial sum a rejected try reports)
+#ifdef TFMPC_AB_EXIT_EVERY_TRIP         // A/B builds: every trip of the loop, as before
+                constexpr bool kExitEveryTrip = true;
+#else
+                constexpr bool kExitEveryTrip = kAheadRoll > 2;
+#endif
+                if (SEARCH && early_exit && may_stop && (kExitEveryTrip || (t0 & 3) == (t_lo & 3))) {
                     bool open = false;                       // a trying column whose partial cost may still end at or below J_hat
     #pragma unroll
                     for (int k = 0; k < NA; ++k) open = open || (trying && !((DEFER ? partial(k) : J[k]) > reject_above));
