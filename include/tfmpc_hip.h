@@ -67,7 +67,8 @@ int tfmpc_version(void);
  * Q_uu(t)^-1 -- which for a time-invariant LQ env at mu = 0 do not depend on the trajectory, so the recomputed ones would be the same bits -- and
  * runs only the vector recursion for k_t, V_x: results agree to fp32 rounding), TFMPC_GROUP_STORED (1 .. 16, default 4: how many step sizes of a
  * line search of the 2 x 2 lane-group kernel keep their candidate trajectory in the workspace; a pass that adopts another one rolls it out once
- * more -- same bits, for tests and A/B timing) are read ONCE per process, at the first use of the library; afterwards only
+ * more -- same bits, for tests and A/B timing), TFMPC_BOX_SPECULATE (off | n, default 0: after n rejected passes in a row the helper team of a
+ * control-limited instance runs the backward passes of its next passes beside its own -- same bits) are read ONCE per process, at the first use of the library; afterwards only
  * this call changes them (value NULL or "" = back to the dispatcher's own choice).  Returns TFMPC_ERR_ARG
  * for an unknown name.  Process-wide; not meant to be flipped while other threads launch. */
 int tfmpc_set_option(const char *name, const char *value);

@@ -97,7 +97,7 @@ def test_every_documented_option_is_known_to_the_library():
     """tfmpc_set_option / tfmpc_get_option (host code only): every name include/tfmpc_hip.h and INTEGRATION.md document is accepted, the value read
     back is the value set, an unknown name and an over-long value are argument errors, and the previous override is restored."""
     names = ("TFMPC_LQR_KERNEL", "TFMPC_LQR_MFMA", "TFMPC_ILQR_KERNEL", "TFMPC_COSTATE_WAVES", "TFMPC_ILQR_RETRY", "TFMPC_COSTATE_COUPLING",
-             "TFMPC_LQR_WAVES", "TFMPC_BOX_HELPERS", "TFMPC_BOX_HELP_AFTER", "TFMPC_ILQR_LQ_REUSE", "TFMPC_GROUP_STORED")
+             "TFMPC_LQR_WAVES", "TFMPC_BOX_HELPERS", "TFMPC_BOX_HELP_AFTER", "TFMPC_ILQR_LQ_REUSE", "TFMPC_GROUP_STORED", "TFMPC_BOX_SPECULATE")
     import os
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "tfmpc_hip.h")).read()
     for name in names:

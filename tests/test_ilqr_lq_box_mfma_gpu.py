@@ -228,6 +228,41 @@ def test_start_cost_block_order_changes_no_result():
     assert float(J0.max()) > 4.0 * float(J0.median())
 
 
+def test_speculative_sweeps_change_no_result():
+    """Round 6: a helper team also runs the backward passes of its owner's NEXT passes -- the same trajectory, mu and delta advanced by the
+    rejection update -- beside the owner's own sweep, and a pass that follows a rejection takes the helper's gains from the board instead of
+    sweeping (TFMPC_BOX_SPECULATE = rejections in a row before a team speculates, default 0: always; off: never).  The batch: 5 000 instances of
+    bench.py's stable control-limited workload, among them its ten longest (runs of up to seven rejected passes; 64 of the longest one's 142
+    passes are rejections).  With the claim threshold lowered to 1 every instance that makes a second pass asks for a team: every output must equal
+    the launch without speculation, and the one without helpers, bit for bit.  (No decision trace in those launches: a traced solve does not
+    speculate.)"""
+    import workloads
+    w = workloads.control_limited_stable(65536)
+    heavy = [22144, 56392, 62458, 49081, 61167, 52665, 34822, 64256, 43257, 65334]
+    idx = np.array(sorted(set(heavy) | set(range(4990))))
+    B, T = len(idx), w["T"]
+    pick = lambda a: a[torch.as_tensor(idx, device=a.device)] if torch.is_tensor(a) else a[idx]
+    solver = iLQR(LQEnv(pick(w["F"]), pick(w["f"]), pick(w["C"]), pick(w["c"]), low=w["low"], high=w["high"]))
+    x0d, u0 = pick(w["x0"]), pick(w["u0"])
+    outs = {}
+    for helpers, spec, after in (("off", None, None), (None, "off", "1"), (None, None, None), (None, "0", "1"), (None, "1", "1"), ("3", "0", "1"), (None, "2", "3")):
+        with _hip.option("TFMPC_BOX_HELPERS", helpers), _hip.option("TFMPC_BOX_SPECULATE", spec), _hip.option("TFMPC_BOX_HELP_AFTER", after):
+            o = solver.solve_device(x0d, T, u_init=u0)
+            torch.cuda.synchronize()
+            outs[(helpers, spec, after)] = {k: v.clone() for k, v in o.items() if torch.is_tensor(v) and k != "workspace"}
+    ref = outs[("off", None, None)]
+    for key, other in outs.items():
+        for name in ("states", "actions", "costs", "iterations", "status"):
+            assert torch.equal(ref[name], other[name]), (key, name)
+    traced = solver.solve_device(x0d, T, u_init=u0, trace_rows=160)
+    torch.cuda.synchronize()
+    valid = torch.arange(160, device="cuda")[None, :] < traced["trace_len"][:, None]
+    rejected = int(((traced["trace"][..., 8] == 0) & valid).sum())
+    assert rejected > 80, rejected                        # the batch does have runs of rejections to speculate on
+    for name in ("states", "actions", "costs", "iterations", "status"):
+        assert torch.equal(ref[name], traced[name]), name
+
+
 def _board_header(workspace, B, n, m, T):
     """The helper teams' board (ilqr_lq_box_mfma.hip: BoxBoardHeader) read back from the caller's workspace: it sits in the candidate-trajectory
     slab behind the gain slabs K[B][T][m][n], k[B][T][m], on the next 256-byte boundary."""

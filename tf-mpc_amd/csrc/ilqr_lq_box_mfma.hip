@@ -137,12 +137,20 @@ struct BoxTeam {
     int present;                        // helper blocks that have checked in
     int done[8];                        // done[r]: the last request helper r has answered
     float res[8][4];                    // its J and residual for the step sizes 2 + 2 r, 3 + 2 r
-    int pad[20];
+    int kind;                           // the request: 0 = roll out step sizes, 1 = speculative sweeps (round 6, see `speculate`)
+    int gains;                          // rollouts: the gains to use -- -1 the owner's workspace, h >= 0 the set helper h's sweep left on the board
+    float mu, delta;                    // sweeps: the owner's solve-level mu, delta (helper h applies the rejection update h + 1 times)
+    int pad[16];
 };
 static_assert(sizeof(BoxBoardHeader) == 256 && sizeof(BoxTeam) == 256, "board layout");
 __host__ __device__ inline size_t box_traj_floats(int T) { return (size_t)(T + 1) * kZld; }
 __host__ __device__ inline size_t box_cost_floats(int T) { return (size_t)((T + 1 + 3) & ~3); }
-__host__ __device__ inline size_t box_team_floats(int T) { return box_traj_floats(T) + 2 * kBoxHelpers * (box_traj_floats(T) + box_cost_floats(T)); }
+// K[T][m][n] | k[T][m] of one speculative sweep, then four floats of its result (dV1, dV2, g_norm, failed << 16 | flags as bits)
+__host__ __device__ inline size_t box_gain_floats(int T) { return (size_t)(((size_t)T * M * N + (size_t)T * M + 3) & ~(size_t)3) + 4; }
+__host__ __device__ inline size_t box_team_floats(int T)
+{
+    return box_traj_floats(T) + 2 * kBoxHelpers * (box_traj_floats(T) + box_cost_floats(T)) + kBoxHelpers * box_gain_floats(T);
+}
 __host__ __device__ inline size_t box_board_bytes(int teams, int T) { return sizeof(BoxBoardHeader) + (size_t)teams * (sizeof(BoxTeam) + box_team_floats(T) * sizeof(float)); }
 __device__ __forceinline__ int ld_acquire(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int ld_relaxed(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -268,19 +276,11 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
     };
 
     // ---- operands resident in registers for the whole solve ------------------------------
-    float Fb0[4], Fb1[4];
+    // (the SWEEP's share of them as a function of the instance: a helper of a team runs speculative sweeps for its owner since round 6 -- see
+    // `speculate` -- and loads them again when the team changes hands, as it does the rollout's)
     f32x4 Cd00, Cd01t, Cd11;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int k = 4 * q + r, ku = N + k;
-        Fb0[r] = Fxx(k, i);
-        Fb1[r] = (i < M) ? Fxu(k, i) : 0.0f;
-        Cd00[r] = Cs(k, i);
-        Cd01t[r] = (k < M) ? Cs(N + k, i) : 0.0f;
-        float c11 = 0.0f;
-        if (ku < D && i < M) c11 = (k >= m && i == k) ? 1.0f : Cs(ku, N + i);     // unit diagonal on padded actions
-        Cd11[r] = c11;
-    }
+    ConstFrag Fc0, Fc1;
+    float Gcol[8], Grow[8];
     const int fi = lane >> 2, fc = lane & 3;       // F rows for x' = F z + f
     const int ka = lane >> 3, jc = lane & 7;       // K rows for du = K dx
     // what a ROLLOUT needs of the instance (a helper loads these again when its team changes hands; the sweep's operands are the owner's alone)
@@ -288,25 +288,39 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
     float Ca0[6], Ca1[6];                          // A operand of C Z (k = 4s + q)
     f32x4 cq0, cq1;
     box_rollout_operands(Fg, fg, Cg, cg, n, m, lane, Fr, f_i, Ca0, Ca1, cq0, cq1);
-    const ConstFrag Fc0 = const_frag(f32x4{Fb0[0], Fb0[1], Fb0[2], Fb0[3]});
-    const ConstFrag Fc1 = const_frag(f32x4{Fb1[0], Fb1[1], Fb1[2], Fb1[3]});
     // Gram matrices of the regularisation, constant on this env (ilqr.py:127,133-134 with f_x, f_u fixed):
     //   column layout (lane c32): Gcol[e] = (F_u^T [F_x | . | F_u])[e][c]  -> added to the elimination input
     //   row layout (lane r8):     Grow[j] = (F_u^T F_u)[r8][j]             -> added to the QP's H
     // The same ascending-k FMA chain in both, so G_uu[a][b] == G_uu[b][a] bit for bit.
-    float Gcol[8], Grow[8];
+    auto load_sweep_operands = [&]() {              // (reads Fg, Cg of the current instance through Fxx / Fxu / Cs)
+        float Fb0[4], Fb1[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float gc = 0.0f, gr = 0.0f;
-        for (int k = 0; k < n; ++k) {
-            const float fue = Fxu(k, e);
-            const float other = c32 < N ? Fxx(k, c32) : (c32 < N + M ? Fxu(k, c32 - N) : 0.0f);
-            gc = fmaf(fue, other, gc);
-            gr = fmaf(Fxu(k, r8), fue, gr);
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * q + r, ku = N + k;
+            Fb0[r] = Fxx(k, i);
+            Fb1[r] = (i < M) ? Fxu(k, i) : 0.0f;
+            Cd00[r] = Cs(k, i);
+            Cd01t[r] = (k < M) ? Cs(N + k, i) : 0.0f;
+            float c11 = 0.0f;
+            if (ku < D && i < M) c11 = (k >= m && i == k) ? 1.0f : Cs(ku, N + i);     // unit diagonal on padded actions
+            Cd11[r] = c11;
         }
-        Gcol[e] = gc;
-        Grow[e] = gr;
-    }
+        Fc0 = const_frag(f32x4{Fb0[0], Fb0[1], Fb0[2], Fb0[3]});
+        Fc1 = const_frag(f32x4{Fb1[0], Fb1[1], Fb1[2], Fb1[3]});
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float gc = 0.0f, gr = 0.0f;
+            for (int k = 0; k < n; ++k) {
+                const float fue = Fxu(k, e);
+                const float other = c32 < N ? Fxx(k, c32) : (c32 < N + M ? Fxu(k, c32 - N) : 0.0f);
+                gc = fmaf(fue, other, gc);
+                gr = fmaf(Fxu(k, r8), fue, gr);
+            }
+            Gcol[e] = gc;
+            Grow[e] = gr;
+        }
+    };
+    load_sweep_operands();
     // action bounds of row r8 (padded actions: any box around 0; their Q_u is 0 and their H row the unit vector)
     const float low_r = r8 < m ? a.env.low[r8] : -1.0f, high_r = r8 < m ? a.env.high[r8] : 1.0f;
     const float low_k = ka < m ? a.env.low[ka] : 0.0f, high_k = ka < m ? a.env.high[ka] : 0.0f;   // rollout: action row ka
@@ -827,39 +841,67 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
             reinterpret_cast<f32x4 *>(dst)[idx] = reinterpret_cast<const f32x4 *>(src)[idx];
     };
     auto helper_bufs = [&](int r, int second) { return tbuf + trajF + (size_t)(2 * r + second) * (trajF + costF); };
+    // the gains of helper h's speculative sweep: K[T][m][n] | k[T][m], behind the candidate buffers of the team
+    const size_t gainF = box_gain_floats(T);
+    auto spec_gains = [&](int h) { return tbuf + trajF + (size_t)(2 * kBoxHelpers) * (trajF + costF) + (size_t)h * gainF; };
+    auto use_gains = [&](int set) {                 // -1: the instance's workspace; h: what helper h's sweep left on the board
+        if (set < 0) { Kg = a.wsK + (size_t)b * T * m * n; kg = a.wsk + (size_t)b * T * m; }
+        else { Kg = spec_gains(set); kg = Kg + (size_t)T * m * n; }
+    };
     if (helper) {
         for (;;) {
-            // request my_seq of instance b: the nominal trajectory from the board, the step sizes of this role, both candidates back
+            // request my_seq of instance b: the nominal trajectory from the board, then ...
             copy16(nom, tbuf, trajF);
             __syncthreads();
-            const int ai = 2 + 2 * role;
-            float JA = 0.0f, rA = 0.0f, JB = 0.0f, rB = 0.0f;
-            if (ai + 1 < cfg.n_alphas) forward2(cfg.alphas[ai], cfg.alphas[ai + 1], JA, rA, JB, rB);
-            else if (ai < cfg.n_alphas) forward(cfg.alphas[ai], JA, rA);
-            __syncthreads();
-            if (ai < cfg.n_alphas) {
-                copy16(helper_bufs(role, 0), cand, trajF);
-                copy16(helper_bufs(role, 0) + trajF, ccand, costF);
+            const int kind = __builtin_amdgcn_readfirstlane(tm->kind);
+            if (kind == 1) {
+                // ... a SPECULATIVE SWEEP (see `speculate`): the backward pass the owner would run role + 1 rejected passes from now -- the same
+                // trajectory, mu and delta advanced by that many rejection updates (ilqr.py:267-270) -- gains into this helper's set on the board
+                float mu_h = tm->mu, delta_h = tm->delta;
+                for (int j = 0; j <= role; ++j) {
+                    delta_h = fmaxf(cfg.delta_0, delta_h * cfg.delta_0);
+                    mu_h = fmaxf(cfg.mu_min, mu_h * delta_h);
+                }
+                cz_pass(nom, Tp, cand, true);           // l_z(t) of the nominal trajectory, as the owner's pass forms them
+                __syncthreads();
+                use_gains(role);
+                const StepResult sr = backward(cand, mu_h);
+                if (lane == 0) {                        // (behind the gains: the answers of later rollout requests overwrite `res`)
+                    float *out = spec_gains(role) + gainF - 4;
+                    out[0] = sr.dV1; out[1] = sr.dV2; out[2] = sr.g_norm;
+                    out[3] = __builtin_bit_cast(float, (sr.failed ? 0x10000 : 0) | (sr.flags & 0xFFFF));
+                }
+            } else {
+                // ... the step sizes of this role, both candidates back
+                use_gains(__builtin_amdgcn_readfirstlane(tm->gains));
+                const int ai = 2 + 2 * role;
+                float JA = 0.0f, rA = 0.0f, JB = 0.0f, rB = 0.0f;
+                if (ai + 1 < cfg.n_alphas) forward2(cfg.alphas[ai], cfg.alphas[ai + 1], JA, rA, JB, rB);
+                else if (ai < cfg.n_alphas) forward(cfg.alphas[ai], JA, rA);
+                __syncthreads();
+                if (ai < cfg.n_alphas) {
+                    copy16(helper_bufs(role, 0), cand, trajF);
+                    copy16(helper_bufs(role, 0) + trajF, ccand, costF);
+                }
+                if (ai + 1 < cfg.n_alphas) {
+                    copy16(helper_bufs(role, 1), cand2, trajF);
+                    copy16(helper_bufs(role, 1) + trajF, ccand2, costF);
+                }
+                if (lane == 0) { tm->res[role][0] = JA; tm->res[role][1] = rA; tm->res[role][2] = JB; tm->res[role][3] = rB; }
             }
-            if (ai + 1 < cfg.n_alphas) {
-                copy16(helper_bufs(role, 1), cand2, trajF);
-                copy16(helper_bufs(role, 1) + trajF, ccand2, costF);
-            }
-            if (lane == 0) { tm->res[role][0] = JA; tm->res[role][1] = rA; tm->res[role][2] = JB; tm->res[role][3] = rB; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             if (lane == 0) st_relaxed(&tm->done[role], my_seq);
             my_seq = next_request(my_seq);
             if (my_seq < 0) return;
             const int nb = __builtin_amdgcn_readfirstlane(tm->req_b);
-            if (nb != b) {                              // the team has a new owner: that instance's F, f, C, c and gains
+            if (nb != b) {                              // the team has a new owner: that instance's F, f, C, c (rollout AND sweep operands)
                 b = nb;
                 Fg = a.env.p[0] + (size_t)b * a.env.stride[0];
                 fg = a.env.p[1] + (size_t)b * a.env.stride[1];
                 Cg = a.env.p[2] + (size_t)b * a.env.stride[2];
                 cg = a.env.p[3] + (size_t)b * a.env.stride[3];
-                Kg = a.wsK + (size_t)b * T * m * n;
-                kg = a.wsk + (size_t)b * T * m;
                 box_rollout_operands(Fg, fg, Cg, cg, n, m, lane, Fr, f_i, Ca0, Ca1, cq0, cq1);
+                load_sweep_operands();
             }
         }
     }
@@ -899,6 +941,26 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
         return true;
     };
 
+    auto answered_since = [&](int r_, int seq) {            // ... has helper r answered request `seq` or a later one?  (the same bounded wait)
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (ld_acquire(&tm->done[r_]) - seq < 0) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) return false;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        return true;
+    };
+    // SPECULATIVE SWEEPS (round 6; the round-5 verdict's item 5).  What is left of a helped instance's time is its sweeps -- one wave's dependent
+    // chain that no helper shortens -- and the longest instance of bench.py's stable control-limited batch spends 64 of its 142 passes in RUNS of
+    // rejections (7, 7, 6, 4, 6, ...: `tools/probes/r5_box_straggler.py`), in which the trajectory does not change and mu, delta follow the
+    // rejection update (ilqr.py:267-270): the sweeps of the NEXT passes of such a run are known in advance.  So (after `a.speculate` rejections in a
+    // row -- default 0: in every pass; < 0: never) the owner posts, before its own sweep, a SWEEP request: helper h runs the backward pass of
+    // h + 1 rejections from now while the owner runs this pass's -- each the code the owner would run, on the same inputs: the same gains, bit for
+    // bit -- and leaves its gains and (dV1, dV2, g_norm, failed, flags) on the board.  A pass that follows a rejection then takes the next
+    // helper's sweep instead of running its own (its line search, and the team's rollouts, read the gains from the board); an accepted pass
+    // drops what is left.  A speculated sweep that failed to factorise is dropped with everything after it and the owner probes the levels
+    // itself, as the reference does.  Not while a decision trace or the clamp masks are recorded (a helper's sweep would log into the
+    // owner's rows).  Waits are the bounded ones of the team protocol.
+    int spec_left = 0, spec_next = 0, spec_seq = 0, rejected_run = 0;
     // ---- iLQR.solve (ilqr.py:214-283) ------------------------------------------------------------------------------
     float mu = 0.0f, delta = 1.0f;                                         // :215-216
     int status = 0, attempts = 0, iteration = 0;
@@ -957,9 +1019,48 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
                 status |= res.flags;
                 return res;
             };
+            // (see `speculate`) this pass's sweep from a helper, or the request for the next passes' in front of this pass's own
+            bool from_helper = false;
+            if constexpr (TEAMS) {
+                if (team >= 0 && spec_left > 0) {
+                    if (!answered_since(spec_next, spec_seq)) {
+                        team_lost = true; team = -1; spec_left = 0;
+                    } else {
+                        const float *res_h = spec_gains(spec_next) + gainF - 4;
+                        const int bits = __builtin_bit_cast(int, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, res_h[3])));
+                        if (!(bits & 0x10000)) {
+                            r = StepResult{0.0f, res_h[0], res_h[1], res_h[2], false, bits & 0xFFFF};
+                            status |= r.flags;
+                            use_gains(spec_next);
+                            from_helper = true;
+                            ++spec_next; --spec_left;
+                        } else {
+                            spec_left = 0;                                  // failed to factorise: the owner probes the levels itself
+                        }
+                    }
+                }
+                if (!from_helper) {
+                    use_gains(-1);
+                    spec_left = 0;
+                    if (team >= 0 && a.speculate >= 0 && rejected_run >= a.speculate && !a.trace.rows && !a.trace.clamp) {
+                        for (int r_ = 0; r_ < kBoxHelpers && !team_lost; ++r_)
+                            if (!answered_since(r_, my_seq)) team_lost = true;  // (one request at a time)
+                        if (team_lost) {
+                            team = -1;
+                        } else {
+                            copy16(tbuf, nom, trajF);
+                            if (lane == 0) { tm->req_b = b; tm->kind = 1; tm->mu = mu; tm->delta = delta; }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                            ++my_seq;
+                            if (lane == 0) st_relaxed(&tm->seq, my_seq);
+                            spec_seq = my_seq; spec_next = 0; spec_left = kBoxHelpers;
+                        }
+                    }
+                }
+            }
             // one call site for the sweep: lo_fail = highest level known to fail, hi_ok = lowest known to factorise
             int lo_fail = -1, hi_ok = 1 << 20, probe = (BRACKET && r_hint > 0) ? r_hint - 1 : 0, level = 0;
-            for (;;) {
+            for (; !from_helper;) {
                 r = attempt(probe);
                 if constexpr (MODE == 2) {
                     // the sample only asks "does the first backward pass need a regularisation level >= 1?" (box_decide_kernel): answered by the first
@@ -1016,13 +1117,13 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
             if (TEAMS && team >= 0) {
                 // with a team: post the request (nominal trajectory; the gains of this sweep are in HBM) -- once the previous one has been answered
                 // by every helper (one request at a time; they had a whole sweep for it)
-                for (int r_ = 0; r_ < kBoxHelpers && 2 + 2 * r_ < cfg.n_alphas && !team_lost; ++r_)
-                    if (!answered(r_)) team_lost = true;
+                for (int r_ = 0; r_ < kBoxHelpers && !team_lost; ++r_)
+                    if (!answered_since(r_, my_seq)) team_lost = true;      // (also the helpers a short list of step sizes leaves idle: they answer every request)
                 if (team_lost) {
-                    team = -1;
+                    team = -1; spec_left = 0;
                 } else {
                     copy16(tbuf, nom, trajF);
-                    if (lane == 0) tm->req_b = b;
+                    if (lane == 0) { tm->req_b = b; tm->kind = 0; tm->gains = from_helper ? spec_next - 1 : -1; }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     ++my_seq;
                     if (lane == 0) st_relaxed(&tm->seq, my_seq);
@@ -1104,8 +1205,10 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
             if (accept) {                                                   // :259-266
                 delta = fminf(1.0f / cfg.delta_0, delta / cfg.delta_0);
                 mu = (mu * delta > cfg.mu_min) ? mu * delta : 0.0f;
+                spec_left = 0; rejected_run = 0;                            // (a new trajectory: what the helpers swept is of no use)
                 break;
             }
+            ++rejected_run;
 #ifdef TFMPC_BOX_PROBE
             if (repeats > 0) --repeats; else repeats = level;           // a rejected pass at level r is followed by r identical ones
 #endif
@@ -1266,6 +1369,7 @@ int ilqr_lq_box_mfma_launch(const IlqrLqArgs &a, hipStream_t stream)
             run.board = reinterpret_cast<void *>(p1);
             run.helper_teams = teams;
             run.help_after = option_int(kOptBoxHelpAfter, kBoxHelpAfter);       // (TFMPC_BOX_HELP_AFTER: tests lower it to make every instance claim)
+            run.speculate = option_is(kOptBoxSpeculate, "off") ? -1 : option_int(kOptBoxSpeculate, 0);      // (TFMPC_BOX_SPECULATE=off | rejections in a row first; stable batch of bench.py, off / 0 / 1 / 2: 52.7 / 41.5 / 42.1 / 45.9 ms)
             if (hipMemsetAsync(run.board, 0, sizeof(BoxBoardHeader) + (size_t)teams * sizeof(BoxTeam), stream) != hipSuccess) return TFMPC_ERR_LAUNCH;
         }
     }

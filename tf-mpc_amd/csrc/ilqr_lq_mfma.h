@@ -29,6 +29,7 @@ struct IlqrLqArgs {
     void *board;                 // ilqr_lq_box_mfma.hip: HBM for the helper teams' board (any alignment), or null: no helpers
     size_t board_bytes;
     int helper_teams, help_after;   // (set by the launcher) teams of helper blocks; passes an instance makes before it may claim one
+    int speculate;                  // (set by the launcher) rejected passes in a row after which a team runs speculative sweeps; < 0: never
     const int32_t *gate;         // (set by the launcher) MODE 0 runs only if (*gate != 0) == (gate_value != 0); null: always
     int gate_value;
     float *wsMinv;               // ilqr_lq_mfma.hip / ilqr_lq_mfma32.hip: -Q_uu(t)^-1 [B][T][8][8] / [B][T][16][16] for the gain-reusing later passes, or null: full pass every time

@@ -11,7 +11,7 @@ namespace tfmpc {
 namespace {
 
 constexpr int kMaxLen = 32;
-const char *const kNames[kOptCount] = {"TFMPC_LQR_KERNEL", "TFMPC_LQR_MFMA", "TFMPC_ILQR_KERNEL", "TFMPC_COSTATE_WAVES", "TFMPC_ILQR_RETRY", "TFMPC_COSTATE_COUPLING", "TFMPC_LQR_WAVES", "TFMPC_BOX_HELPERS", "TFMPC_BOX_HELP_AFTER", "TFMPC_ILQR_LQ_REUSE", "TFMPC_GROUP_STORED"};
+const char *const kNames[kOptCount] = {"TFMPC_LQR_KERNEL", "TFMPC_LQR_MFMA", "TFMPC_ILQR_KERNEL", "TFMPC_COSTATE_WAVES", "TFMPC_ILQR_RETRY", "TFMPC_COSTATE_COUPLING", "TFMPC_LQR_WAVES", "TFMPC_BOX_HELPERS", "TFMPC_BOX_HELP_AFTER", "TFMPC_ILQR_LQ_REUSE", "TFMPC_GROUP_STORED", "TFMPC_BOX_SPECULATE"};
 
 struct Table {
     char value[kOptCount][kMaxLen];
