@@ -79,12 +79,16 @@ def test_ilqr_entry_points_reject_bad_arguments(lib):
     assert lib.tfmpc_ilqr_workspace_bytes(4, 3, 5, 5) == slabs(4, 3, 5, 5) + 4 * 5 * 64 * 4
     # ... plus, for n == m <= 32, the wave-major trajectory buffers of the 16-per-wave costate kernel: per wave two
     # buffers of (T + 1) + T tiles of 64 lanes x 4 rows and (T + 1) x 64 stage costs, T x 64 selector bytes, one time step's
-    # worth of "nowhere" for the counted unconditional stores, 8 x 7 checkpoint tile sets of the multi-wave groups and, with one tile,
-    # three 16-byte pieces per lane and time step for the coefficients of the two-part costate sweep (round 5)
+    # worth of "nowhere" for the counted unconditional stores, 8 x 7 checkpoint tile sets of the multi-wave groups; and, with one tile, behind
+    # the slices of all groups, three 16-byte pieces per lane and time step for the coefficients of the two-part costate sweep -- for at most 512
+    # groups, the launches whose forms read them (round 5; round 6: no longer in every group's slice)
     wave = lambda tiles, T: (2 * ((T + 1) * tiles * 256 + T * tiles * 256 + (T + 1) * 64) * 4 + T * 64 + 255
-                             + (tiles * 256 + 64) * 4 + (8 * 7 * tiles * 256 + (T * 3 * 256 if tiles == 1 else 0)) * 4) // 256 * 256
-    assert lib.tfmpc_ilqr_workspace_bytes(4, 3, 3, 5) == slabs(4, 3, 3, 5) + 1 * wave(1, 5)      # n <= 4: 64 instances per wave
+                             + (tiles * 256 + 64) * 4 + 8 * 7 * tiles * 256 * 4) // 256 * 256
+    coef = lambda groups, T: min(groups, 512) * (T * 3 * 256 * 4)
+    assert lib.tfmpc_ilqr_workspace_bytes(4, 3, 3, 5) == slabs(4, 3, 3, 5) + 1 * wave(1, 5) + coef(1, 5)      # n <= 4: 64 instances per wave
     assert lib.tfmpc_ilqr_workspace_bytes(40, 32, 32, 7) == slabs(40, 32, 32, 7) + 3 * wave(2, 7)  # 16 per wave, two tiles
+    big = lib.tfmpc_ilqr_workspace_bytes(65536, 4, 4, 100)                                          # 1 024 groups: the slab is capped
+    assert big == slabs(65536, 4, 4, 100) + 65536 * 100 * 64 * 4 + 1024 * wave(1, 100) + coef(1024, 100)      # (n + m > 6: the LQ kernel's slab too)
     # ... plus, for the 2-D envs, one scratch block of line-search candidates per wavefront (5 T + 1 rows of 64 lanes)
     assert lib.tfmpc_ilqr_workspace_bytes(4, 2, 2, 5) >= slabs(4, 2, 2, 5) + 4 * (5 * 5 + 1) * 64 * 4
     assert lib.tfmpc_ilqr_workspace_bytes(0, 2, 2, 5) == 0

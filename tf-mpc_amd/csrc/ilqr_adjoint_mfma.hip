@@ -1242,7 +1242,11 @@ __host__ __device__ constexpr size_t adjoint_mfma_checkpoint_floats(int NT) { re
 // the sweep coefficients of a one-tile group (Reservoir, `kSweepCoefficients` in the kernel): [time step][cA | l_x | 1 / (|u| + 1)][lane]
 // 16-byte pieces behind the checkpoint tiles
 constexpr int kCoefPieces = 3;
+// (the slab used to sit in EVERY group's slice of every one-tile shape -- + 315 MB at B = 65 536, n = m = 4 that no kernel touched.
+// Only the four- / eight-wave forms read it, and those exist for at most kCoefGroups groups: it now sits once behind the groups' slices.)
+constexpr int kCoefGroups = 512;
 __host__ __device__ constexpr size_t adjoint_mfma_coefficient_floats(int NT, int T) { return NT == 1 ? (size_t)T * kCoefPieces * kTileElems : 0; }
+__host__ __device__ constexpr size_t adjoint_mfma_coefficient_bytes(int NT, int T) { return (adjoint_mfma_coefficient_floats(NT, T) * sizeof(float) + 255) & ~(size_t)255; }
 // bytes of one wave's slice of the wave-major workspace (sized for fp32 containers; the 16-bit ones use half of each buffer)
 __host__ __device__ constexpr size_t adjoint_mfma_wave_bytes(int NT, int T)
 {
@@ -1251,7 +1255,7 @@ __host__ __device__ constexpr size_t adjoint_mfma_wave_bytes(int NT, int T)
     // is a constant the LDS-DMA ring's s_waitcnt vmcnt(N) can count (see `rollout`)
     return (2 * ((size_t)(T + 1) * NT * kTileElems + (size_t)T * NT * kTileElems + (size_t)(T + 1) * kCostLd) * sizeof(float) +
             (size_t)T * kWave + 255 + ((size_t)NT * kTileElems + kCostLd) * sizeof(float) +
-            (adjoint_mfma_checkpoint_floats(NT) + adjoint_mfma_coefficient_floats(NT, T)) * sizeof(float)) & ~(size_t)255;
+            adjoint_mfma_checkpoint_floats(NT) * sizeof(float)) & ~(size_t)255;
 }
 
 // ---- round 3: groups of NW waves, one step-size chain per wave ----------------------------------------------------------
@@ -1451,7 +1455,10 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
     TT *const trash = reinterpret_cast<TT *>(wave_ws + ((2 * (kXs + kUs + kCs) * sizeof(float) + (size_t)T * kWave + 15) & ~(size_t)15));
     // the checkpoint tiles behind the trash slot: [chain of the pass][segment boundary - 1][tile][lane] 16-byte pieces, fp32
     float *const ckpt = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(trash) + ((size_t)NT * kTileElems + kCostLd) * sizeof(float));
-    float *const coef = ckpt + adjoint_mfma_checkpoint_floats(NT);      // [t][piece][lane] 16-byte pieces
+    // the sweep coefficients of this group, [t][piece][lane] 16-byte pieces: behind the slices of ALL groups (launches of <= kCoefGroups groups only;
+    // the launcher keeps the forms that use them to such launches)
+    float *const coef = reinterpret_cast<float *>(static_cast<unsigned char *>(a.wave_ws) + (size_t)gridDim.x * adjoint_mfma_wave_bytes(NT, T) +
+                                                   (size_t)blockIdx.x * adjoint_mfma_coefficient_bytes(NT, T));
     const int t_seg = NW > 1 ? (T + NW - 1) / NW : T;    // segment w of a stored rollout: steps [w t_seg, min((w + 1) t_seg, T))
     const float *const x0p = a.x0 + b * n;
     int flip = 0;
@@ -2211,7 +2218,8 @@ size_t ilqr_adjoint_mfma_workspace_bytes(int B, int n, int m, int T)
     if (B <= 0 || n != m || n < 1 || n > 32 || T < 0) return 0;
     const int pk = n <= 4 ? 4 : (n <= 8 ? 2 : 1);                   // as in ilqr_adjoint_mfma_launch
     const size_t waves = ((size_t)B + kCols * pk - 1) / (kCols * pk);
-    return waves * adjoint_mfma_wave_bytes(n > 16 ? 2 : 1, T);
+    const int nt = n > 16 ? 2 : 1;
+    return waves * adjoint_mfma_wave_bytes(nt, T) + (waves < (size_t)kCoefGroups ? waves : (size_t)kCoefGroups) * adjoint_mfma_coefficient_bytes(nt, T);
 }
 
 bool ilqr_adjoint_mfma_supported(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg)
@@ -2339,6 +2347,7 @@ int ilqr_adjoint_mfma_launch(const TfmpcEnv &env, const TfmpcIlqrConfig &cfg, co
     int nw = (forced == 1 || forced == 2 || forced == 4 || forced == 8) ? forced
              : (groups <= 256 ? 8 : (groups <= 512 ? 4 : (groups <= 1024 && env.n <= 16 ? 2 : 1)));
     if (cfg.storage_bf16 && nw > 2) nw = 2;                          // (16-bit containers: the one- and two-wave forms)
+    if (groups > kCoefGroups && nw > 2) nw = 2;                      // (a forced four- / eight-wave form on more groups than the coefficient slab is sized for)
     const dim3 block(kWave * nw), grid((a.B + kCols * pk - 1) / (kCols * pk));
     int part = (env.kind == TFMPC_ENV_HVAC ? 0 : 4) + (env.n > 16 ? 0 : (pk == 1 ? 1 : (pk == 2 ? 2 : 3)));
     // Reservoir with a promised chain topology, in the form a large batch takes (one wave per group, fp32 containers, two tiles): the
