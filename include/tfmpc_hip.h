@@ -293,6 +293,10 @@ int tfmpc_ilqr_forward_f32(const TfmpcEnv *env, int B, int T, const float *x, co
  * board (TFMPC_BOX_HELPERS: ~60 KB per team) in the candidate-trajectory part: no extra bytes.  The workspace handed to
  * tfmpc_ilqr_solve_f32 must be 256-byte aligned (TFMPC_ERR_WORKSPACE otherwise). */
 size_t tfmpc_ilqr_workspace_bytes(int B, int n, int m, int T);
+/* The same for ONE env (round 6): only the parts the kernels of that env kind read -- never more than tfmpc_ilqr_workspace_bytes of its shape, and
+ * hundreds of MB less at large batches (an HVAC / Reservoir batch does not carry the LQ kernels' slab, an LQ batch not the costate kernel's buffers,
+ * neither the 2-D envs' scratch).  tfmpc_ilqr_solve*_f32 accept either size.  0 for a null env or a bad shape. */
+size_t tfmpc_ilqr_workspace_bytes_for(const TfmpcEnv *env, int B, int T);
 
 /* iLQR.solve (ilqr.py:214-283) in ONE launch: each wave runs its instance's whole
  * iteration loop (linearise on the fly, regularised backward pass with the local

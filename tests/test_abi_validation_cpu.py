@@ -92,6 +92,13 @@ def test_ilqr_entry_points_reject_bad_arguments(lib):
     # ... plus, for the 2-D envs, one scratch block of line-search candidates per wavefront (5 T + 1 rows of 64 lanes)
     assert lib.tfmpc_ilqr_workspace_bytes(4, 2, 2, 5) >= slabs(4, 2, 2, 5) + 4 * (5 * 5 + 1) * 64 * 4
     assert lib.tfmpc_ilqr_workspace_bytes(0, 2, 2, 5) == 0
+    # the size for ONE env (round 6): the slabs + only what that env kind's kernels read -- and the solve accepts it
+    for kind, extra in ((_hip.ENV_LQ, 65536 * 100 * 64 * 4), (_hip.ENV_RESERVOIR, 1024 * wave(1, 100) + coef(1024, 100)), (_hip.ENV_HVAC, 1024 * wave(1, 100) + coef(1024, 100))):
+        e = _env(kind=kind, n=4, m=4)
+        assert lib.tfmpc_ilqr_workspace_bytes_for(byref(e), 65536, 100) == slabs(65536, 4, 4, 100) + extra, kind
+    nav = lib.tfmpc_ilqr_workspace_bytes_for(byref(_env(kind=_hip.ENV_NAVIGATION, n=2, m=2)), 4, 5)
+    assert slabs(4, 2, 2, 5) + 4 * (5 * 5 + 1) * 64 * 4 <= nav < lib.tfmpc_ilqr_workspace_bytes(4, 2, 2, 5)       # (its scratch, not the costate kernel's buffers)
+    assert lib.tfmpc_ilqr_workspace_bytes_for(NULL, 4, 5) == 0
     assert lib.tfmpc_boxqp_f32(4, 0, d, d, d, d, d, d, d, d, NULL) == ERR_ARG
     assert lib.tfmpc_boxqp_f32(4, 3, NULL, d, d, d, d, d, d, d, NULL) == ERR_ARG
     assert lib.tfmpc_boxqp_f32(0, 3, d, d, d, d, d, d, d, d, NULL) == 0

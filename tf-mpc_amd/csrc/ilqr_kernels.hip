@@ -196,8 +196,15 @@ int tfmpc_ilqr_forward_f32(const TfmpcEnv *env, int B, int T, const float *x, co
 // the 16-instances-per-wave HVAC / Reservoir kernel.  Offsets in bytes from a 256-byte aligned base.
 struct IlqrWsLayout {
     size_t K, k, x, u, c, lane, wave, minv, total;
-    IlqrWsLayout(int B, int n, int m, int T)
+    // kind < 0: the size that serves EVERY env of the shape (tfmpc_ilqr_workspace_bytes); a kind: only the parts the kernels of that env kind
+    // read (tfmpc_ilqr_workspace_bytes_for -- the three optional parts are hundreds of MB at large batches: an HVAC batch does not need the LQ
+    // kernels' slab, an LQ batch not the costate kernel's buffers).  The offsets of the parts that exist do not depend on it beyond what precedes them.
+    IlqrWsLayout(int B, int n, int m, int T, int kind = -1)
     {
+        const bool all = kind < 0;
+        const bool want_lane = all || kind == TFMPC_ENV_NAVLQR || kind == TFMPC_ENV_NAVIGATION;
+        const bool want_wave = all || kind == TFMPC_ENV_HVAC || kind == TFMPC_ENV_RESERVOIR;
+        const bool want_minv = all || kind == TFMPC_ENV_LQ;
         const size_t f = sizeof(float);
         K = 0;
         k = K + (size_t)B * T * m * n * f;
@@ -205,10 +212,11 @@ struct IlqrWsLayout {
         u = x + (size_t)B * (T + 1) * n * f;
         c = u + (size_t)B * T * m * f;
         lane = round256(c + (size_t)B * (T + 1) * f);
-        wave = lane + round256(ilqr_lane_extra_workspace_bytes(B, n, m, T));
-        minv = round256(wave + ilqr_adjoint_mfma_workspace_bytes(B, n, m, T));
-        total = minv + ilqr_lq_mfma_reuse_workspace_bytes(B, n, m, T)        // -Q_uu^-1 of the LQ env's first pass (ilqr_lq_mfma.hip, REUSE) ...
-                     + ilqr_lq_mfma32_reuse_workspace_bytes(B, n, m, T);     // ... or of its large-tile twin (the two shape ranges are disjoint)
+        wave = lane + (want_lane ? round256(ilqr_lane_extra_workspace_bytes(B, n, m, T)) : 0);
+        minv = round256(wave + (want_wave ? ilqr_adjoint_mfma_workspace_bytes(B, n, m, T) : 0));
+        total = minv + (want_minv ? ilqr_lq_mfma_reuse_workspace_bytes(B, n, m, T)        // -Q_uu^-1 of the LQ env's first pass (ilqr_lq_mfma.hip, REUSE) ...
+                                        + ilqr_lq_mfma32_reuse_workspace_bytes(B, n, m, T)     // ... or of its large-tile twin (the two shape ranges are disjoint)
+                                  : 0);
     }
     static size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
 };
@@ -217,6 +225,12 @@ size_t tfmpc_ilqr_workspace_bytes(int B, int n, int m, int T)
 {
     if (B <= 0 || n <= 0 || m <= 0 || T < 0) return 0;
     return IlqrWsLayout(B, n, m, T).total;
+}
+
+size_t tfmpc_ilqr_workspace_bytes_for(const TfmpcEnv *env, int B, int T)
+{
+    if (!env || B <= 0 || env->n <= 0 || env->m <= 0 || T < 0) return 0;
+    return IlqrWsLayout(B, env->n, env->m, T, env->kind).total;
 }
 
 // which kernel family the last tfmpc_ilqr_solve[_trace]_f32 of this thread went to (a traced solve of HVAC / Reservoir, or of a
@@ -256,7 +270,7 @@ int tfmpc_ilqr_solve_trace_qp_f32(const TfmpcEnv *env, const TfmpcIlqrConfig *cf
     if (B == 0) return TFMPC_OK;
     if (!x0 || !states || !costs || !iterations || !status || (T > 0 && (!u_init || !actions))) return TFMPC_ERR_ARG;
     const int n = env->n, m = env->m;
-    const IlqrWsLayout lay(B, n, m, T);
+    const IlqrWsLayout lay(B, n, m, T, env->kind);      // (what THIS env's kernels read: a caller may size by tfmpc_ilqr_workspace_bytes_for or by the shape)
     if (!workspace || workspace_bytes < lay.total || (reinterpret_cast<uintptr_t>(workspace) & 255u)) return TFMPC_ERR_WORKSPACE;
     char *const base = static_cast<char *>(workspace);
     hipStream_t st = static_cast<hipStream_t>(stream);

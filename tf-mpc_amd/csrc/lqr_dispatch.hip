@@ -84,7 +84,7 @@ int run(const LqrArgs &a, bool bw, bool fw, bool general, void *stream)
 
 extern "C" {
 
-int tfmpc_version(void) { return 300; }      // 300 (round 6): tfmpc_ilqr_solve_trace_qp_f32, TFMPC_ILQR_LQ_REUSE; 200: TFMPC_TRACE_COLS 11, TfmpcEnv::coupling_shift, status bits 0x20 / 0x40
+int tfmpc_version(void) { return 310; }      // 310: tfmpc_ilqr_workspace_bytes_for, the costate kernel's coefficient slab behind the groups' slices; 300 (round 6): tfmpc_ilqr_solve_trace_qp_f32, TFMPC_ILQR_LQ_REUSE; 200: TFMPC_TRACE_COLS 11, TfmpcEnv::coupling_shift, status bits 0x20 / 0x40
 
 const char *tfmpc_lqr_kernel_name(int n, int m, int T)
 {

@@ -49,7 +49,7 @@ ENV_LQ, ENV_NAVLQR, ENV_NAVIGATION, ENV_HVAC, ENV_RESERVOIR, ENV_USER = range(6)
 ENV_MAX_PARAMS = 10
 MAX_ALPHAS = 16
 TRACE_COLS = 11          # TFMPC_TRACE_COLS
-MIN_VERSION = 300        # tfmpc_version() this binding was written against (include/tfmpc_hip.h)
+MIN_VERSION = 310        # tfmpc_version() this binding was written against (include/tfmpc_hip.h)
 
 
 class TfmpcEnv(ctypes.Structure):
@@ -76,6 +76,7 @@ _SIGNATURES.update({
     "tfmpc_ilqr_backward_f32": (_I, [_I, _I, _I, _I] + [_P] * 12 + [_P, _P, _I, _P, _L] + [_P] * 6 + [_P]),
     "tfmpc_ilqr_forward_f32": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P]),
     "tfmpc_ilqr_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "tfmpc_ilqr_workspace_bytes_for": (_Z, [_P, _I, _I]),
     "tfmpc_ilqr_solve_f32": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "tfmpc_ilqr_solve_trace_f32": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _P]),
     "tfmpc_ilqr_solve_trace_qp_f32": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _P]),

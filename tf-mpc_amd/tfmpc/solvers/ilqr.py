@@ -409,7 +409,9 @@ class iLQR:
         costs = alloc((B, T + 1), device=dev)
         iterations = torch.zeros((B,), dtype=torch.int32, device=dev)
         status = torch.zeros((B,), dtype=torch.int32, device=dev)
-        ws_bytes = int(lib.tfmpc_ilqr_workspace_bytes(B, n, m, T))
+        # (what this env's kernels read: the shape-only size carries every env kind's optional parts -- 0.8 GB of them at the headline batch)
+        sized = getattr(lib, "tfmpc_ilqr_workspace_bytes_for", None)
+        ws_bytes = int(sized(ctypes.byref(env), B, T)) if sized is not None and not getattr(lib, "path", None) else int(lib.tfmpc_ilqr_workspace_bytes(B, n, m, T))
         if workspace is None or workspace.numel() * workspace.element_size() < ws_bytes:
             workspace = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
         cfg = self._c_config()
