@@ -1337,16 +1337,17 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
     __shared__ u32x4 op_rest_all[NW][NT == 2 && !kChain ? 4 * kWave : 1];  // MatOp<2, true>: the non-leading parts of the operand, per wave
     __shared__ float x_sweep[NW > 1 ? 4 : 1][kWave];           // wave 0 -> the others: J_hat, dV1, g_norm, max |k|
     __shared__ float x_pass[2][NW][2][kWave];                  // [pass parity][wave][J | cut short][lane]
-    // Round 6, groups of four / eight waves: a chain GIVES UP once it cannot matter.  The search takes, per column, the FIRST step size (in the
+    // Round 6, groups of eight waves: a chain GIVES UP once it cannot matter.  The search takes, per column, the FIRST step size (in the
     // reference's order, ilqr.py:323-353) whose rollout is accepted; wave w rolls out position w of the pass.  So when every wave below w has finished
     // and every trying column was accepted by one of them, position w decides nothing -- and on a chip where the chains of a pass share SIMDs in pairs
     // (a res4 pass: positions 0 - 4 take 17 - 83 k cycles, 5 - 7 next to a partner 103 - 110 k, and the group waits for the slowest) the pass is over
     // when the positions that CAN matter are (three of res4's first five iterations accept by position 2 in every column of a group).  Each wave posts,
     // when its rollout ends, which trying columns it accepts (`give_acc`, a lane mask) and then its bit in `give_posted`; a chain polls that word every
-    // fourth step (one LDS read) and stops -- reporting "cut short", as the cost-based early exit does -- when the bits below it are all set and their
-    // masks cover the trying columns.  No wave ever WAITS on another here (a poll that fails changes nothing), and what a given-up chain would have
+    // fourth step (one LDS read, consumed at the NEXT poll) and stops -- reporting "cut short", as the cost-based early exit does -- once the waves
+    // 0 .. p have ALL posted for some p below it and their masks cover the trying columns (it does not wait for the waves between p and itself: they
+    // give up on the same evidence).  No wave ever WAITS on another here (a poll that fails changes nothing), and what a given-up chain would have
     // reported is read by no column: the results are the same bits.  The chains of the earlier positions are given issue priority (s_setprio) over
-    // their SIMD partners, so that the ones that can matter finish first.  Slots alternate with the pass parity; a wave clears its bit of the
+    // their SIMD partners (measured neutral; kept for the ordering it suggests).  Slots alternate with the pass parity; a wave clears its bit of the
     // OTHER slot when it posts (nobody reads that slot between the two barriers around this pass).
 #ifdef TFMPC_AB_NO_GIVE_UP             // A/B builds
     constexpr bool kGiveUp = false;
