@@ -848,8 +848,29 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
         if (set < 0) { Kg = a.wsK + (size_t)b * T * m * n; kg = a.wsk + (size_t)b * T * m; }
         else { Kg = spec_gains(set); kg = Kg + (size_t)T * m * n; }
     };
-    if (helper) {
+    // HELPER: serve requests until one asks for a SWEEP (true: the nominal trajectory is in `nom`, mu_out is this helper's mu, the gains go to its set on
+    // the board) or every owner has finished (false).  The sweep itself runs at the ONE call site of `backward`, in the solve loop below -- a second
+    // inlined copy of the sweep cost the team instantiation 200 more spilled registers (264 against 56), on every instance of the batch.
+    bool helper_first = true;
+    auto helper_next_sweep = [&](float &mu_out) -> bool {
         for (;;) {
+            if (!helper_first) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) st_relaxed(&tm->done[role], my_seq);
+                my_seq = next_request(my_seq);
+                if (my_seq < 0) return false;
+                const int nb = __builtin_amdgcn_readfirstlane(tm->req_b);
+                if (nb != b) {                          // the team has a new owner: that instance's F, f, C, c (rollout AND sweep operands)
+                    b = nb;
+                    Fg = a.env.p[0] + (size_t)b * a.env.stride[0];
+                    fg = a.env.p[1] + (size_t)b * a.env.stride[1];
+                    Cg = a.env.p[2] + (size_t)b * a.env.stride[2];
+                    cg = a.env.p[3] + (size_t)b * a.env.stride[3];
+                    box_rollout_operands(Fg, fg, Cg, cg, n, m, lane, Fr, f_i, Ca0, Ca1, cq0, cq1);
+                    load_sweep_operands();
+                }
+            }
+            helper_first = false;
             // request my_seq of instance b: the nominal trajectory from the board, then ...
             copy16(nom, tbuf, trajF);
             __syncthreads();
@@ -862,49 +883,28 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
                     delta_h = fmaxf(cfg.delta_0, delta_h * cfg.delta_0);
                     mu_h = fmaxf(cfg.mu_min, mu_h * delta_h);
                 }
-                cz_pass(nom, Tp, cand, true);           // l_z(t) of the nominal trajectory, as the owner's pass forms them
-                __syncthreads();
                 use_gains(role);
-                const StepResult sr = backward(cand, mu_h);
-                if (lane == 0) {                        // (behind the gains: the answers of later rollout requests overwrite `res`)
-                    float *out = spec_gains(role) + gainF - 4;
-                    out[0] = sr.dV1; out[1] = sr.dV2; out[2] = sr.g_norm;
-                    out[3] = __builtin_bit_cast(float, (sr.failed ? 0x10000 : 0) | (sr.flags & 0xFFFF));
-                }
-            } else {
-                // ... the step sizes of this role, both candidates back
-                use_gains(__builtin_amdgcn_readfirstlane(tm->gains));
-                const int ai = 2 + 2 * role;
-                float JA = 0.0f, rA = 0.0f, JB = 0.0f, rB = 0.0f;
-                if (ai + 1 < cfg.n_alphas) forward2(cfg.alphas[ai], cfg.alphas[ai + 1], JA, rA, JB, rB);
-                else if (ai < cfg.n_alphas) forward(cfg.alphas[ai], JA, rA);
-                __syncthreads();
-                if (ai < cfg.n_alphas) {
-                    copy16(helper_bufs(role, 0), cand, trajF);
-                    copy16(helper_bufs(role, 0) + trajF, ccand, costF);
-                }
-                if (ai + 1 < cfg.n_alphas) {
-                    copy16(helper_bufs(role, 1), cand2, trajF);
-                    copy16(helper_bufs(role, 1) + trajF, ccand2, costF);
-                }
-                if (lane == 0) { tm->res[role][0] = JA; tm->res[role][1] = rA; tm->res[role][2] = JB; tm->res[role][3] = rB; }
+                mu_out = mu_h;
+                return true;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            if (lane == 0) st_relaxed(&tm->done[role], my_seq);
-            my_seq = next_request(my_seq);
-            if (my_seq < 0) return;
-            const int nb = __builtin_amdgcn_readfirstlane(tm->req_b);
-            if (nb != b) {                              // the team has a new owner: that instance's F, f, C, c (rollout AND sweep operands)
-                b = nb;
-                Fg = a.env.p[0] + (size_t)b * a.env.stride[0];
-                fg = a.env.p[1] + (size_t)b * a.env.stride[1];
-                Cg = a.env.p[2] + (size_t)b * a.env.stride[2];
-                cg = a.env.p[3] + (size_t)b * a.env.stride[3];
-                box_rollout_operands(Fg, fg, Cg, cg, n, m, lane, Fr, f_i, Ca0, Ca1, cq0, cq1);
-                load_sweep_operands();
+            // ... the step sizes of this role, both candidates back
+            use_gains(__builtin_amdgcn_readfirstlane(tm->gains));
+            const int ai = 2 + 2 * role;
+            float JA = 0.0f, rA = 0.0f, JB = 0.0f, rB = 0.0f;
+            if (ai + 1 < cfg.n_alphas) forward2(cfg.alphas[ai], cfg.alphas[ai + 1], JA, rA, JB, rB);
+            else if (ai < cfg.n_alphas) forward(cfg.alphas[ai], JA, rA);
+            __syncthreads();
+            if (ai < cfg.n_alphas) {
+                copy16(helper_bufs(role, 0), cand, trajF);
+                copy16(helper_bufs(role, 0) + trajF, ccand, costF);
             }
+            if (ai + 1 < cfg.n_alphas) {
+                copy16(helper_bufs(role, 1), cand2, trajF);
+                copy16(helper_bufs(role, 1) + trajF, ccand2, costF);
+            }
+            if (lane == 0) { tm->res[role][0] = JA; tm->res[role][1] = rA; tm->res[role][2] = JB; tm->res[role][3] = rB; }
         }
-    }
+    };
     // owner: claim a free team whose helpers are all resident (lane 0's compare-and-swap decides)
     auto try_claim = [&]() {
         if (ld_relaxed(&board->claimed) >= a.helper_teams) return;
@@ -995,6 +995,9 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
             StepResult r;
             bool grads_ready = false;
             trace_row = iteration + attempts;
+            if constexpr (TEAMS) {
+                if (helper && !helper_next_sweep(mu)) return;              // (a helper: its next sweep's mu; level 0 of `attempt` below is that sweep)
+            }
             auto attempt = [&](int level) {
                 float mu_l = mu, delta_l = delta;
                 for (int j = 0; j < level; ++j) {
@@ -1022,7 +1025,7 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
             // (see `speculate`) this pass's sweep from a helper, or the request for the next passes' in front of this pass's own
             bool from_helper = false;
             if constexpr (TEAMS) {
-                if (team >= 0 && spec_left > 0) {
+                if (!helper && team >= 0 && spec_left > 0) {
                     if (!answered_since(spec_next, spec_seq)) {
                         team_lost = true; team = -1; spec_left = 0;
                     } else {
@@ -1039,7 +1042,7 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
                         }
                     }
                 }
-                if (!from_helper) {
+                if (!from_helper && !helper) {
                     use_gains(-1);
                     spec_left = 0;
                     if (team >= 0 && a.speculate >= 0 && rejected_run >= a.speculate && !a.trace.rows && !a.trace.clamp) {
@@ -1062,6 +1065,9 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
             int lo_fail = -1, hi_ok = 1 << 20, probe = (BRACKET && r_hint > 0) ? r_hint - 1 : 0, level = 0;
             for (; !from_helper;) {
                 r = attempt(probe);
+                if constexpr (TEAMS) {
+                    if (helper) break;                                      // (one sweep, whatever it says)
+                }
                 if constexpr (MODE == 2) {
                     // the sample only asks "does the first backward pass need a regularisation level >= 1?" (box_decide_kernel): answered by the first
                     // sweep -- finding the level itself made the sample pass as long as its slowest instance's climb (2.0 ms of a 54 ms launch)
@@ -1087,6 +1093,16 @@ __global__ __launch_bounds__(kWave, TFMPC_BOX_EU) void ilqr_lq_box_mfma_kernel(I
             if constexpr (MODE == 1) {
                 if (lane == 0) reinterpret_cast<int32_t *>(a.wsq)[b] = give_up ? 41 : level;
                 return;
+            }
+            if constexpr (TEAMS) {
+                if (helper) {                           // the speculative sweep's result, behind its gains (the answers of later rollout requests overwrite `res`)
+                    if (lane == 0) {
+                        float *out = spec_gains(role) + gainF - 4;
+                        out[0] = r.dV1; out[1] = r.dV2; out[2] = r.g_norm;
+                        out[3] = __builtin_bit_cast(float, (r.failed ? 0x10000 : 0) | (r.flags & 0xFFFF));
+                    }
+                    continue;                           // (helper_next_sweep posts `done` and waits for the next request)
+                }
             }
             if (level > 0) status |= TFMPC_ST_NOT_PD;
             r_hint = give_up ? 0 : level;
