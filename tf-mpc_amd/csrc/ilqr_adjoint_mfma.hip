@@ -2002,7 +2002,10 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(TFMP
         // group does, on the 2 048 wave slots that 512 groups leave (n = 32, B = 8 192: HVAC 5.59 -> 4.89 ms, Reservoir 4.99 -> 4.78; with one
         // tile the second chain costs what the saved passes bring: hvac6 2.46 -> 2.43, n = 16 HVAC 2.26 -> 2.40)
 #ifndef TFMPC_GROUP4_ALPHAS
-#define TFMPC_GROUP4_ALPHAS (NT == 2 ? 2 : 1)
+// (round 6, after the instruction trims -- tools/probes/r6_g4_alphas.py, one against two, ms: hvac6 1.851 / 1.809, Reservoir n = 16 2.19 / 2.09; but
+// res4 at 512 groups 1.98 / 2.05, Reservoir n = 8 2.37 / 2.89, HVAC n = 12 1.83 / 1.85: two for HVAC with two instances per column and for one-tile
+// Reservoir with one)
+#define TFMPC_GROUP4_ALPHAS ((NT == 2 || (KIND == TFMPC_ENV_HVAC && PK == 2) || (KIND == TFMPC_ENV_RESERVOIR && PK == 1)) ? 2 : 1)
 #endif
         constexpr int NA = NW == 1 ? Env::kSearchAlphas : (NW == 4 ? TFMPC_GROUP4_ALPHAS : 1);
         static_assert(NA * NW <= kMaxGroupWaves || NW == 1, "checkpoint tiles of a pass");
