@@ -298,12 +298,6 @@ def test_reservoir_cfg5_every_pass_teacher_forced():
     print(f"  selector: {agree} of {decided} clear-margin entries agree ({entries} moved entries in all)")
     assert decided > 0.5 * entries and agree == decided
     assert stats["decision mismatch"] == 0, details[:5]
-    # mismatch_share > 0 (the slow, every-pass sampling only): a share of passes of the HEAVY groups may disagree in numbers -- measured: 4 of 2 059,
-    # all one attempt-cap instance (costs ~1e12: fp32 cannot pose it) whose box-QP the device and the restatement leave on different iterates at four
-    # time steps -- the QP stops when a step improves its objective by < 1e-8 of its value (optimization.py:27-29), here ~1e4 absolute -- so that the
-    # feed-forward k_t, which the device does not export, and with it g_norm differ by 4.6 %; K_t, the candidates and every decision agree.
-    order = set(pos[int(b)] for b in groups.get("in order", []))
-    bad = [i for (i, p, d, nxt), v in zip(where, verdicts) if v[1] == "mismatch"]
-    assert len(bad) <= int(mismatch_share * stats["passes"]) and not (set(bad) & order), (len(bad), details[:5])
+    assert stats["numbers mismatch"] == 0, details[:5]
     assert stats["numbers loose"] <= max(2, stats["passes"] // 100), details[:5]
     assert stats["numbers ok"] + stats["numbers loose"] >= 0.9 * stats["passes"], dict(stats)
