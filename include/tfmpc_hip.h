@@ -65,7 +65,7 @@ int tfmpc_version(void);
  * TFMPC_BOX_HELP_AFTER (passes before an instance may claim a team, default 8), TFMPC_ILQR_LQ_REUSE (0: the matrix-core iLQR kernel of the
  * unbounded LQ env runs the full backward pass in every iteration, as ilqr.py:94-172 does; default: from the second pass on it keeps K_t and
  * Q_uu(t)^-1 -- which for a time-invariant LQ env at mu = 0 do not depend on the trajectory, so the recomputed ones would be the same bits -- and
- * runs only the vector recursion for k_t, V_x: results agree to fp32 rounding), TFMPC_GROUP_STORED (1 .. 16, default 4: how many step sizes of a
+ * runs only the vector recursion for k_t, V_x: results agree to fp32 rounding), TFMPC_GROUP_STORED (1 .. 4, default 4: how many step sizes of a
  * line search of the 2 x 2 lane-group kernel keep their candidate trajectory in the workspace; a pass that adopts another one rolls it out once
  * more -- same bits, for tests and A/B timing), TFMPC_BOX_SPECULATE (off | n, default 0: after n rejected passes in a row the helper team of a
  * control-limited instance runs the backward passes of its next passes beside its own -- same bits) are read ONCE per process, at the first use of the library; afterwards only

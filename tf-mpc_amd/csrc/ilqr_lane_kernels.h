@@ -487,10 +487,10 @@ struct SolveArgsLane {
     int *queue;              // group kernel only: the next instance nobody has taken yet (zeroed by the launcher)
     TraceArgs trace;         // group kernel only: the optional decision trace
 };
-// (TFMPC_GROUP_STORED, tests and A/B timing: 16 = every step size keeps its candidate, as before round 6; 1 = almost every backtracking pass replays;
-// what the default is about: ScratchSink)
+// (TFMPC_GROUP_STORED = 1 .. 4, tests and A/B timing: fewer columns of the block in use -- 1 = almost every backtracking pass replays; what the
+// default is about: ScratchSink)
 constexpr int kStoredCandidates = 4;
-inline int group_stored_candidates(int requested) { return requested < 1 ? kStoredCandidates : (requested > 16 ? 16 : requested); }
+inline int group_stored_candidates(int requested) { return requested < 1 || requested > kStoredCandidates ? kStoredCandidates : requested; }
 
 template <int KIND, int N, int M, class Store, bool PRE = false>
 __device__ inline LaneBackward backward_lane(const LaneEnv<KIND, N, M> &env, int T, float mu, bool bounded,
@@ -892,19 +892,21 @@ struct GroupStore {
 // group's scratch, one column per STORED step size (x_0 never changes).
 // Round 6: only the first `stored` step sizes of a group keep their candidates (default kStoredCandidates = 4: 99.8 % of cfg4's passes adopt
 // index 0 .. 3 -- 67 439 / 40 349 / 14 888 / 3 400 of 126 321, and the slowest instances, which set the launch time, index 3 --,
-// tools/probes/r6_cfg4_alpha_hist.py), in a block of the group's own: [row][stored] floats, 16 bytes a row.  Every lane used to write its column
+// tools/probes/r6_cfg4_alpha_hist.py), in a block of the group's own: [row][4] floats, 16 bytes a row.  Every lane used to write its column
 // of a [row][64 lanes] block -- 64 KB per wave and pass, of which the adoption read one column at 64-byte sector granularity: 4.35 GB of HBM traffic per
 // launch of 16 384 instances against 0.26 GB algorithmic (the round-5 verdict's item 8).  A pass that adopts a step size beyond the stored ones (0.2 %)
 // rolls THAT step size out once more on the whole group into column 0 -- the same function on the same inputs: the same bits -- and adopts it from there.
 template <int N, int M>
 struct ScratchSink {
+    static constexpr int kStride = 4;     // floats between rows = columns of the block (kStoredCandidates; a constant: the row index times a
+                                          // run-time stride is an integer multiply per store, five per lane and time step -- + 8 % on the user-env form)
     float *col;                  // group's scratch block + this lane's column
-    int T, stride;               // floats between rows (= stored columns)
+    int T;
     bool live;                   // only the stored step sizes keep their candidate
     __host__ __device__ static int rows(int T) { return T * N + T * M + T + 1; }
-    __device__ void x(int t, int i, float v) const { if (live && t > 0) col[((t - 1) * N + i) * stride] = v; }
-    __device__ void u(int t, int a, float v) const { if (live) col[(T * N + t * M + a) * stride] = v; }
-    __device__ void c(int t, float v) const { if (live) col[(T * N + T * M + t) * stride] = v; }
+    __device__ void x(int t, int i, float v) const { if (live && t > 0) col[((t - 1) * N + i) * kStride] = v; }
+    __device__ void u(int t, int a, float v) const { if (live) col[(T * N + t * M + a) * kStride] = v; }
+    __device__ void c(int t, float v) const { if (live) col[(T * N + T * M + t) * kStride] = v; }
 };
 
 // Round 4: PERSISTENT groups with an instance QUEUE.  A launch used to give every group exactly one instance, so a wave lasted as
@@ -940,10 +942,10 @@ __global__ __launch_bounds__(64, TFMPC_GROUP_LANE_EU) void ilqr_group_solve_kern
     const bool leader = gl == 0;
     const int my_alpha_idx = (gl < cfg.n_alphas) ? gl : cfg.n_alphas - 1;
     const float my_alpha = cfg.alphas[my_alpha_idx];
-    // this group's block of the wave's scratch: [row][stored] (see ScratchSink); a.stored: 1 .. 16 (TFMPC_GROUP_STORED; the launcher's default 4)
+    // this group's block of the wave's scratch: [row][4] (see ScratchSink); a.stored: how many of the four columns are in use (TFMPC_GROUP_STORED)
     const int stored = a.stored;
     float *scratch = a.scratch + ((size_t)blockIdx.x * GROUPS + grp) * ScratchSink<N, M>::rows(T) * G;
-    const ScratchSink<N, M> sink{scratch + (gl < stored ? gl : 0), T, stored, gl < stored && gl < cfg.n_alphas};
+    const ScratchSink<N, M> sink{scratch + (gl < stored ? gl : 0), T, gl < stored && gl < cfg.n_alphas};
     Store st{lane_lds + grp, T};
 
     // ---- per-group state of the machine --------------------------------------------------------------------------------
@@ -1032,20 +1034,36 @@ __global__ __launch_bounds__(64, TFMPC_GROUP_LANE_EU) void ilqr_group_solve_kern
                 if (leader) trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, r.J, r.g_norm, -1, 0.0f, 0.0f, -1, -1.0f, level);
                 finished = true;
             } else {
-                // all step sizes at once, one per lane (ilqr.py:322-353), candidates into the scratch columns
-                float J, residual;
+                // all step sizes at once, one per lane (ilqr.py:322-353), candidates into the scratch columns.  ONE call site of the rollout: a pass
+                // that adopts a step size whose candidate was not kept (ScratchSink) takes a second trip through it -- the whole group on that step
+                // size, lane 0 writing column 0 (a second inlined copy of the rollout cost the user-env instantiation of this kernel 10 %)
+                float J = 0.0f, residual = 0.0f, res_chosen = 0.0f;
+                bool accept = false, small_step = false;
+                int chosen = 0, column = 0;
+                float alpha_roll = my_alpha;
+                ScratchSink<N, M> sink_roll = sink;
                 TFMPC_PROBE_START();
-                forward_lane<KIND, N, M>(env, T, my_alpha, low, high, st, sink, J, residual);
+                for (int trip = 0; trip < 2; ++trip) {
+                    float J_trip, residual_trip;
+                    forward_lane<KIND, N, M>(env, T, alpha_roll, low, high, st, sink_roll, J_trip, residual_trip);
+                    if (trip == 1) break;                   // (the candidate of the adopted step size is in column 0 now)
+                    J = J_trip; residual = residual_trip;
+                    const float delta_J = -my_alpha * (r.dV1 + my_alpha * r.dV2);
+                    const float dcost = r.J - J;
+                    const float z = (delta_J > 0.0f) ? dcost / delta_J : sgnf(dcost);
+                    const bool ok = gl < cfg.n_alphas && z >= cfg.c1;
+                    const unsigned mask = (unsigned)((__ballot(ok) >> (grp * G)) & 0xFFFFu);
+                    accept = mask != 0;
+                    chosen = accept ? (__ffs(mask) - 1) : cfg.n_alphas - 1;     // first accepted, else the last tried
+                    res_chosen = __shfl(residual, grp * G + chosen, 64);
+                    small_step = res_chosen < cfg.atol;                          // :253-257
+                    column = chosen;
+                    if (!((small_step || accept) && chosen >= stored)) break;    // (group-uniform) nothing to adopt, or its candidate was kept
+                    alpha_roll = cfg.alphas[chosen];
+                    sink_roll = ScratchSink<N, M>{scratch, T, leader};
+                    column = 0;
+                }
                 TFMPC_PROBE(5);
-                const float delta_J = -my_alpha * (r.dV1 + my_alpha * r.dV2);
-                const float dcost = r.J - J;
-                const float z = (delta_J > 0.0f) ? dcost / delta_J : sgnf(dcost);
-                const bool ok = gl < cfg.n_alphas && z >= cfg.c1;
-                const unsigned mask = (unsigned)((__ballot(ok) >> (grp * G)) & 0xFFFFu);
-                const bool accept = mask != 0;
-                const int chosen = accept ? (__ffs(mask) - 1) : cfg.n_alphas - 1;     // first accepted, else the last tried
-                const float res_chosen = __shfl(residual, grp * G + chosen, 64);
-                const bool small_step = res_chosen < cfg.atol;                   // :253-257
                 if (a.trace.rows) {
                     const float J_chosen = __shfl(J, grp * G + chosen, 64);
                     if (leader) trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, r.J, r.g_norm, chosen,
@@ -1054,20 +1072,13 @@ __global__ __launch_bounds__(64, TFMPC_GROUP_LANE_EU) void ilqr_group_solve_kern
                 if (small_step || accept) {
                     // adopt the chosen step size's candidate: its scratch column becomes the nominal trajectory
                     TFMPC_PROBE_START();
-                    int column = chosen;
-                    if (chosen >= stored) {             // (group-uniform) not kept: once more, the whole group on that step size, lane 0 writes column 0
-                        float J_again, residual_again;
-                        const ScratchSink<N, M> again{scratch, T, stored, leader};
-                        forward_lane<KIND, N, M>(env, T, cfg.alphas[chosen], low, high, st, again, J_again, residual_again);
-                        column = 0;
-                    }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     const float *col = scratch + column;
                     const int rx = T * N, ru = T * M;
-                    for (int rr = gl; rr < rx; rr += G) st.at(N + rr) = col[rr * stored];
-                    for (int rr = gl; rr < ru; rr += G) st.at(st.uoff() + rr) = col[(rx + rr) * stored];
-                    for (int rr = gl; rr <= T; rr += G) chat[rr] = col[(rx + ru + rr) * stored];
+                    for (int rr = gl; rr < rx; rr += G) st.at(N + rr) = col[rr * ScratchSink<N, M>::kStride];
+                    for (int rr = gl; rr < ru; rr += G) st.at(st.uoff() + rr) = col[(rx + rr) * ScratchSink<N, M>::kStride];
+                    for (int rr = gl; rr <= T; rr += G) chat[rr] = col[(rx + ru + rr) * ScratchSink<N, M>::kStride];
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     TFMPC_PROBE(6);
                 }
