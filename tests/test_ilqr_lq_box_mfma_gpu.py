@@ -228,6 +228,30 @@ def test_start_cost_block_order_changes_no_result():
     assert float(J0.max()) > 4.0 * float(J0.median())
 
 
+def test_start_cost_order_with_unordered_costs():
+    """The sort key of the start-cost order is the float's order-preserving integer image: a start that is NaN, +-inf, huge or zero must land in a bin
+    (NaN first) and change nothing but the order -- outputs equal the launch in instance order bit for bit (NaN == NaN here)."""
+    B, n, m, T, bound = 4500, 16, 8, 20, 0.5
+    F, f, C, c, x0 = _problem(B, n, m, seed=83, scale=0.18)
+    x0 = x0.copy()
+    x0[7] = np.nan; x0[100, 0] = np.inf; x0[2000] *= 1e18; x0[2001] *= 1e-30; x0[4499] = 0.0; x0[3000, 3] = -np.inf
+    solver = iLQR(LQEnv(F, f, C, c, low=-bound, high=bound), max_iterations=6)
+    x0d = torch.as_tensor(x0[..., None], device="cuda")
+    u0 = torch.zeros(B, T, m, 1, device="cuda")
+    outs = {}
+    for mode in (None, "levels"):
+        with _hip.option("TFMPC_ILQR_RETRY", mode):
+            o = solver.solve_device(x0d, T, u_init=u0)
+            torch.cuda.synchronize()
+            outs[mode] = {k: v.clone() for k, v in o.items() if torch.is_tensor(v) and k != "workspace"}
+    for name in ("states", "actions", "costs"):
+        assert torch.equal(torch.nan_to_num(outs[None][name], nan=-7.0, posinf=7e37, neginf=-7e37),
+                           torch.nan_to_num(outs["levels"][name], nan=-7.0, posinf=7e37, neginf=-7e37)), name
+    for name in ("iterations", "status"):
+        assert torch.equal(outs[None][name], outs["levels"][name]), name
+    assert int(outs[None]["status"][7]) & _hip.ST_NAN
+
+
 def test_speculative_sweeps_change_no_result():
     """Round 6: a helper team also runs the backward passes of its owner's NEXT passes -- the same trajectory, mu and delta advanced by the
     rejection update -- beside the owner's own sweep, and a pass that follows a rejection takes the helper's gains from the board instead of
