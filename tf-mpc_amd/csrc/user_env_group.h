@@ -58,14 +58,25 @@ __device__ __forceinline__ void user_group_rollout(const float *p, const float *
 #pragma unroll
     for (int i = 0; i < N; ++i) { x[i] = x0[i]; if (keep) xs[i] = x[i]; }
     float J = 0.0f, rmax = 0.0f;
+    // (the inputs of step t + 1 are requested while step t is evaluated: a register ring of depth one, refilled unconditionally with a clamped index)
+    float uh_n[M], k_n[M];
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+        uh_n[a] = T > 0 ? uhat[a] : 0.0f;
+        k_n[a] = (!START && T > 0) ? kg[a] : 0.0f;
+    }
     for (int t = 0; t < T; ++t) {
+        const int tn = t + 1 < T ? t + 1 : t;
 #pragma unroll
         for (int a = 0; a < M; ++a) {
+            const float uh_c = uh_n[a], k_c = k_n[a];
+            uh_n[a] = uhat[(size_t)tn * M + a];
+            if constexpr (!START) k_n[a] = kg[(size_t)tn * M + a];
             if constexpr (START) {
-                u[a] = uhat[(size_t)t * M + a];                                                          // ilqr.py:53-82
+                u[a] = uh_c;                                                                             // ilqr.py:53-82
             } else {
-                const float du = alpha * kg[(size_t)t * M + a];                                          // :193-194 (K == 0)
-                u[a] = fminf(fmaxf(uhat[(size_t)t * M + a] + du, low[a]), high[a]);                      // :196-197
+                const float du = alpha * k_c;                                                            // :193-194 (K == 0)
+                u[a] = fminf(fmaxf(uh_c + du, low[a]), high[a]);                                         // :196-197
                 rmax = fmaxf(rmax, fabsf(du));                                                            // :206
             }
             if (keep) us[(size_t)t * M + a] = u[a];
@@ -138,11 +149,24 @@ __global__ __launch_bounds__(kWave) void ilqr_user_costate_group_kernel(TfmpcEnv
                 for (int i = 0; i < N; ++i) Vx[i] = __shfl(c.d, row0 + i, kWave);
             }
             float dV1 = 0.0f, gsum = 0.0f;
+            // (the nominal point of step t - 1 is requested while step t is evaluated: a register ring of depth one, refilled unconditionally with a clamped index)
+            float xn_[N], un_[M];
+            if (T > 0) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) xn_[i] = xhat[(size_t)(T - 1) * N + i];
+#pragma unroll
+                for (int aa = 0; aa < M; ++aa) un_[aa] = uhat[(size_t)(T - 1) * M + aa];
+            }
             for (int t = T - 1; t >= 0; --t) {
 #pragma unroll
-                for (int i = 0; i < N; ++i) x[i] = xhat[(size_t)t * N + i];
+                for (int i = 0; i < N; ++i) x[i] = xn_[i];
 #pragma unroll
-                for (int aa = 0; aa < M; ++aa) u[aa] = uhat[(size_t)t * M + aa];
+                for (int aa = 0; aa < M; ++aa) u[aa] = un_[aa];
+                const int tp = t > 0 ? t - 1 : 0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) xn_[i] = xhat[(size_t)tp * N + i];
+#pragma unroll
+                for (int aa = 0; aa < M; ++aa) un_[aa] = uhat[(size_t)tp * M + aa];
                 float acc;
                 const float l = Env<TFMPC_ENV_USER>::adjoint_direction(e, x, u, Vx, gl, acc);
                 float p1 = 0.0f, gmax = 0.0f;
