@@ -10,8 +10,9 @@
 //   * backward: lane j < n + m of a row evaluates direction j (Env<USER>::adjoint_direction, the function the wave kernel calls), Q_x comes back to every
 //     lane of the row by a row-wide shuffle, the sums / maxima over the actions are the row part of wave_sum / wave_max (the same four DPP steps: in the
 //     wave kernel the other three rows hold exact zeros), so dV1, g_norm, J_hat are the wave kernel's bits;
-//   * line search: lane s of a row rolls out step size s, the lane of the step size accepted last time stores its candidate on the way, a ballot within
-//     the row picks the first step size that passes (ilqr.py:322-353); another choice is rolled out once more by the whole row, lane 0 storing;
+//   * line search: lane s of a row rolls out step size s, the lanes around the step size accepted last time store their candidates on the way (four
+//     slots, see kUserGroupSlots), a ballot within the row picks the first step size that passes (ilqr.py:322-353); a choice outside the stored ones is
+//     rolled out once more by the whole row, lane 0 storing;
 //   * the solve state machine is the wave kernel's, replicated per row; rows that have finished idle until the wave's last one has.
 // Arithmetic per instance is that of the wave kernel, operation for operation: outputs and decision traces are bit-identical (tests/test_fxenv_gpu.py).
 #pragma once
@@ -94,8 +95,19 @@ __device__ __forceinline__ void user_group_rollout(const float *p, const float *
     rmax_out = rmax;
 }
 
+// Candidates of the line search: the lanes of the step sizes guess - 1 .. guess + 2 (guess = the index accepted last) store theirs, in four slots per
+// instance -- slot 1 is the candidate slab every solve kernel has (wsx, wsu, wsc), slots 0, 2, 3 the extra part of this kernel's workspace.  The index
+// moves between passes (res4: -1 / 0 / +1 / +2 in 8 / 23 / 37 / 17 % of the passes, hvac6 18 / 17 / 11 / 7 %; tools/probes/r6_alpha_moves.py): with
+// the guess alone stored, four passes of five rolled the chosen step size out a second time -- a third of an iteration's work.
+constexpr int kUserGroupSlots = 4, kUserGroupSlotOfGuess = 1;
+__host__ __device__ inline size_t user_group_candidate_floats(int n, int m, int T) { return (size_t)(T + 1) * n + (size_t)T * m + (size_t)(T + 1); }
+__host__ __device__ inline size_t user_group_extra_bytes(int B, int n, int m, int T)
+{
+    return (size_t)B * (kUserGroupSlots - 1) * user_group_candidate_floats(n, m, T) * sizeof(float);
+}
+
 template <int N, int M>
-__global__ __launch_bounds__(kWave) void ilqr_user_costate_group_kernel(TfmpcEnv env, TfmpcIlqrConfig cfg, SolveArgs a)
+__global__ __launch_bounds__(kWave) void ilqr_user_costate_group_kernel(TfmpcEnv env, TfmpcIlqrConfig cfg, SolveArgs a, float *extra)
 {
     using UG = UserGroup<N, M>;
     constexpr int G = UG::G, D = UG::D, GROUPS = kWave / G;
@@ -118,6 +130,11 @@ __global__ __launch_bounds__(kWave) void ilqr_user_costate_group_kernel(TfmpcEnv
     float *xhat = a.states + (size_t)b * (T + 1) * N, *uhat = a.actions + (size_t)b * T * M, *chat = a.costs + (size_t)b * (T + 1);
     float *kg = a.wsk + (size_t)b * T * M;
     float *xc = a.wsx + (size_t)b * (T + 1) * N, *uc = a.wsu + (size_t)b * T * M, *cc = a.wsc + (size_t)b * (T + 1);
+    const size_t candF = user_group_candidate_floats(N, M, T);
+    float *const extra_b = extra + (size_t)b * (kUserGroupSlots - 1) * candF;
+    auto slot_x = [&](int s_) { return s_ == kUserGroupSlotOfGuess ? xc : extra_b + (size_t)(s_ - (s_ > kUserGroupSlotOfGuess ? 1 : 0)) * candF; };
+    auto slot_u = [&](int s_) { return s_ == kUserGroupSlotOfGuess ? uc : slot_x(s_) + (size_t)(T + 1) * N; };
+    auto slot_c = [&](int s_) { return s_ == kUserGroupSlotOfGuess ? cc : slot_u(s_) + (size_t)T * M; };
     const int row0 = grp * G;                          // first lane of this row
 
     // start (ilqr.py:218): the nominal trajectory from the injected actions -- every lane of the row the same program, lane 0 stores
@@ -194,7 +211,10 @@ __global__ __launch_bounds__(kWave) void ilqr_user_costate_group_kernel(TfmpcEnv
                 const int mine = gl < cfg.n_alphas ? gl : cfg.n_alphas - 1;
                 const float alpha = cfg.alphas[mine];
                 float J, rmax;
-                user_group_rollout<N, M, false>(pr, low, high, T, alpha, xhat, uhat, kg, gl == guess && live, xc, uc, cc, J, rmax);
+                const int my_slot = gl - guess + kUserGroupSlotOfGuess;     // (lanes beyond the step sizes repeat the last one: they store nothing)
+                const bool stores = my_slot >= 0 && my_slot < kUserGroupSlots && gl < cfg.n_alphas && live;
+                const int ms = stores ? my_slot : kUserGroupSlotOfGuess;
+                user_group_rollout<N, M, false>(pr, low, high, T, alpha, xhat, uhat, kg, stores, slot_x(ms), slot_u(ms), slot_c(ms), J, rmax);
                 const float delta_J = -alpha * (dV1 + alpha * 0.0f);                                     // :339 (dV2 == 0)
                 const float dcost = J_hat - J;
                 const float z = (delta_J > 0.0f) ? dcost / delta_J : ((dcost > 0.0f) ? 1.0f : ((dcost < 0.0f) ? -1.0f : 0.0f));   // :342-346
@@ -204,10 +224,12 @@ __global__ __launch_bounds__(kWave) void ilqr_user_costate_group_kernel(TfmpcEnv
                 const float J_chosen = __shfl(J, row0 + chosen, kWave);
                 const float residual = __shfl(rmax, row0 + chosen, kWave);
                 wsync();
-                if (chosen != guess) {                  // (row-uniform) not the stored one: once more, the whole row on that step size, lane 0 stores
+                int from = chosen - guess + kUserGroupSlotOfGuess;          // the slot the chosen step size's candidate is in
+                if (from < 0 || from >= kUserGroupSlots) {                    // (row-uniform) not stored: once more, the whole row on that step size, lane 0 stores
                     float J2, r2;
                     user_group_rollout<N, M, false>(pr, low, high, T, cfg.alphas[chosen], xhat, uhat, kg, leader && live, xc, uc, cc, J2, r2);
                     wsync();
+                    from = kUserGroupSlotOfGuess;
                 }
                 if (accept) last_index = chosen;
                 const bool small_step = residual < cfg.atol;                  // :253-257 (taken even if rejected)
@@ -216,9 +238,10 @@ __global__ __launch_bounds__(kWave) void ilqr_user_costate_group_kernel(TfmpcEnv
                                 residual, 0);
                 if (small_step || accept) {             // the candidate becomes the nominal trajectory
                     if (live) {
-                        for (int idx = gl; idx < (T + 1) * N; idx += G) xhat[idx] = xc[idx];
-                        for (int idx = gl; idx < T * M; idx += G) uhat[idx] = uc[idx];
-                        for (int idx = gl; idx <= T; idx += G) chat[idx] = cc[idx];
+                        const float *xf = slot_x(from), *uf = slot_u(from), *cf = slot_c(from);
+                        for (int idx = gl; idx < (T + 1) * N; idx += G) xhat[idx] = xf[idx];
+                        for (int idx = gl; idx < T * M; idx += G) uhat[idx] = uf[idx];
+                        for (int idx = gl; idx <= T; idx += G) chat[idx] = cf[idx];
                     }
                     wsync();
                 }
