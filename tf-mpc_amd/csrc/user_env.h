@@ -203,11 +203,20 @@ template <> struct Env<TFMPC_ENV_USER> {
 #pragma unroll
         for (int i = 0; i < N; ++i) { x[i] = xhat[i]; if (keep) xc[i] = x[i]; }
         float J = 0.0f, rmax = 0.0f;
+        // (round 6: the inputs of step t + 1 are requested while step t is evaluated -- a register ring of depth one, refilled unconditionally with a
+        // clamped index; on the sixteen-lanes-per-instance form of this search, user_env_group.h, that was 17 - 29 % of a solve)
+        float uh_n[M], k_n[M];
+#pragma unroll
+        for (int a = 0; a < M; ++a) { uh_n[a] = T > 0 ? uhat[a] : 0.0f; k_n[a] = T > 0 ? kg[a] : 0.0f; }
         for (int t = 0; t < T; ++t) {
+            const int tn = t + 1 < T ? t + 1 : t;
 #pragma unroll
             for (int a = 0; a < M; ++a) {
-                const float du = alpha * kg[(size_t)t * M + a];                                          // :193-194 (K == 0)
-                u[a] = fminf(fmaxf(uhat[(size_t)t * M + a] + du, e.low[a]), e.high[a]);                  // :196-197
+                const float uh_c = uh_n[a], k_c = k_n[a];
+                uh_n[a] = uhat[(size_t)tn * M + a];
+                k_n[a] = kg[(size_t)tn * M + a];
+                const float du = alpha * k_c;                                                            // :193-194 (K == 0)
+                u[a] = fminf(fmaxf(uh_c + du, e.low[a]), e.high[a]);                                     // :196-197
                 rmax = fmaxf(rmax, fabsf(du));                                                            // :206
                 if (keep) uc[(size_t)t * M + a] = u[a];
             }
