@@ -189,6 +189,7 @@ struct SolveArgs {
     float *wsK, *wsk, *wsx, *wsu, *wsc;     // per-instance scratch: gains and the candidate trajectory
     int only_flagged;                       // second-chance launch: solve only instances with kIlqrRetryBit set
     TraceArgs trace;                        // optional decision trace (tfmpc_ilqr_solve_trace_f32)
+    float *spec_extra;                      // user envs on the costate path: three more candidate trajectories per instance (user_env.h), or null
 };
 
 // iLQR.solve (ilqr.py:214-283): the whole iteration loop of one instance in one wave.
@@ -252,17 +253,23 @@ __global__ __launch_bounds__(kWave) void ilqr_solve_kernel(TfmpcEnv env, TfmpcIl
             float residual = 0.0f, J = 0.0f;
             int ai_last = -1;
             bool searched = false;
+            int adopt_slot = 1;                          // (user envs on the costate path: where the candidate to adopt is, see speculative_search)
+            float *adopt_extra = nullptr;
             if constexpr (kAdjoint && KIND == TFMPC_ENV_USER) {
                 // a user env on the costate path: every step size at once, one per lane (user_env.h: speculative_search); the candidate of the
                 // guessed step size is stored on the way, any other chosen one is rolled out again below -- the same arithmetic per step size
                 if (!cfg.storage_bf16 && cfg.n_alphas <= kWave) {
                     int chosen = 0;
-                    Env<KIND>::speculative_search(e, cfg, T, xhat, uhat, kg, r.J, r.dV1, last_index < cfg.n_alphas ? last_index : 0, xc, uc, cc, chosen, accept, J, residual);
+                    float *extra = a.spec_extra ? a.spec_extra + (size_t)b * (Env<KIND>::kSlots - 1) * Env<KIND>::candidate_floats(T) : nullptr;
+                    Env<KIND>::speculative_search(e, cfg, T, xhat, uhat, kg, r.J, r.dV1, last_index < cfg.n_alphas ? last_index : 0, xc, uc, cc, extra, chosen, accept, J,
+                                                  residual, adopt_slot);
                     wsync();
-                    if (chosen != (last_index < cfg.n_alphas ? last_index : 0)) {
+                    if (adopt_slot < 0) {               // not among the stored candidates: once more
                         forward_pass<KIND, false>(s, e, T, cfg.alphas[chosen], xhat, uhat, Kg, kg, xc, uc, cc, J, residual);
                         wsync();
+                        adopt_slot = Env<KIND>::kSlotOfGuess;
                     }
+                    adopt_extra = extra;
                     ai_last = chosen;
                     if (accept) last_index = chosen;
                     searched = true;
@@ -283,9 +290,15 @@ __global__ __launch_bounds__(kWave) void ilqr_solve_kernel(TfmpcEnv env, TfmpcIl
                 trace_write(a.trace, b, iteration + attempts, iteration, mu, delta, r.J, r.g_norm, ai_last,
                             ai_last >= 0 ? cfg.alphas[ai_last] : 0.0f, J, accept ? 1 : 0, residual, level);
             if (small_step || accept) {
-                for (int idx = lane; idx < (T + 1) * n; idx += kWave) xhat[idx] = xc[idx];
-                for (int idx = lane; idx < T * m; idx += kWave) uhat[idx] = uc[idx];
-                for (int idx = lane; idx <= T; idx += kWave) chat[idx] = cc[idx];
+                const float *xf = xc, *uf = uc, *cf = cc;
+                if constexpr (kAdjoint && KIND == TFMPC_ENV_USER) {
+                    float *xs_, *us_, *cs_;
+                    Env<KIND>::slot_pointers(adopt_slot, T, xc, uc, cc, adopt_extra, xs_, us_, cs_);
+                    xf = xs_; uf = us_; cf = cs_;
+                }
+                for (int idx = lane; idx < (T + 1) * n; idx += kWave) xhat[idx] = xf[idx];
+                for (int idx = lane; idx < T * m; idx += kWave) uhat[idx] = uf[idx];
+                for (int idx = lane; idx <= T; idx += kWave) chat[idx] = cf[idx];
                 wsync();
             }
             if (small_step) { converged = true; break; }

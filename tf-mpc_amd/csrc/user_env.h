@@ -190,14 +190,29 @@ template <> struct Env<TFMPC_ENV_USER> {
     // lane of a wave evaluates anyway (wave-uniform in the sequential rollout), so lane s rolls out step size s for the price of one rollout.  Lane `guess`
     // (the step size the previous pass accepted) stores its candidate as it goes; the reference's rule -- the FIRST step size with z >= c1, else the last
     // one, rejected (:322-353) -- is a ballot.  `chosen` != `guess`: the caller rolls the chosen one out again (forward_pass, same arithmetic: same bits).
+    // `extra` (round 6; may be null): room for three more candidates of this instance, [x | u | c] each -- the lanes of the step sizes guess - 1 ..
+    // guess + 2 then all store theirs (slot 1 = xc, uc, cc; the accepted index moves between passes: with the guess alone stored four passes of five
+    // rolled the chosen step size out again, tools/probes/r6_alpha_moves.py).  `from_slot` <- the slot the chosen candidate is in, -1: not stored.
+    static constexpr int kSlots = 4, kSlotOfGuess = 1;
+    static __host__ __device__ size_t candidate_floats(int T) { return (size_t)(T + 1) * N + (size_t)T * M + (size_t)(T + 1); }
+    static __device__ void slot_pointers(int slot, int T, float *xc, float *uc, float *cc, float *extra, float *&xs, float *&us, float *&cs)
+    {
+        if (slot == kSlotOfGuess || !extra) { xs = xc; us = uc; cs = cc; return; }
+        xs = extra + (size_t)(slot - (slot > kSlotOfGuess ? 1 : 0)) * candidate_floats(T);
+        us = xs + (size_t)(T + 1) * N;
+        cs = us + (size_t)T * M;
+    }
     static __device__ void speculative_search(const EnvLds &e, const TfmpcIlqrConfig &cfg, int T, const float *xhat, const float *uhat, const float *kg,
-                                              float J_hat, float dV1, int guess, float *xc, float *uc, float *cc, int &chosen, bool &accept, float &J_out,
-                                              float &residual_out)
+                                              float J_hat, float dV1, int guess, float *xc_, float *uc_, float *cc_, float *extra, int &chosen, bool &accept,
+                                              float &J_out, float &residual_out, int &from_slot)
     {
         const int lane = lane_id();
         const int mine = lane < cfg.n_alphas ? lane : cfg.n_alphas - 1;
         const float alpha = cfg.alphas[mine];
-        const bool keep = lane == guess;
+        const int my_slot = lane - guess + kSlotOfGuess;
+        const bool keep = lane < cfg.n_alphas && (extra ? (my_slot >= 0 && my_slot < kSlots) : lane == guess);
+        float *xc, *uc, *cc;
+        slot_pointers(keep ? my_slot : kSlotOfGuess, T, xc_, uc_, cc_, extra, xc, uc, cc);
         const float *p = e.p[0];
         float x[N], xn[N], u[M];
 #pragma unroll
@@ -238,6 +253,8 @@ template <> struct Env<TFMPC_ENV_USER> {
         chosen = accept ? __builtin_ctzll(pass) : cfg.n_alphas - 1;
         J_out = __shfl(J, chosen, kWave);
         residual_out = __shfl(rmax, chosen, kWave);
+        const int slot = chosen - guess + kSlotOfGuess;
+        from_slot = extra ? ((slot >= 0 && slot < kSlots) ? slot : -1) : (chosen == guess ? kSlotOfGuess : -1);
     }
 
     template <class S>
