@@ -302,12 +302,14 @@ def test_costate_form_of_a_user_env_equals_its_dense_form(which):
 
 @pytest.mark.gpu
 @needs_hipcc
-@pytest.mark.parametrize("which,B,T", [("reservoir4", 203, 40), ("hvac6", 130, 33), ("reservoir7", 57, 25), ("reservoir4", 1, 12)])
+@pytest.mark.parametrize("which,B,T", [("reservoir4", 203, 40), ("hvac6", 130, 33), ("reservoir7", 57, 25), ("reservoir4", 1, 12),
+                                       ("hvac12", 75, 30), ("reservoir10", 41, 21), ("hvac16", 9, 17)])
 def test_sixteen_lanes_per_instance_equal_the_wave_per_instance_kernel(which, B, T):
     """Round 6: a small user env on the costate path (n + m <= 16) runs SIXTEEN LANES per instance, four instances per wave (csrc/user_env_group.h) --
     the wave-per-instance kernel's two programs, one direction of z per lane in the backward pass and one step size per lane in the line search, in the
     16-lane rows of a wave.  The same arithmetic per instance, operation for operation: every output and the whole decision trace equal the
-    wave-per-instance kernel's (`force_wave_kernel`) bit for bit; B is not a multiple of four, so the last wave carries idle rows."""
+    wave-per-instance kernel's (`force_wave_kernel`) bit for bit; B is not a multiple of four, so the last wave carries idle rows.
+    From n + m = 17 to 32 (hvac12, reservoir10, hvac16 = all 32 lanes) the same kernel runs THIRTY-TWO lanes per instance, two instances per wave."""
     cfg, builtin, python_env, xr, _ = _case(which)
     env = python_env.to_device_env()
     assert env.zero_cost_hessian
@@ -325,11 +327,11 @@ def test_sixteen_lanes_per_instance_equal_the_wave_per_instance_kernel(which, B,
             outs[wave] = ({k: v.clone() for k, v in o.items() if torch.is_tensor(v) and k != "workspace"}, solver.last_kernel)
         finally:
             env._library().force_wave_kernel(False)
-    assert outs[False][1].startswith("costate_group") and outs[True][1].startswith("wave")
+    assert outs[False][1].startswith("costate_group (%d lanes" % (16 if 2 * n <= 16 else 32)) and outs[True][1].startswith("wave")
     for key in ("states", "actions", "costs", "iterations", "status", "trace_len"):
         assert torch.equal(outs[False][0][key], outs[True][0][key]), key
     assert torch.equal(torch.nan_to_num(outs[False][0]["trace"], nan=-7.0), torch.nan_to_num(outs[True][0]["trace"], nan=-7.0))
-    assert int(outs[False][0]["trace_len"].max()) >= 3 and (B == 1 or len(torch.unique(outs[False][0]["trace"][:, :3, 5])) >= 2)      # (the searches do backtrack)
+    assert int(outs[False][0]["trace_len"].max()) >= 3 and (B < 40 or len(torch.unique(outs[False][0]["trace"][:, :3, 5])) >= 2)      # (the searches do backtrack)
 
 
 @pytest.mark.gpu

@@ -15,27 +15,40 @@
 //     rolled out once more by the whole row, lane 0 storing;
 //   * the solve state machine is the wave kernel's, replicated per row; rows that have finished idle until the wave's last one has.
 // Arithmetic per instance is that of the wave kernel, operation for operation: outputs and decision traces are bit-identical (tests/test_fxenv_gpu.py).
+// G = 32 (16 < n + m <= 32, n_alphas <= 32): the same kernel with TWO ROWS per instance, two instances per wave -- the sums / maxima take wave_sum's
+// fifth step as well (rows 1, 3 += rows 0, 2) and the instance's total is read from the last lane of its second row.
 #pragma once
 
 #include "ilqr_wave_kernels.h"
 
 namespace tfmpc {
 
-template <int N, int M>
+template <int N, int M, int G_ = 16>
 struct UserGroup {
-    static constexpr int G = 16, D = N + M;
-    static_assert(D <= G, "one direction of z = [x; u] per lane of a row");
+    static constexpr int G = G_, D = N + M;
+    static_assert(G == 16 || G == 32, "a row of sixteen lanes, or two");
+    static_assert(D <= G, "one direction of z = [x; u] per lane of a group");
 
-    // sum over the row of 16 (the first four steps of wave_sum)
+    // a value of the last lane of each lane's own group of 32
+    static __device__ __forceinline__ unsigned of_last_lane(unsigned v)
+    {
+        const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 31), b = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+        return lane_id() < 32 ? a : b;
+    }
+    // sum over the group (the first four / five steps of wave_sum)
     static __device__ __forceinline__ float row_sum(float v)
     {
         v += dpp_move<kDppQuadXor1>(0.0f, v);
         v += dpp_move<kDppQuadXor2>(0.0f, v);
         v += dpp_move<kDppRowHalfMirror>(0.0f, v);
         v += dpp_move<kDppRowMirror>(0.0f, v);
+        if constexpr (G == 32) {
+            v += dpp_move<kDppRowBcast15, 0xA>(0.0f, v);           // rows 1, 3 += rows 0, 2
+            v = __builtin_bit_cast(float, of_last_lane(__builtin_bit_cast(unsigned, v)));
+        }
         return v;
     }
-    // maximum over the row of non-negative values (the first four steps of wave_max)
+    // maximum over the group of non-negative values (the first four / five steps of wave_max)
     static __device__ __forceinline__ float row_max(float v)
     {
         unsigned u = __builtin_bit_cast(unsigned, v);
@@ -44,6 +57,10 @@ struct UserGroup {
         step(__builtin_amdgcn_update_dpp((int)u, (int)u, kDppQuadXor2, 0xF, 0xF, false));
         step(__builtin_amdgcn_update_dpp((int)u, (int)u, kDppRowHalfMirror, 0xF, 0xF, false));
         step(__builtin_amdgcn_update_dpp((int)u, (int)u, kDppRowMirror, 0xF, 0xF, false));
+        if constexpr (G == 32) {
+            step(__builtin_amdgcn_update_dpp((int)u, (int)u, kDppRowBcast15, 0xA, 0xF, false));
+            u = of_last_lane(u);
+        }
         return __builtin_bit_cast(float, u);
     }
 };
@@ -106,10 +123,10 @@ __host__ __device__ inline size_t user_group_extra_bytes(int B, int n, int m, in
     return (size_t)B * (kUserGroupSlots - 1) * user_group_candidate_floats(n, m, T) * sizeof(float);
 }
 
-template <int N, int M>
+template <int N, int M, int LANES = 16>
 __global__ __launch_bounds__(kWave) void ilqr_user_costate_group_kernel(TfmpcEnv env, TfmpcIlqrConfig cfg, SolveArgs a, float *extra)
 {
-    using UG = UserGroup<N, M>;
+    using UG = UserGroup<N, M, LANES>;
     constexpr int G = UG::G, D = UG::D, GROUPS = kWave / G;
     extern __shared__ float smem[];
     const int lane = lane_id(), grp = lane / G, gl = lane % G, T = a.T;
@@ -218,7 +235,7 @@ __global__ __launch_bounds__(kWave) void ilqr_user_costate_group_kernel(TfmpcEnv
                 const float delta_J = -alpha * (dV1 + alpha * 0.0f);                                     // :339 (dV2 == 0)
                 const float dcost = J_hat - J;
                 const float z = (delta_J > 0.0f) ? dcost / delta_J : ((dcost > 0.0f) ? 1.0f : ((dcost < 0.0f) ? -1.0f : 0.0f));   // :342-346
-                const unsigned pass = (unsigned)((__ballot(gl < cfg.n_alphas && z >= cfg.c1) >> row0) & 0xFFFFull);
+                const unsigned pass = (unsigned)((__ballot(gl < cfg.n_alphas && z >= cfg.c1) >> row0) & (G == 32 ? 0xFFFFFFFFull : 0xFFFFull));
                 const bool accept = pass != 0u;
                 const int chosen = accept ? __builtin_ctz(pass) : cfg.n_alphas - 1;
                 const float J_chosen = __shfl(J, row0 + chosen, kWave);

@@ -1,4 +1,5 @@
-"""A Python-defined HVAC with n = 12 (n + m = 24 > 16: the wave-per-instance costate kernel) at B = 8 192, T = 100, <= 12 iterations: ms per solve."""
+"""A Python-defined HVAC with n = 12 (n + m = 24: thirty-two lanes per instance since round 6; before: the wave-per-instance costate kernel) and n = 20
+(n + m = 40: the wave kernel) at B = 8 192, T = 100, <= 12 iterations: ms per solve."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for _p in ('tf-mpc_amd', 'tests', ''): sys.path.insert(0, os.path.join(ROOT, _p))
