@@ -497,6 +497,22 @@ def deviceenv_rate(B=16384, T=50):
             small[name] = {"ms_per_batch": dt_s * 1e3, "iterations_per_s": its_s / dt_s, "cost_proved_piecewise_linear": bool(env_py.zero_cost_hessian),
                            "builtin_env_same_generic_wave_kernel_ms": dt_w * 1e3, "builtin_env_specialised_kernel_ms": dt_d * 1e3}
         from_python["piecewise_linear_envs_B16384_T100"] = small
+        # ... and one of 17 <= n + m <= 32 (HVAC, n = 12 rooms): thirty-two lanes per instance, two instances per wave (B = 8 192, T = 100, <= 12 iterations)
+        from tfmpc.envs.hvac import HVAC
+        cfg12 = problems.hvac_config(12, seed=5)
+        env12 = torch_envs.hvac(cfg12, "cuda").to_device_env()
+        s12 = iLQR(env12, max_iterations=12)
+        x12 = np.random.default_rng(3).uniform(10.0, 30.0, size=(8192, 12, 1)).astype(np.float32)
+        u12 = iLQR(HVAC.load(cfg12)).random_actions(100, 8192, seed=2)
+        out12 = s12.solve_device(x12, 100, u_init=u12)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            out12 = s12.solve_device(x12, 100, u_init=u12, workspace=out12["workspace"])
+        torch.cuda.synchronize()
+        dt12 = (time.perf_counter() - t0) / 3
+        from_python["hvac12_B8192_T100"] = {"ms_per_batch": dt12 * 1e3, "iterations_per_s": float((out12["iterations"].double() + 1).sum()) / dt12,
+                                            "kernel": s12.last_kernel}
     except Exception as exc:                                  # noqa: BLE001
         from_python = dict(from_python, error=repr(exc))
     return {"from_python_functions": from_python, "iterations_per_s": its_u / dt_u, "ms_per_batch": dt_u * 1e3, "mean_iterations": its_u / B, "batch": B, "horizon": T,
@@ -836,6 +852,7 @@ def summarise_extras(extra):
                                                                     ("navigation_cold_start", "navigation_warm_start", "res4_cold_start", "res4_warm_start")],
            "deviceenv_from_python_Mit_s": r3((get(extra, "deviceenv_user_env", "from_python_functions", "iterations_per_s") or 0) / 1e6),
            "res4_hvac6_from_python_ms": [r3(get(extra, "deviceenv_user_env", "from_python_functions", "piecewise_linear_envs_B16384_T100", k, "ms_per_batch")) for k in ("res4", "hvac6")],
+           "hvac12_from_python_ms": r3(get(extra, "deviceenv_user_env", "from_python_functions", "hvac12_B8192_T100", "ms_per_batch")),
            "format": "[ms per batch, roofline frac (, algorithmic flop rate / fp32 peak; ilqr_api_warm: executed flop rate / fp32 peak)]"}
     for key, short in (("cfg5_hvac_ilqr_n32", "cfg5_hvac"), ("cfg5_reservoir_ilqr_n32", "cfg5_reservoir"), ("hvac6_reference_config_ilqr", "hvac6"),
                        ("res4_reference_config_ilqr", "res4"), ("cfg5_literal_dims_ilqr_lq_n32_m16", "literal_dims"), ("lqr_n32_m16", "lqr_n32_m16")):
