@@ -23,7 +23,9 @@ def test_the_librarys_lane_group_kernels_have_no_private_segment():
         subprocess.run([check_ring_waits.hipcc_path(), *check_ring_waits.FLAGS, "--cuda-device-only", "-S", src, "-o", out], check=True,
                        capture_output=True)
         text = open(out).read()
-    found = re.findall(r"\.name:\s+(\S*ilqr_group_solve_kernel\S*)\n\s+\.private_segment_fixed_size:\s+(\d+)(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)
+    found = re.findall(r"\.name:\s+(\S*ilqr_group_solve_kernel\S*)\n\s+\.private_segment_fixed_size:\s+(\d+)(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)",
+                       text)
     assert len(found) >= 4, found          # Navigation and NavigationLQR, one and four instances per wave
-    for name, private, spills in found:
-        assert int(private) == 0 and int(spills) == 0, (name, private, spills)
+    for name, private, vgprs, spills in found:
+        # (beyond 256 registers the compiler parks vector registers in accumulation registers: a spill by another name)
+        assert int(private) == 0 and int(spills) == 0 and int(vgprs) <= 256, (name, private, vgprs, spills)
