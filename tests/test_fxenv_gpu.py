@@ -157,6 +157,20 @@ def test_the_generated_source_compiles_without_a_gpu():
     assert lib.tfmpc_userenv_state_size() == 4 and lib.tfmpc_userenv_action_size() == 4
 
 
+@needs_hipcc
+@pytest.mark.parametrize("which,lanes", [("reservoir4", 16), ("hvac12", 32)])
+def test_the_lane_packed_costate_kernel_is_in_the_companion_library(which, lanes):
+    """Without a GPU: the companion library of a Python env whose cost is proved piecewise linear carries the row kernel instantiated for its size --
+    sixteen lanes per instance up to n + m = 16, thirty-two up to 32 (csrc/user_env_group.h; the kernel's name is in the code object's metadata)."""
+    n = int(which[9:]) if which.startswith("reservoir") else int(which[4:])
+    cfg = (dict(problems.RES4_CONFIG) if n == 4 else dict(problems.reservoir_config(n, seed=5))) if which.startswith("reservoir") else problems.hvac_config(n, seed=5)
+    env = (torch_envs.reservoir if which.startswith("reservoir") else torch_envs.hvac)(cfg).to_device_env()
+    assert env.zero_cost_hessian
+    path = deviceenv.build(env.source, n, n, env.n_zones, True)
+    blob = open(path, "rb").read()
+    assert (b"ilqr_user_costate_group_kernelILi%dELi%dELi%dEE" % (n, n, lanes)) in blob
+
+
 # ---- on the device ---------------------------------------------------------------------------------------------------------------------------------
 
 def _case(which):
