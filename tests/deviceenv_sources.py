@@ -111,3 +111,24 @@ template <class S> __device__ S final_cost(const float *p, const S *x)          
 def lq_params(F, f, C, c):
     B = F.shape[0]
     return np.concatenate([F.reshape(B, -1), f.reshape(B, -1), C.reshape(B, -1), c.reshape(B, -1)], axis=1).astype(np.float32)
+
+
+# an env of the user's own (not one of the reference's): tests/test_deviceenv_gpu.py, tools/probes/r6_pendulum_rate.py
+PENDULUM = """
+// a damped pendulum with a torque limit: x = [angle, angular velocity], u = [torque]; p = dt, g / l, damping, target angle, q_angle, q_velocity, r
+template <class S> __device__ void transition(const float *p, const S *x, const S *u, S *x_next)
+{
+    x_next[0] = x[0] + p[0] * x[1];
+    x_next[1] = x[1] + p[0] * (u[0] - p[1] * sin(x[0]) - p[2] * x[1]);
+}
+template <class S> __device__ S cost(const float *p, const S *x, const S *u)
+{
+    const S e = x[0] - p[3];
+    return p[4] * e * e + p[5] * x[1] * x[1] + p[6] * u[0] * u[0];
+}
+template <class S> __device__ S final_cost(const float *p, const S *x)
+{
+    const S e = x[0] - p[3];
+    return 10.0f * (p[4] * e * e + p[5] * x[1] * x[1]);
+}
+"""

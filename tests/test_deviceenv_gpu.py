@@ -218,14 +218,15 @@ def test_lq_env_as_device_source_against_the_builtin_lq_env(n, m, T, bound):
 
 @pytest.mark.gpu
 @needs_hipcc
-@pytest.mark.parametrize("T,bound,B", [(6, None, 4), (30, 0.5, 300), (25, None, 2500)])
-def test_a_two_by_two_user_env_that_needs_more_registers_takes_a_lane_group_kernel_without_spills(T, bound, B):
+@pytest.mark.parametrize("n,m,T,bound,B", [(2, 2, 6, None, 4), (2, 2, 30, 0.5, 300), (2, 2, 25, None, 2500), (2, 1, 50, 0.3, 64), (1, 1, 12, None, 9),
+                                           (3, 1, 30, 0.5, 300), (1, 2, 20, 0.4, 2500), (1, 3, 16, None, 100), (2, 1, 40, None, 2100)])
+def test_tiny_user_envs_take_a_lane_group_kernel_without_spills(n, m, T, bound, B):
     """Round 6: the LQ env of lqr.py:36-57 as a 2 x 2 DeviceEnv source needs ~200 vector registers in the lane-group kernel; at that kernel's usual
     budget (three waves per SIMD: 168) it spilled 37 of them, and the spilled instantiation lost scalars -- the first case below HUNG, larger batches
     returned garbage (csrc/ilqr_lane_kernels.h).  The launcher now asks the runtime for an instantiation without a private segment (one wave's budget
-    here).  Against the same env on the generic wave kernel and the built-in LQ env."""
+    here).  The same round opened the kernel to every dense env with n + m <= 4 (a pendulum is 2 x 1): the other shapes below.  Against the same env
+    on the generic wave kernel and the built-in LQ env."""
     from tfmpc.envs.lq import LQEnv
-    n = m = 2
     F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=16)
     F = F * 0.3
     low, high = (None, None) if bound is None else (-bound, bound)
@@ -262,32 +263,16 @@ def test_a_two_by_two_user_env_that_needs_more_registers_takes_a_lane_group_kern
     assert int(out["trace_len"].min()) >= 1
 
 
-PENDULUM = """
-// a damped pendulum with a torque limit: x = [angle, angular velocity], u = [torque]; p = dt, g / l, damping, target angle, q_angle, q_velocity, r
-template <class S> __device__ void transition(const float *p, const S *x, const S *u, S *x_next)
-{
-    x_next[0] = x[0] + p[0] * x[1];
-    x_next[1] = x[1] + p[0] * (u[0] - p[1] * sin(x[0]) - p[2] * x[1]);
-}
-template <class S> __device__ S cost(const float *p, const S *x, const S *u)
-{
-    const S e = x[0] - p[3];
-    return p[4] * e * e + p[5] * x[1] * x[1] + p[6] * u[0] * u[0];
-}
-template <class S> __device__ S final_cost(const float *p, const S *x)
-{
-    const S e = x[0] - p[3];
-    return 10.0f * (p[4] * e * e + p[5] * x[1] * x[1]);
-}
-"""
+PENDULUM = sources.PENDULUM
+
 
 
 @pytest.mark.gpu
 @needs_hipcc
-def test_a_pendulum_written_as_device_source():
-    """The canonical "env of your own": a torque-limited pendulum (n = 2, m = 1, smooth dense cost) as DeviceEnv source -- the generic wave kernel
-    (the lane-group kernel serves n = m = 2 only) -- and the solve does what iLQR is for: the cost falls well below the start's on every instance,
-    inside the torque limits, with no flag raised."""
+def test_a_pendulum_written_as_device_source_runs_the_lane_group_kernel():
+    """The canonical "env of your own": a torque-limited pendulum (n = 2, m = 1, smooth dense cost) as DeviceEnv source -- lane-group kernel (round
+    6: n + m <= 4) against the generic wave kernel on the same source, and the solve does what iLQR is for: the cost falls well below the start's
+    on every instance, inside the torque limits, with no flag raised."""
     B, T = 512, 60
     rng = np.random.default_rng(5)
     params = np.array([0.05, 9.81, 0.1, 0.0, 1.0, 0.1, 0.01], dtype=np.float32)
@@ -298,8 +283,17 @@ def test_a_pendulum_written_as_device_source():
     start_cost = _np(s.start(x0, T, u_init=u0)[2]).sum(1)
     out = s.solve_device(x0, T, u_init=u0)
     torch.cuda.synchronize()
-    assert s.last_kernel.startswith("wave")
-    cu = _np(out["costs"]).sum(1)
+    assert s.last_kernel.startswith("lane_group")
+    out = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items() if k != "workspace"}
+    user._library().force_wave_kernel(True)
+    try:
+        wave = s.solve_device(x0, T, u_init=u0)
+        torch.cuda.synchronize()
+        assert s.last_kernel.startswith("wave")
+    finally:
+        user._library().force_wave_kernel(False)
+    cu, cw = _np(out["costs"]).sum(1), _np(wave["costs"]).sum(1)
     assert int((out["status"] & ~_hip.ST_NOT_PD).abs().sum()) == 0
+    assert np.median(np.abs(cu - cw) / np.abs(cw)) <= 1e-4 and (out["iterations"] == wave["iterations"]).float().mean() >= 0.8
     assert np.all(cu <= start_cost * (1 + 1e-6)) and np.median(cu / start_cost) < 0.5
     assert np.all(np.abs(_np(out["actions"])) <= 4.0 + 1e-6)

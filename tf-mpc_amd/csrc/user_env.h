@@ -374,7 +374,7 @@ template <> struct Env<TFMPC_ENV_USER> {
 
 }  // namespace tfmpc
 
-// ---- tiny user envs (n = m = 2, user_env_kernels.hip.in: TFMPC_USER_LANE_GROUP): the lane-group kernel (16 lanes per instance, all step sizes of the line search at once, persistent groups +
+// ---- tiny user envs (n + m <= 4, user_env_kernels.hip.in: TFMPC_USER_LANE_GROUP): the lane-group kernel (16 lanes per instance, all step sizes of the line search at once, persistent groups +
 // instance queue: ilqr_lane_kernels.h) on LaneEnv<TFMPC_ENV_USER>.  One lane evaluates the user's functions as ordinary scalar code; the whole
 // quadratic model of a timestep is the "precomputed part" of the linearisation (kPre floats), which the kernel evaluates for all timesteps at once,
 // one per lane, whenever the nominal trajectory changes -- D dual evaluations of `transition` and D (D + 1) / 2 second-order ones of `cost` each.

@@ -1,0 +1,50 @@
+"""Dense user envs with n + m <= 4 on the lane-group kernel (round 6) against the generic wave kernel of the same companion library: the LQ env of
+lqr.py:36-57 as DeviceEnv source, shapes 1x1 .. 3x1 / 1x3 / 2x2, random batch sizes (both launch forms), horizons, limits.  Two fp32 programs:
+iterations must agree on >= 80 % of the instances and the costs to 1e-4 (median), no status flag but NOT_PD.  Exit status 1 on any failure.
+    python tools/probes/r6_lane_user_fuzz.py [seed] [cases]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for _p in ('tf-mpc_amd', 'tests', ''): sys.path.insert(0, os.path.join(ROOT, _p))
+import numpy as np, torch, problems
+import deviceenv_sources as sources
+from tfmpc import _hip
+from tfmpc.envs.deviceenv import DeviceEnv
+from tfmpc.solvers.ilqr import iLQR
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 48
+shapes = [(1, 1), (2, 1), (1, 2), (3, 1), (1, 3), (2, 2)]
+bad = 0
+for case in range(cases):
+    n, m = shapes[case % len(shapes)]
+    B = int(rng.choice([int(rng.integers(1, 40)), int(rng.integers(40, 2048)), int(rng.integers(2049, 6000))]))
+    T = int(rng.integers(3, 80))
+    bound = None if rng.random() < 0.4 else float(rng.uniform(0.1, 1.0))
+    its = int(rng.integers(2, 12))
+    F, f, C, c, x0 = problems.make_lqr_batch_fast(B, n, m, seed=int(rng.integers(1, 10000)))
+    F = F * 0.3
+    low, high = (None, None) if bound is None else (-bound, bound)
+    user = DeviceEnv(sources.lq_source(n, m), n, m, params=sources.lq_params(F, f, C, c), low=low, high=high)
+    u0 = np.clip(0.1 * rng.normal(size=(B, T, m, 1)), -(bound or 1.0), bound or 1.0).astype(np.float32)
+    x0 = x0.astype(np.float32)[..., None]
+    s = iLQR(user, max_iterations=its)
+    out = s.solve_device(x0, T, u_init=u0)
+    torch.cuda.synchronize()
+    kernel = s.last_kernel
+    out = {k: v.clone() for k, v in out.items() if torch.is_tensor(v) and k != "workspace"}
+    user._library().force_wave_kernel(True)
+    try:
+        wave = s.solve_device(x0, T, u_init=u0)
+        torch.cuda.synchronize()
+    finally:
+        user._library().force_wave_kernel(False)
+    same = float((out["iterations"] == wave["iterations"]).float().mean())
+    cu, cw = out["costs"].double().sum(1).cpu().numpy(), wave["costs"].double().sum(1).cpu().numpy()
+    rel = float(np.median(np.abs(cu - cw) / np.abs(cw)))
+    flags = int((out["status"] & ~_hip.ST_NOT_PD).abs().sum())
+    ok = kernel.startswith("lane_group") and same >= 0.8 and rel <= 1e-4 and flags == 0 and (bound is None or float(out["actions"].abs().max()) <= bound + 1e-6)
+    bad += 0 if ok else 1
+    print(f"case {case:2d}: {n}x{m} B={B:4d} T={T:2d} bound={bound if bound is None else round(bound, 2)} iterations<={its:2d}  {kernel[:10]}  same iterations {same:.3f}  "
+          f"median cost difference {rel:.1e}  flags {flags}  {'ok' if ok else 'FAILED'}", flush=True)
+print("failed cases:", bad)
+sys.exit(1 if bad else 0)
