@@ -513,6 +513,23 @@ def deviceenv_rate(B=16384, T=50):
         dt12 = (time.perf_counter() - t0) / 3
         from_python["hvac12_B8192_T100"] = {"ms_per_batch": dt12 * 1e3, "iterations_per_s": float((out12["iterations"].double() + 1).sum()) / dt12,
                                             "kernel": s12.last_kernel}
+        # ... and an env that is none of the reference's: a torque-limited pendulum (n = 2, m = 1) as device source -- dense tiny envs (n + m <= 4) run
+        # the lane-group kernel since round 6 (B = 16 384, T = 50, <= 30 iterations)
+        import deviceenv_sources as more_sources
+        pend = DeviceEnv(more_sources.PENDULUM, 2, 1, params=np.array([0.05, 9.81, 0.1, 0.0, 1.0, 0.1, 0.01], dtype=np.float32), low=-4.0, high=4.0)
+        rp = np.random.default_rng(5)
+        xp = np.stack([rp.uniform(-1.2, 1.2, size=16384), rp.uniform(-1.0, 1.0, size=16384)], axis=1).astype(np.float32)[..., None]
+        up = np.zeros((16384, 50, 1, 1), dtype=np.float32)
+        sp = iLQR(pend, max_iterations=30)
+        outp = sp.solve_device(xp, 50, u_init=up)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            outp = sp.solve_device(xp, 50, u_init=up, workspace=outp["workspace"])
+        torch.cuda.synchronize()
+        dtp = (time.perf_counter() - t0) / 5
+        from_python["pendulum_device_source_B16384_T50"] = {"ms_per_batch": dtp * 1e3, "iterations_per_s": float((outp["iterations"].double() + 1).sum()) / dtp,
+                                                            "kernel": sp.last_kernel}
     except Exception as exc:                                  # noqa: BLE001
         from_python = dict(from_python, error=repr(exc))
     return {"from_python_functions": from_python, "iterations_per_s": its_u / dt_u, "ms_per_batch": dt_u * 1e3, "mean_iterations": its_u / B, "batch": B, "horizon": T,
@@ -853,6 +870,7 @@ def summarise_extras(extra):
            "deviceenv_from_python_Mit_s": r3((get(extra, "deviceenv_user_env", "from_python_functions", "iterations_per_s") or 0) / 1e6),
            "res4_hvac6_from_python_ms": [r3(get(extra, "deviceenv_user_env", "from_python_functions", "piecewise_linear_envs_B16384_T100", k, "ms_per_batch")) for k in ("res4", "hvac6")],
            "hvac12_from_python_ms": r3(get(extra, "deviceenv_user_env", "from_python_functions", "hvac12_B8192_T100", "ms_per_batch")),
+           "pendulum_device_source_Mit_s": r3((get(extra, "deviceenv_user_env", "from_python_functions", "pendulum_device_source_B16384_T50", "iterations_per_s") or 0) / 1e6),
            "format": "[ms per batch, roofline frac (, algorithmic flop rate / fp32 peak; ilqr_api_warm: executed flop rate / fp32 peak)]"}
     for key, short in (("cfg5_hvac_ilqr_n32", "cfg5_hvac"), ("cfg5_reservoir_ilqr_n32", "cfg5_reservoir"), ("hvac6_reference_config_ilqr", "hvac6"),
                        ("res4_reference_config_ilqr", "res4"), ("cfg5_literal_dims_ilqr_lq_n32_m16", "literal_dims"), ("lqr_n32_m16", "lqr_n32_m16")):
