@@ -350,6 +350,32 @@ def test_sixteen_lanes_per_instance_equal_the_wave_per_instance_kernel(which, B,
 
 @pytest.mark.gpu
 @needs_hipcc
+def test_a_pendulum_in_plain_torch_lands_on_the_lane_group_kernel():
+    """An env of the user's own, written as three torch functions: traced, translated (sin included), compiled -- and, being dense with n + m <= 4,
+    solved by the lane-group kernel (round 6); the same numbers as the hand-written device source of the same model."""
+    import deviceenv_sources as sources
+    from tfmpc.envs.deviceenv import DeviceEnv
+    B, T = 256, 60
+    rng = np.random.default_rng(5)
+    x0 = np.stack([rng.uniform(-1.2, 1.2, size=B), rng.uniform(-1.0, 1.0, size=B)], axis=1).astype(np.float32)[..., None]
+    u0 = np.zeros((B, T, 1, 1), dtype=np.float32)
+    python_env = torch_envs.pendulum("cuda")
+    s = iLQR(python_env, max_iterations=30)
+    assert s.compile_error is None, s.compile_error
+    out = s.solve_device(x0, T, u_init=u0)
+    torch.cuda.synchronize()
+    assert s.last_kernel.startswith("lane_group"), s.last_kernel
+    hand = DeviceEnv(sources.PENDULUM, 2, 1, params=np.array([0.05, 9.81, 0.1, 0.0, 1.0, 0.1, 0.01], dtype=np.float32), low=-4.0, high=4.0)
+    ref = iLQR(hand, max_iterations=30).solve_device(x0, T, u_init=u0)
+    torch.cuda.synchronize()
+    cu, cr = _np(out["costs"]).sum(1), _np(ref["costs"]).sum(1)
+    assert int(out["status"].abs().sum()) == 0
+    assert (out["iterations"] == ref["iterations"]).float().mean() >= 0.9 and np.median(np.abs(cu - cr) / np.abs(cr)) <= 1e-4
+    assert np.all(np.abs(_np(out["actions"])) <= 4.0 + 1e-6)
+
+
+@pytest.mark.gpu
+@needs_hipcc
 def test_ilqr_takes_the_device_path_for_a_python_env_by_itself_and_falls_back_when_it_cannot():
     """`iLQR(TorchEnv(...))`: the functions are translated and compiled when possible -- the reference user changes nothing -- and an env the translator
     cannot take (here: torch.erf) runs the host-driven loop, with the reason kept."""

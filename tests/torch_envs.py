@@ -87,3 +87,19 @@ def hvac(cfg, device="cpu"):
         return torch.sum(penalties(x))
 
     return TorchEnv(transition, cost, final_cost, n, n, 0.0, 1.0, device=device)
+
+
+def pendulum(device="cpu", dt=0.05, g_over_l=9.81, damping=0.1, torque=4.0):
+    """An env that is none of the reference's: a damped pendulum with a torque limit, x = [angle, angular velocity], u = [torque] (the same model as
+    tests/deviceenv_sources.py: PENDULUM) -- three plain torch functions, as a user would write them."""
+    def transition(x, u):
+        theta, omega = x[0], x[1]
+        return torch.stack([theta + dt * omega, omega + dt * (u[0] - g_over_l * torch.sin(theta) - damping * omega)])
+
+    def cost(x, u):
+        return x[0] ** 2 + 0.1 * x[1] ** 2 + 0.01 * u[0] ** 2
+
+    def final_cost(x):
+        return 10.0 * (x[0] ** 2 + 0.1 * x[1] ** 2)
+
+    return TorchEnv(transition, cost, final_cost, 2, 1, np.full((1, 1), -torque), np.full((1, 1), torque), device=device)
