@@ -50,8 +50,8 @@ def test_translation_of_the_three_envs_and_where_their_constants_go():
 
 def test_unsupported_operations_and_python_branches_are_refused_with_a_clear_error():
     good = lambda x: (x ** 2).sum()
-    with pytest.raises(fxsource.UnsupportedOperation, match="erf"):
-        TorchEnv(lambda x, u: torch.erf(x) + u, lambda x, u: good(x), good, 2, 2).to_device_env()
+    with pytest.raises(fxsource.UnsupportedOperation, match="lgamma"):
+        TorchEnv(lambda x, u: torch.lgamma(x) + u, lambda x, u: good(x), good, 2, 2).to_device_env()
     def branchy(x, u):
         if x[0] > 0:                                # a Python branch on the state: a trace would keep one side only
             return x + u
@@ -118,6 +118,27 @@ def test_activation_and_statistics_vocabulary():
     assert not lin(lambda x, u: (x * u).sum()) and not lin(lambda x, u: torch.sqrt(1.0 + x.abs()).sum()) and not lin(lambda x, u: (x ** 2).sum())
 
 
+def test_vehicle_and_arm_vocabulary():
+    """Round 6: tan / atan / asin / acos / atan2 / sinh / cosh / erf -- values of the translated statements against torch (their derivatives: the
+    dual-number forms in csrc/user_env.h, held against torch.func on the device in test_the_bicycle_from_python...)."""
+    def transition(x, u):
+        return torch.stack([torch.tan(0.3 * x[0]) + torch.atan(x[1]), torch.asin(0.5 * torch.tanh(x[2])) + torch.acos(0.4 * torch.sin(u[0])),
+                            torch.sinh(0.2 * x[0]) - torch.cosh(0.1 * u[1]) + torch.erf(x[1])])
+
+    def cost(x, u):
+        return torch.atan2(x[0], 1.0 + x[1] ** 2) ** 2 + torch.arctan2(torch.sin(x[2]), torch.cos(x[2])) ** 2 + (u ** 2).sum()
+
+    final = lambda x: torch.atan2(x[1], x[0]) ** 2
+    src, params, info = fxsource.translate_ex(transition, cost, final, 3, 2)
+    assert not info["cost_is_piecewise_linear"]
+    rng = np.random.default_rng(2)
+    for _ in range(4):
+        x, u = rng.normal(size=3).astype(np.float32), rng.normal(size=2).astype(np.float32)
+        assert np.allclose(_evaluate(src, "transition", params, x, u), transition(torch.as_tensor(x), torch.as_tensor(u)).numpy(), rtol=2e-5, atol=1e-6)
+        assert np.isclose(_evaluate(src, "cost", params, x, u), float(cost(torch.as_tensor(x), torch.as_tensor(u))), rtol=2e-5)
+        assert np.isclose(_evaluate(src, "final_cost", params, x, None), float(final(torch.as_tensor(x))), rtol=2e-5)
+
+
 def _evaluate(source, name, p, x, u):
     """Runs the emitted statements of one function as Python (they are one assignment each, in C syntax that is also Python's but for the
     ternary, the float suffix and a few names)."""
@@ -125,7 +146,8 @@ def _evaluate(source, name, p, x, u):
     body = source[source.index(f" {name}(const float *p"):]
     body = body[body.index("{") + 1:body.index("\n}")]
     env = {"p": p, "x": x, "u": u, "x_next": [0.0] * len(x), "sqrt": math.sqrt, "sqrtf": math.sqrt, "exp": math.exp, "expf": math.exp,
-           "log": math.log, "sin": math.sin, "cos": math.cos, "tanh": math.tanh, "abs": abs, "fabsf": abs, "max": lambda a, b: a if a >= b else b,
+           "log": math.log, "sin": math.sin, "cos": math.cos, "tanh": math.tanh, "abs": abs, "fabsf": abs, "tan": math.tan, "atan": math.atan, "asin": math.asin,
+           "acos": math.acos, "sinh": math.sinh, "cosh": math.cosh, "erf": math.erf, "atan2": math.atan2, "atan2f": math.atan2, "max": lambda a, b: a if a >= b else b,
            "min": lambda a, b: a if a <= b else b, "fmaxf": max, "fminf": min, "pow": pow, "powf": pow, "S": float, "true": True, "false": False}
     env["tfmpc"] = type("ns", (), {"ad": type("ad", (), {"prim": staticmethod(float)})})
     result = None
@@ -350,6 +372,41 @@ def test_sixteen_lanes_per_instance_equal_the_wave_per_instance_kernel(which, B,
 
 @pytest.mark.gpu
 @needs_hipcc
+def test_the_bicycle_from_python_has_torch_funcs_derivatives_and_drives_to_its_goal():
+    """A kinematic bicycle written in plain torch (tan, atan2 of sin / cos, ...: round 6's vocabulary): every derivative tensor of the compiled env
+    against torch.func autodiff of the very functions that were translated (first AND second order: the nested dual numbers of the new
+    functions), and a solve that reduces the cost inside the steering / acceleration limits."""
+    python_env = torch_envs.bicycle("cuda")
+    device_env = python_env.to_device_env()
+    assert not device_env.zero_cost_hessian
+    rng = np.random.default_rng(7)
+    B, T = 10, 7
+    x = np.concatenate([rng.uniform(-2, 9, size=(B, T + 1, 2, 1)), rng.uniform(-1.2, 1.2, size=(B, T + 1, 1, 1)), rng.uniform(0.2, 4, size=(B, T + 1, 1, 1))], axis=2).astype(np.float32)
+    u = np.concatenate([rng.uniform(-2, 2, size=(B, T, 1, 1)), rng.uniform(-0.5, 0.5, size=(B, T, 1, 1))], axis=2).astype(np.float32)
+    got = iLQR(device_env).derivatives(x, u)
+    torch.cuda.synchronize()
+    tm = python_env.get_linear_transition(x[:, :-1], u)
+    cm = python_env.get_quadratic_cost(x[:, :-1], u)
+    names = [f"{t}.{f}" for t, tup in zip("tc", got[:2]) for f in tup._fields]
+    for name, a, b in zip(names, list(got[0]) + list(got[1]), list(tm) + list(cm)):
+        a, b = _np(a), _np(b).reshape(_np(a).shape)
+        assert np.abs(a - b).max() <= 5e-5 * max(np.abs(b).max(), 1.0), (name, np.abs(a - b).max(), np.abs(b).max())
+    B, T = 128, 40
+    x0 = np.concatenate([rng.uniform(-1, 1, size=(B, 2, 1)), rng.uniform(-0.5, 0.5, size=(B, 1, 1)), rng.uniform(0.5, 2, size=(B, 1, 1))], axis=1).astype(np.float32)
+    u0 = np.zeros((B, T, 2, 1), dtype=np.float32)
+    s = iLQR(device_env, max_iterations=40)
+    start = _np(s.start(x0, T, u_init=u0)[2]).sum(1)
+    out = s.solve_device(x0, T, u_init=u0)
+    torch.cuda.synchronize()
+    cu = _np(out["costs"]).sum(1)
+    assert int((out["status"] & ~_hip.ST_NOT_PD).abs().sum()) == 0
+    assert np.all(cu <= start * (1 + 1e-6)) and np.median(cu / start) < 0.3
+    act = _np(out["actions"])
+    assert np.all(np.abs(act[:, :, 0]) <= 2.0 + 1e-6) and np.all(np.abs(act[:, :, 1]) <= 0.5 + 1e-6)
+
+
+@pytest.mark.gpu
+@needs_hipcc
 def test_a_pendulum_in_plain_torch_lands_on_the_lane_group_kernel():
     """An env of the user's own, written as three torch functions: traced, translated (sin included), compiled -- and, being dense with n + m <= 4,
     solved by the lane-group kernel (round 6); the same numbers as the hand-written device source of the same model."""
@@ -378,7 +435,7 @@ def test_a_pendulum_in_plain_torch_lands_on_the_lane_group_kernel():
 @needs_hipcc
 def test_ilqr_takes_the_device_path_for_a_python_env_by_itself_and_falls_back_when_it_cannot():
     """`iLQR(TorchEnv(...))`: the functions are translated and compiled when possible -- the reference user changes nothing -- and an env the translator
-    cannot take (here: torch.erf) runs the host-driven loop, with the reason kept."""
+    cannot take (here: torch.lgamma) runs the host-driven loop, with the reason kept."""
     cfg, builtin, python_env, _, _ = _case("navigation")
     solver = iLQR(python_env)
     assert solver.python_env is python_env and solver.compile_error is None and solver.env.kind == _hip.ENV_USER
@@ -391,7 +448,7 @@ def test_ilqr_takes_the_device_path_for_a_python_env_by_itself_and_falls_back_wh
     assert solver.last_kernel.startswith("lane_group") and (its == its_ref).mean() >= 0.9
     assert np.median(np.abs(traj.costs.sum(1) - ref.costs.sum(1)) / np.abs(ref.costs.sum(1))) <= 1e-5
     g = torch.as_tensor(np.array(cfg["goal"], dtype=np.float32).reshape(-1), device="cuda")
-    odd = TorchEnv(lambda x, u: x + torch.erf(u), lambda x, u: ((x - g) ** 2).sum(), lambda x: ((x - g) ** 2).sum(), 2, 2, -1.0, 1.0)
+    odd = TorchEnv(lambda x, u: x + torch.lgamma(2.0 + u), lambda x, u: ((x - g) ** 2).sum(), lambda x: ((x - g) ** 2).sum(), 2, 2, -1.0, 1.0)
     fallback = iLQR(odd, max_iterations=3)
     assert fallback.python_env is None and isinstance(fallback.compile_error, fxsource.UnsupportedOperation) and fallback.env is odd
     out = fallback.solve_device(x0[:4], 10, u_init=u0[:4, :10])

@@ -103,3 +103,24 @@ def pendulum(device="cpu", dt=0.05, g_over_l=9.81, damping=0.1, torque=4.0):
         return 10.0 * (x[0] ** 2 + 0.1 * x[1] ** 2)
 
     return TorchEnv(transition, cost, final_cost, 2, 1, np.full((1, 1), -torque), np.full((1, 1), torque), device=device)
+
+
+def bicycle(device="cpu", dt=0.1, wheelbase=2.5, goal=(8.0, 3.0, 0.4)):
+    """Another env that is none of the reference's: a kinematic bicycle -- x = [px, py, heading, speed], u = [acceleration, steering angle] -- with a
+    heading error wrapped through atan2: tan / atan2 / cos / sin, the vocabulary of a vehicle model."""
+    gx, gy, gh = goal
+
+    def transition(x, u):
+        px, py, th, v = x[0], x[1], x[2], x[3]
+        return torch.stack([px + dt * v * torch.cos(th), py + dt * v * torch.sin(th), th + dt * v / wheelbase * torch.tan(u[1]), v + dt * u[0]])
+
+    def heading_error(th):
+        return torch.atan2(torch.sin(th - gh), torch.cos(th - gh))
+
+    def cost(x, u):
+        return 0.1 * ((x[0] - gx) ** 2 + (x[1] - gy) ** 2) + 0.5 * heading_error(x[2]) ** 2 + 0.01 * x[3] ** 2 + 0.05 * u[0] ** 2 + 0.5 * u[1] ** 2
+
+    def final_cost(x):
+        return 5.0 * ((x[0] - gx) ** 2 + (x[1] - gy) ** 2) + 5.0 * heading_error(x[2]) ** 2 + x[3] ** 2
+
+    return TorchEnv(transition, cost, final_cost, 4, 2, np.array([[-2.0], [-0.5]]), np.array([[2.0], [0.5]]), device=device)

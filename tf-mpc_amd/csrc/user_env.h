@@ -86,6 +86,14 @@ __device__ __forceinline__ float log_(float x) { return ::logf(x); }
 __device__ __forceinline__ float sin_(float x) { return ::sinf(x); }
 __device__ __forceinline__ float cos_(float x) { return ::cosf(x); }
 __device__ __forceinline__ float tanh_(float x) { return ::tanhf(x); }
+__device__ __forceinline__ float tan_(float x) { return ::tanf(x); }
+__device__ __forceinline__ float atan_(float x) { return ::atanf(x); }
+__device__ __forceinline__ float asin_(float x) { return ::asinf(x); }
+__device__ __forceinline__ float acos_(float x) { return ::acosf(x); }
+__device__ __forceinline__ float sinh_(float x) { return ::sinhf(x); }
+__device__ __forceinline__ float cosh_(float x) { return ::coshf(x); }
+__device__ __forceinline__ float erf_(float x) { return ::erff(x); }
+__device__ __forceinline__ float atan2_(float y, float x) { return ::atan2f(y, x); }
 __device__ __forceinline__ float pow_(float x, float p) { return ::powf(x, p); }
 __device__ __forceinline__ float abs_(float x) { return ::fabsf(x); }
 template <class T> __device__ __forceinline__ Dual<T> sqrt(const Dual<T> &a);
@@ -96,6 +104,23 @@ template <class T> __device__ __forceinline__ Dual<T> cos(const Dual<T> &a);
 template <class T> __device__ __forceinline__ Dual<T> tanh(const Dual<T> &a);
 template <class T> __device__ __forceinline__ Dual<T> pow(const Dual<T> &a, float p);
 template <class T> __device__ __forceinline__ Dual<T> abs(const Dual<T> &a);
+// (round 6: what a vehicle or arm model is made of -- tan, the inverse trigonometric functions incl. atan2, the hyperbolic pair, erf)
+template <class T> __device__ __forceinline__ Dual<T> tan(const Dual<T> &a);
+template <class T> __device__ __forceinline__ Dual<T> atan(const Dual<T> &a);
+template <class T> __device__ __forceinline__ Dual<T> asin(const Dual<T> &a);
+template <class T> __device__ __forceinline__ Dual<T> acos(const Dual<T> &a);
+template <class T> __device__ __forceinline__ Dual<T> sinh(const Dual<T> &a);
+template <class T> __device__ __forceinline__ Dual<T> cosh(const Dual<T> &a);
+template <class T> __device__ __forceinline__ Dual<T> erf(const Dual<T> &a);
+template <class T> __device__ __forceinline__ Dual<T> atan2(const Dual<T> &y, const Dual<T> &x);
+template <class T> __device__ __forceinline__ Dual<T> tan_(const Dual<T> &a) { return tan(a); }
+template <class T> __device__ __forceinline__ Dual<T> atan_(const Dual<T> &a) { return atan(a); }
+template <class T> __device__ __forceinline__ Dual<T> asin_(const Dual<T> &a) { return asin(a); }
+template <class T> __device__ __forceinline__ Dual<T> acos_(const Dual<T> &a) { return acos(a); }
+template <class T> __device__ __forceinline__ Dual<T> sinh_(const Dual<T> &a) { return sinh(a); }
+template <class T> __device__ __forceinline__ Dual<T> cosh_(const Dual<T> &a) { return cosh(a); }
+template <class T> __device__ __forceinline__ Dual<T> erf_(const Dual<T> &a) { return erf(a); }
+template <class T> __device__ __forceinline__ Dual<T> atan2_(const Dual<T> &y, const Dual<T> &x) { return atan2(y, x); }
 template <class T> __device__ __forceinline__ Dual<T> sqrt_(const Dual<T> &a) { return sqrt(a); }
 template <class T> __device__ __forceinline__ Dual<T> exp_(const Dual<T> &a) { return exp(a); }
 template <class T> __device__ __forceinline__ Dual<T> log_(const Dual<T> &a) { return log(a); }
@@ -111,6 +136,19 @@ template <class T> __device__ __forceinline__ Dual<T> sin(const Dual<T> &a) { re
 template <class T> __device__ __forceinline__ Dual<T> cos(const Dual<T> &a) { return Dual<T>(cos_(a.v), -(a.d * sin_(a.v))); }
 template <class T> __device__ __forceinline__ Dual<T> tanh(const Dual<T> &a) { const T t = tanh_(a.v); return Dual<T>(t, a.d * (1.0f - t * t)); }
 template <class T> __device__ __forceinline__ Dual<T> pow(const Dual<T> &a, float p) { return Dual<T>(pow_(a.v, p), a.d * (p * pow_(a.v, p - 1.0f))); }
+template <class T> __device__ __forceinline__ Dual<T> tan(const Dual<T> &a) { const T t = tan_(a.v); return Dual<T>(t, a.d * (1.0f + t * t)); }
+template <class T> __device__ __forceinline__ Dual<T> atan(const Dual<T> &a) { return Dual<T>(atan_(a.v), a.d / (1.0f + a.v * a.v)); }
+template <class T> __device__ __forceinline__ Dual<T> asin(const Dual<T> &a) { return Dual<T>(asin_(a.v), a.d / sqrt_(1.0f - a.v * a.v)); }
+template <class T> __device__ __forceinline__ Dual<T> acos(const Dual<T> &a) { return Dual<T>(acos_(a.v), -(a.d / sqrt_(1.0f - a.v * a.v))); }
+template <class T> __device__ __forceinline__ Dual<T> sinh(const Dual<T> &a) { return Dual<T>(sinh_(a.v), a.d * cosh_(a.v)); }
+template <class T> __device__ __forceinline__ Dual<T> cosh(const Dual<T> &a) { return Dual<T>(cosh_(a.v), a.d * sinh_(a.v)); }
+template <class T> __device__ __forceinline__ Dual<T> erf(const Dual<T> &a) { return Dual<T>(erf_(a.v), a.d * (1.1283791670955126f * exp_(-(a.v * a.v)))); }
+template <class T> __device__ __forceinline__ Dual<T> atan2(const Dual<T> &y, const Dual<T> &x)
+{
+    return Dual<T>(atan2_(y.v, x.v), (y.d * x.v - x.d * y.v) / (x.v * x.v + y.v * y.v));
+}
+template <class T> __device__ __forceinline__ Dual<T> atan2(const Dual<T> &y, float x) { return atan2(y, Dual<T>(x)); }
+template <class T> __device__ __forceinline__ Dual<T> atan2(float y, const Dual<T> &x) { return atan2(Dual<T>(y), x); }
 // |y|' = sign(y), 0 at 0; max / min: a tie goes to the first argument (TensorFlow's gradients: SURVEY.md Appendix A.3)
 template <class T> __device__ __forceinline__ Dual<T> abs(const Dual<T> &a)
 {

@@ -212,8 +212,16 @@ class _Translator:
                 pass
         lin = a.lin and (fn == "abs" or a.kind != "S")     # |y| keeps a value piecewise affine; sqrt, exp, ... do not
         if a.kind == "f":                                   # plain float: the C names (no overload resolution between float and dual forms)
-            fn = {"sqrt": "sqrtf", "exp": "expf", "log": "logf", "sin": "sinf", "cos": "cosf", "tanh": "tanhf", "abs": "fabsf"}.get(fn, fn)
+            fn = {"sqrt": "sqrtf", "exp": "expf", "log": "logf", "sin": "sinf", "cos": "cosf", "tanh": "tanhf", "abs": "fabsf", "tan": "tanf", "atan": "atanf",
+                  "asin": "asinf", "acos": "acosf", "sinh": "sinhf", "cosh": "coshf", "erf": "erff"}.get(fn, fn)
         return self.prog.new(a.kind, f"{fn}({a.code})", lin)
+
+    def atan2(self, y, x):
+        y, x = self._num(self._as_e(y)), self._num(self._as_e(x))
+        if y.val is not None and x.val is not None and not (_is_param(y) or _is_param(x)):
+            return _lit(math.atan2(y.val, x.val))
+        kind = "S" if "S" in (y.kind, x.kind) else "f"
+        return self.prog.new(kind, f"{'atan2' if kind == 'S' else 'atan2f'}({y.code}, {x.code})", False)
 
     def neg(self, a):
         a = self._num(self._as_e(a))
@@ -450,6 +458,17 @@ class _Translator:
     def op_cos(self, a): return self._map1(a, lambda e: self._unary(e, "cos", math.cos))
     def op_tanh(self, a): return self._map1(a, lambda e: self._unary(e, "tanh", math.tanh))
     def op_abs(self, a): return self._map1(a, lambda e: self._unary(e, "abs", abs))
+    # (round 6: vehicle / arm models -- csrc/user_env.h holds their dual-number forms)
+    def op_tan(self, a): return self._map1(a, lambda e: self._unary(e, "tan", math.tan))
+    def op_atan(self, a): return self._map1(a, lambda e: self._unary(e, "atan", math.atan))
+    def op_asin(self, a): return self._map1(a, lambda e: self._unary(e, "asin", math.asin))
+    def op_acos(self, a): return self._map1(a, lambda e: self._unary(e, "acos", math.acos))
+    def op_sinh(self, a): return self._map1(a, lambda e: self._unary(e, "sinh", math.sinh))
+    def op_cosh(self, a): return self._map1(a, lambda e: self._unary(e, "cosh", math.cosh))
+    def op_erf(self, a): return self._map1(a, lambda e: self._unary(e, "erf", math.erf))
+    def op_atan2(self, a, b): return self._map2(a, b, self.atan2)
+    op_arctan2 = op_atan2
+    op_arctan, op_arcsin, op_arccos = op_atan, op_asin, op_acos
     def op_reciprocal(self, a): return self._map1(a, lambda e: self.div(_lit(1.0), e))
     def op_sigmoid(self, a):
         return self._map1(a, lambda e: self.div(_lit(1.0), self.add(_lit(1.0), self._unary(self.neg(e), "exp", math.exp))))
