@@ -929,8 +929,8 @@ struct ScratchSink {
 // vector registers must not be launched: this kernel keeps ~120 scalars in lanes of vector registers (SGPR spills), leaves the wave with part of
 // its lanes retired (GROUPS = 1) or diverged, and with vector-register spills on top the emitted code loses scalars -- measured: wrong status words,
 // a hang, a memory fault (an LQ env as 2 x 2 user source, 37 spilled registers at EU = 3; clean at EU = 1).  The launchers therefore ask the runtime
-// for the instantiation's private segment and take one whose size is ZERO (user_env_kernels.hip.in: EU = 3, then 1, else another kernel);
-// tests/test_abi_validation_cpu.py holds the library's own instantiations to that.
+// for the instantiation's private segment and register count and take one that spills nothing (user_env_kernels.hip.in: EU = 3, then 1, else
+// another kernel); tests/test_lane_group_private_segment_cpu.py holds the library's own instantiations to that.
 template <int KIND, int N, int M, int GROUPS, int EU = TFMPC_GROUP_LANE_EU>
 __global__ __launch_bounds__(64, EU) void ilqr_group_solve_kernel(TfmpcEnv genv, TfmpcIlqrConfig cfg, SolveArgsLane a)
 {
