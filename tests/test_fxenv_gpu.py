@@ -407,6 +407,42 @@ def test_the_bicycle_from_python_has_torch_funcs_derivatives_and_drives_to_its_g
 
 @pytest.mark.gpu
 @needs_hipcc
+def test_the_textbook_cart_pole_from_python():
+    """The canonical iLQR example as three torch functions (n = 4, m = 1: the generic wave kernel): torch.func's derivatives on the device, and
+    a solve from a tilted start with zero initial controls inside the force limit -- the cost falls on every instance and the pole ends UPRIGHT
+    (the open-loop start lets it fall, so the local optimum iLQR finds from there brings it up the other way round: upright modulo a turn)."""
+    python_env = torch_envs.cartpole("cuda")
+    device_env = python_env.to_device_env()
+    rng = np.random.default_rng(9)
+    B, T = 10, 7
+    x = rng.uniform(-1, 1, size=(B, T + 1, 4, 1)).astype(np.float32)
+    u = rng.uniform(-10, 10, size=(B, T, 1, 1)).astype(np.float32)
+    got = iLQR(device_env).derivatives(x, u)
+    torch.cuda.synchronize()
+    tm = python_env.get_linear_transition(x[:, :-1], u)
+    cm = python_env.get_quadratic_cost(x[:, :-1], u)
+    names = [f"{t}.{f}" for t, tup in zip("tc", got[:2]) for f in tup._fields]
+    for name, a, b in zip(names, list(got[0]) + list(got[1]), list(tm) + list(cm)):
+        a, b = _np(a), _np(b).reshape(_np(a).shape)
+        assert np.abs(a - b).max() <= 5e-5 * max(np.abs(b).max(), 1.0), (name, np.abs(a - b).max(), np.abs(b).max())
+    B, T = 128, 100
+    x0 = np.concatenate([rng.uniform(-0.5, 0.5, size=(B, 2, 1)), rng.uniform(-0.3, 0.3, size=(B, 1, 1)), rng.uniform(-0.3, 0.3, size=(B, 1, 1))], axis=1).astype(np.float32)
+    u0 = np.zeros((B, T, 1, 1), dtype=np.float32)
+    s = iLQR(device_env, max_iterations=50)
+    start = _np(s.start(x0, T, u_init=u0)[2]).sum(1)
+    out = s.solve_device(x0, T, u_init=u0)
+    torch.cuda.synchronize()
+    assert s.last_kernel.startswith("wave")
+    cu = _np(out["costs"]).sum(1)
+    assert int((out["status"] & ~_hip.ST_NOT_PD).abs().sum()) == 0
+    assert np.all(cu <= start * (1 + 1e-6)) and np.median(cu / start) < 0.9
+    assert np.all(np.abs(_np(out["actions"])) <= 10.0 + 1e-6)
+    angle = _np(out["states"])[:, -1, 2, 0]
+    assert np.median(np.abs(np.arctan2(np.sin(angle), np.cos(angle)))) < 0.15
+
+
+@pytest.mark.gpu
+@needs_hipcc
 def test_a_pendulum_in_plain_torch_lands_on_the_lane_group_kernel():
     """An env of the user's own, written as three torch functions: traced, translated (sin included), compiled -- and, being dense with n + m <= 4,
     solved by the lane-group kernel (round 6); the same numbers as the hand-written device source of the same model."""

@@ -124,3 +124,24 @@ def bicycle(device="cpu", dt=0.1, wheelbase=2.5, goal=(8.0, 3.0, 0.4)):
         return 5.0 * ((x[0] - gx) ** 2 + (x[1] - gy) ** 2) + 5.0 * heading_error(x[2]) ** 2 + x[3] ** 2
 
     return TorchEnv(transition, cost, final_cost, 4, 2, np.array([[-2.0], [-0.5]]), np.array([[2.0], [0.5]]), device=device)
+
+
+def cartpole(device="cpu", dt=0.02, m_cart=1.0, m_pole=0.1, half_length=0.5, gravity=9.81, force=10.0):
+    """The textbook cart-pole (Barto, Sutton & Anderson's equations): x = [position, velocity, angle from upright, angular velocity], u = [force]."""
+    total, pml = m_cart + m_pole, m_pole * half_length
+
+    def transition(x, u):
+        pos, vel, th, om = x[0], x[1], x[2], x[3]
+        s, c = torch.sin(th), torch.cos(th)
+        temp = (u[0] + pml * om ** 2 * s) / total
+        th_acc = (gravity * s - c * temp) / (half_length * (4.0 / 3.0 - m_pole * c ** 2 / total))
+        acc = temp - pml * th_acc * c / total
+        return torch.stack([pos + dt * vel, vel + dt * acc, th + dt * om, om + dt * th_acc])
+
+    def cost(x, u):
+        return 0.1 * x[0] ** 2 + 0.01 * x[1] ** 2 + 1.0 - torch.cos(x[2]) + 0.01 * x[3] ** 2 + 0.001 * u[0] ** 2
+
+    def final_cost(x):
+        return 10.0 * (x[0] ** 2 + 0.1 * x[1] ** 2 + 2.0 * (1.0 - torch.cos(x[2])) + 0.1 * x[3] ** 2)
+
+    return TorchEnv(transition, cost, final_cost, 4, 1, np.full((1, 1), -force), np.full((1, 1), force), device=device)
