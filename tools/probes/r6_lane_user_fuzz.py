@@ -1,6 +1,6 @@
 """Dense user envs with n + m <= 4 on the lane-group kernel (round 6) against the generic wave kernel of the same companion library: the LQ env of
 lqr.py:36-57 as DeviceEnv source, shapes 1x1 .. 3x1 / 1x3 / 2x2, random batch sizes (both launch forms), horizons, limits.  Two fp32 programs:
-iterations must agree on >= 80 % of the instances and the costs to 1e-4 (median), no status flag but NOT_PD.  Exit status 1 on any failure.
+iterations must agree on >= 80 % of the instances and the costs to 1e-4 (median), the same status flags (NOT_PD apart).  Exit status 1 on any failure.
     python tools/probes/r6_lane_user_fuzz.py [seed] [cases]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -41,10 +41,12 @@ for case in range(cases):
     same = float((out["iterations"] == wave["iterations"]).float().mean())
     cu, cw = out["costs"].double().sum(1).cpu().numpy(), wave["costs"].double().sum(1).cpu().numpy()
     rel = float(np.median(np.abs(cu - cw) / np.abs(cw)))
-    flags = int((out["status"] & ~_hip.ST_NOT_PD).abs().sum())
+    # (a flag the wave kernel raises too -- e.g. a box-QP at its 100-iteration cap, optimization.py:13 -- is the problem's, not the kernel's)
+    flags = int(((out["status"] & ~_hip.ST_NOT_PD) != (wave["status"] & ~_hip.ST_NOT_PD)).sum())
+    raised = int((out["status"] & ~_hip.ST_NOT_PD).abs().sum())
     ok = kernel.startswith("lane_group") and same >= 0.8 and rel <= 1e-4 and flags == 0 and (bound is None or float(out["actions"].abs().max()) <= bound + 1e-6)
     bad += 0 if ok else 1
     print(f"case {case:2d}: {n}x{m} B={B:4d} T={T:2d} bound={bound if bound is None else round(bound, 2)} iterations<={its:2d}  {kernel[:10]}  same iterations {same:.3f}  "
-          f"median cost difference {rel:.1e}  flags {flags}  {'ok' if ok else 'FAILED'}", flush=True)
+          f"median cost difference {rel:.1e}  status words that differ {flags} (flag bits raised: {raised})  {'ok' if ok else 'FAILED'}", flush=True)
 print("failed cases:", bad)
 sys.exit(1 if bad else 0)
