@@ -60,9 +60,27 @@ int boxqp_lane2_launch(int B, const float *H, const float *q, const float *low, 
 
 bool ilqr_lane_group_fits(int T) { return GroupStore<2, 2, 4, 3>::bytes(T) <= 64 * 1024; }
 
+// The group kernel must not run from an instantiation that spills (ilqr_lane_kernels.h).  The build is held to that by
+// tests/test_lane_group_private_segment_cpu.py; a library built by another compiler is asked here, once per process, and answers with the wave kernel.
+template <int KIND>
+static bool group_kernels_spill_nothing()
+{
+    static const bool clean = [] {
+        const void *kerns[2] = {reinterpret_cast<const void *>(ilqr_group_solve_kernel<KIND, 2, 2, 1>), reinterpret_cast<const void *>(ilqr_group_solve_kernel<KIND, 2, 2, 4>)};
+        for (const void *k : kerns) {
+            hipFuncAttributes attr{};
+            if (hipFuncGetAttributes(&attr, k) != hipSuccess || attr.localSizeBytes != 0 || attr.numRegs > 256) return false;
+        }
+        return true;
+    }();
+    return clean;
+}
+
 bool ilqr_lane_supported(const TfmpcEnv &env)
 {
     if (env.n != 2 || env.m != 2) return false;
+    if (env.kind == TFMPC_ENV_NAVLQR && !group_kernels_spill_nothing<TFMPC_ENV_NAVLQR>()) return false;
+    if (env.kind == TFMPC_ENV_NAVIGATION && !group_kernels_spill_nothing<TFMPC_ENV_NAVIGATION>()) return false;
     if (env.kind == TFMPC_ENV_NAVLQR) return true;
     if (env.kind == TFMPC_ENV_NAVIGATION) return env.stride[1] == 0 && env.stride[2] == 0 && env.n_zones <= 8;
     return false;
